@@ -1,0 +1,313 @@
+"""On-disk formats of the HINGE filter / maximal / layout path (numpy side).
+
+Writers and readers for the DAZZ_DB stub/index/track files and the DALIGNER
+``.las`` overlap file, used by the synthetic-data generator, the tests and
+``bench.py``.  The product's C++ ingest (``hinge_amd/host/las_reader.cpp``,
+``db_reader.cpp``) reads the same bytes; this module is the independent
+Python statement of the formats so the two can be checked against each other.
+
+Reference for the layouts (file:line under the reference tree):
+  * ``.las`` header ``int64 novl; int32 tspace``  - src/lib/LAInterface.cpp:604-605
+  * ``.las`` record = ``Overlap`` minus its leading pointer (40 bytes)
+                                                   - src/include/align.h:126-132,332-337,
+                                                     src/lib/align.c:3042-3049
+  * trace = ``tlen`` bytes (tspace <= 125) of (diffs, b-advance) pairs
+                                                   - src/include/align.h:98-110,
+                                                     src/lib/LAInterface.cpp:607-614
+  * ``NAME.db`` text stub                          - src/include/DB.h:299-303
+  * ``.NAME.idx`` = HITS_DB (112 B) + n x HITS_READ (40 B)
+                                                   - src/include/DB.h:214-288
+  * ``.NAME.qual.anno/.data`` track                - src/lib/DB.c:1097-1100,1238-1270
+"""
+from __future__ import annotations
+
+import os
+import struct
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+TRACE_XOVR = 125          # src/include/align.h:58
+DB_QV = 0x03FF            # src/include/DB.h:210
+DB_CSS = 0x0400
+DB_BEST = 0x0800          # src/include/DB.h:212
+COMP_FLAG = 0x1           # src/include/align.h:155  COMP(x) = (x & 0x1)
+
+HITS_DB_FMT = "<iiii4fi4xqiiiii4xqi4xqqq"       # 112 bytes
+HITS_DB_SIZE = struct.calcsize(HITS_DB_FMT)
+assert HITS_DB_SIZE == 112
+
+HITS_READ_DTYPE = np.dtype(
+    {
+        "names": ["origin", "rlen", "fpulse", "boff", "coff", "flags"],
+        "formats": ["<i4", "<i4", "<i4", "<i8", "<i8", "<i4"],
+        "offsets": [0, 4, 8, 16, 24, 32],
+        "itemsize": 40,
+    }
+)
+
+LAS_REC_DTYPE = np.dtype(
+    {
+        "names": ["tlen", "diffs", "abpos", "bbpos", "aepos", "bepos", "flags", "aread", "bread"],
+        "formats": ["<i4", "<i4", "<i4", "<i4", "<i4", "<i4", "<u4", "<i4", "<i4"],
+        "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32],
+        "itemsize": 40,
+    }
+)
+
+
+# --------------------------------------------------------------------------------------
+# DAZZ_DB
+# --------------------------------------------------------------------------------------
+
+def db_paths(db_name: str) -> Tuple[str, str, str, str]:
+    """(stub, idx, bps, track-prefix) for ``--db db_name`` (name may or may not end in .db)."""
+    d, b = os.path.split(db_name)
+    if b.endswith(".db"):
+        b = b[:-3]
+    d = d or "."
+    return (
+        os.path.join(d, b + ".db"),
+        os.path.join(d, "." + b + ".idx"),
+        os.path.join(d, "." + b + ".bps"),
+        os.path.join(d, "." + b),
+    )
+
+
+def write_db(
+    db_name: str,
+    rlen: np.ndarray,
+    block_first: Optional[Sequence[int]] = None,
+    cutoff: int = 0,
+    all_flag: int = 1,
+    flags: Optional[np.ndarray] = None,
+    write_bases: bool = True,
+) -> None:
+    """Write NAME.db, .NAME.idx and (optionally) .NAME.bps for reads of the given lengths.
+
+    ``block_first`` = untrimmed first-read index of every block plus the total (DBsplit's
+    table); defaults to a single block.  With ``cutoff=0, all_flag=1`` nothing is trimmed.
+    """
+    rlen = np.asarray(rlen, dtype=np.int32)
+    n = int(rlen.shape[0])
+    stub, idx, bps, _ = db_paths(db_name)
+    if flags is None:
+        flags = np.full(n, DB_BEST | 850, dtype=np.int32)
+    flags = np.asarray(flags, dtype=np.int32)
+    keep = ((flags & DB_BEST) >= (0 if all_flag else DB_BEST)) & (rlen >= cutoff)
+    treads = int(keep.sum())
+    if block_first is None:
+        block_first = [0, n]
+    block_first = list(block_first)
+    tcum = np.concatenate([[0], np.cumsum(keep)])
+    with open(stub, "w") as f:
+        f.write("files = %9d\n" % 1)
+        f.write("  %9d %s %s\n" % (n, "synth", "synth"))
+        f.write("blocks = %9d\n" % (len(block_first) - 1))
+        f.write("size = %9d cutoff = %9d all = %1d\n" % (200, cutoff, all_flag))
+        for u in block_first:
+            f.write(" %9d %9d\n" % (u, int(tcum[u])))
+    rec = np.zeros(n, dtype=HITS_READ_DTYPE)
+    rec["origin"] = np.arange(n, dtype=np.int32)
+    rec["rlen"] = rlen
+    rec["fpulse"] = 0
+    nbytes = (rlen.astype(np.int64) + 3) >> 2
+    rec["boff"] = np.concatenate([[0], np.cumsum(nbytes)[:-1]]) if n else 0
+    rec["coff"] = -1
+    rec["flags"] = flags
+    hdr = struct.pack(
+        HITS_DB_FMT,
+        n, treads, cutoff, all_flag, 0.25, 0.25, 0.25, 0.25,
+        int(rlen.max()) if n else 0, int(rlen.astype(np.int64).sum()),
+        n, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    )
+    with open(idx, "wb") as f:
+        f.write(hdr)
+        f.write(rec.tobytes())
+    if write_bases:
+        with open(bps, "wb") as f:
+            total = int(nbytes.sum())
+            chunk = bytes(1 << 20)
+            while total > 0:
+                w = min(total, len(chunk))
+                f.write(chunk[:w])
+                total -= w
+
+
+def read_db_index(db_name: str) -> dict:
+    """Read .NAME.idx + NAME.db; returns trimmed read lengths the way Open_DB+Trim_DB see them
+    (src/lib/DB.c:395-578, 585-683)."""
+    stub, idx, _, _ = db_paths(db_name)
+    with open(idx, "rb") as f:
+        hdr = struct.unpack(HITS_DB_FMT, f.read(HITS_DB_SIZE))
+        ureads, treads = hdr[0], hdr[1]
+        rec = np.frombuffer(f.read(ureads * 40), dtype=HITS_READ_DTYPE)
+    cutoff, all_flag = 0, 1
+    with open(stub) as f:
+        lines = f.read().split("\n")
+    for ln in lines:
+        if ln.startswith("size ="):
+            toks = ln.replace("=", " ").split()
+            cutoff = int(toks[3])
+            all_flag = int(toks[5])
+    if cutoff <= 0 and all_flag:
+        keep = np.ones(ureads, dtype=bool)
+    else:
+        keep = ((rec["flags"] & DB_BEST) >= (0 if all_flag else DB_BEST)) & (rec["rlen"] >= cutoff)
+    return {
+        "ureads": ureads,
+        "treads": treads,
+        "cutoff": cutoff,
+        "all": all_flag,
+        "rlen": rec["rlen"][keep].astype(np.int32),
+        "keep": keep,
+    }
+
+
+def write_qual_track(db_name: str, qv_per_read: List[np.ndarray]) -> None:
+    """Write the ``qual`` track (.NAME.qual.anno / .NAME.qual.data): one byte per tspace segment."""
+    _, _, _, pre = db_paths(db_name)
+    n = len(qv_per_read)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    for i, q in enumerate(qv_per_read):
+        offs[i + 1] = offs[i] + len(q)
+    with open(pre + ".qual.anno", "wb") as f:
+        f.write(struct.pack("<ii", n, 8))
+        f.write(offs.tobytes())
+    with open(pre + ".qual.data", "wb") as f:
+        for q in qv_per_read:
+            f.write(np.asarray(q, dtype=np.uint8).tobytes())
+
+
+def read_qual_track(db_name: str) -> Optional[List[np.ndarray]]:
+    _, _, _, pre = db_paths(db_name)
+    if not os.path.exists(pre + ".qual.anno"):
+        return None
+    with open(pre + ".qual.anno", "rb") as f:
+        tracklen, size = struct.unpack("<ii", f.read(8))
+        offs = np.frombuffer(f.read(8 * (tracklen + 1)), dtype=np.int64)
+    data = np.fromfile(pre + ".qual.data", dtype=np.uint8)
+    return [data[offs[i]:offs[i + 1]] for i in range(tracklen)]
+
+
+# --------------------------------------------------------------------------------------
+# .las
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class LasRecords:
+    """Raw .las records exactly as stored on disk (B coordinates of complemented overlaps are in
+    the reverse-complemented B frame) plus the concatenated trace bytes."""
+
+    tspace: int
+    rec: np.ndarray            # LAS_REC_DTYPE [novl]
+    trace: np.ndarray          # uint8 [sum tlen * tbytes]
+    trace_off: np.ndarray      # int64 [novl + 1] byte offsets into trace
+
+    @property
+    def novl(self) -> int:
+        return int(self.rec.shape[0])
+
+
+def write_las(path: str, recs: LasRecords) -> None:
+    tbytes = 1 if recs.tspace <= TRACE_XOVR else 2
+    novl = recs.novl
+    rec_b = recs.rec.view(np.uint8).reshape(novl, 40) if novl else np.zeros((0, 40), np.uint8)
+    tlen_b = (recs.trace_off[1:] - recs.trace_off[:-1]).astype(np.int64)
+    assert np.array_equal(tlen_b, recs.rec["tlen"].astype(np.int64) * tbytes)
+    # interleave records and traces into one byte buffer
+    out_off = np.concatenate([[0], np.cumsum(40 + tlen_b)]).astype(np.int64)
+    buf = np.zeros(int(out_off[-1]), dtype=np.uint8)
+    if novl:
+        idx = out_off[:-1, None] + np.arange(40)[None, :]
+        buf[idx.reshape(-1)] = rec_b.reshape(-1)
+        # trace bytes: destination = out_off[i] + 40 + k
+        tot = int(tlen_b.sum())
+        if tot:
+            owner = np.repeat(np.arange(novl), tlen_b)
+            within = np.arange(tot) - np.repeat(recs.trace_off[:-1], tlen_b)
+            buf[out_off[owner] + 40 + within] = recs.trace
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qi", novl, recs.tspace))
+        f.write(buf.tobytes())
+
+
+def read_las(path: str) -> LasRecords:
+    """Sequential header-hop parse (record boundaries are only discoverable through tlen)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    novl, tspace = struct.unpack("<qi", raw[:12].tobytes())
+    tbytes = 1 if tspace <= TRACE_XOVR else 2
+    rec = np.zeros(novl, dtype=LAS_REC_DTYPE)
+    toff = np.zeros(novl + 1, dtype=np.int64)
+    pos = 12
+    starts = np.zeros(novl, dtype=np.int64)
+    mv = memoryview(raw)
+    for i in range(novl):
+        starts[i] = pos
+        tlen = struct.unpack_from("<i", mv, pos)[0]
+        toff[i + 1] = toff[i] + tlen * tbytes
+        pos += 40 + tlen * tbytes
+    if novl:
+        idx = starts[:, None] + np.arange(40)[None, :]
+        rec = raw[idx.reshape(-1)].reshape(novl, 40).copy().view(LAS_REC_DTYPE).reshape(novl)
+        tl = (toff[1:] - toff[:-1])
+        tot = int(tl.sum())
+        owner = np.repeat(np.arange(novl), tl)
+        within = np.arange(tot) - np.repeat(toff[:-1], tl)
+        trace = raw[starts[owner] + 40 + within].copy()
+    else:
+        trace = np.zeros(0, np.uint8)
+    return LasRecords(tspace=tspace, rec=rec, trace=trace, trace_off=toff)
+
+
+@dataclass
+class Pileups:
+    """SoA pile-up arrays in the layout the C-ABI takes (include/hinge_hip.h): the overlaps of
+    every A read in .las order, self-overlaps removed, B coordinates on the forward strand
+    (the flip of src/lib/LAInterface.cpp:1619-1626 already applied)."""
+
+    n_reads: int
+    row_ptr: np.ndarray     # int64 [n_reads + 1]
+    a_span: np.ndarray      # int32 [n, 2]  (abpos, aepos)
+    b_span: np.ndarray      # int32 [n, 2]  (bbpos, bepos) forward strand
+    b_flag: np.ndarray      # uint32 [n]    bread | comp << 31
+    las_index: np.ndarray   # int64 [n] index of the record in the .las file
+    self_a: np.ndarray      # int32 [m] A id of the removed self-overlaps
+    self_span: np.ndarray   # int32 [m, 4] abpos, aepos, bbpos', bepos'
+
+    @property
+    def n_ovl(self) -> int:
+        return int(self.b_flag.shape[0])
+
+
+def pileups_from_las(recs: LasRecords, rlen: np.ndarray) -> Pileups:
+    r = recs.rec
+    n_reads = int(len(rlen))
+    comp = (r["flags"] & COMP_FLAG).astype(np.int32)
+    blen = np.asarray(rlen, dtype=np.int32)[r["bread"]] if recs.novl else np.zeros(0, np.int32)
+    bb = np.where(comp == 1, blen - r["bepos"], r["bbpos"]).astype(np.int32)
+    be = np.where(comp == 1, blen - r["bbpos"], r["bepos"]).astype(np.int32)
+    is_self = r["aread"] == r["bread"]
+    keep = ~is_self
+    a = r["aread"][keep]
+    if len(a) > 1:
+        assert np.all(a[1:] >= a[:-1]), ".las must be sorted by A read"
+    counts = np.bincount(a, minlength=n_reads).astype(np.int64)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    a_span = np.stack([r["abpos"][keep], r["aepos"][keep]], axis=1).astype(np.int32)
+    b_span = np.stack([bb[keep], be[keep]], axis=1).astype(np.int32)
+    b_flag = (r["bread"][keep].astype(np.uint32) | (comp[keep].astype(np.uint32) << np.uint32(31)))
+    self_span = np.stack(
+        [r["abpos"][is_self], r["aepos"][is_self], bb[is_self], be[is_self]], axis=1
+    ).astype(np.int32)
+    return Pileups(
+        n_reads=n_reads,
+        row_ptr=row_ptr,
+        a_span=np.ascontiguousarray(a_span),
+        b_span=np.ascontiguousarray(b_span),
+        b_flag=np.ascontiguousarray(b_flag),
+        las_index=np.nonzero(keep)[0].astype(np.int64),
+        self_a=r["aread"][is_self].astype(np.int32),
+        self_span=self_span,
+    )

@@ -1,0 +1,373 @@
+"""Seeded synthetic DAZZ_DB + DALIGNER overlap generator.
+
+The reference's datasets are fetched by its demo scripts (demo/ecoli_demo/run.sh:1) and need
+DALIGNER, neither of which exists here, so BASELINE.json's configs are restated as synthetic
+inputs: a linear genome with planted repeat families, reads sampled
+uniformly on both strands (optionally chimeric), overlaps = true interval intersections of at
+least ``min_ovl`` bases plus the repeat-induced cross-copy local alignments that create the
+coverage jumps `hinge filter` annotates, written in the exact on-disk formats of
+``hinge_amd.formats``.  Everything is vectorised numpy so the E. coli 160x restatement
+(~3e7 overlap records) is generated in well under a minute.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import formats
+
+
+@dataclass
+class SynthSpec:
+    genome_len: int = 120_000
+    coverage: float = 40.0
+    len_dist: str = "uniform"          # "uniform" | "lognormal"
+    len_min: int = 3000
+    len_max: int = 11000
+    len_mean: float = 8500.0           # lognormal mean
+    len_sigma: float = 0.35            # lognormal sigma (of log)
+    n_repeat_families: int = 1
+    repeat_len: Tuple[int, int] = (4000, 4000)
+    repeat_copies: Tuple[int, int] = (2, 2)
+    inverted_copies: bool = True
+    chimera_frac: float = 0.0
+    min_ovl: int = 1000
+    end_jitter: int = 25
+    indel_max: int = 6
+    tspace: int = 100
+    seed: int = 1
+    n_blocks: int = 1
+    with_qv: bool = False
+    tie_quantum: int = 0               # >0: snap alignment end points to this grid (heavy ties)
+
+
+@dataclass
+class SynthData:
+    spec: SynthSpec
+    rlen: np.ndarray                   # int32 [n_reads]
+    aread: np.ndarray
+    bread: np.ndarray
+    comp: np.ndarray                   # uint8
+    ab: np.ndarray
+    ae: np.ndarray
+    bb: np.ndarray                     # forward-strand B coordinates
+    be: np.ndarray
+    block_first: List[int] = field(default_factory=list)
+    qv: Optional[List[np.ndarray]] = None
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.rlen.shape[0])
+
+    @property
+    def novl(self) -> int:
+        return int(self.aread.shape[0])
+
+
+def _expand_pairs(t0: np.ndarray, t1: np.ndarray, min_ovl: int):
+    """All (i, j), i < j in t0-sorted order, whose intervals intersect by >= min_ovl."""
+    order = np.argsort(t0, kind="stable")
+    s0 = t0[order]
+    s1 = t1[order]
+    n = len(s0)
+    hi = np.searchsorted(s0, s1 - min_ovl, side="right")       # j < hi  <=>  t0_j <= t1_i - min_ovl
+    lo = np.arange(n) + 1
+    cnt = np.maximum(hi - lo, 0).astype(np.int64)
+    tot = int(cnt.sum())
+    if tot == 0:
+        z = np.zeros(0, np.int64)
+        return z, z
+    i_idx = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    start = np.repeat(np.cumsum(cnt) - cnt, cnt)
+    j_idx = np.repeat(lo.astype(np.int64), cnt) + (np.arange(tot, dtype=np.int64) - start)
+    ok = (np.minimum(s1[i_idx], s1[j_idx]) - s0[j_idx]) >= min_ovl
+    return order[i_idx[ok]], order[j_idx[ok]]
+
+
+def generate(spec: SynthSpec) -> SynthData:
+    rng = np.random.default_rng(spec.seed)
+    G = spec.genome_len
+
+    # ---- repeat families: non-overlapping copies on the genome -------------------------
+    fam_len: List[int] = []
+    copies = []                                       # (family, pos, orient)
+    occupied: List[Tuple[int, int]] = []
+    for f in range(spec.n_repeat_families):
+        L = int(rng.integers(spec.repeat_len[0], spec.repeat_len[1] + 1))
+        k = int(rng.integers(spec.repeat_copies[0], spec.repeat_copies[1] + 1))
+        fam_len.append(L)
+        for _ in range(k):
+            for _try in range(200):
+                p = int(rng.integers(2000, max(2001, G - L - 2000)))
+                if all(p + L + 3000 < a or p > b + 3000 for a, b in occupied):
+                    occupied.append((p, p + L))
+                    o = 1 if (not spec.inverted_copies or rng.random() < 0.7) else -1
+                    copies.append((f, p, o))
+                    break
+
+    # ---- reads ---------------------------------------------------------------------------
+    mean_len = (spec.len_min + spec.len_max) / 2 if spec.len_dist == "uniform" else spec.len_mean
+    n_reads = max(4, int(round(G * spec.coverage / mean_len)))
+    if spec.len_dist == "uniform":
+        lens = rng.integers(spec.len_min, spec.len_max + 1, size=n_reads)
+    else:
+        mu = np.log(spec.len_mean) - 0.5 * spec.len_sigma ** 2
+        lens = np.clip(rng.lognormal(mu, spec.len_sigma, size=n_reads), spec.len_min, spec.len_max).astype(np.int64)
+    lens = np.minimum(lens, G // 2)
+    starts = rng.integers(0, G - lens + 1)
+    # reads are stored in DB order = order of genome start only loosely (shuffle like a real run)
+    perm = rng.permutation(n_reads)
+    lens, starts = lens[perm], starts[perm]
+    strand = np.where(rng.random(n_reads) < 0.5, 1, -1).astype(np.int64)
+
+    # segments: (read, roff, gs, ge, strand)
+    seg_read = [np.arange(n_reads, dtype=np.int64)]
+    seg_roff = [np.zeros(n_reads, np.int64)]
+    seg_gs = [starts.astype(np.int64)]
+    seg_ge = [(starts + lens).astype(np.int64)]
+    seg_s = [strand]
+    n_chim = int(round(spec.chimera_frac * n_reads))
+    if n_chim > 0:
+        chim = rng.choice(n_reads, size=n_chim, replace=False)
+        cut = (lens[chim] * rng.uniform(0.3, 0.7, size=n_chim)).astype(np.int64)
+        # first part keeps [gs, gs+cut) (strand +) or [ge-cut, ge) (strand -); second part elsewhere
+        L2 = lens[chim] - cut
+        gs2 = rng.integers(0, G - L2 + 1)
+        s2 = np.where(rng.random(n_chim) < 0.5, 1, -1).astype(np.int64)
+        g0, g1 = seg_gs[0].copy(), seg_ge[0].copy()
+        plus = strand[chim] == 1
+        g1[chim[plus]] = g0[chim[plus]] + cut[plus]
+        g0[chim[~plus]] = g1[chim[~plus]] - cut[~plus]
+        seg_gs[0], seg_ge[0] = g0, g1
+        seg_read.append(chim.astype(np.int64))
+        seg_roff.append(cut)
+        seg_gs.append(gs2.astype(np.int64))
+        seg_ge.append((gs2 + L2).astype(np.int64))
+        seg_s.append(s2)
+    seg_read = np.concatenate(seg_read)
+    seg_roff = np.concatenate(seg_roff)
+    seg_gs = np.concatenate(seg_gs)
+    seg_ge = np.concatenate(seg_ge)
+    seg_s = np.concatenate(seg_s)
+
+    # An "entry" maps a frame interval [t0,t1) onto a read linearly: rpos(t) = c + sg * t.
+    def entry_map(roff, gs, ge, s, g_of_t_sign, g_of_t_off):
+        # g(t) = g_of_t_off + g_of_t_sign * t ; rpos(g) = roff + (g-gs) if s>0 else roff + (ge-g)
+        sg = s * g_of_t_sign
+        c = np.where(s > 0, roff + g_of_t_off - gs, roff + ge - g_of_t_off)
+        return c, sg
+
+    rec_a, rec_b, rec_ab, rec_ae, rec_bb, rec_be, rec_comp = [], [], [], [], [], [], []
+
+    def emit(i, j, e_read, e_t0, e_t1, e_c, e_sg):
+        """Emit both directed records for entry pairs (i, j)."""
+        for (x, y) in ((i, j), (j, i)):
+            lo = np.maximum(e_t0[x], e_t0[y])
+            hi = np.minimum(e_t1[x], e_t1[y])
+            if spec.end_jitter > 0:
+                lo = lo + rng.integers(0, spec.end_jitter + 1, size=len(lo))
+                hi = hi - rng.integers(0, spec.end_jitter + 1, size=len(hi))
+            if spec.tie_quantum > 0:
+                q = spec.tie_quantum
+                lo = ((lo + q - 1) // q) * q
+                hi = (hi // q) * q
+            ok = hi - lo >= max(spec.min_ovl - 2 * spec.end_jitter - 2 * spec.tie_quantum, 200)
+            lo, hi, xx, yy = lo[ok], hi[ok], x[ok], y[ok]
+            pa0 = e_c[xx] + e_sg[xx] * lo
+            pa1 = e_c[xx] + e_sg[xx] * hi
+            pb0 = e_c[yy] + e_sg[yy] * lo
+            pb1 = e_c[yy] + e_sg[yy] * hi
+            ab = np.minimum(pa0, pa1)
+            ae = np.maximum(pa0, pa1)
+            bb = np.minimum(pb0, pb1)
+            be = np.maximum(pb0, pb1)
+            if spec.indel_max > 0:
+                d = rng.integers(0, spec.indel_max + 1, size=len(bb))
+                side = rng.random(len(bb)) < 0.5
+                bb = np.where(side, bb + d, bb)
+                be = np.where(side, be, be - d)
+            rec_a.append(e_read[xx])
+            rec_b.append(e_read[yy])
+            rec_ab.append(ab)
+            rec_ae.append(ae)
+            rec_bb.append(bb)
+            rec_be.append(be)
+            rec_comp.append((e_sg[xx] != e_sg[yy]).astype(np.uint8))
+
+    # ---- true overlaps: frame = genome --------------------------------------------------
+    c, sg = entry_map(seg_roff, seg_gs, seg_ge, seg_s, 1, 0)
+    i, j = _expand_pairs(seg_gs, seg_ge, spec.min_ovl)
+    keep = seg_read[i] != seg_read[j]
+    emit(i[keep], j[keep], seg_read, seg_gs, seg_ge, c, sg)
+
+    # ---- repeat-induced overlaps: frame = repeat coordinate of each family ---------------
+    for f, L in enumerate(fam_len):
+        e_read, e_t0, e_t1, e_c, e_sg, e_copy = [], [], [], [], [], []
+        for ci, (ff, p, o) in enumerate(copies):
+            if ff != f:
+                continue
+            x0 = np.maximum(seg_gs, p)
+            x1 = np.minimum(seg_ge, p + L)
+            hit = np.nonzero(x1 - x0 >= spec.min_ovl)[0]
+            if len(hit) == 0:
+                continue
+            if o > 0:
+                t0 = x0[hit] - p
+                t1 = x1[hit] - p
+                cc, ss = entry_map(seg_roff[hit], seg_gs[hit], seg_ge[hit], seg_s[hit], 1, p)
+            else:
+                t0 = p + L - x1[hit]
+                t1 = p + L - x0[hit]
+                cc, ss = entry_map(seg_roff[hit], seg_gs[hit], seg_ge[hit], seg_s[hit], -1, p + L)
+            e_read.append(seg_read[hit]); e_t0.append(t0); e_t1.append(t1)
+            e_c.append(cc); e_sg.append(ss); e_copy.append(np.full(len(hit), ci))
+        if not e_read:
+            continue
+        e_read = np.concatenate(e_read); e_t0 = np.concatenate(e_t0); e_t1 = np.concatenate(e_t1)
+        e_c = np.concatenate(e_c); e_sg = np.concatenate(e_sg); e_copy = np.concatenate(e_copy)
+        i, j = _expand_pairs(e_t0, e_t1, spec.min_ovl)
+        keep = e_copy[i] != e_copy[j]
+        emit(i[keep], j[keep], e_read, e_t0, e_t1, e_c, e_sg)
+
+    aread = np.concatenate(rec_a).astype(np.int32)
+    bread = np.concatenate(rec_b).astype(np.int32)
+    ab = np.concatenate(rec_ab).astype(np.int32)
+    ae = np.concatenate(rec_ae).astype(np.int32)
+    bb = np.concatenate(rec_bb).astype(np.int32)
+    be = np.concatenate(rec_be).astype(np.int32)
+    comp = np.concatenate(rec_comp).astype(np.uint8)
+    rl = lens.astype(np.int32)
+    ok = (ab >= 0) & (ae <= rl[aread]) & (bb >= 0) & (be <= rl[bread]) & (ae - ab >= 100) & (be - bb >= 100)
+    aread, bread, ab, ae, bb, be, comp = (v[ok] for v in (aread, bread, ab, ae, bb, be, comp))
+
+    # LAsort order: (aread, bread, comp, abpos)
+    order = np.lexsort((ab, comp, bread, aread))
+    aread, bread, ab, ae, bb, be, comp = (v[order] for v in (aread, bread, ab, ae, bb, be, comp))
+
+    # every read needs >= 1 overlap at both ends of the id range (the reference leaves reads
+    # outside [first A, last A] without a .mas line: src/filter/filter.cpp:516-517,696)
+    nb = max(1, spec.n_blocks)
+    block_first = [int(round(k * n_reads / nb)) for k in range(nb)] + [n_reads]
+
+    qv = None
+    if spec.with_qv:
+        qv = []
+        for L in rl:
+            nseg = (int(L) + spec.tspace - 1) // spec.tspace
+            q = rng.integers(5, 38, size=nseg).astype(np.uint8)
+            nbad = int(rng.integers(0, 3))
+            for _ in range(nbad):
+                s = int(rng.integers(0, max(1, nseg)))
+                w = int(rng.integers(1, 5))
+                q[s:s + w] = 45
+            qv.append(q)
+    return SynthData(spec=spec, rlen=rl, aread=aread, bread=bread, comp=comp, ab=ab, ae=ae,
+                     bb=bb, be=be, block_first=block_first, qv=qv)
+
+
+def make_traces(d: SynthData, sel: Optional[np.ndarray] = None):
+    """(diffs, b-advance) byte pairs per tspace-segment of A (src/include/align.h:98-110)."""
+    ts = d.spec.tspace
+    ab = d.ab if sel is None else d.ab[sel]
+    ae = d.ae if sel is None else d.ae[sel]
+    bb = d.bb if sel is None else d.bb[sel]
+    be = d.be if sel is None else d.be[sel]
+    nseg = ((ae.astype(np.int64) + ts - 1) // ts - ab.astype(np.int64) // ts)
+    tot = int(nseg.sum())
+    off = np.concatenate([[0], np.cumsum(nseg)]).astype(np.int64)
+    owner = np.repeat(np.arange(len(ab), dtype=np.int64), nseg)
+    k = np.arange(tot, dtype=np.int64) - off[owner]
+    base = (ab[owner].astype(np.int64) // ts) * ts
+    a0 = np.maximum(base + k * ts, ab[owner])
+    a1 = np.minimum(base + (k + 1) * ts, ae[owner])
+    alen = a1 - a0
+    diff = (be.astype(np.int64) - bb) - (ae.astype(np.int64) - ab)      # <= 0 by construction
+    adj = np.where(k < np.abs(diff)[owner], np.sign(diff)[owner], 0)
+    adv = alen + adj
+    # put any remainder (|diff| > nseg) on the last segment
+    rem = np.sign(diff) * np.maximum(np.abs(diff) - nseg, 0)
+    last = off[1:] - 1
+    adv[last] += rem
+    assert adv.min() >= 0 and adv.max() <= 255, (adv.min(), adv.max())
+    tr = np.zeros(2 * tot, dtype=np.uint8)
+    tr[0::2] = np.minimum(alen // 8, 255).astype(np.uint8)
+    tr[1::2] = adv.astype(np.uint8)
+    return tr, (2 * off).astype(np.int64)
+
+
+def to_las_records(d: SynthData, sel: Optional[np.ndarray] = None) -> formats.LasRecords:
+    idx = np.arange(d.novl) if sel is None else sel
+    tr, toff = make_traces(d, idx)
+    rec = np.zeros(len(idx), dtype=formats.LAS_REC_DTYPE)
+    comp = d.comp[idx].astype(np.int32)
+    blen = d.rlen[d.bread[idx]]
+    rec["tlen"] = (toff[1:] - toff[:-1]).astype(np.int32)
+    rec["diffs"] = ((d.ae[idx] - d.ab[idx]) // 8).astype(np.int32)
+    rec["abpos"] = d.ab[idx]
+    rec["aepos"] = d.ae[idx]
+    rec["bbpos"] = np.where(comp == 1, blen - d.be[idx], d.bb[idx])
+    rec["bepos"] = np.where(comp == 1, blen - d.bb[idx], d.be[idx])
+    rec["flags"] = comp.astype(np.uint32)
+    rec["aread"] = d.aread[idx]
+    rec["bread"] = d.bread[idx]
+    return formats.LasRecords(tspace=d.spec.tspace, rec=rec, trace=tr, trace_off=toff)
+
+
+def write_dataset(d: SynthData, directory: str, name: str = "G", write_bases: bool = True) -> str:
+    """Write NAME.db/.idx/.bps (+qual track), NAME.las and, for n_blocks > 1, NAME.k.las."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    db = os.path.join(directory, name)
+    formats.write_db(db, d.rlen, block_first=d.block_first, write_bases=write_bases)
+    if d.qv is not None:
+        formats.write_qual_track(db, d.qv)
+    formats.write_las(os.path.join(directory, name + ".las"), to_las_records(d))
+    if d.spec.n_blocks > 1:
+        for k in range(d.spec.n_blocks):
+            lo, hi = d.block_first[k], d.block_first[k + 1]
+            sel = np.nonzero((d.aread >= lo) & (d.aread < hi))[0]
+            formats.write_las(os.path.join(directory, "%s.%d.las" % (name, k + 1)), to_las_records(d, sel))
+    return db
+
+
+def to_pileups(d: SynthData) -> formats.Pileups:
+    """SoA pile-ups straight from the generator (no file round trip) for bench.py."""
+    keep = d.aread != d.bread
+    a = d.aread[keep]
+    counts = np.bincount(a, minlength=d.n_reads).astype(np.int64)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    sl = ~keep
+    return formats.Pileups(
+        n_reads=d.n_reads,
+        row_ptr=row_ptr,
+        a_span=np.ascontiguousarray(np.stack([d.ab[keep], d.ae[keep]], axis=1).astype(np.int32)),
+        b_span=np.ascontiguousarray(np.stack([d.bb[keep], d.be[keep]], axis=1).astype(np.int32)),
+        b_flag=np.ascontiguousarray(d.bread[keep].astype(np.uint32) | (d.comp[keep].astype(np.uint32) << np.uint32(31))),
+        las_index=np.nonzero(keep)[0].astype(np.int64),
+        self_a=d.aread[sl].astype(np.int32),
+        self_span=np.stack([d.ab[sl], d.ae[sl], d.bb[sl], d.be[sl]], axis=1).astype(np.int32),
+    )
+
+
+# BASELINE.json configs restated
+CONFIGS = {
+    "tiny": SynthSpec(genome_len=120_000, coverage=40, seed=7),
+    "tiny_qv": SynthSpec(genome_len=120_000, coverage=40, seed=8, with_qv=True),
+    "tiny_mlas": SynthSpec(genome_len=150_000, coverage=35, seed=9, n_blocks=3, n_repeat_families=2),
+    "ties": SynthSpec(genome_len=100_000, coverage=60, seed=10, tie_quantum=100, end_jitter=0, indel_max=0,
+                      n_repeat_families=2, repeat_copies=(2, 3)),
+    "chimera": SynthSpec(genome_len=150_000, coverage=40, seed=11, chimera_frac=0.05, n_repeat_families=2),
+    "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
+                                 repeat_len=(1000, 5000), repeat_copies=(2, 3)),
+    "cfg2_ecoli160": SynthSpec(genome_len=4_600_000, coverage=160, len_dist="lognormal", len_mean=8500,
+                               len_min=1500, len_max=40000, seed=2, n_repeat_families=1,
+                               repeat_len=(5000, 5000), repeat_copies=(7, 7)),
+    "cfg3_nctc": SynthSpec(genome_len=5_000_000, coverage=100, len_dist="lognormal", len_mean=8000,
+                           len_min=1500, len_max=40000, seed=3, n_repeat_families=40,
+                           repeat_len=(1000, 8000), repeat_copies=(2, 6), chimera_frac=0.02),
+    "cfg4_yeast": SynthSpec(genome_len=12_000_000, coverage=80, len_dist="lognormal", len_mean=8000,
+                            len_min=1500, len_max=40000, seed=4, n_repeat_families=20,
+                            repeat_len=(1000, 6000), repeat_copies=(2, 5), n_blocks=8),
+}

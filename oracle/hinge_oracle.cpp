@@ -1,0 +1,1077 @@
+// TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+// CPU oracle for the HINGE filter / maximal / layout hot path: a single-threaded, statement-level
+// restatement of the three stage programs' main() bodies, exported with a C ABI for ctypes.
+//
+//   oracle_filter   restates /root/reference/src/filter/filter.cpp:300-1118
+//   oracle_maximal  restates /root/reference/src/maximal/maximal.cpp:370-895
+//   oracle_layout   restates /root/reference/src/layout/hinging.cpp:347-610, 729-2148
+//
+// PARITY PIN: the library functions underneath (profileCoverage, trim_overlap, AddTypesAsymmetric,
+// GetMatchingPosition, getOverlap, INIReader, comparators + std::sort) are pinned against the
+// reference's own compiled code (oracle/_ref, built from the reference sources where they lie).
+// The three main() bodies cannot be built here (they include spdlog / Boost.Graph, both absent
+// from this image, and the reference ships no tests or golden vectors for them), so for the
+// stage-level outputs this oracle is "parity unpinned": it is a careful restatement, not a
+// checked one.  Where the reference has undefined behaviour (no read >= 5000 bp, reads outside
+// [first A, last A] of the .las) the oracle returns an error code instead of guessing.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include <set>
+#include <sstream>
+#include <fstream>
+#include <unordered_map>
+#include "oracle_core.h"
+
+using namespace oracle;
+
+namespace {
+
+struct FilterParams {
+    int LENGTH_THRESHOLD, N_ITER, ALN_THRESHOLD, MIN_COV, CUT_OFF, THETA, THETA2, N_PROC, EST_COV;
+    int reso = 40;
+    bool use_qv_mask, use_coverage_mask;
+    int COVERAGE_FRACTION, MIN_RA, MAX_RA, RA_GAP, NO_HINGE_REGION, HINGE_MIN_SUPPORT;
+    int HINGE_BIN_PILEUP_THRESHOLD, HINGE_READ_UNBRIDGED_THRESHOLD, HINGE_BIN_LENGTH, HINGE_TOLERANCE_LENGTH;
+    bool delete_telomere, USE_TWO_MATCHES;
+    explicit FilterParams(const Ini& r) {
+        LENGTH_THRESHOLD = r.get_int("filter", "length_threshold", -1);
+        N_ITER = r.get_int("filter", "n_iter", -1);
+        ALN_THRESHOLD = r.get_int("filter", "aln_threshold", -1);
+        MIN_COV = r.get_int("filter", "min_cov", -1);
+        CUT_OFF = r.get_int("filter", "cut_off", -1);
+        THETA = r.get_int("filter", "theta", -1);
+        THETA2 = (int)r.get_int("filter", "theta2", 0);
+        N_PROC = r.get_int("running", "n_proc", 4);
+        EST_COV = r.get_int("filter", "ec", 0);
+        use_qv_mask = r.get_bool("filter", "use_qv", true);
+        use_coverage_mask = r.get_bool("filter", "coverage", true);
+        COVERAGE_FRACTION = (int)r.get_int("filter", "coverage_frac_repeat_annotation", 3);
+        MIN_RA = (int)r.get_int("filter", "min_repeat_annotation_threshold", 10);
+        MAX_RA = (int)r.get_int("filter", "max_repeat_annotation_threshold", 20);
+        RA_GAP = (int)r.get_int("filter", "repeat_annotation_gap_threshold", 300);
+        NO_HINGE_REGION = (int)r.get_int("filter", "no_hinge_region", 500);
+        HINGE_MIN_SUPPORT = (int)r.get_int("filter", "hinge_min_support", 7);
+        HINGE_BIN_PILEUP_THRESHOLD = (int)r.get_int("filter", "hinge_min_pileup", 7);
+        HINGE_READ_UNBRIDGED_THRESHOLD = (int)r.get_int("filter", "hinge_unbridged", 6);
+        HINGE_BIN_LENGTH = (int)r.get_int("filter", "hinge_bin", 100);
+        HINGE_TOLERANCE_LENGTH = (int)r.get_int("filter", "hinge_tolerance_length", 100);
+        HINGE_BIN_LENGTH = 2 * HINGE_TOLERANCE_LENGTH;                      // filter.cpp:405
+        delete_telomere = (int)r.get_int("layout", "del_telomere", 0);      // filter.cpp:406 (sic)
+        USE_TWO_MATCHES = (int)r.get_int("layout", "use_two_matches", 1);
+    }
+};
+
+void free_alns(std::vector<Ovl*>& aln) {
+    for (size_t i = 0; i < aln.size(); i++) delete aln[i];
+    aln.clear();
+}
+
+// QV mask, filter.cpp:309-312,340-369
+void qv_masks(std::vector<std::vector<int>>& QV, int n_read, int tspace, std::vector<IPair>& QV_mask) {
+    for (int i = 0; i < n_read; i++)
+        for (size_t j = 0; j < QV[i].size(); j++) QV[i][j] = int(QV[i][j] < 40);
+    for (int i = 0; i < n_read; i++) {
+        int s = 0, e = 0;
+        int max = 0, maxs = s, maxe = e;
+        for (size_t j = 0; j < QV[i].size(); j++) {
+            if ((QV[i][j] == 1) && (j < QV[i].size() - 1)) {
+                e++;
+            } else {
+                if (e - s > max) { maxe = e; maxs = s; max = e - s; }
+                s = j + 1;
+                e = j + 1;
+            }
+        }
+        QV_mask[i] = IPair(maxs * tspace, maxe * tspace);
+    }
+}
+
+// One side of the hinge scan, filter.cpp:867-1068.  type -1: supporters' (abpos, left overhang)
+// ascending; type +1: (aepos, right overhang) descending.
+void call_hinge(int type, int pos, const std::vector<Ovl*>& pile, const std::vector<IPair>& maskvec, int i,
+                const FilterParams& P, std::vector<IPair>& out) {
+    bool bridged = true;
+    int support = 0;
+    std::vector<IPair> other;
+    for (size_t k = 0; k < pile.size(); k++) {
+        int left_overhang = 0, right_overhang = 0;   // (uninitialised in the reference if comp is neither 0 nor 1)
+        int temp_id = pile[k]->b;
+        if (pile[k]->comp == 0) {
+            right_overhang = std::max(maskvec[temp_id].second - pile[k]->be, 0);
+            left_overhang = std::max(pile[k]->bb - maskvec[temp_id].first, 0);
+        } else if (pile[k]->comp == 1) {
+            right_overhang = std::max(pile[k]->bb - maskvec[temp_id].first, 0);
+            left_overhang = std::max(maskvec[temp_id].second - pile[k]->be, 0);
+        }
+        if (type == -1) {
+            if (right_overhang > P.THETA)
+                if ((pile[k]->ae > pos - P.HINGE_TOLERANCE_LENGTH) && (pile[k]->ae < pos + P.HINGE_TOLERANCE_LENGTH)) {
+                    other.push_back(IPair(pile[k]->ab, left_overhang));
+                    support++;
+                }
+        } else {
+            if (left_overhang > P.THETA)
+                if ((pile[k]->ab > pos - P.HINGE_TOLERANCE_LENGTH) && (pile[k]->ab < pos + P.HINGE_TOLERANCE_LENGTH)) {
+                    other.push_back(IPair(pile[k]->ae, right_overhang));
+                    support++;
+                }
+        }
+    }
+    if (support < P.HINGE_MIN_SUPPORT) return;
+    if (type == -1) std::sort(other.begin(), other.end(), pairAscend);
+    else std::sort(other.begin(), other.end(), pairDescend);
+
+    int considered = 0, to_end = 0;
+    for (int id = 0; id < (int)other.size(); ++id) {
+        bool near_end = type == -1 ? (other[id].first - maskvec[i].first < P.HINGE_BIN_LENGTH)
+                                   : (maskvec[i].second - other[id].first < P.HINGE_BIN_LENGTH);
+        int spread = type == -1 ? (other[id].first - other[0].first) : (other[0].first - other[id].first);
+        if (near_end) {
+            considered++;
+            to_end++;
+            if ((to_end > P.HINGE_READ_UNBRIDGED_THRESHOLD) ||
+                ((considered > P.HINGE_READ_UNBRIDGED_THRESHOLD) && (spread > P.HINGE_BIN_LENGTH))) {
+                bridged = false;
+                break;
+            }
+        } else if (other[id].second < P.THETA) {
+            considered++;
+            if ((to_end > P.HINGE_READ_UNBRIDGED_THRESHOLD) ||
+                ((considered > P.HINGE_READ_UNBRIDGED_THRESHOLD) && (spread > P.HINGE_BIN_LENGTH))) {
+                bridged = false;
+                break;
+            }
+        } else if (other[id].second > P.THETA) {
+            considered++;
+            int id1 = id + 1;
+            int pileup_length = 1;
+            while (id1 < (int)other.size()) {
+                int d = type == -1 ? (other[id1].first - other[id].first) : (other[id].first - other[id1].first);
+                if (d < P.HINGE_BIN_LENGTH) { pileup_length++; id1++; }
+                else break;
+            }
+            if (pileup_length > P.HINGE_BIN_PILEUP_THRESHOLD) { bridged = true; break; }
+        }
+    }
+    if ((!bridged) && (support > P.HINGE_MIN_SUPPORT)) out.push_back(IPair(pos, type));
+}
+
+}  // namespace
+
+extern "C" {
+
+// Return codes: 0 ok; 1 = the reference's "return 1" paths (bad config, no alignments);
+// -1 unreadable DB (reference exit(1)); -3 = reference behaviour undefined for this input.
+int oracle_filter(const char* name_db, const char* las_base, int mlas, const char* prefix, const char* name_config,
+                  const char* name_restrict) {
+    DB db;
+    if (open_db(name_db, db) != 0) return -1;
+    int n_read = (int)db.rlen.size();
+    std::vector<Read*> reads;
+    for (int i = 0; i < n_read; i++) { Read* r = new Read(); r->id = i; r->len = db.rlen[i]; reads.push_back(r); }
+    std::vector<std::vector<int>> QV;
+    bool has_qv = true;
+    if (load_qv(db, QV) != 0) has_qv = false;
+
+    std::string name_las_str = las_name(las_base, mlas != 0);
+    std::vector<std::string> name_las_list;
+    if (mlas) name_las_list = las_parts(name_las_str);
+    else name_las_list.push_back(name_las_str);
+    if (name_las_list.empty()) return -3;
+
+    std::set<int> reads_to_keep, reads_to_keep_initial;
+    if (name_restrict && strlen(name_restrict) > 0) {
+        std::ifstream rf(name_restrict);
+        std::string line;
+        while (std::getline(rf, line)) {
+            std::stringstream ss; ss << line; int num = 0; ss >> num; reads_to_keep.insert(num);
+        }
+    }
+
+    LasHeader h0;
+    if (las_header(name_las_list[0], h0) != 0) return -1;
+    std::vector<IPair> QV_mask(n_read);
+    if (has_qv) qv_masks(QV, n_read, h0.tspace, QV_mask);
+
+    Ini reader(name_config);
+    if (reader.error < 0) return 1;
+    FilterParams P(reader);
+    int MIN_COV = P.MIN_COV;
+    bool use_qv_mask = P.use_qv_mask && has_qv;
+    const int reso = P.reso;
+
+    std::vector<Ovl*> aln;
+    std::vector<std::vector<IPair>> coverages(n_read), cutoff_coverages(n_read), cgs(n_read);
+    std::vector<IPair> maskvec;
+    std::vector<std::vector<IPair>> repeat_annotation;
+    std::unordered_map<int, std::vector<IPair>> hinges;
+
+    std::string out(prefix);
+    FILE* cov = fopen((out + ".coverage.txt").c_str(), "w");
+    fclose(fopen((out + ".homologous.txt").c_str(), "w"));
+    FILE* rep = fopen((out + ".repeat.txt").c_str(), "w");
+    fclose(fopen((out + ".filtered.fasta").c_str(), "w"));
+    FILE* hg = fopen((out + ".hinges.txt").c_str(), "w");
+    FILE* mask = fopen((out + ".mas").c_str(), "w");
+    FILE* comask = fopen((out + ".cmas").c_str(), "w");
+    FILE* covflag = fopen((out + ".cov.flag").c_str(), "w");
+    FILE* selfflag = fopen((out + ".self.flag").c_str(), "w");
+    int rc = 0;
+
+    for (int part = 0; part < (int)name_las_list.size(); part++) {
+        LasHeader h;
+        if (load_overlaps(name_las_list[part], db, aln, h) != 0) { rc = -1; break; }
+        if (h.novl == 0) { rc = 1; break; }
+        int r_begin = aln.front()->a;
+        int r_end = aln.back()->a;
+
+        std::vector<std::vector<Ovl*>> idx_pileup;
+        std::unordered_map<int, std::vector<IPair>> self_aln_list;
+        for (int i = 0; i < n_read; i++) {
+            idx_pileup.push_back(std::vector<Ovl*>());
+            repeat_annotation.push_back(std::vector<IPair>());
+            maskvec.push_back(IPair());
+        }
+        for (size_t i = 0; i < aln.size(); i++) {
+            if (aln[i]->a == aln[i]->b) {
+                aln[i]->active = false;
+                self_aln_list[aln[i]->a].push_back(IPair(aln[i]->ab, aln[i]->ae));
+                self_aln_list[aln[i]->a].push_back(IPair(aln[i]->bb, aln[i]->be));
+            }
+            if (aln[i]->active) idx_pileup[aln[i]->a].push_back(aln[i]);
+        }
+        std::set<int> self_match_reads;
+        for (auto it : self_aln_list) {
+            float c = 0.0;
+            for (size_t i = 0; i < it.second.size(); i++) c += it.second[i].second - it.second[i].first;
+            c /= float(reads[it.first]->len);
+            if ((c > 4.5) && (reads[it.first]->len > 10000)) self_match_reads.insert(it.first);
+        }
+        for (int i = 0; i < n_read; i++) std::sort(idx_pileup[i].begin(), idx_pileup[i].end(), compare_overlap);
+
+        // filter.cpp:569-583 (idx_ab / idx_pileup_dedup) feeds only the --restrictreads debug path
+        std::vector<std::unordered_map<int, std::vector<Ovl*>>> idx_ab;
+        if (reads_to_keep.size() > 0) {
+            idx_ab.resize(n_read);
+            for (size_t i = 0; i < aln.size(); i++) idx_ab[aln[i]->a][aln[i]->b] = std::vector<Ovl*>();
+            for (size_t i = 0; i < aln.size(); i++) idx_ab[aln[i]->a][aln[i]->b].push_back(aln[i]);
+            for (int i = 0; i < n_read; i++)
+                for (auto it = idx_ab[i].begin(); it != idx_ab[i].end(); it++)
+                    std::sort(it->second.begin(), it->second.end(), compare_overlap);
+        }
+
+        for (int i = r_begin; i <= r_end; i++) {
+            std::vector<IPair> coverage, cutoff_coverage, cg;
+            profile_coverage(idx_pileup[i], cutoff_coverage, reso, P.CUT_OFF);
+            profile_coverage(idx_pileup[i], coverage, reso, 0);
+            fprintf(cov, "read %d ", i);
+            for (size_t j = 0; j < coverage.size(); j++) fprintf(cov, "%d,%d ", coverage[j].first, coverage[j].second);
+            fprintf(cov, "\n");
+            if (coverage.size() >= 2)
+                for (size_t j = 0; j < coverage.size() - 1; j++)
+                    cg.push_back(IPair(coverage[j].first, coverage[j + 1].second - coverage[j].second));
+            else cg.push_back(IPair(0, 0));
+            coverages[i] = coverage;
+            cutoff_coverages[i] = cutoff_coverage;
+            cgs[i] = cg;
+        }
+
+        int num_slot = 0;
+        long int total_cov = 0;
+        std::vector<int> read_coverage;
+        for (int i = r_begin; i <= r_end; i++) {
+            if (reads[i]->len < 5000) continue;
+            long int read_cov = 0;
+            int read_slot = 0;
+            for (size_t j = 0; j < coverages[i].size(); j++) { read_cov += coverages[i][j].second; read_slot++; }
+            total_cov += read_cov;
+            num_slot += read_slot;
+            int mean_read_cov = read_cov / std::max(1, read_slot);
+            read_coverage.push_back(mean_read_cov);
+        }
+        if (read_coverage.empty() || num_slot == 0) { rc = -3; break; }   // reference: UB / SIGFPE
+        size_t median_id = read_coverage.size() / 2;
+        if (median_id > 0) std::nth_element(read_coverage.begin(), read_coverage.begin() + median_id, read_coverage.end());
+        int cov_est = read_coverage[median_id];
+        if (P.EST_COV != 0) cov_est = P.EST_COV;
+        if (MIN_COV < cov_est / 3) MIN_COV = cov_est / 3;
+
+        if (reads_to_keep.size() > 0) {
+            reads_to_keep_initial = reads_to_keep;
+            for (auto iter = reads_to_keep_initial.begin(); iter != reads_to_keep_initial.end(); ++iter) {
+                int i = *iter;
+                for (auto it = idx_ab[i].begin(); it != idx_ab[i].end(); it++)
+                    if (it->second.size() > 0) reads_to_keep.insert(it->second[0]->b);
+            }
+        }
+
+        for (int i = r_begin; i <= r_end; i++) {
+            for (size_t j = 0; j < cutoff_coverages[i].size(); j++) {
+                cutoff_coverages[i][j].second -= MIN_COV;
+                if (cutoff_coverages[i][j].second < 0) cutoff_coverages[i][j].second = 0;
+            }
+            int start = 0, end = start;
+            int maxlen = 0, maxstart = 0, maxend = 0;
+            int start_coord = 0, end_coord = 0, max_start_coord = 0, max_end_coord = 0;
+            for (size_t j = 0; j < cutoff_coverages[i].size(); j++) {
+                if (cutoff_coverages[i][j].second > 0) {
+                    end = cutoff_coverages[i][j].first;
+                    end_coord = j;
+                } else {
+                    if (end > start) {
+                        if (end - start - reso > maxlen) {
+                            maxlen = end - start - reso;
+                            maxstart = start + reso;
+                            maxend = end;
+                            max_start_coord = start_coord + 1;
+                            max_end_coord = end_coord;
+                        }
+                    }
+                    start = cutoff_coverages[i][j].first;
+                    start_coord = j;
+                    end_coord = start_coord;
+                    end = start;
+                }
+            }
+            int start_coverage = 0, end_coverage = 0;
+            if (max_end_coord - max_start_coord + 1 > 20) {
+                for (int d = 0; d < 10; d++) {
+                    start_coverage += cutoff_coverages[i][max_start_coord + d].second + MIN_COV;
+                    end_coverage += cutoff_coverages[i][max_end_coord - d].second + MIN_COV;
+                }
+                start_coverage = start_coverage / 10;
+                end_coverage = end_coverage / 10;
+            } else {
+                int limit = (max_end_coord - max_start_coord) / 2;
+                for (int d = 0; d < limit; d++) {
+                    start_coverage += cutoff_coverages[i][max_start_coord + d].second + MIN_COV;
+                    end_coverage += cutoff_coverages[i][max_end_coord - d].second + MIN_COV;
+                }
+                if (limit == 0) { start_coverage = 0; end_coverage = 0; }
+                else { start_coverage = start_coverage / limit; end_coverage = end_coverage / limit; }
+            }
+            if (P.delete_telomere) {
+                if ((start_coverage >= 10 * end_coverage) || (end_coverage >= 10 * start_coverage)) fprintf(covflag, "%d\n", i);
+                if (self_match_reads.find(i) != self_match_reads.end()) fprintf(selfflag, "%d\n", i);
+            }
+            if (reads_to_keep.size() > 0)
+                if (reads_to_keep.find(i) == reads_to_keep.end()) { maxend = maxstart; QV_mask[i].second = QV_mask[i].first; }
+            fprintf(comask, "%d %d %d\n", i, max_start_coord, max_end_coord);
+            if (use_qv_mask && P.use_coverage_mask)
+                maskvec[i] = IPair(std::max(maxstart, QV_mask[i].first), std::min(maxend, QV_mask[i].second));
+            else if (P.use_coverage_mask && !use_qv_mask)
+                maskvec[i] = IPair(maxstart, maxend);
+            else
+                maskvec[i] = IPair(QV_mask[i].first, QV_mask[i].second);
+            fprintf(mask, "%d %d %d\n", i, maskvec[i].first, maskvec[i].second);
+        }
+
+        for (int i = r_begin; i <= r_end; i++) {
+            std::vector<IPair> anno;
+            for (int j = 0; j < (int)cgs[i].size() - 1; j++) {
+                if ((cgs[i][j].first >= maskvec[i].first + P.NO_HINGE_REGION) &&
+                    (cgs[i][j].first <= maskvec[i].second - P.NO_HINGE_REGION)) {
+                    int thr = std::min(std::max((coverages[i][j].second + MIN_COV) / P.COVERAGE_FRACTION, P.MIN_RA), P.MAX_RA);
+                    if (cgs[i][j].second > thr) anno.push_back(IPair(cgs[i][j].first, 1));
+                    else if (cgs[i][j].second < -thr) anno.push_back(IPair(cgs[i][j].first, -1));
+                }
+            }
+            repeat_annotation[i] = anno;
+        }
+        for (int i = r_begin; i <= r_end; i++) {
+            std::vector<IPair>& ra = repeat_annotation[i];
+            for (auto iter = ra.begin(); iter < ra.end();) {
+                if (iter + 1 < ra.end()) {
+                    if (((iter->second == 1) && ((iter + 1)->second == 1)) && ((iter + 1)->first - iter->first < P.RA_GAP))
+                        ra.erase(iter + 1);
+                    else if (((iter->second == -1) && ((iter + 1)->second == -1)) && ((iter + 1)->first - iter->first < P.RA_GAP))
+                        iter = ra.erase(iter);
+                    else iter++;
+                } else iter++;
+            }
+        }
+
+        fclose(fopen("debug.txt", "w"));   // filter.cpp:837
+        for (int i = r_begin; i <= r_end; i++) {
+            hinges[i] = std::vector<IPair>();
+            int coverage_at_start = 0, num_at_start = 0, num_at_end = 0, coverage_at_end = 0;
+            for (size_t j = 0; j < coverages[i].size(); j++) {
+                if ((coverages[i][j].first <= maskvec[i].first + P.NO_HINGE_REGION) && (coverages[i][j].first >= maskvec[i].first)) {
+                    coverage_at_start += coverages[i][j].second; num_at_start++;
+                }
+                if ((coverages[i][j].first <= maskvec[i].second) && (coverages[i][j].first >= maskvec[i].second - P.NO_HINGE_REGION)) {
+                    coverage_at_end += coverages[i][j].second; num_at_end++;
+                }
+            }
+            float avg_end = (float)coverage_at_end / num_at_end;
+            float avg_start = (float)coverage_at_start / num_at_start;
+            if (std::abs(avg_end - avg_start) < 10) continue;
+            for (size_t j = 0; j < repeat_annotation[i].size(); j++)
+                call_hinge(repeat_annotation[i][j].second == -1 ? -1 : 1, repeat_annotation[i][j].first, idx_pileup[i],
+                           maskvec, i, P, hinges[i]);
+        }
+
+        if (rep) {
+            for (int i = r_begin; i <= r_end; i++) {
+                fprintf(rep, "%d ", i);
+                for (size_t j = 0; j < repeat_annotation[i].size(); j++)
+                    fprintf(rep, "%d %d ", repeat_annotation[i][j].first, repeat_annotation[i][j].second);
+                fprintf(rep, "\n");
+            }
+            fclose(rep);       // filter.cpp:1086: closed inside the part loop
+            rep = NULL;
+        }
+        for (int i = r_begin; i < r_end; i++) {   // filter.cpp:1091: excludes r_end
+            fprintf(hg, "%d ", i);
+            for (size_t j = 0; j < hinges[i].size(); j++) fprintf(hg, "%d %d ", hinges[i][j].first, hinges[i][j].second);
+            fprintf(hg, "\n");
+        }
+        free_alns(aln);
+    }
+    free_alns(aln);
+    if (rep) fclose(rep);
+    fclose(cov); fclose(hg); fclose(mask); fclose(comask); fclose(covflag); fclose(selfflag);
+    for (auto r : reads) delete r;
+    return rc;
+}
+
+int oracle_maximal(const char* name_db, const char* las_base, int mlas, const char* prefix, const char* name_config) {
+    DB db;
+    if (open_db(name_db, db) != 0) return -1;
+    int n_read = (int)db.rlen.size();
+    std::vector<Read*> reads;
+    for (int i = 0; i < n_read; i++) { Read* r = new Read(); r->id = i; r->len = db.rlen[i]; reads.push_back(r); }
+    std::string name_las_str = las_name(las_base, mlas != 0);
+    std::vector<std::string> name_las_list;
+    if (mlas) name_las_list = las_parts(name_las_str);
+    else name_las_list.push_back(name_las_str);
+    Ini reader(name_config);
+    if (reader.error < 0) return 1;
+    FilterParams P(reader);
+    int MIN_COV = P.MIN_COV;
+    const int reso = P.reso;
+    std::string out(prefix);
+
+    std::vector<Ovl*> aln;
+    std::vector<std::vector<IPair>> coverages(n_read);
+    FILE* cov = fopen((out + ".coverage.txt").c_str(), "w");
+    fclose(fopen((out + ".homologous.txt").c_str(), "w"));
+    fclose(fopen((out + ".filtered.fasta").c_str(), "w"));
+    FILE* contained_out = fopen((out + ".contained.txt").c_str(), "w");
+    FILE* maximal_reads = fopen((out + ".max").c_str(), "w");
+
+    FILE* mask_file = fopen((out + ".mas").c_str(), "r");
+    if (!mask_file) return -1;
+    int read, rs, re;
+    std::vector<char> has_mask(n_read, 0);
+    while (fscanf(mask_file, "%d %d %d", &read, &rs, &re) != EOF) {
+        reads[read]->effective_start = rs; reads[read]->effective_end = re; has_mask[read] = 1;
+    }
+    fclose(mask_file);
+    for (int i = 0; i < n_read; i++)
+        if (!has_mask[i]) return -3;    // reference reads uninitialised effective_start/end here
+    for (int i = 0; i < n_read; i++)
+        if (reads[i]->effective_end - reads[i]->effective_start < P.LENGTH_THRESHOLD) reads[i]->active = false;
+
+    int rc = 0;
+    for (int part = 0; part < (int)name_las_list.size(); part++) {
+        LasHeader h;
+        if (load_overlaps(name_las_list[part], db, aln, h) != 0) { rc = -1; break; }
+        if (h.novl == 0) { rc = 1; break; }
+        int r_begin = aln.front()->a;
+        int r_end = aln.back()->a;
+        std::vector<std::vector<Ovl*>> idx_pileup(n_read);
+        std::vector<std::unordered_map<int, std::vector<Ovl*>>> idx_ab(n_read);
+        for (size_t i = 0; i < aln.size(); i++) {
+            if (aln[i]->a == aln[i]->b) aln[i]->active = false;
+            if (aln[i]->active) idx_pileup[aln[i]->a].push_back(aln[i]);
+        }
+        for (int i = 0; i < n_read; i++) std::sort(idx_pileup[i].begin(), idx_pileup[i].end(), compare_overlap);
+        for (size_t i = 0; i < aln.size(); i++) idx_ab[aln[i]->a][aln[i]->b] = std::vector<Ovl*>();
+        for (size_t i = 0; i < aln.size(); i++) idx_ab[aln[i]->a][aln[i]->b].push_back(aln[i]);
+        for (int i = 0; i < n_read; i++)
+            for (auto it = idx_ab[i].begin(); it != idx_ab[i].end(); it++)
+                std::sort(it->second.begin(), it->second.end(), compare_overlap);
+
+        for (int i = r_begin; i <= r_end; i++) {
+            std::vector<IPair> coverage, cutoff_coverage;
+            profile_coverage(idx_pileup[i], cutoff_coverage, reso, P.CUT_OFF);
+            profile_coverage(idx_pileup[i], coverage, reso, 0);
+            fprintf(cov, "read %d ", i);
+            for (size_t j = 0; j < coverage.size(); j++) fprintf(cov, "%d,%d ", coverage[j].first, coverage[j].second);
+            fprintf(cov, "\n");
+            coverages[i] = coverage;
+        }
+        (void)MIN_COV;   // maximal.cpp:712-749 recomputes the median but nothing downstream reads it
+
+        for (int i = r_begin; i <= r_end; i++) {
+            bool contained = false;
+            if (reads[i]->active == false) continue;
+            int containing_read = 0;   // uninitialised in the reference; only printed when set
+            for (auto it = idx_ab[i].begin(); it != idx_ab[i].end(); it++) {
+                std::sort(it->second.begin(), it->second.end(), compare_overlap);
+                for (int w = 0; w < 2; w++) {
+                    if (w == 0 ? (it->second.size() > 0) : ((it->second.size() > 1) && P.USE_TWO_MATCHES)) {
+                        Ovl* ovl = it->second[w];
+                        bool ca = process_alignment(ovl, reads[ovl->a], reads[ovl->b], P.ALN_THRESHOLD, P.THETA, P.THETA2, true);
+                        if (ca == true) containing_read = ovl->b;
+                        if (reads[ovl->b]->active == true) contained = contained || ca;
+                    }
+                }
+            }
+            if (contained) {
+                reads[i]->active = false;
+                fprintf(contained_out, "%d\t%d\n", i, containing_read);
+            }
+        }
+        for (int i = r_begin; i <= r_end; i++)
+            if (reads[i]->active) fprintf(maximal_reads, "%d\n", i);
+        free_alns(aln);
+    }
+    free_alns(aln);
+    fclose(cov); fclose(contained_out); fclose(maximal_reads);
+    for (auto r : reads) delete r;
+    return rc;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// layout (hinging.cpp)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Hinge {
+    int pos, type;
+    bool active;
+    Hinge(int p, int t, bool a) : pos(p), type(t), active(a) {}
+    Hinge() : pos(0), type(1), active(true) {}
+};
+
+#define HINGED_EDGE 1
+#define UNHINGED_EDGE -1
+
+void print_overlap(FILE* f, Ovl* m) {   // hinging.cpp:188-248
+    int direction = m->comp;
+    int hinged = 0;   // uninitialised in the reference for other types (never printed then)
+    if ((m->type == FORWARD) || (m->type == BACKWARD)) hinged = UNHINGED_EDGE;
+    else if ((m->type == FORWARD_INTERNAL) || (m->type == BACKWARD_INTERNAL)) hinged = HINGED_EDGE;
+    if ((m->type == FORWARD_INTERNAL) || (m->type == FORWARD))
+        fprintf(f, "%d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d] [%d %d] [%d %d]\n", m->a, m->b, m->length, 0, direction,
+                hinged, m->eff_ab, m->eff_ae, m->eff_bb, m->eff_be, m->eff_a_rs, m->eff_a_re, m->eff_b_rs, m->eff_b_re,
+                m->ab, m->ae, m->bb, m->be);
+    else if ((m->type == BACKWARD_INTERNAL) || (m->type == BACKWARD))
+        fprintf(f, "%d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d] [%d %d] [%d %d]\n", m->b, m->a, m->length, direction, 0,
+                hinged, m->eff_bb, m->eff_be, m->eff_ab, m->eff_ae, m->eff_b_rs, m->eff_b_re, m->eff_a_rs, m->eff_a_re,
+                m->ab, m->ae, m->bb, m->be);
+}
+
+void print_overlap2(FILE* f, Ovl* m, int hinge_pos) {   // hinging.cpp:253-344
+    int direction = m->comp;
+    if (m->type == FORWARD)
+        fprintf(f, "%d %d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->a, m->b, m->length, 0, direction, 0, -1,
+                m->eff_ab, m->eff_ae, m->eff_bb, m->eff_be, m->eff_a_rs, m->eff_a_re, m->eff_b_rs, m->eff_b_re);
+    else if (m->type == BACKWARD)
+        fprintf(f, "%d %d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->b, m->a, m->length, direction, 0, 0, -1,
+                m->eff_bb, m->eff_be, m->eff_ab, m->eff_ae, m->eff_b_rs, m->eff_b_re, m->eff_a_rs, m->eff_a_re);
+    else if (m->type == FORWARD_INTERNAL)
+        fprintf(f, "%d %d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->a, m->b, m->length, 0, direction, 1, hinge_pos,
+                m->eff_ab, m->eff_ae, m->eff_bb, m->eff_be, m->eff_a_rs, m->eff_a_re, m->eff_b_rs, m->eff_b_re);
+    else if (m->type == BACKWARD_INTERNAL)
+        fprintf(f, "%d %d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->b, m->a, m->length, direction, 0, -1, hinge_pos,
+                m->eff_bb, m->eff_be, m->eff_ab, m->eff_ae, m->eff_b_rs, m->eff_b_re, m->eff_a_rs, m->eff_a_re);
+}
+
+void print_match13(FILE* f, Ovl* m) {
+    fprintf(f, "%d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d] \n", m->a, m->b, m->length, m->comp, (int)m->type, m->eff_ab,
+            m->eff_ae, m->eff_bb, m->eff_be, m->eff_a_rs, m->eff_a_re, m->eff_b_rs, m->eff_b_re);
+}
+
+void print_g(FILE* f, const char* fmt, int x, int y, Ovl* m) {
+    fprintf(f, fmt, x, y, m->length, m->eff_ab, m->eff_ae, m->eff_bb, m->eff_be, m->eff_a_rs, m->eff_a_re, m->eff_b_rs, m->eff_b_re);
+}
+
+// connected components of an undirected multigraph; only component sizes reach the output
+// (hinging.cpp:1644-1675), so any labelling works in place of boost::connected_components.
+std::vector<int> components(int n, const std::vector<IPair>& edges) {
+    std::vector<int> parent(n);
+    for (int i = 0; i < n; i++) parent[i] = i;
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (auto& e : edges) { int a = find(e.first), b = find(e.second); if (a != b) parent[a] = b; }
+    std::vector<int> comp(n);
+    for (int i = 0; i < n; i++) comp[i] = find(i);
+    return comp;
+}
+
+void parse_pairs_file(const char* path, std::unordered_map<int, std::vector<IPair>>& m, std::vector<int>* order) {
+    // hinging.cpp:887-912 / 917-936: getline + stringstream, pairs with r1 != 0 and r2 != 0
+    std::ifstream f(path);
+    std::string line;
+    while (std::getline(f, line)) {
+        std::stringstream ss;
+        ss << line << "\n";   // getline(char**) keeps the newline the reference feeds to the stream
+        int num = 0;
+        ss >> num;
+        m[num] = std::vector<IPair>();
+        if (order) order->push_back(num);
+        while (!ss.eof()) {
+            int r1 = 0, r2 = 0;
+            ss >> r1 >> r2;
+            if ((r1 != 0) && (r2 != 0)) m[num].push_back(IPair(r1, r2));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int oracle_layout(const char* name_db, const char* las_base, int mlas, const char* prefix, const char* out_name_c,
+                             const char* name_config) {
+    DB db;
+    if (open_db(name_db, db) != 0) return -1;
+    int n_read = (int)db.rlen.size();
+    std::vector<Read*> reads;
+    for (int i = 0; i < n_read; i++) { Read* r = new Read(); r->id = i; r->len = db.rlen[i]; reads.push_back(r); }
+    std::string out(prefix), out_name(out_name_c);
+    FILE* deadend_out = fopen((out_name + ".deadends.txt").c_str(), "w");
+    FILE* garbage_out = fopen((out + ".garbage.txt").c_str(), "w");
+
+    Ini reader(name_config);
+    if (reader.error < 0) return 1;
+    int LENGTH_THRESHOLD = int(reader.get_int("filter", "length_threshold", -1));
+    int ALN_THRESHOLD = (int)reader.get_int("filter", "aln_threshold", -1);
+    int THETA = (int)reader.get_int("filter", "theta", -1);
+    int THETA2 = (int)reader.get_int("filter", "theta2", 0);
+    int HINGE_SLACK = (int)reader.get_int("layout", "hinge_slack", 1000);
+    int HINGE_TOLERANCE = (int)reader.get_int("layout", "hinge_tolerance", 150);
+    int KILL_HINGE_OVERLAP_ALLOWANCE = (int)reader.get_int("layout", "kill_hinge_overlap", 300);
+    int KILL_HINGE_INTERNAL_ALLOWANCE = (int)reader.get_int("layout", "kill_hinge_internal", 40);
+    int MATCHING_HINGE_SLACK = (int)reader.get_int("layout", "matching_hinge_slack", 200);
+    int NUM_EVENTS_TELOMERE = (int)reader.get_int("layout", "num_events_telomere", 7);
+    int MIN_CONNECTED_COMPONENT_SIZE = (int)reader.get_int("layout", "min_connected_component_size", 8);
+    bool USE_TWO_MATCHES = (int)reader.get_int("layout", "use_two_matches", 1);
+    bool KEEP_ONLY_MAX = (int)reader.get_int("layout", "keep_only_matches_between_maximal_reads", 1);
+    bool delete_telomere = (int)reader.get_int("layout", "del_telomeres", 0);   // hinging.cpp:803 (sic)
+
+    std::vector<char> has_mask(n_read, 0);
+    {
+        FILE* mask_file = fopen((out + ".mas").c_str(), "r");
+        if (!mask_file) return -1;
+        int read, rs, re;
+        while (fscanf(mask_file, "%d %d %d", &read, &rs, &re) != EOF) {
+            reads[read]->effective_start = rs; reads[read]->effective_end = re; has_mask[read] = 1;
+        }
+        fclose(mask_file);
+    }
+    for (int i = 0; i < n_read; i++) if (!has_mask[i]) return -3;
+
+    std::unordered_map<int, std::vector<IPair>> marked_repeats, marked_hinges;
+    {
+        std::vector<int> order;
+        parse_pairs_file((out + ".repeat.txt").c_str(), marked_repeats, &order);
+        for (int num : order)
+            if (delete_telomere && ((int)marked_repeats[num].size() > NUM_EVENTS_TELOMERE)) reads[num]->active = false;
+        parse_pairs_file((out + ".hinges.txt").c_str(), marked_hinges, NULL);
+    }
+    for (int i = 0; i < n_read; i++) {
+        if (reads[i]->effective_end - reads[i]->effective_start < LENGTH_THRESHOLD) {
+            reads[i]->active = false;
+            fprintf(garbage_out, "%d\n", i);
+        }
+    }
+    fclose(garbage_out);
+
+    std::vector<std::unordered_map<int, std::vector<Ovl*>>> idx_ab(n_read);
+    std::vector<std::vector<Ovl*>> matches_forward(n_read), matches_backward(n_read);
+    std::vector<Ovl*> kept;   // for cleanup
+
+    // ---- GetAlignment, hinging.cpp:347-610 -------------------------------------------------
+    {
+        std::vector<bool> maximal_read(n_read, false);
+        std::ifstream max_reads_file(out + ".max");
+        std::string read_line;
+        while (std::getline(max_reads_file, read_line)) maximal_read[atoi(read_line.c_str())] = true;
+        for (int i = 0; i < n_read; i++) reads[i]->active = (reads[i]->active) && (maximal_read[i]);
+        std::string name_las_str = las_name(las_base, mlas != 0);
+        std::vector<std::string> name_las_list;
+        if (mlas) name_las_list = las_parts(name_las_str);
+        else name_las_list.push_back(name_las_str);
+        for (int part = 0; part < (int)name_las_list.size(); part++) {
+            std::vector<Ovl*> aln;
+            LasHeader h;
+            if (load_overlaps(name_las_list[part], db, aln, h) != 0) return -1;
+            if (aln.empty()) return -3;
+            int r_begin = aln.front()->a;
+            int r_end = aln.back()->a;
+            for (size_t i = 0; i < aln.size(); i++) {
+                if (aln[i]->a == aln[i]->b) aln[i]->active = false;
+                if ((reads[aln[i]->a]->active) && ((reads[aln[i]->b]->active) && KEEP_ONLY_MAX))
+                    idx_ab[aln[i]->a][aln[i]->b] = std::vector<Ovl*>();
+            }
+            for (size_t i = 0; i < aln.size(); i++)
+                if ((reads[aln[i]->a]->active) && ((reads[aln[i]->b]->active) && KEEP_ONLY_MAX))
+                    idx_ab[aln[i]->a][aln[i]->b].push_back(aln[i]);
+            for (size_t i = 0; i < aln.size(); i++) {
+                if (!((reads[aln[i]->a]->active) && ((reads[aln[i]->b]->active) && KEEP_ONLY_MAX))) delete aln[i];
+                else kept.push_back(aln[i]);
+            }
+            for (int i = r_begin; i <= r_end; i++) {
+                bool contained = false;
+                if (reads[i]->active == false) continue;
+                for (auto it = idx_ab[i].begin(); it != idx_ab[i].end(); it++) {
+                    std::sort(it->second.begin(), it->second.end(), compare_overlap);
+                    for (int w = 0; w < 2; w++) {
+                        if (w == 0 ? (it->second.size() > 0) : ((it->second.size() > 1) && USE_TWO_MATCHES)) {
+                            Ovl* ovl = it->second[w];
+                            bool ca = process_alignment(ovl, reads[ovl->a], reads[ovl->b], ALN_THRESHOLD, THETA, THETA2, true);
+                            if (reads[ovl->b]->active == true) contained = contained || ca;
+                            if ((ovl->type == FORWARD) || (ovl->type == FORWARD_INTERNAL)) matches_forward[i].push_back(ovl);
+                            else if ((ovl->type == BACKWARD) || (ovl->type == BACKWARD_INTERNAL)) matches_backward[i].push_back(ovl);
+                        }
+                    }
+                }
+                if (contained) reads[i]->active = false;   // "[contained] Should not happen"
+            }
+        }
+    }
+
+    for (int i = 0; i < n_read; i++)
+        if (reads[i]->active) {
+            std::sort(matches_forward[i].begin(), matches_forward[i].end(), compare_overlap_weight);
+            std::sort(matches_backward[i].begin(), matches_backward[i].end(), compare_overlap_weight);
+        }
+
+    // debug dumps in the cwd, hinging.cpp:1074-1150
+    {
+        FILE* G_out = fopen("edges.g_out.txt", "w");
+        for (int i = 0; i < n_read; i++)
+            if (reads[i]->active)
+                for (size_t j = 0; j < matches_forward[i].size(); j++)
+                    if (reads[matches_forward[i][j]->b]->active) { print_match13(G_out, matches_forward[i][j]); break; }
+        fprintf(G_out, "bkw\n");
+        for (int i = 0; i < n_read; i++)
+            if (reads[i]->active)
+                for (size_t j = 0; j < matches_backward[i].size(); j++)
+                    if (reads[matches_backward[i][j]->b]->active) { print_match13(G_out, matches_backward[i][j]); break; }
+        fclose(G_out);   // (left open in the reference; flushed at exit)
+        FILE* ob = fopen("edges.fwd.backup.txt", "w");
+        for (int i = 0; i < n_read; i++)
+            if (reads[i]->active)
+                for (size_t j = 0; j < matches_forward[i].size(); j++)
+                    if (reads[matches_forward[i][j]->b]->active) print_match13(ob, matches_forward[i][j]);
+        fclose(ob);
+        ob = fopen("edges.bkw.backup.txt", "w");
+        for (int i = 0; i < n_read; i++)
+            if (reads[i]->active)
+                for (size_t j = 0; j < matches_backward[i].size(); j++)
+                    if (reads[matches_backward[i][j]->b]->active) print_match13(ob, matches_backward[i][j]);
+        fclose(ob);
+    }
+
+    FILE* out_g1 = fopen((out_name + ".edges.1").c_str(), "w");
+    FILE* out_g2 = fopen((out_name + ".edges.2").c_str(), "w");
+    FILE* out_hg = fopen((out_name + ".edges.hinges").c_str(), "w");
+    FILE* out_hg2 = fopen((out_name + ".edges.hinges2").c_str(), "w");
+    FILE* out_greedy = fopen((out_name + ".edges.greedy").c_str(), "w");
+    FILE* out_skipped = fopen((out_name + ".edges.skipped").c_str(), "w");
+
+    std::unordered_map<int, std::vector<Hinge>> hinges_vec, killed_hinges_vec, new_killed_hinges_vec;
+    for (int i = 0; i < n_read; i++) {
+        hinges_vec[i] = std::vector<Hinge>();
+        std::set<IPair> surviving(marked_hinges[i].begin(), marked_hinges[i].end());
+        for (size_t j = 0; j < marked_hinges[i].size(); j++)
+            hinges_vec[i].push_back(Hinge(marked_hinges[i][j].first, marked_hinges[i][j].second, true));
+        for (size_t j = 0; j < marked_repeats[i].size(); j++)
+            if (surviving.find(marked_repeats[i][j]) == surviving.end())
+                killed_hinges_vec[i].push_back(Hinge(marked_repeats[i][j].first, marked_repeats[i][j].second, false));
+    }
+    {
+        FILE* killed_out = fopen((out + ".killed.hinges").c_str(), "w");
+        for (int i = 0; i < n_read; i++) {
+            fprintf(killed_out, "%d ", i);
+            for (size_t j = 0; j < killed_hinges_vec[i].size(); j++)
+                fprintf(killed_out, "%d %d ", killed_hinges_vec[i][j].type, killed_hinges_vec[i][j].pos);
+            fprintf(killed_out, "\n");
+        }
+        fclose(killed_out);
+    }
+
+    // hinge kill by bridging matches, hinging.cpp:1262-1321
+    for (int i = 0; i < n_read; i++) {
+        if (!reads[i]->active) continue;
+        for (size_t j = 0; j < matches_forward[i].size(); j++) {
+            Ovl* m = matches_forward[i][j];
+            if (m->active && ((m->type == FORWARD) || (m->type == FORWARD_INTERNAL)) && reads[m->b]->active)
+                for (size_t k = 0; k < hinges_vec[i].size(); k++)
+                    if ((((m->eff_ab < hinges_vec[i][k].pos + KILL_HINGE_INTERNAL_ALLOWANCE) && (m->type == FORWARD_INTERNAL)) ||
+                         ((m->eff_ab < hinges_vec[i][k].pos - KILL_HINGE_OVERLAP_ALLOWANCE) && (m->type == FORWARD))) &&
+                        (hinges_vec[i][k].type == 1))
+                        hinges_vec[i][k].active = false;
+        }
+        for (size_t j = 0; j < matches_backward[i].size(); j++) {
+            Ovl* m = matches_backward[i][j];
+            if (m->active && ((m->type == BACKWARD) || (m->type == BACKWARD_INTERNAL)) && reads[m->b]->active)
+                for (size_t k = 0; k < hinges_vec[i].size(); k++)
+                    if ((((m->eff_ae > hinges_vec[i][k].pos - KILL_HINGE_INTERNAL_ALLOWANCE) && (m->type == BACKWARD_INTERNAL)) ||
+                         ((m->eff_ae > hinges_vec[i][k].pos + KILL_HINGE_OVERLAP_ALLOWANCE) && (m->type == BACKWARD))) &&
+                        (hinges_vec[i][k].type == -1))
+                        hinges_vec[i][k].active = false;
+        }
+    }
+
+    // hinge graph, hinging.cpp:1325-1640
+    int num_hinges = 0;
+    for (int i = 0; i < n_read; i++) num_hinges += hinges_vec[i].size();
+    std::map<IPair, int> node_map;
+    std::map<int, IPair> node_map_rev;
+    {
+        int hgc = 0;
+        for (int i = 0; i < (int)hinges_vec.size(); i++)
+            for (int j = 0; j < (int)hinges_vec[i].size(); j++) { node_map[IPair(i, j)] = hgc; node_map_rev[hgc] = IPair(i, j); hgc++; }
+    }
+    std::vector<IPair> graph_edges;
+    FILE* out_hgraph = fopen((out_name + ".hgraph").c_str(), "w");
+    FILE* out_debug = fopen((out_name + ".debug").c_str(), "w");
+    fclose(fopen("overlap_debug.txt", "w"));
+    for (int i = 0; i < n_read; i++) {
+        if (!reads[i]->active) continue;
+        for (int k = 0; k < (int)hinges_vec[i].size(); k++) {
+            for (int dirn = 0; dirn < 2; dirn++) {
+                std::vector<Ovl*>& ms = dirn == 0 ? matches_forward[i] : matches_backward[i];
+                int own_type = dirn == 0 ? 1 : -1;   // hinge type whose edge is written (i, b) in this direction
+                for (size_t j = 0; j < ms.size(); j++) {
+                    Ovl* m = ms[j];
+                    if (!m->active) continue;
+                    bool dir_ok = dirn == 0 ? ((m->type == FORWARD) || (m->type == FORWARD_INTERNAL))
+                                            : ((m->type == BACKWARD) || (m->type == BACKWARD_INTERNAL));
+                    if (!(dir_ok && reads[m->b]->active)) continue;
+                    int pos_B = get_matching_position(m, hinges_vec[i][k].pos);
+                    int req_hinge_type, rev_int = 0;
+                    if (m->comp == 1) { req_hinge_type = -1 * hinges_vec[i][k].type; rev_int = 1; }
+                    else req_hinge_type = hinges_vec[i][k].type;
+                    int b_id = m->b;
+                    for (int l = 0; l < (int)hinges_vec[b_id].size(); l++) {
+                        if ((hinges_vec[b_id][l].pos < pos_B + MATCHING_HINGE_SLACK) && (hinges_vec[b_id][l].pos > pos_B - MATCHING_HINGE_SLACK)) {
+                            if (req_hinge_type == hinges_vec[b_id][l].type) {
+                                if (hinges_vec[i][k].type == own_type) {
+                                    graph_edges.push_back(IPair(node_map[IPair(i, k)], node_map[IPair(b_id, l)]));
+                                    fprintf(out_hgraph, "%d %d %d %d %d %d\n", i, b_id, hinges_vec[i][k].pos, hinges_vec[b_id][l].pos, 1, rev_int);
+                                } else {
+                                    graph_edges.push_back(IPair(node_map[IPair(b_id, l)], node_map[IPair(i, k)]));
+                                    fprintf(out_hgraph, "%d %d %d %d %d %d\n", b_id, i, hinges_vec[b_id][l].pos, hinges_vec[i][k].pos, 1, rev_int);
+                                }
+                            }
+                        }
+                    }
+                    for (int l = 0; l < (int)killed_hinges_vec[b_id].size(); l++) {
+                        if ((killed_hinges_vec[b_id][l].pos < pos_B + MATCHING_HINGE_SLACK) && (killed_hinges_vec[b_id][l].pos > pos_B - MATCHING_HINGE_SLACK)) {
+                            bool type_ok = req_hinge_type == killed_hinges_vec[b_id][l].type;
+                            if (type_ok) {
+                                if (hinges_vec[i][k].type == own_type)
+                                    fprintf(out_hgraph, "%d %d %d %d %d %d\n", i, b_id, hinges_vec[i][k].pos, killed_hinges_vec[b_id][l].pos, 0, rev_int);
+                                else
+                                    fprintf(out_hgraph, "%d %d %d %d %d %d\n", b_id, i, killed_hinges_vec[b_id][l].pos, hinges_vec[i][k].pos, 0, rev_int);
+                            }
+                            if (dirn == 0) {
+                                // forward: inside the type test (hinging.cpp:1467-1493)
+                                if (type_ok && m->type == FORWARD) {
+                                    new_killed_hinges_vec[i].push_back(Hinge(hinges_vec[i][k].pos, hinges_vec[i][k].type, false));
+                                    if (hinges_vec[i][k].type == -1) {
+                                        print_match13(out_debug, m);
+                                        fprintf(out_debug, "%d %d %d %d\n", hinges_vec[i][k].pos, hinges_vec[i][k].type,
+                                                killed_hinges_vec[b_id][l].pos, killed_hinges_vec[b_id][l].type);
+                                    }
+                                }
+                            } else {
+                                // backward: OUTSIDE the type test (hinging.cpp:1612-1622)
+                                if (m->type == BACKWARD)
+                                    new_killed_hinges_vec[i].push_back(Hinge(hinges_vec[i][k].pos, hinges_vec[i][k].type, false));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    fclose(out_hgraph);
+    fclose(out_debug);
+
+    {
+        std::vector<int> component = components(num_hinges, graph_edges);
+        std::map<int, int> component_size;
+        for (size_t i = 0; i != component.size(); ++i) component_size[component[i]] += 1;
+        for (int i = 0; i != (int)component.size(); ++i)
+            if (component_size[component[i]] < MIN_CONNECTED_COMPONENT_SIZE)
+                hinges_vec[node_map_rev[i].first][node_map_rev[i].second].active = false;
+    }
+    {
+        FILE* out_hglist = fopen((out_name + ".hinge.list").c_str(), "w");
+        for (int i = 0; i < n_read; i++)
+            for (size_t j = 0; j < hinges_vec[i].size(); j++)
+                if ((reads[i]->active) && (hinges_vec[i][j].active))
+                    fprintf(out_hglist, "%d %d %d\n", i, marked_hinges[i][j].first, marked_hinges[i][j].second);
+        fclose(out_hglist);
+    }
+
+    // pure greedy graph, hinging.cpp:1724-1860
+    for (int i = 0; i < n_read; i++) {
+        if (!reads[i]->active) continue;
+        for (int dirn = 0; dirn < 2; dirn++) {
+            std::vector<Ovl*>& ms = dirn == 0 ? matches_forward[i] : matches_backward[i];
+            int cnt = 0;
+            for (size_t j = 0; j < ms.size(); j++) {
+                Ovl* m = ms[j];
+                if (m->active && (m->type == (dirn == 0 ? FORWARD : BACKWARD)) && reads[m->b]->active) {
+                    if (cnt < 1) {
+                        print_overlap(out_greedy, m);
+                        if (m->comp == 0) print_g(out_g1, "%d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->a, m->b, m);
+                        else print_g(out_g1, "%d %d' %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->a, m->b, m);
+                        if (m->comp == 0) print_g(out_g2, "%d' %d' %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->b, m->a, m);
+                        else print_g(out_g2, "%d %d' %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m->b, m->a, m);
+                    }
+                    cnt++;
+                }
+            }
+        }
+    }
+
+    fclose(fopen("hinge_debug.txt", "w"));
+    // final selection, hinging.cpp:1911-2148
+    int hinge_pos = -1;
+    for (int i = 0; i < n_read; i++) {
+        if (!reads[i]->active) continue;
+        Ovl* chosen_match = NULL;
+        for (int dirn = 0; dirn < 2; dirn++) {
+            std::vector<Ovl*>& ms = dirn == 0 ? matches_forward[i] : matches_backward[i];
+            int plain = 0, internal = 0;
+            for (size_t j = 0; j < ms.size(); j++) {
+                Ovl* m = ms[j];
+                if (!m->active) continue;
+                if (!reads[m->b]->active) continue;
+                if ((m->type == (dirn == 0 ? FORWARD : BACKWARD)) && (plain == 0)) {
+                    bool poisoned = false;
+                    for (size_t k = 0; k < new_killed_hinges_vec[i].size(); k++) {
+                        const Hinge& nk = new_killed_hinges_vec[i][k];
+                        bool hit;
+                        if (dirn == 0)
+                            hit = ((m->comp != 1) && (nk.type == -1) && (nk.pos > m->eff_be)) ||
+                                  ((m->comp == 1) && (nk.type == 1) && (nk.pos < m->eff_bb));
+                        else
+                            hit = ((m->comp != 1) && (nk.type == 1) && (nk.pos < m->eff_bb)) ||
+                                  ((m->comp == 1) && (nk.type == -1) && (nk.pos > m->eff_be));
+                        if (hit) { print_overlap(out_skipped, m); poisoned = true; }
+                    }
+                    if (!poisoned) { chosen_match = m; hinge_pos = -1; plain = 1; }
+                } else if ((m->type == (dirn == 0 ? FORWARD_INTERNAL : BACKWARD_INTERNAL)) && (hinges_vec[m->b].size() > 0) &&
+                           (internal == 0)) {
+                    int anchor;
+                    int want_type;
+                    if (dirn == 0) { anchor = m->comp == 1 ? m->be : m->bb; want_type = 1 - 2 * m->comp; }
+                    else { anchor = m->comp == 1 ? m->bb : m->be; want_type = -1 + 2 * m->comp; }
+                    for (size_t k = 0; k < hinges_vec[m->b].size(); k++) {
+                        const Hinge& hb = hinges_vec[m->b][k];
+                        if ((anchor > hb.pos - HINGE_TOLERANCE) && (anchor < hb.pos + HINGE_TOLERANCE) && (hb.type == want_type) && hb.active) {
+                            if ((plain == 0) || (m->weight > chosen_match->weight - 2 * HINGE_SLACK)) {
+                                chosen_match = m; plain = 1; internal = 1; hinge_pos = hb.pos;
+                            }
+                            break;
+                        }
+                    }
+                }
+            }
+            if (chosen_match != NULL) {
+                print_overlap(out_hg, chosen_match);
+                print_overlap2(out_hg2, chosen_match, hinge_pos);
+                if (dirn == 0) chosen_match = NULL;   // hinging.cpp:2026 resets only after the forward pass
+            } else {
+                fprintf(deadend_out, "%d\t matches_%s size: %d\n", i, dirn == 0 ? "forward" : "backward", (int)ms.size());
+            }
+        }
+    }
+    fclose(out_g1); fclose(out_g2); fclose(out_hg); fclose(out_hg2); fclose(out_greedy); fclose(out_skipped);
+    fclose(deadend_out);
+    for (auto o : kept) delete o;
+    for (auto r : reads) delete r;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// array-level entry points (unit parity with the reference library and with the HIP kernels)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+// profileCoverage on one pile-up; returns K (number of bins); writes min(K, cap) counts.
+int oracle_profile_coverage(int n, const int* ab, const int* ae, int reso, int cutoff, int* cov_out, int cap) {
+    std::vector<Ovl> store(n);
+    std::vector<Ovl*> v(n);
+    for (int i = 0; i < n; i++) { store[i].ab = ab[i]; store[i].ae = ae[i]; v[i] = &store[i]; }
+    std::vector<IPair> c;
+    profile_coverage(v, c, reso, cutoff);
+    for (int i = 0; i < (int)c.size() && i < cap; i++) cov_out[i] = c[i].second;
+    return (int)c.size();
+}
+
+// ProcessAlignment on one overlap. in: [ab, ae, bb, be, comp, a_es, a_ee, b_es, b_ee], trace (uint16)
+// out: [eff_ab, eff_ae, eff_bb, eff_be, type, active, weight, length, start_idx, end_idx]
+void oracle_process_alignment(const int* in, const uint16_t* trace, int tlen, int aln_threshold, int theta, int theta2, int* out) {
+    Ovl o;
+    o.ab = in[0]; o.ae = in[1]; o.bb = in[2]; o.be = in[3]; o.comp = in[4];
+    o.tlen = tlen;
+    o.trace.assign(trace, trace + tlen);
+    Read A, B;
+    A.effective_start = in[5]; A.effective_end = in[6];
+    B.effective_start = in[7]; B.effective_end = in[8];
+    process_alignment(&o, &A, &B, aln_threshold, theta, theta2, true);
+    out[0] = o.eff_ab; out[1] = o.eff_ae; out[2] = o.eff_bb; out[3] = o.eff_be; out[4] = (int)o.type;
+    out[5] = o.active ? 1 : 0; out[6] = o.weight; out[7] = o.length; out[8] = o.eff_start_idx; out[9] = o.eff_end_idx;
+}
+
+int oracle_matching_position(int ab, int ae, int bb, int be, int comp, const uint16_t* trace, int tlen, int pos_A) {
+    Ovl o;
+    o.ab = ab; o.ae = ae; o.bb = bb; o.be = be; o.comp = comp; o.tlen = tlen;
+    o.trace.assign(trace, trace + tlen);
+    return get_matching_position(&o, pos_A);
+}
+
+// std::sort permutations with the path's three comparator shapes. mode 0: descending key
+// (compare_overlap / compare_overlap_weight / pairDescend), mode 1: ascending (pairAscend).
+void oracle_sort_perm(int n, const int* key, int mode, int* perm) {
+    std::vector<IPair> v(n);
+    for (int i = 0; i < n; i++) v[i] = IPair(key[i], i);
+    if (mode == 0) std::sort(v.begin(), v.end(), pairDescend);
+    else std::sort(v.begin(), v.end(), pairAscend);
+    for (int i = 0; i < n; i++) perm[i] = v[i].second;
+}
+
+// iteration order of std::unordered_map<int, ...> after inserting keys in the given order
+int oracle_umap_order(int n, const int* keys, int* out) {
+    std::unordered_map<int, int> m;
+    for (int i = 0; i < n; i++) m[keys[i]] = 0;
+    int k = 0;
+    for (auto it = m.begin(); it != m.end(); ++it) out[k++] = it->first;
+    return k;
+}
+
+// INI lookups: kind 0 int, 1 bool (def/ret as long), returns via *out; real via oracle_ini_real
+long oracle_ini_int(const char* file, const char* section, const char* name, long def) { Ini r(file); return r.error < 0 ? def : r.get_int(section, name, def); }
+int oracle_ini_bool(const char* file, const char* section, const char* name, int def) { Ini r(file); return r.error < 0 ? def : (int)r.get_bool(section, name, def != 0); }
+double oracle_ini_real(const char* file, const char* section, const char* name, double def) { Ini r(file); return r.error < 0 ? def : r.get_real(section, name, def); }
+int oracle_ini_error(const char* file) { Ini r(file); return r.error; }
+
+// load a .las through the oracle reader into flat arrays (n x 8 ints: a,b,ab,ae,bb,be,comp,tlen)
+long oracle_load_las(const char* name_db, const char* las_path, int* out, long cap) {
+    DB db;
+    if (open_db(name_db, db) != 0) return -1;
+    std::vector<Ovl*> aln;
+    LasHeader h;
+    if (load_overlaps(las_path, db, aln, h) != 0) return -1;
+    long n = (long)aln.size();
+    for (long i = 0; i < n && i < cap; i++) {
+        Ovl* o = aln[i];
+        int* p = out + i * 8;
+        p[0] = o->a; p[1] = o->b; p[2] = o->ab; p[3] = o->ae; p[4] = o->bb; p[5] = o->be; p[6] = o->comp; p[7] = o->tlen;
+    }
+    for (auto o : aln) delete o;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+// TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+// C-ABI shim over the REFERENCE's own compiled library code (LAInterface.cpp, DB.c, align.c, ini.c,
+// INIReader.cpp, compiled unmodified from /root/reference/src by oracle/Makefile into oracle/_ref/).
+// It only marshals flat arrays into the reference's classes and calls the reference's functions, so
+// that tests can pin oracle/ (the restatement) against what the reference itself computes:
+//   LAInterface::openDB / getReadNumber / openAlignmentFile / resetAlignment / getOverlap / getQV
+//   LAInterface::profileCoverage, LOverlap::trim_overlap, LOverlap::AddTypesAsymmetric,
+//   LOverlap::GetMatchingPosition, compare_overlap, compare_overlap_weight, pairAscend, pairDescend,
+//   INIReader.
+// ProcessAlignment itself lives in maximal.cpp / hinging.cpp (not buildable here: spdlog/Boost are
+// absent); its 20-line body is restated below around the real trim_overlap/AddTypesAsymmetric.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include "LAInterface.h"
+#include "INIReader.h"
+
+extern "C" {
+
+long ref_load_las(const char* name_db, const char* las_path, int* out, long cap) {
+    LAInterface la;
+    la.openDB(name_db);
+    int n_read = la.getReadNumber();
+    la.openAlignmentFile(las_path);
+    la.resetAlignment();
+    std::vector<LOverlap*> aln;
+    la.getOverlap(aln, 0, n_read);
+    long n = (long)aln.size();
+    for (long i = 0; i < n && i < cap; i++) {
+        LOverlap* o = aln[i];
+        int* p = out + i * 8;
+        p[0] = o->read_A_id_; p[1] = o->read_B_id_; p[2] = o->read_A_match_start_; p[3] = o->read_A_match_end_;
+        p[4] = o->read_B_match_start_; p[5] = o->read_B_match_end_; p[6] = o->reverse_complement_match_; p[7] = o->trace_pts_len;
+    }
+    for (auto o : aln) delete o;
+    return n;
+}
+
+int ref_tspace(const char* las_path) {
+    LAInterface la;
+    la.openAlignmentFile(las_path);
+    return la.tspace;
+}
+
+int ref_read_lengths(const char* name_db, int* out, int cap) {
+    LAInterface la;
+    la.openDB(name_db);
+    int n = la.getReadNumber();
+    for (int i = 0; i < n && i < cap; i++) out[i] = la.db1->reads[i].rlen;
+    return n;
+}
+
+// getQV: returns -1 if no track, else total byte count; offsets[n+1], values[cap]
+long ref_qv(const char* name_db, long* offsets, int* values, long cap) {
+    LAInterface la;
+    la.openDB(name_db);
+    int n = la.getReadNumber();
+    std::vector<std::vector<int>> QV;
+    if (la.getQV(QV, 0, n) != 0) return -1;
+    long k = 0;
+    for (int i = 0; i < n; i++) {
+        offsets[i] = k;
+        for (size_t j = 0; j < QV[i].size(); j++) { if (k < cap) values[k] = QV[i][j]; k++; }
+    }
+    offsets[n] = k;
+    return k;
+}
+
+int ref_profile_coverage(int n, const int* ab, const int* ae, int reso, int cutoff, int* cov_out, int cap) {
+    LAInterface la;
+    std::vector<LOverlap*> v;
+    for (int i = 0; i < n; i++) {
+        LOverlap* o = new LOverlap();
+        o->trace_pts = NULL;
+        o->read_A_match_start_ = ab[i];
+        o->read_A_match_end_ = ae[i];
+        v.push_back(o);
+    }
+    std::vector<std::pair<int, int>> c;
+    la.profileCoverage(v, c, reso, cutoff);
+    for (int i = 0; i < (int)c.size() && i < cap; i++) cov_out[i] = c[i].second;
+    for (auto o : v) delete o;
+    return (int)c.size();
+}
+
+static LOverlap* make_ovl(int ab, int ae, int bb, int be, int comp, const uint16_t* trace, int tlen) {
+    LOverlap* o = new LOverlap();
+    o->read_A_match_start_ = ab; o->read_A_match_end_ = ae;
+    o->read_B_match_start_ = bb; o->read_B_match_end_ = be;
+    o->reverse_complement_match_ = comp;
+    o->trace_pts_len = tlen;
+    o->trace_pts = (uint16*)malloc(sizeof(uint16) * (tlen > 0 ? tlen : 1));
+    memcpy(o->trace_pts, trace, sizeof(uint16) * tlen);
+    return o;
+}
+
+void ref_process_alignment(const int* in, const uint16_t* trace, int tlen, int aln_threshold, int theta, int theta2, int* out) {
+    LOverlap* m = make_ovl(in[0], in[1], in[2], in[3], in[4], trace, tlen);
+    // body of ProcessAlignment(match, read_A, read_B, ALN_THRESHOLD, THETA, THETA2, trim=true),
+    // maximal.cpp:65-134, around the reference's own trim_overlap / AddTypesAsymmetric
+    m->eff_read_A_read_start_ = in[5]; m->eff_read_A_read_end_ = in[6];
+    m->eff_read_B_read_start_ = in[7]; m->eff_read_B_read_end_ = in[8];
+    m->trim_overlap();
+    if (((m->eff_read_B_match_end_ - m->eff_read_B_match_start_) < aln_threshold) ||
+        ((m->eff_read_A_match_end_ - m->eff_read_A_match_start_) < aln_threshold) || (!m->active)) {
+        m->active = false;
+        m->match_type_ = NOT_ACTIVE;
+    } else {
+        m->AddTypesAsymmetric(theta, theta2);
+    }
+    m->weight = m->eff_read_A_match_end_ - m->eff_read_A_match_start_ + m->eff_read_B_match_end_ - m->eff_read_B_match_start_;
+    m->length = m->read_A_match_end_ - m->read_A_match_start_ + m->read_B_match_end_ - m->read_B_match_start_;
+    out[0] = m->eff_read_A_match_start_; out[1] = m->eff_read_A_match_end_;
+    out[2] = m->eff_read_B_match_start_; out[3] = m->eff_read_B_match_end_;
+    out[4] = (int)m->match_type_; out[5] = m->active ? 1 : 0; out[6] = m->weight; out[7] = m->length;
+    out[8] = m->eff_start_trace_point_index_; out[9] = m->eff_end_trace_point_index_;
+    delete m;
+}
+
+int ref_matching_position(int ab, int ae, int bb, int be, int comp, const uint16_t* trace, int tlen, int pos_A) {
+    LOverlap* m = make_ovl(ab, ae, bb, be, comp, trace, tlen);
+    int r = m->GetMatchingPosition(pos_A);
+    delete m;
+    return r;
+}
+
+// mode 0: compare_overlap on LOverlap* whose length sum is key[i]; mode 1: pairAscend; mode 2: pairDescend;
+// mode 3: compare_overlap_weight
+void ref_sort_perm(int n, const int* key, int mode, int* perm) {
+    if (mode == 1 || mode == 2) {
+        std::vector<std::pair<int, int>> v(n);
+        for (int i = 0; i < n; i++) v[i] = std::pair<int, int>(key[i], i);
+        if (mode == 1) std::sort(v.begin(), v.end(), pairAscend);
+        else std::sort(v.begin(), v.end(), pairDescend);
+        for (int i = 0; i < n; i++) perm[i] = v[i].second;
+        return;
+    }
+    std::vector<LOverlap*> v(n);
+    for (int i = 0; i < n; i++) {
+        LOverlap* o = new LOverlap();
+        o->trace_pts = NULL;
+        o->read_A_match_start_ = 0; o->read_A_match_end_ = key[i];
+        o->read_B_match_start_ = 0; o->read_B_match_end_ = 0;
+        o->weight = key[i];
+        o->tps = i;                       // carries the original index
+        v[i] = o;
+    }
+    if (mode == 0) std::sort(v.begin(), v.end(), compare_overlap);
+    else std::sort(v.begin(), v.end(), compare_overlap_weight);
+    for (int i = 0; i < n; i++) { perm[i] = v[i]->tps; delete v[i]; }
+}
+
+long ref_ini_int(const char* file, const char* section, const char* name, long def) { INIReader r(file); return r.GetInteger(section, name, def); }
+int ref_ini_bool(const char* file, const char* section, const char* name, int def) { INIReader r(file); return (int)r.GetBoolean(section, name, def != 0); }
+double ref_ini_real(const char* file, const char* section, const char* name, double def) { INIReader r(file); return r.GetReal(section, name, def); }
+int ref_ini_error(const char* file) { INIReader r(file); return r.ParseError(); }
+
+}  // extern "C"
