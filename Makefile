@@ -1,0 +1,25 @@
+# Builds everything in-tree for gfx950:
+#   hinge_amd/lib/libhinge_hip.so   HIP kernels + C ABI (include/hinge_hip.h)
+#   oracle/libhinge_oracle.so       CPU oracle (test infrastructure)
+#   oracle/_ref/libhinge_ref.so     reference library code, when /root/reference is present
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+
+CSRC = hinge_amd/csrc
+LIB  = hinge_amd/lib/libhinge_hip.so
+
+all: $(LIB) oracle
+
+$(LIB): $(CSRC)/hinge_capi.hip $(CSRC)/filter_kernels.h $(CSRC)/align_kernels.h $(CSRC)/align_capi.inc $(CSRC)/stdsort_emul.h include/hinge_hip.h
+	mkdir -p hinge_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hinge_capi.hip
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf hinge_amd/lib hinge_amd/bin
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,234 @@
+"""ctypes binding of libhinge_hip.so (include/hinge_hip.h).
+
+There is no fallback: if the HIP library is missing, or no GPU is visible when a context is
+created, this raises.  numpy arrays are passed as plain pointers; torch tensors via data_ptr().
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhinge_hip.so")
+
+HINGE_OK = 0
+ERR_NAMES = {-1: "HINGE_E_ARG", -2: "HINGE_E_DEVICE", -3: "HINGE_E_CAPACITY", -4: "HINGE_E_UNDEFINED", -5: "HINGE_E_RANGE"}
+
+
+class HingeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "HINGE_E_?"), code, msg))
+        self.code = code
+
+
+class FilterParams(C.Structure):
+    """hinge_filter_params: the [filter] keys as filter.cpp:377-406 reads them."""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "reso", "cut_off", "min_cov", "est_cov", "theta", "coverage_fraction", "min_repeat_annotation",
+        "max_repeat_annotation", "repeat_annotation_gap", "no_hinge_region", "hinge_min_support", "hinge_bin_pileup",
+        "hinge_unbridged", "hinge_tolerance", "use_qv_mask", "use_coverage_mask", "delete_telomere")]
+
+
+class CovEstimate(C.Structure):
+    _fields_ = [("cov_est", C.c_int32), ("n_long", C.c_int32), ("total_cov", C.c_int64), ("num_slot", C.c_int64)]
+
+
+# every symbol include/hinge_hip.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = [
+    ("hinge_ctx_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
+    ("hinge_ctx_destroy", None, [_VP]),
+    ("hinge_last_error", C.c_char_p, [_VP]),
+    ("hinge_set_stream", C.c_int, [_VP, _VP]),
+    ("hinge_synchronize", C.c_int, [_VP]),
+    ("hinge_set_reads", C.c_int, [_VP, C.c_int32, _VP, _VP]),
+    ("hinge_set_pileups", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_int]),
+    ("hinge_attach_mask_table", C.c_int, [_VP, _VP]),
+    ("hinge_attach_mean_cov", C.c_int, [_VP, _VP]),
+    ("hinge_clear_masks", C.c_int, [_VP]),
+    ("hinge_filter_stats", C.c_int, [_VP, C.POINTER(FilterParams)]),
+    ("hinge_filter_median", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, C.POINTER(CovEstimate)]),
+    ("hinge_filter_set_min_cov", C.c_int, [_VP, C.c_int32]),
+    ("hinge_filter_get_min_cov", C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    ("hinge_filter_mask_annotate", C.c_int, [_VP, C.POINTER(FilterParams)]),
+    ("hinge_filter_hinges", C.c_int, [_VP, C.POINTER(FilterParams)]),
+    ("hinge_filter_run", C.c_int, [_VP, C.POINTER(FilterParams)]),
+    ("hinge_filter_get_masks", C.c_int, [_VP, _VP, _VP, _VP]),
+    ("hinge_filter_get_annotations", C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    ("hinge_filter_coverage_bins", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
+    ("hinge_filter_counters", C.c_int, [_VP, _VP]),
+    ("hinge_timer_start", C.c_int, [_VP]),
+    ("hinge_timer_stop_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libhinge_hip.so and bind every declared symbol (fails loudly if one is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libhinge_hip.so not built (%s): run `make` / __graft_entry__.build()" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS + EXTRA_SYMBOLS:
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXTRA_SYMBOLS = [
+    ("hinge_debug_force_exact", C.c_int, [_VP, C.c_int]),
+]
+
+
+def _ptr(a) -> Optional[int]:
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return int(a)
+
+
+class Context:
+    """One hinge_ctx (one GPU)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _VP()
+        rc = self.lib.hinge_ctx_create(device, C.byref(h))
+        if rc != HINGE_OK:
+            raise HingeError(rc, "hinge_ctx_create(device=%d) failed: no usable HIP device" % device)
+        self.h = h
+        self._keep = []
+        self.r_begin = 0
+        self.r_end = -1
+        self.n_reads = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hinge_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int):
+        if rc != HINGE_OK:
+            raise HingeError(rc, self.lib.hinge_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr: int):
+        self._ck(self.lib.hinge_set_stream(self.h, _VP(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.lib.hinge_synchronize(self.h))
+
+    def set_reads(self, rlen: np.ndarray, qv_mask: Optional[np.ndarray] = None):
+        rlen = np.ascontiguousarray(rlen, dtype=np.int32)
+        q = None if qv_mask is None else np.ascontiguousarray(qv_mask, dtype=np.int32)
+        self.n_reads = int(rlen.shape[0])
+        self._ck(self.lib.hinge_set_reads(self.h, self.n_reads, _ptr(rlen), _ptr(q)))
+
+    def set_pileups(self, r_begin: int, r_end: int, row_ptr, a_span, b_span, b_flag, n_ovl: Optional[int] = None, on_device: bool = False):
+        if not on_device:
+            row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+            a_span = np.ascontiguousarray(a_span, dtype=np.int32)
+            b_span = np.ascontiguousarray(b_span, dtype=np.int32)
+            b_flag = np.ascontiguousarray(b_flag, dtype=np.uint32)
+            n_ovl = int(b_flag.shape[0])
+        self._keep = [row_ptr, a_span, b_span, b_flag]
+        self.r_begin, self.r_end = int(r_begin), int(r_end)
+        self._ck(self.lib.hinge_set_pileups(self.h, r_begin, r_end, int(n_ovl), _ptr(row_ptr), _ptr(a_span), _ptr(b_span), _ptr(b_flag),
+                                            1 if on_device else 0))
+
+    def attach_mask_table(self, dev_ptr):
+        self._ck(self.lib.hinge_attach_mask_table(self.h, _VP(_ptr(dev_ptr)) if dev_ptr is not None else None))
+
+    def attach_mean_cov(self, dev_ptr):
+        self._ck(self.lib.hinge_attach_mean_cov(self.h, _VP(_ptr(dev_ptr)) if dev_ptr is not None else None))
+
+    def clear_masks(self):
+        self._ck(self.lib.hinge_clear_masks(self.h))
+
+    def force_exact(self, on: bool):
+        self._ck(self.lib.hinge_debug_force_exact(self.h, 1 if on else 0))
+
+    # ---- filter -------------------------------------------------------------------------------
+    def filter_stats(self, p: FilterParams):
+        self._ck(self.lib.hinge_filter_stats(self.h, C.byref(p)))
+
+    def filter_median(self, p: FilterParams, lo: int, hi: int, fetch: bool = True) -> Optional[CovEstimate]:
+        est = CovEstimate()
+        self._ck(self.lib.hinge_filter_median(self.h, C.byref(p), lo, hi, C.byref(est) if fetch else None))
+        return est if fetch else None
+
+    def set_min_cov(self, v: int):
+        self._ck(self.lib.hinge_filter_set_min_cov(self.h, int(v)))
+
+    def get_min_cov(self) -> int:
+        v = C.c_int32()
+        self._ck(self.lib.hinge_filter_get_min_cov(self.h, C.byref(v)))
+        return int(v.value)
+
+    def filter_mask_annotate(self, p: FilterParams):
+        self._ck(self.lib.hinge_filter_mask_annotate(self.h, C.byref(p)))
+
+    def filter_hinges(self, p: FilterParams):
+        self._ck(self.lib.hinge_filter_hinges(self.h, C.byref(p)))
+
+    def filter_run(self, p: FilterParams):
+        self._ck(self.lib.hinge_filter_run(self.h, C.byref(p)))
+
+    def get_masks(self):
+        n = self.r_end - self.r_begin + 1
+        mask = np.zeros((n, 2), np.int32)
+        cmask = np.zeros((n, 2), np.int32)
+        flags = np.zeros(n, np.uint8)
+        self._ck(self.lib.hinge_filter_get_masks(self.h, _ptr(mask), _ptr(cmask), _ptr(flags)))
+        return mask, cmask, flags
+
+    def get_annotations(self):
+        n = self.r_end - self.r_begin + 1
+        off = np.zeros(n + 1, np.int64)
+        self._ck(self.lib.hinge_filter_get_annotations(self.h, _ptr(off), None, None, None))
+        tot = int(off[-1])
+        pos = np.zeros(max(tot, 1), np.int32)
+        typ = np.zeros(max(tot, 1), np.int32)
+        ish = np.zeros(max(tot, 1), np.uint8)
+        self._ck(self.lib.hinge_filter_get_annotations(self.h, _ptr(off), _ptr(pos), _ptr(typ), _ptr(ish)))
+        return off, pos[:tot], typ[:tot], ish[:tot]
+
+    def coverage_bins(self, r0: int, r1: int, reso: int, cutoff: int):
+        n = r1 - r0 + 1
+        nb = np.zeros(n, np.int32)
+        self._ck(self.lib.hinge_filter_coverage_bins(self.h, r0, r1, reso, cutoff, _ptr(nb), None, 0))
+        tot = int(nb.astype(np.int64).sum())
+        cov = np.zeros(max(tot, 1), np.int32)
+        self._ck(self.lib.hinge_filter_coverage_bins(self.h, r0, r1, reso, cutoff, _ptr(nb), _ptr(cov), tot))
+        return nb, cov[:tot]
+
+    def counters(self):
+        out = np.zeros(4, np.int64)
+        self._ck(self.lib.hinge_filter_counters(self.h, _ptr(out)))
+        return out
+
+    def timer_start(self):
+        self._ck(self.lib.hinge_timer_start(self.h))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        self._ck(self.lib.hinge_timer_stop_ms(self.h, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,567 @@
+// C ABI of libhinge_hip (include/hinge_hip.h): context, device memory, launch plumbing.
+// No CPU fallback lives here: without a usable HIP device hinge_ctx_create fails with
+// HINGE_E_DEVICE and every other entry point needs a context.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/hinge_hip.h"
+#include "filter_kernels.h"
+#include "align_kernels.h"
+
+using namespace hinge;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool owned = true;
+};
+
+struct hinge_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+
+    int32_t n_reads = 0, max_rlen = 0;
+    DevBuf rlen, qv_mask;   // int32[n], int2[n]
+    bool has_qv = false;
+
+    int32_t r_begin = 0, r_end = -1;
+    int64_t n_ovl = 0;
+    DevBuf row_ptr, a_span, b_span, b_flag;
+
+    DevBuf mask_own;          // int2[n_reads]
+    int2* mask = nullptr;     // active table (own or attached)
+    DevBuf mean_own;
+    int* mean_cov = nullptr;
+    DevBuf cmask, rflags, nbins0;
+    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list;
+    unsigned anno_cap = 0;
+    DevBuf exact_queue;
+    unsigned exact_cap = 0;
+    DevBuf arena;
+    unsigned long long arena_cap = 0;
+    DevBuf scalars;   // see Scalars
+    int force_exact = 0;
+
+    // trim / classify (maximal, layout)
+    DevBuf trace, trace_off, eff_reads, pair_sel, pair_out;
+    int64_t trace_bytes = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// device scalars, one allocation
+struct Scalars {
+    unsigned long long totals[2];       // total_cov, num_slot
+    unsigned long long arena_used;
+    unsigned counters[2];               // annotation alloc, work count
+    unsigned exact_count;
+    int est[2];                         // cov_est, n_long
+    int min_cov;
+    int status;
+};
+
+#define CK(call)                                                                                         \
+    do {                                                                                                 \
+        hipError_t _e = (call);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(_e);                                \
+            return HINGE_E_DEVICE;                                                                       \
+        }                                                                                                \
+    } while (0)
+
+static int fail(hinge_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static int ensure(hinge_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.owned && b.p && b.bytes >= bytes) return HINGE_OK;
+    if (b.owned && b.p) { (void)hipFree(b.p); b.p = nullptr; }
+    b.owned = true;
+    b.bytes = std::max<size_t>(bytes, 16);
+    CK(hipMalloc(&b.p, b.bytes));
+    return HINGE_OK;
+}
+
+static void release(DevBuf& b) {
+    if (b.owned && b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    b.owned = true;
+}
+
+static Scalars* sc(hinge_ctx* ctx) { return (Scalars*)ctx->scalars.p; }
+
+static FilterDev to_dev(const hinge_filter_params* p) {
+    FilterDev d;
+    d.reso = p->reso; d.cut_off = p->cut_off; d.theta = p->theta;
+    d.cov_frac = p->coverage_fraction; d.min_ra = p->min_repeat_annotation; d.max_ra = p->max_repeat_annotation;
+    d.ra_gap = p->repeat_annotation_gap; d.nhr = p->no_hinge_region;
+    d.sup = p->hinge_min_support; d.pil = p->hinge_bin_pileup; d.unb = p->hinge_unbridged; d.tol = p->hinge_tolerance;
+    d.bin_len = 2 * p->hinge_tolerance;   // filter.cpp:405
+    d.use_qv = p->use_qv_mask; d.use_cov = p->use_coverage_mask; d.del_telo = p->delete_telomere;
+    d.est_cov = p->est_cov;
+    return d;
+}
+
+static int check_params(hinge_ctx* ctx, const hinge_filter_params* p) {
+    if (!p) return fail(ctx, HINGE_E_ARG, "params == NULL");
+    if (p->reso <= 0) return fail(ctx, HINGE_E_ARG, "reso must be > 0");
+    if (p->coverage_fraction == 0) return fail(ctx, HINGE_E_ARG, "coverage_frac_repeat_annotation == 0 divides by zero in the reference");
+    return HINGE_OK;
+}
+
+extern "C" {
+
+int hinge_ctx_create(int device, hinge_ctx** out) {
+    if (!out) return HINGE_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return HINGE_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return HINGE_E_DEVICE;
+    hinge_ctx* ctx = new hinge_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipMalloc(&ctx->scalars.p, sizeof(Scalars)) != hipSuccess) { delete ctx; return HINGE_E_DEVICE; }
+    ctx->scalars.bytes = sizeof(Scalars);
+    (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return HINGE_OK;
+}
+
+void hinge_ctx_destroy(hinge_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
+                     &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
+                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->trace, &ctx->trace_off, &ctx->eff_reads,
+                     &ctx->pair_sel, &ctx->pair_out};
+    for (DevBuf* b : all) release(*b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char* hinge_last_error(const hinge_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+int hinge_set_stream(hinge_ctx* ctx, void* s) {
+    if (!ctx) return HINGE_E_ARG;
+    ctx->stream = (hipStream_t)s;
+    return HINGE_OK;
+}
+
+int hinge_synchronize(hinge_ctx* ctx) {
+    if (!ctx) return HINGE_E_ARG;
+    CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
+int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const int32_t* qv_mask) {
+    if (!ctx || n_reads <= 0 || !rlen) return fail(ctx, HINGE_E_ARG, "hinge_set_reads: bad arguments");
+    CK(hipSetDevice(ctx->device));
+    ctx->n_reads = n_reads;
+    int rc;
+    if ((rc = ensure(ctx, ctx->rlen, sizeof(int) * (size_t)n_reads))) return rc;
+    if ((rc = ensure(ctx, ctx->qv_mask, sizeof(int2) * (size_t)n_reads))) return rc;
+    CK(hipMemcpyAsync(ctx->rlen.p, rlen, sizeof(int) * (size_t)n_reads, hipMemcpyHostToDevice, ctx->stream));
+    ctx->has_qv = qv_mask != nullptr;
+    if (qv_mask) CK(hipMemcpyAsync(ctx->qv_mask.p, qv_mask, sizeof(int2) * (size_t)n_reads, hipMemcpyHostToDevice, ctx->stream));
+    else CK(hipMemsetAsync(ctx->qv_mask.p, 0, sizeof(int2) * (size_t)n_reads, ctx->stream));
+    ctx->max_rlen = 0;
+    for (int i = 0; i < n_reads; i++) ctx->max_rlen = std::max(ctx->max_rlen, rlen[i]);
+    size_t n = (size_t)n_reads;
+    if ((rc = ensure(ctx, ctx->mask_own, sizeof(int2) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->mean_own, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->cmask, sizeof(int2) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->rflags, n))) return rc;
+    if ((rc = ensure(ctx, ctx->nbins0, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->anno_off, sizeof(unsigned) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->work_list, sizeof(int) * n))) return rc;
+    if (!ctx->mask) ctx->mask = (int2*)ctx->mask_own.p;
+    if (!ctx->mean_cov) ctx->mean_cov = (int*)ctx->mean_own.p;
+    CK(hipMemsetAsync(ctx->mask_own.p, 0, sizeof(int2) * n, ctx->stream));
+    CK(hipMemsetAsync(ctx->anno_cnt.p, 0, sizeof(int) * n, ctx->stream));
+    CK(hipMemsetAsync(ctx->anno_off.p, 0, sizeof(unsigned) * n, ctx->stream));
+    CK(hipMemsetAsync(ctx->cmask.p, 0, sizeof(int2) * n, ctx->stream));
+    CK(hipMemsetAsync(ctx->rflags.p, 0, n, ctx->stream));
+    {   // mean_cov defaults to "not in the median"
+        std::vector<int> init(n, MEAN_SENTINEL);
+        CK(hipMemcpyAsync(ctx->mean_own.p, init.data(), sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    return HINGE_OK;
+}
+
+static int adopt(hinge_ctx* ctx, DevBuf& b, const void* src, size_t bytes, int on_device) {
+    if (on_device) {
+        if (b.owned && b.p) (void)hipFree(b.p);
+        b.p = const_cast<void*>(src);
+        b.bytes = bytes;
+        b.owned = false;
+        return HINGE_OK;
+    }
+    if (!b.owned) { b.p = nullptr; b.bytes = 0; b.owned = true; }
+    int rc = ensure(ctx, b, bytes);
+    if (rc) return rc;
+    if (bytes) CK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return HINGE_OK;
+}
+
+int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr, const int32_t* a_span,
+                      const int32_t* b_span, const uint32_t* b_flag, int on_device) {
+    if (!ctx || ctx->n_reads <= 0) return fail(ctx, HINGE_E_ARG, "hinge_set_pileups: call hinge_set_reads first");
+    if (r_begin < 0 || r_end >= ctx->n_reads || r_end < r_begin || n_ovl < 0 || !row_ptr) return fail(ctx, HINGE_E_ARG, "hinge_set_pileups: bad range");
+    CK(hipSetDevice(ctx->device));
+    ctx->r_begin = r_begin; ctx->r_end = r_end; ctx->n_ovl = n_ovl;
+    int rc;
+    if ((rc = adopt(ctx, ctx->row_ptr, row_ptr, sizeof(int64_t) * ((size_t)ctx->n_reads + 1), on_device))) return rc;
+    if ((rc = adopt(ctx, ctx->a_span, a_span, sizeof(int2) * (size_t)n_ovl, on_device))) return rc;
+    if ((rc = adopt(ctx, ctx->b_span, b_span, sizeof(int2) * (size_t)n_ovl, on_device))) return rc;
+    if ((rc = adopt(ctx, ctx->b_flag, b_flag, sizeof(unsigned) * (size_t)n_ovl, on_device))) return rc;
+    // annotation storage: grows on overflow
+    if (ctx->anno_cap == 0) {
+        ctx->anno_cap = (unsigned)std::max<int64_t>(1024, 4LL * (r_end - r_begin + 1));
+        if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
+    }
+    if (ctx->exact_cap == 0) {
+        ctx->exact_cap = 4096;
+        if ((rc = ensure(ctx, ctx->exact_queue, sizeof(int2) * (size_t)ctx->exact_cap))) return rc;
+    }
+    if (ctx->arena_cap == 0) {
+        ctx->arena_cap = 1ull << 22;   // ints
+        if ((rc = ensure(ctx, ctx->arena, sizeof(int) * (size_t)ctx->arena_cap))) return rc;
+    }
+    if (!on_device) CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
+int hinge_attach_mask_table(hinge_ctx* ctx, int32_t* d) {
+    if (!ctx) return HINGE_E_ARG;
+    ctx->mask = d ? (int2*)d : (int2*)ctx->mask_own.p;
+    return HINGE_OK;
+}
+int hinge_attach_mean_cov(hinge_ctx* ctx, int32_t* d) {
+    if (!ctx) return HINGE_E_ARG;
+    ctx->mean_cov = d ? d : (int*)ctx->mean_own.p;
+    return HINGE_OK;
+}
+int hinge_clear_masks(hinge_ctx* ctx) {
+    if (!ctx || !ctx->mask) return HINGE_E_ARG;
+    CK(hipMemsetAsync(ctx->mask, 0, sizeof(int2) * (size_t)ctx->n_reads, ctx->stream));
+    return HINGE_OK;
+}
+
+// hidden knob for tests: route every scanned annotation through the exact path
+int hinge_debug_force_exact(hinge_ctx* ctx, int on) {
+    if (!ctx) return HINGE_E_ARG;
+    ctx->force_exact = on;
+    return HINGE_OK;
+}
+
+static int grid_for_reads(hinge_ctx* ctx, int n_reads_in_part, int waves_per_block) {
+    int blocks = (n_reads_in_part + waves_per_block - 1) / waves_per_block;
+    int cap = ctx->n_cu * 8;
+    return std::max(1, std::min(blocks, cap));
+}
+
+static int kcap_for(hinge_ctx* ctx, const hinge_filter_params* p) {
+    // bins a read can touch: (rlen + cut_off) / reso + 1 (bin_of) + 2 slack, rounded to 4
+    int k = (ctx->max_rlen + std::max(p->cut_off, 0)) / p->reso + 4;
+    return (k + 3) & ~3;
+}
+
+int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemsetAsync(&sc(ctx)->totals[0], 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const int nr = ctx->r_end - ctx->r_begin + 1;
+    const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k_cov_stats, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
+                       (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, sc(ctx)->totals);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
+int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (lo < 0 || hi >= ctx->n_reads || hi < lo) return fail(ctx, HINGE_E_ARG, "median range");
+    CK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_median_select, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov, sc(ctx)->est,
+                       &sc(ctx)->min_cov, &sc(ctx)->status);
+    CK(hipGetLastError());
+    if (out) {
+        Scalars h;
+        CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        out->cov_est = h.est[0];
+        out->n_long = h.est[1];
+        out->total_cov = (int64_t)h.totals[0];
+        out->num_slot = (int64_t)h.totals[1];
+        if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part: the reference is undefined here (filter.cpp:660-666)");
+    }
+    return HINGE_OK;
+}
+
+int hinge_filter_set_min_cov(hinge_ctx* ctx, int32_t v) {
+    if (!ctx) return HINGE_E_ARG;
+    CK(hipMemcpyAsync(&sc(ctx)->min_cov, &v, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* v) {
+    if (!ctx || !v) return HINGE_E_ARG;
+    CK(hipMemcpyAsync(v, &sc(ctx)->min_cov, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
+static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
+    const int kcap = kcap_for(ctx, p);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
+    if (lds > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_mask_annotate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemsetAsync(sc(ctx)->counters, 0, 2 * sizeof(unsigned), ctx->stream));
+    const int nr = ctx->r_end - ctx->r_begin + 1;
+    const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k_mask_annotate, dim3(grid), dim3(BLOCK), lds, ctx->stream, to_dev(p), ctx->r_begin, ctx->r_end,
+                       (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
+                       ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr, (const int*)&sc(ctx)->min_cov, kcap, ctx->mask,
+                       (int2*)ctx->cmask.p, (unsigned char*)ctx->rflags.p, (int2*)ctx->anno_buf.p, (unsigned*)ctx->anno_off.p,
+                       (int*)ctx->anno_cnt.p, sc(ctx)->counters, ctx->anno_cap, (int*)ctx->work_list.p, &sc(ctx)->status);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
+int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
+    CK(hipSetDevice(ctx->device));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+        if ((rc = launch_mask_annotate(ctx, p))) return rc;
+        // the annotation buffer is sized optimistically; grow + rerun on overflow (rare)
+        Scalars h;
+        CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        if (h.status & ST_RANGE) return fail(ctx, HINGE_E_RANGE, "overlap coordinate beyond read length + cut_off");
+        if (!(h.status & ST_ANNO_CAP)) return HINGE_OK;
+        ctx->anno_cap = std::max(ctx->anno_cap * 2, h.counters[0] + 1024);
+        if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
+    }
+    return fail(ctx, HINGE_E_CAPACITY, "annotation buffer kept overflowing");
+}
+
+static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
+    CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, sizeof(unsigned), ctx->stream));
+    CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
+    CK(hipMemsetAsync(ctx->hinge_flag.p, 0, (size_t)ctx->anno_cap, ctx->stream));
+    const int grid = ctx->n_cu * 2;
+    hipLaunchKernelGGL(k_hinge_call, dim3(grid), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
+                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
+                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
+                       (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
+                       (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status);
+    CK(hipGetLastError());
+    hipLaunchKernelGGL(k_hinge_exact, dim3(64), dim3(64), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
+                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
+                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int2*)ctx->exact_queue.p,
+                       (const unsigned*)&sc(ctx)->exact_count, ctx->exact_cap, (int*)ctx->arena.p, &sc(ctx)->arena_used, ctx->arena_cap,
+                       (unsigned char*)ctx->hinge_flag.p, &sc(ctx)->status);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
+// checks the capacity flags of the last hinge pass; grows what overflowed. 1 = rerun needed.
+static int hinges_settle(hinge_ctx* ctx, int* rerun) {
+    Scalars h;
+    CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    *rerun = 0;
+    int rc;
+    if (h.status & ST_QUEUE_CAP) {
+        ctx->exact_cap = std::max(ctx->exact_cap * 2, h.exact_count + 1024);
+        if ((rc = ensure(ctx, ctx->exact_queue, sizeof(int2) * (size_t)ctx->exact_cap))) return rc;
+        *rerun = 1;
+    }
+    if (h.status & ST_ARENA_CAP) {
+        ctx->arena_cap = std::max(ctx->arena_cap * 2, h.arena_used + 1024);
+        if ((rc = ensure(ctx, ctx->arena, sizeof(int) * (size_t)ctx->arena_cap))) return rc;
+        *rerun = 1;
+    }
+    return HINGE_OK;
+}
+
+int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    CK(hipSetDevice(ctx->device));
+    for (int attempt = 0; attempt < 16; attempt++) {
+        CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+        if ((rc = launch_hinges(ctx, p))) return rc;
+        int rerun = 0;
+        if ((rc = hinges_settle(ctx, &rerun))) return rc;
+        if (!rerun) return HINGE_OK;
+    }
+    return fail(ctx, HINGE_E_CAPACITY, "exact-path buffers kept overflowing");
+}
+
+int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p) {
+    // asynchronous single-part pipeline; capacity overflow is reported by the next result getter
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+    if ((rc = hinge_filter_stats(ctx, p))) return rc;
+    if ((rc = hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, nullptr))) return rc;
+    if ((rc = launch_mask_annotate(ctx, p))) return rc;
+    if ((rc = launch_hinges(ctx, p))) return rc;
+    return HINGE_OK;
+}
+
+static int check_status(hinge_ctx* ctx) {
+    Scalars h;
+    CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part");
+    if (h.status & ST_RANGE) return fail(ctx, HINGE_E_RANGE, "overlap coordinate beyond read length + cut_off");
+    if (h.status & (ST_ANNO_CAP | ST_QUEUE_CAP | ST_ARENA_CAP))
+        return fail(ctx, HINGE_E_CAPACITY, "device buffer overflow in hinge_filter_run: use the staged calls (they regrow)");
+    return HINGE_OK;
+}
+
+int hinge_filter_get_masks(hinge_ctx* ctx, int32_t* mask, int32_t* cmask, uint8_t* flags) {
+    if (!ctx) return HINGE_E_ARG;
+    int rc = check_status(ctx);
+    if (rc) return rc;
+    const size_t n = (size_t)(ctx->r_end - ctx->r_begin + 1);
+    if (mask) CK(hipMemcpyAsync(mask, ctx->mask + ctx->r_begin, sizeof(int2) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (cmask) CK(hipMemcpyAsync(cmask, (int2*)ctx->cmask.p + ctx->r_begin, sizeof(int2) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (flags) CK(hipMemcpyAsync(flags, (unsigned char*)ctx->rflags.p + ctx->r_begin, n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
+int hinge_filter_get_annotations(hinge_ctx* ctx, int64_t* off, int32_t* pos, int32_t* type, uint8_t* is_hinge) {
+    if (!ctx || !off) return HINGE_E_ARG;
+    int rc = check_status(ctx);
+    if (rc) return rc;
+    const size_t n = (size_t)(ctx->r_end - ctx->r_begin + 1);
+    std::vector<unsigned> aoff(n);
+    std::vector<int> acnt(n);
+    CK(hipMemcpyAsync(aoff.data(), (unsigned*)ctx->anno_off.p + ctx->r_begin, sizeof(unsigned) * n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipMemcpyAsync(acnt.data(), (int*)ctx->anno_cnt.p + ctx->r_begin, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    Scalars h;
+    CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    off[0] = 0;
+    for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + acnt[i];
+    if (!pos) return HINGE_OK;
+    const size_t tot = h.counters[0];
+    std::vector<int2> buf(tot);
+    std::vector<unsigned char> hf(tot);
+    if (tot) {
+        CK(hipMemcpyAsync(buf.data(), ctx->anno_buf.p, sizeof(int2) * tot, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(hf.data(), ctx->hinge_flag.p, tot, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
+    for (size_t i = 0; i < n; i++)
+        for (int t = 0; t < acnt[i]; t++) {
+            const size_t d = (size_t)off[i] + t, s = (size_t)aoff[i] + t;
+            pos[d] = buf[s].x;
+            if (type) type[d] = buf[s].y;
+            if (is_hinge) is_hinge[d] = hf[s];
+        }
+    return HINGE_OK;
+}
+
+int hinge_filter_coverage_bins(hinge_ctx* ctx, int32_t r0, int32_t r1, int32_t reso, int32_t cutoff, int32_t* nbins, int32_t* cov,
+                               int64_t cov_cap) {
+    if (!ctx || !nbins || r0 < 0 || r1 >= ctx->n_reads || r1 < r0 || reso <= 0) return fail(ctx, HINGE_E_ARG, "coverage_bins: bad arguments");
+    CK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)(r1 - r0 + 1);
+    int* d_nb = nullptr;
+    int64_t* d_off = nullptr;
+    int* d_cov = nullptr;
+    CK(hipMalloc(&d_nb, sizeof(int) * n));
+    const int kcap = ((ctx->max_rlen + std::max(cutoff, 0)) / reso + 4 + 3) & ~3;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * kcap * sizeof(int);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_coverage_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int grid = grid_for_reads(ctx, (int)n, WAVES_PER_BLOCK);
+    CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_coverage_bins, dim3(grid), dim3(BLOCK), lds, ctx->stream, r0, r1, (const int64_t*)ctx->row_ptr.p,
+                       (const int2*)ctx->a_span.p, reso, cutoff, kcap, d_nb, (const int64_t*)nullptr, (int*)nullptr, &sc(ctx)->status);
+    CK(hipMemcpyAsync(nbins, d_nb, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    int rc = HINGE_OK;
+    if (cov) {
+        std::vector<int64_t> off(n + 1, 0);
+        for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + nbins[i];
+        if (off[n] > cov_cap) rc = fail(ctx, HINGE_E_ARG, "coverage_bins: cov_cap too small");
+        else if (off[n] > 0) {
+            CK(hipMalloc(&d_off, sizeof(int64_t) * (n + 1)));
+            CK(hipMalloc(&d_cov, sizeof(int) * (size_t)off[n]));
+            CK(hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_coverage_bins, dim3(grid), dim3(BLOCK), lds, ctx->stream, r0, r1, (const int64_t*)ctx->row_ptr.p,
+                               (const int2*)ctx->a_span.p, reso, cutoff, kcap, d_nb, (const int64_t*)d_off, d_cov, &sc(ctx)->status);
+            CK(hipMemcpyAsync(cov, d_cov, sizeof(int) * (size_t)off[n], hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            int st = 0;
+            CK(hipMemcpy(&st, &sc(ctx)->status, sizeof(int), hipMemcpyDeviceToHost));
+            if (st & ST_RANGE) rc = fail(ctx, HINGE_E_RANGE, "coverage_bins: bins exceed LDS capacity");
+        }
+    }
+    if (d_nb) (void)hipFree(d_nb);
+    if (d_off) (void)hipFree(d_off);
+    if (d_cov) (void)hipFree(d_cov);
+    return rc;
+}
+
+int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
+    if (!ctx || !out) return HINGE_E_ARG;
+    Scalars h;
+    CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    out[0] = h.counters[1];
+    out[1] = std::min(h.exact_count, ctx->exact_cap);
+    out[2] = h.counters[0];
+    size_t tot = h.counters[0];
+    std::vector<unsigned char> hf(tot);
+    if (tot) CK(hipMemcpy(hf.data(), ctx->hinge_flag.p, tot, hipMemcpyDeviceToHost));
+    int64_t nh = 0;
+    for (unsigned char c : hf) nh += c;
+    out[3] = nh;
+    return HINGE_OK;
+}
+
+int hinge_timer_start(hinge_ctx* ctx) {
+    if (!ctx) return HINGE_E_ARG;
+    CK(hipEventRecord(ctx->ev0, ctx->stream));
+    return HINGE_OK;
+}
+int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return HINGE_E_ARG;
+    CK(hipEventRecord(ctx->ev1, ctx->stream));
+    CK(hipEventSynchronize(ctx->ev1));
+    CK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return HINGE_OK;
+}
+
+}  // extern "C"
+
+#include "align_capi.inc"

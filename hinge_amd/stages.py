@@ -1,0 +1,156 @@
+"""Python driver of the `hinge filter` stage over the C ABI (used by tests, bench.py and the
+multi-GPU orchestrator; the installed command-line tools are the C++ programs in hinge_amd/host/).
+
+Same inputs, same output files, same part loop as src/filter/filter.cpp:474-1111; all arithmetic on
+the pile-ups happens in the HIP kernels behind include/hinge_hip.h.  Host work here is file I/O only.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import numpy as np
+
+from . import formats
+from .capi import Context, FilterParams, HingeError
+from .config import IniFile, filter_params
+
+
+def las_list(las_base: str, mlas: bool) -> List[str]:
+    """filter.cpp:228-278 (+ glob() at :35-63)."""
+    if mlas:
+        out, i = [], 1
+        while os.path.exists("%s.%d.las" % (las_base, i)):
+            out.append("%s.%d.las" % (las_base, i))
+            i += 1
+        return out
+    return [las_base if las_base.endswith(".las") else las_base + ".las"]
+
+
+def qv_masks(qv: List[np.ndarray], tspace: int) -> np.ndarray:
+    """filter.cpp:309-312,340-369: longest run of good (<40) segments; the last segment always
+    breaks a run."""
+    out = np.zeros((len(qv), 2), np.int32)
+    for i, q in enumerate(qv):
+        good = (np.asarray(q) < 40)
+        s = e = 0
+        mx = maxs = maxe = 0
+        n = len(good)
+        for j in range(n):
+            if good[j] and j < n - 1:
+                e += 1
+            else:
+                if e - s > mx:
+                    maxe, maxs, mx = e, s, e - s
+                s = e = j + 1
+        out[i] = (maxs * tspace, maxe * tspace)
+    return out
+
+
+def self_match_reads(p: formats.Pileups, rlen: np.ndarray) -> set:
+    """filter.cpp:552-561 (float32 accumulation in record order)."""
+    acc = {}
+    for a, sp in zip(p.self_a, p.self_span):
+        c = acc.get(int(a), np.float32(0.0))
+        c = np.float32(c + np.float32(int(sp[1]) - int(sp[0])))
+        c = np.float32(c + np.float32(int(sp[3]) - int(sp[2])))
+        acc[int(a)] = c
+    out = set()
+    for a, c in acc.items():
+        cov = np.float32(c / np.float32(rlen[a]))
+        if cov > 4.5 and rlen[a] > 10000:
+            out.add(a)
+    return out
+
+
+def run_filter(db_name: str, las_base: str, prefix: str, config: str, mlas: bool = False, device: int = 0,
+               write_coverage: bool = True, force_exact: bool = False, ctx: Optional[Context] = None) -> int:
+    """`hinge filter --db DB --las LAS [--mlas] -x PREFIX --config INI`.  Returns the exit code."""
+    try:
+        idx = formats.read_db_index(db_name)
+    except OSError:
+        return 1
+    rlen = idx["rlen"]
+    n_read = len(rlen)
+    qv = formats.read_qual_track(db_name)
+    has_qv = qv is not None
+    names = las_list(las_base, mlas)
+    if not names:
+        return 1
+    first = formats.read_las(names[0])
+    qvm = qv_masks(qv, first.tspace) if has_qv else None
+    ini = IniFile(config)
+    if ini.error < 0:
+        return 1
+    P: FilterParams = filter_params(ini, has_qv)
+
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = Context(device)
+    ctx.set_reads(rlen, qvm)
+    ctx.force_exact(force_exact)
+    ctx.set_min_cov(P.min_cov)
+
+    f_cov = open(prefix + ".coverage.txt", "w")
+    open(prefix + ".homologous.txt", "w").close()
+    f_rep = open(prefix + ".repeat.txt", "w")
+    open(prefix + ".filtered.fasta", "w").close()
+    f_hg = open(prefix + ".hinges.txt", "w")
+    f_mask = open(prefix + ".mas", "w")
+    f_cmask = open(prefix + ".cmas", "w")
+    f_covflag = open(prefix + ".cov.flag", "w")
+    f_selfflag = open(prefix + ".self.flag", "w")
+    rc = 0
+    try:
+        for part, name in enumerate(names):
+            recs = first if part == 0 else formats.read_las(name)
+            if recs.novl == 0:
+                rc = 1
+                break
+            pile = formats.pileups_from_las(recs, rlen)
+            r_begin = int(recs.rec["aread"][0])
+            r_end = int(recs.rec["aread"][-1])
+            ctx.set_pileups(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+            ctx.filter_stats(P)
+            ctx.filter_median(P, r_begin, r_end, fetch=True)
+            ctx.filter_mask_annotate(P)
+            ctx.filter_hinges(P)
+            mask, cmask, flags = ctx.get_masks()
+            off, pos, typ, ish = ctx.get_annotations()
+            if write_coverage:
+                nb, cov = ctx.coverage_bins(r_begin, r_end, P.reso, 0)
+                o = 0
+                for k, i in enumerate(range(r_begin, r_end + 1)):
+                    c = cov[o:o + nb[k]]
+                    o += nb[k]
+                    f_cov.write("read %d " % i + "".join("%d,%d " % (P.reso * j, v) for j, v in enumerate(c)) + "\n")
+            selfm = self_match_reads(pile, rlen) if P.delete_telomere else set()
+            for k, i in enumerate(range(r_begin, r_end + 1)):
+                if P.delete_telomere:
+                    if flags[k] & 1:
+                        f_covflag.write("%d\n" % i)
+                    if i in selfm:
+                        f_selfflag.write("%d\n" % i)
+                f_cmask.write("%d %d %d\n" % (i, cmask[k, 0], cmask[k, 1]))
+                f_mask.write("%d %d %d\n" % (i, mask[k, 0], mask[k, 1]))
+            open("debug.txt", "w").close()
+            if f_rep is not None:      # closed after the first part, filter.cpp:1086
+                for k, i in enumerate(range(r_begin, r_end + 1)):
+                    s, e = off[k], off[k + 1]
+                    f_rep.write("%d " % i + "".join("%d %d " % (pos[t], typ[t]) for t in range(s, e)) + "\n")
+                f_rep.close()
+                f_rep = None
+            for k, i in enumerate(range(r_begin, r_end)):   # excludes r_end, filter.cpp:1091
+                s, e = off[k], off[k + 1]
+                f_hg.write("%d " % i + "".join("%d %d " % (pos[t], typ[t]) for t in range(s, e) if ish[t]) + "\n")
+    except HingeError as ex:
+        rc = 1 if ex.code == -4 else 2
+        if rc == 2:
+            raise
+    finally:
+        for f in (f_cov, f_rep, f_hg, f_mask, f_cmask, f_covflag, f_selfflag):
+            if f is not None:
+                f.close()
+        if own_ctx:
+            ctx.close()
+    return rc

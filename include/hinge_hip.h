@@ -1,0 +1,135 @@
+/* libhinge_hip - MI355X (gfx950) implementation of the HINGE filter / maximal / layout hot path.
+ *
+ * Drop-in boundary.  The reference has no plugin or FFI seam: its three stage programs
+ * (src/filter/filter.cpp, src/maximal/maximal.cpp, src/layout/hinging.cpp) call a C++ class,
+ * LAInterface (src/include/LAInterface.h:113-233), and a handful of LOverlap methods, and talk to each
+ * other through files.  This C ABI is what those call sites bind instead; every entry point names the
+ * reference code it replaces.  Plain pointers and sizes only, `int` status (0 = ok, <0 = HINGE_E_*),
+ * no exceptions across the boundary, caller-owned host buffers, library-owned device buffers.
+ * One context per GPU; a context is not thread-safe; contexts are independent.
+ *
+ * Data layout handed in (built by the host ingest from the .las in one pass - the replacement of
+ * LAInterface::getOverlap, src/lib/LAInterface.cpp:1519-1634):
+ *   row_ptr[n_reads+1]  int64   CSR by A read over the arrays below
+ *   a_span[n][2]        int32   (abpos, aepos)
+ *   b_span[n][2]        int32   (bbpos, bepos) on the FORWARD strand of B, i.e. after the flip of
+ *                               LAInterface.cpp:1619-1626
+ *   b_flag[n]           uint32  bread | comp << 31
+ * holding, for every A read, its overlaps in .las order with SELF-overlaps (aread == bread) removed -
+ * the reference excludes them from every pile-up (filter.cpp:537-548).
+ */
+#ifndef HINGE_HIP_H
+#define HINGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HINGE_OK 0
+#define HINGE_E_ARG (-1)       /* bad argument / call order                                   */
+#define HINGE_E_DEVICE (-2)    /* HIP runtime error (no GPU, OOM, launch failure)              */
+#define HINGE_E_CAPACITY (-3)  /* an internal device buffer overflowed even after regrowing    */
+#define HINGE_E_UNDEFINED (-4) /* input on which the reference itself is undefined (e.g. no
+                                  read >= 5000 bp in a part: filter.cpp:660-666)               */
+#define HINGE_E_RANGE (-5)     /* coordinate outside the read (bin beyond the LDS histogram)   */
+
+typedef struct hinge_ctx hinge_ctx;
+
+/* [filter] keys of nominal.ini as filter.cpp:377-406 reads them (plus reso = 40, filter.cpp:386). */
+typedef struct hinge_filter_params {
+    int32_t reso;
+    int32_t cut_off;
+    int32_t min_cov;
+    int32_t est_cov;
+    int32_t theta;
+    int32_t coverage_fraction;
+    int32_t min_repeat_annotation;
+    int32_t max_repeat_annotation;
+    int32_t repeat_annotation_gap;
+    int32_t no_hinge_region;
+    int32_t hinge_min_support;
+    int32_t hinge_bin_pileup;
+    int32_t hinge_unbridged;
+    int32_t hinge_tolerance;
+    int32_t use_qv_mask;       /* already AND-ed with "qual track present" (filter.cpp:409)    */
+    int32_t use_coverage_mask;
+    int32_t delete_telomere;
+} hinge_filter_params;
+
+typedef struct hinge_cov_estimate {
+    int32_t cov_est;           /* median of per-read mean coverage, filter.cpp:660-664         */
+    int32_t n_long;            /* reads with len >= 5000 in the part                           */
+    int64_t total_cov;         /* filter.cpp:652                                               */
+    int64_t num_slot;          /* filter.cpp:653                                               */
+} hinge_cov_estimate;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int hinge_ctx_create(int device, hinge_ctx** out);
+void hinge_ctx_destroy(hinge_ctx* ctx);
+const char* hinge_last_error(const hinge_ctx* ctx);
+/* Run all launches on this hipStream_t (e.g. torch's current stream); NULL = the null stream. */
+int hinge_set_stream(hinge_ctx* ctx, void* hip_stream);
+int hinge_synchronize(hinge_ctx* ctx);
+
+/* ---- inputs -------------------------------------------------------------------------------- */
+/* Read table: replaces LAInterface::openDB/getRead lengths (LAInterface.cpp:133-185,1195-1286) and
+ * the QV mask of filter.cpp:340-369 (qv_mask may be NULL = no qual track). Host pointers.        */
+int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const int32_t* qv_mask);
+/* Pile-ups of one part (one .las file): A reads r_begin..r_end inclusive (filter.cpp:516-517).
+ * on_device = 0: host pointers, copied; on_device = 1: device pointers, adopted (caller keeps them
+ * alive).  row_ptr always has n_reads+1 entries (empty rows outside the part).                   */
+int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr,
+                      const int32_t* a_span, const int32_t* b_span, const uint32_t* b_flag, int on_device);
+/* Optional: use a caller-owned DEVICE buffer int32[n_reads][2] as the all-read mask table (so a
+ * collective can fill other ranks' rows in place).  NULL returns to the library-owned table.      */
+int hinge_attach_mask_table(hinge_ctx* ctx, int32_t* d_mask_all);
+int hinge_attach_mean_cov(hinge_ctx* ctx, int32_t* d_mean_cov);
+/* Reset the mask table to (0,0) (the state maskvec has before the first part, filter.cpp:534).   */
+int hinge_clear_masks(hinge_ctx* ctx);
+
+/* ---- filter: coverage -> mask -> repeat annotation -> hinges ----------------------------------- */
+/* K1: per-read sum of the cutoff-0 coverage bins and the bin count (profileCoverage,
+ * LAInterface.cpp:4298-4320, as used by filter.cpp:642-656). Fills mean_cov[i] for len >= 5000.   */
+int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p);
+/* Median of mean_cov over [lo, hi] (nth_element, filter.cpp:660-664) and the MIN_COV update of
+ * filter.cpp:671-678 done on the device scalar. If `out` is non-NULL the estimate is copied back
+ * (synchronises).                                                                                 */
+int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out);
+/* Get / set the running MIN_COV (it carries across parts, filter.cpp:677-678).                     */
+int hinge_filter_set_min_cov(hinge_ctx* ctx, int32_t min_cov);
+int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* min_cov);
+/* K2: coverage mask (filter.cpp:696-789) + repeat annotation and merge (filter.cpp:796-829) + the
+ * fp32 end-coverage gate (filter.cpp:842-865) for reads r_begin..r_end; writes their mask rows.  */
+int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p);
+/* K3: hinge calling (filter.cpp:867-1068) for the reads that passed the gate; reads the whole mask
+ * table (masks of B reads).                                                                       */
+int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p);
+/* All of the above for one single-GPU part, asynchronously on the stream, no host round trip.    */
+int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p);
+
+/* ---- filter results (host buffers; these synchronise) ---------------------------------------- */
+/* mask/cmask: int32[n][2] for reads r_begin..r_end (n = r_end-r_begin+1); flags: bit0 = .cov.flag
+ * condition (filter.cpp:758). Any pointer may be NULL.                                            */
+int hinge_filter_get_masks(hinge_ctx* ctx, int32_t* mask, int32_t* cmask, uint8_t* flags);
+/* Repeat annotations and hinges as CSR over reads r_begin..r_end: off[n+1]; pos/type[off[n]];
+ * is_hinge[off[n]] marks the annotations promoted to hinges (same order as .repeat.txt).
+ * Call with pos == NULL to get only `off` (to size the arrays).                                   */
+int hinge_filter_get_annotations(hinge_ctx* ctx, int64_t* off, int32_t* pos, int32_t* type, uint8_t* is_hinge);
+/* Cutoff-`cutoff` coverage bins (the .coverage.txt payload, filter.cpp:599-602) for reads
+ * r0..r1 inclusive: nbins[r1-r0+1]; if cov != NULL, bins of read i start at sum(nbins[<i]).      */
+int hinge_filter_coverage_bins(hinge_ctx* ctx, int32_t r0, int32_t r1, int32_t reso, int32_t cutoff, int32_t* nbins,
+                               int32_t* cov, int64_t cov_cap);
+/* Counters of the last hinge pass: [0] reads that reached hinge calling, [1] annotations resolved on
+ * the exact (std::sort-replaying) path, [2] total annotations, [3] total hinges.                  */
+int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
+
+/* ---- device event timing helper for bench.py (HIP events on the ctx stream) -------------------- */
+int hinge_timer_start(hinge_ctx* ctx);
+int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HINGE_HIP_H */

@@ -1,0 +1,91 @@
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NOMINAL_INI = """[filter]
+length_threshold = 1000;
+quality_threshold = 0.23;
+n_iter = 3; // filter iteration
+aln_threshold = 1000;
+min_cov = 5;
+cut_off = 300;
+theta = 300;
+use_qv = true;
+
+[running]
+n_proc = 12;
+
+[layout]
+hinge_slack = 1000
+min_connected_component_size = 8
+"""
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle
+    return oracle.oracle_lib()
+
+
+@pytest.fixture(scope="session")
+def ref_lib():
+    import oracle
+    lib = oracle.ref_lib()
+    if lib is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    return lib
+
+
+def write_ini(path, extra_filter="", extra_layout=""):
+    txt = NOMINAL_INI.replace("use_qv = true;\n", "use_qv = true;\n" + extra_filter)
+    txt = txt + extra_layout
+    with open(path, "w") as f:
+        f.write(txt)
+    return path
+
+
+@pytest.fixture(scope="session")
+def datasets(tmp_path_factory):
+    """Synthetic DB + .las datasets written once per session: name -> (dir, SynthData)."""
+    from hinge_amd import synth
+    root = tmp_path_factory.mktemp("synth")
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            d = synth.generate(synth.CONFIGS[name])
+            wd = os.path.join(str(root), name)
+            synth.write_dataset(d, wd, "G")
+            write_ini(os.path.join(wd, "nominal.ini"))
+            cache[name] = (wd, d)
+        return cache[name]
+
+    return get
+
+
+def run_in(wd, fn, *args):
+    old = os.getcwd()
+    os.chdir(wd)
+    try:
+        return fn(*args)
+    finally:
+        os.chdir(old)
+
+
+def clone_dataset(src, dst):
+    """Copy the input files of a dataset directory (not stage outputs) into dst."""
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src):
+        if f.endswith((".las", ".db", ".ini")) or f.startswith(".G."):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    return dst

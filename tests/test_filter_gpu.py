@@ -1,0 +1,56 @@
+"""GPU parity: `hinge filter` through the C ABI / HIP kernels vs the CPU oracle, byte for byte."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from conftest import clone_dataset, run_in, write_ini
+
+pytestmark = pytest.mark.gpu
+
+FILTER_FILES = [".mas", ".cmas", ".repeat.txt", ".hinges.txt", ".coverage.txt", ".cov.flag", ".self.flag"]
+
+
+def _oracle_filter(lib, wd, mlas, ini="nominal.ini"):
+    las = b"G" if mlas else b"G.las"
+    return run_in(wd, lib.oracle_filter, b"G", las, 1 if mlas else 0, b"G", ini.encode(), b"")
+
+
+def _hip_filter(wd, mlas, ini="nominal.ini", **kw):
+    from hinge_amd import stages
+    return run_in(wd, stages.run_filter, "G", "G" if mlas else "G.las", "G", ini, mlas, 0, True, kw.get("force_exact", False))
+
+
+def _compare(wd_o, wd_h):
+    bad = [s for s in FILTER_FILES if not filecmp.cmp(os.path.join(wd_o, "G" + s), os.path.join(wd_h, "G" + s), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
+
+
+@pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("tiny_mlas", True), ("tiny_mlas", False),
+                                       ("ties", False), ("chimera", False)])
+@pytest.mark.parametrize("exact", [False, True])
+def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas, exact):
+    src, _ = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, mlas) == 0
+    assert _hip_filter(wd_h, mlas, force_exact=exact) == 0
+    _compare(wd_o, wd_h)
+    # the comparison must not be vacuous
+    nh = sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.hinges.txt")))
+    na = sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.repeat.txt")))
+    assert na > 0 and nh > 0
+
+
+@pytest.mark.parametrize("extra", ["ec = 60\n", "coverage = false\n", "hinge_min_support = 3\nhinge_unbridged = 2\nhinge_min_pileup = 3\n",
+                                   "no_hinge_region = 200\nrepeat_annotation_gap_threshold = 100\n"])
+def test_filter_ini_variants(datasets, oracle_lib, tmp_path, extra):
+    src, _ = datasets("tiny_qv")
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    for wd in (wd_o, wd_h):
+        write_ini(os.path.join(wd, "v.ini"), extra_filter=extra, extra_layout="del_telomere = 1\n")
+    assert _oracle_filter(oracle_lib, wd_o, False, "v.ini") == 0
+    assert _hip_filter(wd_h, False, "v.ini") == 0
+    _compare(wd_o, wd_h)
