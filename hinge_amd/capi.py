@@ -61,6 +61,14 @@ SYMBOLS = [
     ("hinge_filter_get_annotations", C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     ("hinge_filter_coverage_bins", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
     ("hinge_filter_counters", C.c_int, [_VP, _VP]),
+    ("hinge_filter_begin_async", C.c_int, [_VP]),
+    ("hinge_filter_mask_annotate_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
+    ("hinge_filter_hinges_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
+    ("hinge_filter_check", C.c_int, [_VP]),
+    ("hinge_profile_enable", C.c_int, [_VP, C.c_int]),
+    ("hinge_profile_kernels", C.c_int, []),
+    ("hinge_profile_kernel_name", C.c_char_p, [C.c_int]),
+    ("hinge_profile_report", C.c_int, [_VP, _VP, _VP]),
     ("hinge_timer_start", C.c_int, [_VP]),
     ("hinge_timer_stop_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
 ]
@@ -224,6 +232,28 @@ class Context:
         out = np.zeros(4, np.int64)
         self._ck(self.lib.hinge_filter_counters(self.h, _ptr(out)))
         return out
+
+    def begin_async(self):
+        self._ck(self.lib.hinge_filter_begin_async(self.h))
+
+    def filter_mask_annotate_async(self, p: FilterParams):
+        self._ck(self.lib.hinge_filter_mask_annotate_async(self.h, C.byref(p)))
+
+    def filter_hinges_async(self, p: FilterParams):
+        self._ck(self.lib.hinge_filter_hinges_async(self.h, C.byref(p)))
+
+    def check(self):
+        self._ck(self.lib.hinge_filter_check(self.h))
+
+    def profile_enable(self, max_launches: int):
+        self._ck(self.lib.hinge_profile_enable(self.h, int(max_launches)))
+
+    def profile_report(self):
+        k = self.lib.hinge_profile_kernels()
+        ms = np.zeros(k, np.float64)
+        cnt = np.zeros(k, np.int64)
+        self._ck(self.lib.hinge_profile_report(self.h, _ptr(ms), _ptr(cnt)))
+        return {self.lib.hinge_profile_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
 
     def timer_start(self):
         self._ck(self.lib.hinge_timer_start(self.h))

@@ -52,6 +52,34 @@ struct hinge_ctx {
     int64_t trace_bytes = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // per-kernel HIP-event timing (bench.py roofline): pairs recorded around every launch
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_used = 0;
+    std::vector<int> prof_kid;
+};
+
+enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY, KID_COUNT };
+static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_select", "k_mask_annotate", "k_hinge_call", "k_hinge_exact",
+                                                     "k_coverage_bins", "k_trim_classify"};
+
+struct ProfScope {
+    hinge_ctx* c;
+    bool on;
+    ProfScope(hinge_ctx* ctx, int kid) : c(ctx), on(false) {
+        if (c->prof_on && c->prof_used + 2 <= c->prof_pool.size()) {
+            on = true;
+            c->prof_kid.push_back(kid);
+            (void)hipEventRecord(c->prof_pool[c->prof_used], c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream);
+            c->prof_used += 2;
+        }
+    }
 };
 
 // device scalars, one allocation
@@ -147,6 +175,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -288,6 +317,7 @@ int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipMemsetAsync(&sc(ctx)->totals[0], 0, 2 * sizeof(unsigned long long), ctx->stream));
     const int nr = ctx->r_end - ctx->r_begin + 1;
     const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
+    ProfScope _ps(ctx, KID_STATS);
     hipLaunchKernelGGL(k_cov_stats, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, sc(ctx)->totals);
     CK(hipGetLastError());
@@ -299,8 +329,9 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
     if (rc) return rc;
     if (lo < 0 || hi >= ctx->n_reads || hi < lo) return fail(ctx, HINGE_E_ARG, "median range");
     CK(hipSetDevice(ctx->device));
+    { ProfScope _ps(ctx, KID_MEDIAN);
     hipLaunchKernelGGL(k_median_select, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov, sc(ctx)->est,
-                       &sc(ctx)->min_cov, &sc(ctx)->status);
+                       &sc(ctx)->min_cov, &sc(ctx)->status); }
     CK(hipGetLastError());
     if (out) {
         Scalars h;
@@ -317,8 +348,7 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
 
 int hinge_filter_set_min_cov(hinge_ctx* ctx, int32_t v) {
     if (!ctx) return HINGE_E_ARG;
-    CK(hipMemcpyAsync(&sc(ctx)->min_cov, &v, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemsetD32Async((hipDeviceptr_t)&sc(ctx)->min_cov, v, 1, ctx->stream));   // stream-ordered, no sync
     return HINGE_OK;
 }
 int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* v) {
@@ -336,6 +366,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipMemsetAsync(sc(ctx)->counters, 0, 2 * sizeof(unsigned), ctx->stream));
     const int nr = ctx->r_end - ctx->r_begin + 1;
     const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
+    ProfScope _ps(ctx, KID_MASK_ANNOTATE);
     hipLaunchKernelGGL(k_mask_annotate, dim3(grid), dim3(BLOCK), lds, ctx->stream, to_dev(p), ctx->r_begin, ctx->r_end,
                        (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
                        ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr, (const int*)&sc(ctx)->min_cov, kcap, ctx->mask,
@@ -371,12 +402,14 @@ static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
     CK(hipMemsetAsync(ctx->hinge_flag.p, 0, (size_t)ctx->anno_cap, ctx->stream));
     const int grid = ctx->n_cu * 2;
+    { ProfScope _ps(ctx, KID_HINGE_CALL);
     hipLaunchKernelGGL(k_hinge_call, dim3(grid), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
                        (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
-                       (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status);
+                       (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status); }
     CK(hipGetLastError());
+    ProfScope _ps2(ctx, KID_HINGE_EXACT);
     hipLaunchKernelGGL(k_hinge_exact, dim3(64), dim3(64), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int2*)ctx->exact_queue.p,
@@ -427,6 +460,7 @@ int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p) {
     if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
     CK(hipSetDevice(ctx->device));
     CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+    CK(hipMemsetD32Async((hipDeviceptr_t)&sc(ctx)->min_cov, p->min_cov, 1, ctx->stream));   // single part: MIN_COV starts at the ini value
     if ((rc = hinge_filter_stats(ctx, p))) return rc;
     if ((rc = hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, nullptr))) return rc;
     if ((rc = launch_mask_annotate(ctx, p))) return rc;
@@ -546,6 +580,58 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     int64_t nh = 0;
     for (unsigned char c : hf) nh += c;
     out[3] = nh;
+    return HINGE_OK;
+}
+
+// staged launches without the host round trip (multi-GPU pipeline: collectives sit between them);
+// capacity / range flags accumulate in the status word and are reported by hinge_filter_check.
+int hinge_filter_begin_async(hinge_ctx* ctx) {
+    if (!ctx) return HINGE_E_ARG;
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+    return HINGE_OK;
+}
+int hinge_filter_mask_annotate_async(hinge_ctx* ctx, const hinge_filter_params* p) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    return launch_mask_annotate(ctx, p);
+}
+int hinge_filter_hinges_async(hinge_ctx* ctx, const hinge_filter_params* p) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    return launch_hinges(ctx, p);
+}
+int hinge_filter_check(hinge_ctx* ctx) {
+    if (!ctx) return HINGE_E_ARG;
+    return check_status(ctx);
+}
+
+int hinge_profile_enable(hinge_ctx* ctx, int max_launches) {
+    if (!ctx) return HINGE_E_ARG;
+    CK(hipSetDevice(ctx->device));
+    ctx->prof_on = max_launches > 0;
+    ctx->prof_used = 0;
+    ctx->prof_kid.clear();
+    while (ctx->prof_pool.size() < 2 * (size_t)std::max(max_launches, 0)) {
+        hipEvent_t e;
+        CK(hipEventCreate(&e));
+        ctx->prof_pool.push_back(e);
+    }
+    return HINGE_OK;
+}
+// total milliseconds and launch count per kernel since hinge_profile_enable; arrays of hinge_profile_kernels() entries
+int hinge_profile_kernels(void) { return KID_COUNT; }
+const char* hinge_profile_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? KERNEL_NAMES[id] : ""; }
+int hinge_profile_report(hinge_ctx* ctx, double* total_ms, int64_t* count) {
+    if (!ctx || !total_ms || !count) return HINGE_E_ARG;
+    CK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < KID_COUNT; k++) { total_ms[k] = 0; count[k] = 0; }
+    for (size_t i = 0; i < ctx->prof_kid.size(); i++) {
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, ctx->prof_pool[2 * i], ctx->prof_pool[2 * i + 1]));
+        total_ms[ctx->prof_kid[i]] += ms;
+        count[ctx->prof_kid[i]] += 1;
+    }
     return HINGE_OK;
 }
 

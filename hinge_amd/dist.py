@@ -1,0 +1,215 @@
+"""Multi-GPU `hinge filter`: one process per GPU, reads sharded by DAZZ_DB block (contiguous read-id
+ranges, the unit HPC.daligner/LAmerge already emit one sorted .las for: filter.cpp:35-63,474), with
+the path's three real exchange steps as RCCL all-gathers over xGMI (torch.distributed backend "nccl";
+"gloo" on CPU in the tests):
+
+  1. per-read mean coverage  -> median / MIN_COV            (filter.cpp:642-678, a global reduction)
+  2. per-read masks          -> maskvec[B] of every B read  (filter.cpp:778-787 feeding :883-890)
+  3. hinge lists             -> global hinge list on rank 0 (the input of `hinge layout`)
+
+All three are small (4-12 bytes per read); they are latency-bound, never xGMI-bandwidth-bound, so a
+plain all-gather of equal-sized padded shards is used rather than anything bucketed.
+
+Two semantics, both exact:
+  * "merged": the result equals the reference run on ONE merged .las over all blocks (global median,
+    every mask visible).
+  * "mlas":   the result equals the reference's sequential `--mlas` loop: MIN_COV is a running max
+    over parts (prefix max over ranks) and, while part p is processed, masks of reads in later parts
+    are still (0,0).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MEAN_SENTINEL = -(2 ** 31)
+
+
+@dataclass
+class BlockTable:
+    """Read-id range [first[k], first[k+1]) of every block; block k lives on rank k % world."""
+
+    first: List[int]
+
+    @property
+    def n_blocks(self) -> int:
+        return len(self.first) - 1
+
+    @property
+    def n_reads(self) -> int:
+        return self.first[-1]
+
+    def size(self, k: int) -> int:
+        return self.first[k + 1] - self.first[k]
+
+    @property
+    def max_size(self) -> int:
+        return max(self.size(k) for k in range(self.n_blocks))
+
+
+class Exchange:
+    """The collectives of the path on equal-sized padded shards (one block per rank)."""
+
+    def __init__(self, blocks: BlockTable, device: torch.device, group=None):
+        self.blocks = blocks
+        self.device = device
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert blocks.n_blocks == self.world, "one block per rank"
+        self.S = blocks.max_size
+
+    @property
+    def my_range(self) -> Tuple[int, int]:
+        return self.blocks.first[self.rank], self.blocks.first[self.rank + 1]
+
+    def all_gather_rows(self, table: torch.Tensor) -> None:
+        """table[n_reads, ...]: every rank has filled the rows of its own block; on return every rank
+        holds all rows.  One all_gather_into_tensor of world x S padded rows."""
+        if self.world == 1:
+            return
+        lo, hi = self.my_range
+        tail = table.shape[1:]
+        send = torch.zeros((self.S,) + tuple(tail), dtype=table.dtype, device=table.device)
+        send[: hi - lo] = table[lo:hi]
+        recv = torch.empty((self.world * self.S,) + tuple(tail), dtype=table.dtype, device=table.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        for k in range(self.world):
+            a, b = self.blocks.first[k], self.blocks.first[k + 1]
+            if k != self.rank:
+                table[a:b] = recv[k * self.S: k * self.S + (b - a)]
+
+    def all_gather_scalar(self, v: int) -> List[int]:
+        if self.world == 1:
+            return [int(v)]
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+        out = torch.empty(self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return [int(x) for x in out.cpu().tolist()]
+
+    def gather_lists(self, rows: torch.Tensor, count: int) -> Optional[torch.Tensor]:
+        """Variable-length int32 row lists (e.g. (read, pos, type) hinges) -> concatenated in rank order
+        on every rank: counts all-gather, then one padded all-gather."""
+        if self.world == 1:
+            return rows[:count]
+        counts = self.all_gather_scalar(count)
+        cap = max(max(counts), 1)
+        send = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        send[:count] = rows[:count]
+        recv = torch.empty((self.world * cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return torch.cat([recv[k * cap: k * cap + counts[k]] for k in range(self.world)], dim=0)
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+
+def mlas_min_cov(ini_min_cov: int, cov_ests: Sequence[int], est_cov_override: int = 0) -> List[int]:
+    """MIN_COV seen by each part of the sequential --mlas loop: a running max (filter.cpp:671-678)."""
+    out, m = [], ini_min_cov
+    for c in cov_ests:
+        if est_cov_override != 0:
+            c = est_cov_override
+        q = int(c / 3) if c >= 0 else -int(-c / 3)    # C division truncates toward zero
+        if m < q:
+            m = q
+        out.append(m)
+    return out
+
+
+class ShardedFilter:
+    """One rank's share of a sharded `hinge filter` pass.
+
+    `backend` does the per-block compute; the product backend is HipBackend below (HIP kernels through
+    the C ABI).  Tests may pass another object with the same four methods to exercise the exchange
+    logic on CPU with gloo.
+    """
+
+    def __init__(self, backend, exchange: Exchange, mode: str = "merged"):
+        assert mode in ("merged", "mlas")
+        self.b = backend
+        self.x = exchange
+        self.mode = mode
+        n = exchange.blocks.n_reads
+        dev = exchange.device
+        self.mean_cov = torch.full((n,), MEAN_SENTINEL, dtype=torch.int32, device=dev)
+        self.mask = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        self.b.attach(self.mean_cov, self.mask)
+
+    def step(self, fetch_hinges: bool = True):
+        x, b = self.x, self.b
+        lo, hi = x.my_range
+        b.begin()
+        b.stats()                                   # fills mean_cov[lo:hi]
+        if self.mode == "merged":
+            x.all_gather_rows(self.mean_cov)        # exchange 1
+            b.median(0, x.blocks.n_reads - 1)       # same global median on every rank (device side)
+        else:
+            est = b.median_fetch(lo, hi - 1)        # per-part median (host scalar)
+            ests = x.all_gather_scalar(est)         # exchange 1 (8 bytes per rank)
+            b.set_min_cov(mlas_min_cov(b.ini_min_cov, ests, b.est_cov)[x.rank])
+        b.mask_annotate()                           # fills mask[lo:hi]
+        x.all_gather_rows(self.mask)                # exchange 2
+        if self.mode == "mlas" and hi < x.blocks.n_reads:
+            self.mask[hi:] = 0                      # later parts are not masked yet when part p runs
+        b.hinges()
+        if not fetch_hinges:
+            return None
+        rows, count = b.hinge_rows()                # (read, pos, type) int32 rows on the device
+        return x.gather_lists(rows, count)          # exchange 3
+
+
+class HipBackend:
+    """Per-block compute through libhinge_hip (HIP kernels); tensors are torch CUDA tensors."""
+
+    def __init__(self, ctx, params, rlen: np.ndarray, qv_mask: Optional[np.ndarray], r_begin: int, r_end: int,
+                 row_ptr: torch.Tensor, a_span: torch.Tensor, b_span: torch.Tensor, b_flag: torch.Tensor):
+        self.ctx, self.p = ctx, params
+        self.ini_min_cov = int(params.min_cov)
+        self.est_cov = int(params.est_cov)
+        self.r_begin, self.r_end = r_begin, r_end
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_reads(rlen, qv_mask)
+        self._tensors = (row_ptr, a_span, b_span, b_flag)
+        ctx.set_pileups(r_begin, r_end, row_ptr, a_span, b_span, b_flag, n_ovl=int(b_flag.shape[0]), on_device=True)
+        ctx.set_min_cov(self.ini_min_cov)
+
+    def attach(self, mean_cov: torch.Tensor, mask: torch.Tensor):
+        self.mean_cov, self.mask = mean_cov, mask
+        self.ctx.attach_mean_cov(mean_cov)
+        self.ctx.attach_mask_table(mask)
+
+    def begin(self):
+        self.ctx.set_min_cov(self.ini_min_cov)    # stream-ordered 4-byte set, no host sync
+        self.ctx.begin_async()
+
+    def stats(self):
+        self.ctx.filter_stats(self.p)
+
+    def median(self, lo: int, hi: int):
+        self.ctx.filter_median(self.p, lo, hi, fetch=False)
+
+    def median_fetch(self, lo: int, hi: int) -> int:
+        return int(self.ctx.filter_median(self.p, lo, hi, fetch=True).cov_est)
+
+    def set_min_cov(self, v: int):
+        self.ctx.set_min_cov(v)
+
+    def mask_annotate(self):
+        self.ctx.filter_mask_annotate_async(self.p)
+
+    def hinges(self):
+        self.ctx.filter_hinges_async(self.p)
+
+    def hinge_rows(self):
+        off, pos, typ, ish = self.ctx.get_annotations()
+        reads = np.repeat(np.arange(self.r_begin, self.r_end + 1, dtype=np.int32), np.diff(off).astype(np.int64))
+        sel = ish.astype(bool)
+        rows = np.stack([reads[sel], pos[sel], typ[sel]], axis=1).astype(np.int32) if sel.any() else np.zeros((0, 3), np.int32)
+        t = torch.from_numpy(np.ascontiguousarray(rows)).to(self.mask.device)
+        return t, int(t.shape[0])

@@ -216,18 +216,21 @@ def write_las(path: str, recs: LasRecords) -> None:
     rec_b = recs.rec.view(np.uint8).reshape(novl, 40) if novl else np.zeros((0, 40), np.uint8)
     tlen_b = (recs.trace_off[1:] - recs.trace_off[:-1]).astype(np.int64)
     assert np.array_equal(tlen_b, recs.rec["tlen"].astype(np.int64) * tbytes)
-    # interleave records and traces into one byte buffer
+    # interleave records and traces into one byte buffer: both keep their relative order, so a
+    # boolean "is header byte" mask places them without per-byte index arrays
     out_off = np.concatenate([[0], np.cumsum(40 + tlen_b)]).astype(np.int64)
-    buf = np.zeros(int(out_off[-1]), dtype=np.uint8)
+    total = int(out_off[-1])
+    buf = np.zeros(total, dtype=np.uint8)
     if novl:
-        idx = out_off[:-1, None] + np.arange(40)[None, :]
-        buf[idx.reshape(-1)] = rec_b.reshape(-1)
-        # trace bytes: destination = out_off[i] + 40 + k
-        tot = int(tlen_b.sum())
-        if tot:
-            owner = np.repeat(np.arange(novl), tlen_b)
-            within = np.arange(tot) - np.repeat(recs.trace_off[:-1], tlen_b)
-            buf[out_off[owner] + 40 + within] = recs.trace
+        marker = np.zeros(total + 1, dtype=np.int8)
+        marker[out_off[:-1]] = 1
+        if tlen_b.min() > 0:
+            marker[out_off[:-1] + 40] = -1
+        else:
+            np.add.at(marker, out_off[:-1] + 40, -1)  # a zero-length trace makes two records adjacent
+        is_hdr = np.cumsum(marker[:-1], dtype=np.int8).astype(bool)
+        buf[is_hdr] = rec_b.reshape(-1)
+        buf[~is_hdr] = recs.trace
     with open(path, "wb") as f:
         f.write(struct.pack("<qi", novl, recs.tspace))
         f.write(buf.tobytes())

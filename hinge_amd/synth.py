@@ -79,11 +79,19 @@ def _expand_pairs(t0: np.ndarray, t1: np.ndarray, min_ovl: int):
     if tot == 0:
         z = np.zeros(0, np.int64)
         return z, z
-    i_idx = np.repeat(np.arange(n, dtype=np.int64), cnt)
-    start = np.repeat(np.cumsum(cnt) - cnt, cnt)
-    j_idx = np.repeat(lo.astype(np.int64), cnt) + (np.arange(tot, dtype=np.int64) - start)
-    ok = (np.minimum(s1[i_idx], s1[j_idx]) - s0[j_idx]) >= min_ovl
+    idt = np.int32 if tot < 2**31 - 1 and n < 2**31 - 1 else np.int64
+    i_idx = np.repeat(np.arange(n, dtype=idt), cnt)
+    # j runs lo[i] .. hi[i]-1 within each i group: global arange minus the group's start offset
+    shift = (lo.astype(np.int64) - (np.cumsum(cnt) - cnt))
+    j_idx = (np.arange(tot, dtype=np.int64) + np.repeat(shift, cnt)).astype(idt)
+    s0c = s0.astype(np.int32) if s1.max() < 2**31 - 1 else s0
+    s1c = s1.astype(np.int32) if s1.max() < 2**31 - 1 else s1
+    ok = (np.minimum(s1c[i_idx], s1c[j_idx]) - s0c[j_idx]) >= min_ovl
     return order[i_idx[ok]], order[j_idx[ok]]
+
+
+def d_bits_ok(n_reads: int, max_len: int) -> bool:
+    return 2 * int(n_reads).bit_length() + 1 + int(max_len).bit_length() + 1 <= 62
 
 
 def generate(spec: SynthSpec) -> SynthData:
@@ -243,7 +251,14 @@ def generate(spec: SynthSpec) -> SynthData:
     aread, bread, ab, ae, bb, be, comp = (v[ok] for v in (aread, bread, ab, ae, bb, be, comp))
 
     # LAsort order: (aread, bread, comp, abpos)
-    order = np.lexsort((ab, comp, bread, aread))
+    if d_bits_ok(len(rl), int(rl.max())):
+        kb = int(len(rl)).bit_length()
+        pb = int(rl.max()).bit_length() + 1
+        key = (((aread.astype(np.int64) << kb) | bread.astype(np.int64)) << 1 | comp.astype(np.int64)) << pb | ab.astype(np.int64)
+        order = np.argsort(key, kind="stable")
+        del key
+    else:
+        order = np.lexsort((ab, comp, bread, aread))
     aread, bread, ab, ae, bb, be, comp = (v[order] for v in (aread, bread, ab, ae, bb, be, comp))
 
     # every read needs >= 1 overlap at both ends of the id range (the reference leaves reads
@@ -268,31 +283,43 @@ def generate(spec: SynthSpec) -> SynthData:
 
 
 def make_traces(d: SynthData, sel: Optional[np.ndarray] = None):
-    """(diffs, b-advance) byte pairs per tspace-segment of A (src/include/align.h:98-110)."""
+    """(diffs, b-advance) byte pairs per tspace-segment of A (src/include/align.h:98-110).
+
+    Interior segments advance A by exactly tspace, so only the first and last pair of every overlap
+    need per-record arithmetic; the B-side length difference (<= indel_max) is spread one base per
+    segment from the front."""
     ts = d.spec.tspace
-    ab = d.ab if sel is None else d.ab[sel]
-    ae = d.ae if sel is None else d.ae[sel]
-    bb = d.bb if sel is None else d.bb[sel]
-    be = d.be if sel is None else d.be[sel]
-    nseg = ((ae.astype(np.int64) + ts - 1) // ts - ab.astype(np.int64) // ts)
-    tot = int(nseg.sum())
+    ab = (d.ab if sel is None else d.ab[sel]).astype(np.int64)
+    ae = (d.ae if sel is None else d.ae[sel]).astype(np.int64)
+    bb = (d.bb if sel is None else d.bb[sel]).astype(np.int64)
+    be = (d.be if sel is None else d.be[sel]).astype(np.int64)
+    n = len(ab)
+    nseg = (ae + ts - 1) // ts - ab // ts
     off = np.concatenate([[0], np.cumsum(nseg)]).astype(np.int64)
-    owner = np.repeat(np.arange(len(ab), dtype=np.int64), nseg)
-    k = np.arange(tot, dtype=np.int64) - off[owner]
-    base = (ab[owner].astype(np.int64) // ts) * ts
-    a0 = np.maximum(base + k * ts, ab[owner])
-    a1 = np.minimum(base + (k + 1) * ts, ae[owner])
-    alen = a1 - a0
-    diff = (be.astype(np.int64) - bb) - (ae.astype(np.int64) - ab)      # <= 0 by construction
-    adj = np.where(k < np.abs(diff)[owner], np.sign(diff)[owner], 0)
-    adv = alen + adj
-    # put any remainder (|diff| > nseg) on the last segment
-    rem = np.sign(diff) * np.maximum(np.abs(diff) - nseg, 0)
-    last = off[1:] - 1
-    adv[last] += rem
-    assert adv.min() >= 0 and adv.max() <= 255, (adv.min(), adv.max())
-    tr = np.zeros(2 * tot, dtype=np.uint8)
-    tr[0::2] = np.minimum(alen // 8, 255).astype(np.uint8)
+    tot = int(off[-1])
+    base = (ab // ts) * ts
+    first_len = np.where(nseg == 1, ae - ab, base + ts - ab)
+    last_len = np.where(nseg == 1, ae - ab, ae - (base + (nseg - 1) * ts))
+    adv = np.full(tot, ts, dtype=np.int16)
+    dif = np.full(tot, ts // 8, dtype=np.uint8)
+    if n:
+        adv[off[:-1]] = first_len
+        adv[off[1:] - 1] = last_len
+        dif[off[:-1]] = first_len // 8
+        dif[off[1:] - 1] = last_len // 8
+        diff = (be - bb) - (ae - ab)
+        mag = np.abs(diff)
+        sgn = np.sign(diff).astype(np.int16)
+        for j in range(int(min(mag.max(), nseg.max()))):
+            m = (mag > j) & (nseg > j)
+            adv[off[:-1][m] + j] += sgn[m]
+        rem = np.maximum(mag - nseg, 0)
+        if rem.any():
+            m = rem > 0
+            adv[off[1:][m] - 1] += (sgn[m] * rem[m]).astype(np.int16)
+        assert adv.min() >= 0 and adv.max() <= 255, (adv.min(), adv.max())
+    tr = np.empty(2 * tot, dtype=np.uint8)
+    tr[0::2] = dif
     tr[1::2] = adv.astype(np.uint8)
     return tr, (2 * off).astype(np.int64)
 

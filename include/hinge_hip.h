@@ -125,6 +125,21 @@ int hinge_filter_coverage_bins(hinge_ctx* ctx, int32_t r0, int32_t r1, int32_t r
  * the exact (std::sort-replaying) path, [2] total annotations, [3] total hinges.                  */
 int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
 
+/* Staged launches with no host round trip, for pipelines that put a collective between the stages
+ * (multi-GPU): begin clears the status word, check reports HINGE_E_* flags raised since begin.     */
+int hinge_filter_begin_async(hinge_ctx* ctx);
+int hinge_filter_mask_annotate_async(hinge_ctx* ctx, const hinge_filter_params* p);
+int hinge_filter_hinges_async(hinge_ctx* ctx, const hinge_filter_params* p);
+int hinge_filter_check(hinge_ctx* ctx);
+
+/* Per-kernel timing with HIP events recorded around every launch on the context's stream.
+ * enable(max_launches > 0) starts a fresh recording; report() synchronises and returns total ms and
+ * launch count per kernel id in [0, hinge_profile_kernels()).                                     */
+int hinge_profile_enable(hinge_ctx* ctx, int max_launches);
+int hinge_profile_kernels(void);
+const char* hinge_profile_kernel_name(int id);
+int hinge_profile_report(hinge_ctx* ctx, double* total_ms, int64_t* count);
+
 /* ---- device event timing helper for bench.py (HIP events on the ctx stream) -------------------- */
 int hinge_timer_start(hinge_ctx* ctx);
 int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms);
