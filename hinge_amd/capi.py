@@ -61,7 +61,6 @@ SYMBOLS = [
     ("hinge_filter_get_annotations", C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     ("hinge_filter_coverage_bins", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
     ("hinge_filter_counters", C.c_int, [_VP, _VP]),
-    ("hinge_filter_begin_async", C.c_int, [_VP]),
     ("hinge_filter_mask_annotate_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_hinges_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_check", C.c_int, [_VP]),
@@ -94,6 +93,7 @@ def load_library() -> C.CDLL:
 
 EXTRA_SYMBOLS = [
     ("hinge_debug_force_exact", C.c_int, [_VP, C.c_int]),
+    ("hinge_debug_pileup_order", C.c_int, [_VP, C.c_int32, _VP, _VP]),
 ]
 
 
@@ -171,8 +171,15 @@ class Context:
     def clear_masks(self):
         self._ck(self.lib.hinge_clear_masks(self.h))
 
-    def force_exact(self, on: bool):
-        self._ck(self.lib.hinge_debug_force_exact(self.h, 1 if on else 0))
+    def force_exact(self, mode):
+        """0 normal, 1 everything through k_hinge_exact, 2 always use the in-kernel exact pile-up order."""
+        self._ck(self.lib.hinge_debug_force_exact(self.h, int(mode)))
+
+    def debug_pileup_order(self, keys: np.ndarray) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        pos = np.zeros(max(len(keys), 1), np.int32)
+        self._ck(self.lib.hinge_debug_pileup_order(self.h, len(keys), _ptr(keys), _ptr(pos)))
+        return pos[:len(keys)]
 
     # ---- filter -------------------------------------------------------------------------------
     def filter_stats(self, p: FilterParams):
@@ -232,9 +239,6 @@ class Context:
         out = np.zeros(4, np.int64)
         self._ck(self.lib.hinge_filter_counters(self.h, _ptr(out)))
         return out
-
-    def begin_async(self):
-        self._ck(self.lib.hinge_filter_begin_async(self.h))
 
     def filter_mask_annotate_async(self, p: FilterParams):
         self._ck(self.lib.hinge_filter_mask_annotate_async(self.h, C.byref(p)))

@@ -1,14 +1,16 @@
 // HIP kernels (gfx950 / CDNA4) of the `hinge filter` hot path.  Integer / indexing work, HBM-bound:
 // no MFMA.  One 64-lane wavefront owns one A read; its pile-up is streamed with coalesced 8-byte
-// loads, turned into difference histograms with LDS atomics, prefix-scanned with wavefront shuffles,
+// loads, turned into difference histograms with LDS atomics, prefix-scanned with DPP row shifts,
 // and the mask / annotation / gate logic runs on the scanned bins while they are still in LDS.
 //
 // Reference semantics restated per kernel (file:line under /root/reference/src):
 //   k_cov_stats       profileCoverage(cutoff 0) sums as used by filter/filter.cpp:642-656
-//   k_median_select   nth_element median + MIN_COV update, filter/filter.cpp:660-678
+//   k_median_hist /   nth_element median + MIN_COV update, filter/filter.cpp:660-678
+//   k_median_select
 //   k_mask_annotate   filter/filter.cpp:696-829 and the gate of :842-865
-//   k_hinge_call      filter/filter.cpp:867-1068 (order-insensitive fast path)
-//   k_hinge_exact     the same, replaying std::sort exactly (filter.cpp:565-567,914,1010)
+//   k_hinge_call      filter/filter.cpp:867-1068, tie order of std::sort replayed in LDS
+//   k_hinge_exact     the same for the rare cases that need the whole pile-up's std::sort order
+//                     (filter.cpp:565-567) or overflow the LDS lists
 //   k_coverage_bins   lib/LAInterface.cpp:4298-4320 (materialised bins for .coverage.txt)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -21,8 +23,9 @@ namespace hinge {
 constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = WAVE * WAVES_PER_BLOCK;
-constexpr int SUP_CAP = 1024;           // supporters per annotation kept in LDS (per wave)
 constexpr int MEAN_SENTINEL = INT_MIN;  // mean_cov of reads that do not enter the median
+
+constexpr int MED_BINS = 4096;  // one-pass median histogram range
 
 // status word bits (device -> host)
 constexpr int ST_RANGE = 1;        // bin index beyond the LDS histogram
@@ -41,59 +44,73 @@ struct FilterDev {   // device copy of hinge_filter_params + derived values
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+template <int RESO>
 __device__ __forceinline__ int bin_of(int v, int reso) {
     // index of the first bin k with v < k*reso  (profileCoverage consumes events `< i*reso`)
     if (v < 0) return 0;
-    return (reso == 40 ? v / 40 : v / reso) + 1;
+    if constexpr (RESO > 0) return v / RESO + 1;   // reso is 40 in the reference (filter.cpp:386): constant division
+    else return v / reso + 1;
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+// ---- wavefront primitives on DPP (no LDS round trips) ------------------------------------------
+// dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_old(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v) {   // inclusive +scan over the 64 lanes
+    v += dpp_or_old<0x111, 0xf>(0, v);
+    v += dpp_or_old<0x112, 0xf>(0, v);
+    v += dpp_or_old<0x114, 0xf>(0, v);
+    v += dpp_or_old<0x118, 0xf>(0, v);
+    v += dpp_or_old<0x142, 0xa>(0, v);
+    v += dpp_or_old<0x143, 0xc>(0, v);
     return v;
 }
+__device__ __forceinline__ int wave_incl_max_scan(int v) {
+    v = max(v, dpp_or_old<0x111, 0xf>(INT_MIN, v));
+    v = max(v, dpp_or_old<0x112, 0xf>(INT_MIN, v));
+    v = max(v, dpp_or_old<0x114, 0xf>(INT_MIN, v));
+    v = max(v, dpp_or_old<0x118, 0xf>(INT_MIN, v));
+    v = max(v, dpp_or_old<0x142, 0xa>(INT_MIN, v));
+    v = max(v, dpp_or_old<0x143, 0xc>(INT_MIN, v));
+    return v;
+}
+__device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readlane(v, WAVE - 1); }
+__device__ __forceinline__ int wave_sum(int v) { return wave_last(wave_incl_scan(v)); }
+__device__ __forceinline__ int wave_max(int v) { return wave_last(wave_incl_max_scan(v)); }
 __device__ __forceinline__ long long wave_sum64(long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return v;
+    // 64-bit sum as two 32-bit scans with carry: low words summed as unsigned halves
+    const unsigned lo = (unsigned)v;
+    const int hi = (int)(v >> 32);
+    const int s_lo16 = wave_sum((int)(lo & 0xffffu));
+    const int s_hi16 = wave_sum((int)(lo >> 16));
+    const int s_hi = wave_sum(hi);
+    return ((long long)s_hi << 32) + ((long long)(unsigned)s_hi16 << 16) + (long long)(unsigned)s_lo16;
 }
 __device__ __forceinline__ long long wave_max64(long long v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { long long t = __shfl_xor(v, d); v = t > v ? t : v; }
     return v;
 }
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_incl_max_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int t = __shfl_up(v, d);
-        if (lane >= d) v = max(v, t);
-    }
-    return v;
+__device__ __forceinline__ int shfl_up1(int v, int fill) {   // lane l gets lane l-1, lane 0 gets fill
+    int t = __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    return t;
 }
 
+template <int RESO>
 __device__ __forceinline__ int nbins_of(int n_ovl, int max_ev, int reso) {
     // K of profileCoverage: 0 for an empty pile-up, else one bin past the one that consumes max_ev
     if (n_ovl == 0) return 0;
-    return bin_of(max_ev, reso) + 1;
+    return bin_of<RESO>(max_ev, reso) + 1;
 }
 
 // ------------------------------------------------------------------------------------------------
 // K1: per-read cutoff-0 coverage sum and bin count without materialising the bins:
 //     sum_k cov[k] = sum_o (bin_of(aepos) - bin_of(abpos)),  K = bin_of(max event) + 1.
 // ------------------------------------------------------------------------------------------------
+template <int RESO>
 __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                      const int2* __restrict__ a_span, const int* __restrict__ rlen, int reso,
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
@@ -102,36 +119,46 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
     const int wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * BLOCK) >> 6;
     long long blk_cov = 0, blk_slot = 0;
-    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        long long sum = 0;
+    int i = r_begin + wave;
+    int64_t s = 0, e = 0;
+    int rl = 0;
+    if (i <= r_end) { s = row_ptr[i]; e = row_ptr[i + 1]; rl = rlen[i]; }
+    while (i <= r_end) {
+        // prefetch the next read's row while this one streams
+        const int inext = i + nwaves;
+        int64_t sn = 0, en = 0;
+        int rln = 0;
+        if (inext <= r_end) { sn = row_ptr[inext]; en = row_ptr[inext + 1]; rln = rlen[inext]; }
+        int sum = 0;
         int mx = INT_MIN;
         int64_t k = s + lane;
-        for (; k + WAVE < e; k += 2 * WAVE) {   // two loads in flight per lane
-            int2 v0 = a_span[k];
-            int2 v1 = a_span[k + WAVE];
-            sum += (bin_of(v0.y, reso) - bin_of(v0.x, reso)) + (bin_of(v1.y, reso) - bin_of(v1.x, reso));
-            mx = max(mx, max(max(v0.x, v0.y), max(v1.x, v1.y)));
+        for (; k + 3 * WAVE < e; k += 4 * WAVE) {   // four loads in flight per lane
+            const int2 v0 = a_span[k], v1 = a_span[k + WAVE], v2 = a_span[k + 2 * WAVE], v3 = a_span[k + 3 * WAVE];
+            sum += (bin_of<RESO>(v0.y, reso) - bin_of<RESO>(v0.x, reso)) + (bin_of<RESO>(v1.y, reso) - bin_of<RESO>(v1.x, reso)) +
+                   (bin_of<RESO>(v2.y, reso) - bin_of<RESO>(v2.x, reso)) + (bin_of<RESO>(v3.y, reso) - bin_of<RESO>(v3.x, reso));
+            mx = max(max(mx, max(max(v0.x, v0.y), max(v1.x, v1.y))), max(max(v2.x, v2.y), max(v3.x, v3.y)));
         }
-        if (k < e) {
-            int2 v0 = a_span[k];
-            sum += bin_of(v0.y, reso) - bin_of(v0.x, reso);
+        for (; k < e; k += WAVE) {
+            const int2 v0 = a_span[k];
+            sum += bin_of<RESO>(v0.y, reso) - bin_of<RESO>(v0.x, reso);
             mx = max(mx, max(v0.x, v0.y));
         }
-        sum = wave_sum64(sum);
+        // per-lane partial sums fit 32 bits (<= 2^31 / 64 bins*overlaps per lane); widen for the total
+        const long long tot = wave_sum64((long long)sum);
         mx = wave_max(mx);
         if (lane == 0) {
-            const int K = nbins_of((int)(e - s), mx, reso);
+            const int K = nbins_of<RESO>((int)(e - s), mx, reso);
             nbins0[i] = K;
-            if (rlen[i] >= 5000) {
-                long long m = sum / (long long)max(1, K);   // C division, filter.cpp:654
+            if (rl >= 5000) {
+                const long long m = tot / (long long)max(1, K);   // C division, filter.cpp:654
                 mean_cov[i] = (int)m;
-                blk_cov += sum;
+                blk_cov += tot;
                 blk_slot += K;
             } else {
                 mean_cov[i] = MEAN_SENTINEL;
             }
         }
+        i = inext; s = sn; e = en; rl = rln;
     }
     if (lane == 0 && (blk_cov != 0 || blk_slot != 0)) {
         atomicAdd(&totals[0], (unsigned long long)blk_cov);
@@ -140,11 +167,87 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// Median select (one workgroup, 4-pass 8-bit radix select over the non-sentinel means) and the
-// MIN_COV update.  est[0]=cov_est est[1]=n_long.
+// Median, fast path: one multi-block pass.  Every block histograms its slice of mean_cov into LDS
+// (values 0..MED_BINS-1), merges into a global histogram, and the last block to finish walks the
+// histogram to the element of rank n/2, applies the MIN_COV update and clears the scratch for the
+// next launch.  Values outside the range set med[MED_BINS+2] and leave the job to k_median_select.
+// med layout: [0..MED_BINS) histogram, [MED_BINS] valid count, [MED_BINS+1] blocks done,
+//             [MED_BINS+2] out-of-range flag, [MED_BINS+3] "median already written" flag
 // ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
+                                                     unsigned* __restrict__ med, int* __restrict__ est, int* __restrict__ min_cov,
+                                                     int* __restrict__ status) {
+    __shared__ unsigned hist[MED_BINS];
+    __shared__ unsigned s_valid, s_oor, s_last;
+    const int tid = threadIdx.x;
+    for (int b = tid; b < MED_BINS; b += blockDim.x) hist[b] = 0;
+    if (tid == 0) { s_valid = 0; s_oor = 0; s_last = 0; }
+    __syncthreads();
+    unsigned nv = 0, oor = 0;
+    for (int i = lo + blockIdx.x * blockDim.x + tid; i <= hi; i += gridDim.x * blockDim.x) {
+        const int v = mean_cov[i];
+        if (v == MEAN_SENTINEL) continue;
+        nv++;
+        if (v >= 0 && v < MED_BINS) atomicAdd(&hist[v], 1u);
+        else oor = 1;
+    }
+    if (nv) atomicAdd(&s_valid, nv);
+    if (oor) atomicOr(&s_oor, 1u);
+    __syncthreads();
+    for (int b = tid; b < MED_BINS; b += blockDim.x)
+        if (hist[b]) atomicAdd(&med[b], hist[b]);
+    if (tid == 0) {
+        if (s_valid) atomicAdd(&med[MED_BINS], s_valid);
+        if (s_oor) atomicOr(&med[MED_BINS + 2], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(&med[MED_BINS + 1], 1u);
+        s_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // last block: all merges are visible at device scope; read them back with agent-scope loads
+    for (int b = tid; b < MED_BINS; b += blockDim.x) {
+        hist[b] = __hip_atomic_load(&med[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        med[b] = 0;   // clean for the next launch
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned nvalid = __hip_atomic_load(&med[MED_BINS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned bad = __hip_atomic_load(&med[MED_BINS + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        med[MED_BINS] = 0; med[MED_BINS + 1] = 0; med[MED_BINS + 2] = 0;
+        if (nvalid == 0) {
+            est[0] = 0; est[1] = 0;
+            atomicOr(status, ST_NO_LONG_READ);
+            med[MED_BINS + 3] = 1;
+        } else if (bad) {
+            med[MED_BINS + 3] = 0;   // k_median_select does the general case
+        } else {
+            unsigned r = nvalid / 2;   // median_id = size/2, filter.cpp:660
+            int b = 0;
+            for (; b < MED_BINS; ++b) {
+                if (r < hist[b]) break;
+                r -= hist[b];
+            }
+            int cov_est = b;
+            est[0] = cov_est;
+            est[1] = (int)nvalid;
+            if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
+            if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;       // filter.cpp:677-678
+            med[MED_BINS + 3] = 1;
+        }
+    }
+}
+
+// General median (any int32 values): one workgroup, 4-pass 8-bit radix select.  Returns at once
+// when k_median_hist already produced the answer.
 __global__ __launch_bounds__(1024) void k_median_select(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
-                                                        int* __restrict__ est, int* __restrict__ min_cov, int* __restrict__ status) {
+                                                        const unsigned* __restrict__ med, int* __restrict__ est,
+                                                        int* __restrict__ min_cov, int* __restrict__ status) {
+    if (med[MED_BINS + 3] != 0) return;
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_rank, s_nvalid;
     const int tid = threadIdx.x;
@@ -159,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_median_select(const int* __restrict__ 
         if (tid == 0) { est[0] = 0; est[1] = 0; atomicOr(status, ST_NO_LONG_READ); }
         return;
     }
-    if (tid == 0) { s_prefix = 0; s_rank = nvalid / 2; }   // median_id = size/2, filter.cpp:660
+    if (tid == 0) { s_prefix = 0; s_rank = nvalid / 2; }
     __syncthreads();
     for (int pass = 3; pass >= 0; --pass) {
         if (tid < 256) hist[tid] = 0;
@@ -188,8 +291,8 @@ __global__ __launch_bounds__(1024) void k_median_select(const int* __restrict__ 
         int cov_est = (int)(s_prefix ^ 0x80000000u);
         est[0] = cov_est;
         est[1] = (int)nvalid;
-        if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
-        if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;       // filter.cpp:677-678
+        if (est_cov_override != 0) cov_est = est_cov_override;
+        if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;
     }
 }
 
@@ -198,12 +301,14 @@ __global__ __launch_bounds__(1024) void k_median_select(const int* __restrict__ 
 // LDS per wave: h0[kcap] (cutoff-0 difference histogram -> coverage), hc[kcap] (cutoff CUT_OFF;
 // reused as the candidate-annotation list once the mask is known).
 // ------------------------------------------------------------------------------------------------
+template <int RESO>
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                          const int2* __restrict__ a_span, const int* __restrict__ rlen,
                                                          const int2* __restrict__ qv_mask, const int* __restrict__ d_min_cov, int kcap,
                                                          int2* __restrict__ mask, int2* __restrict__ cmask,
                                                          unsigned char* __restrict__ rflags, int2* __restrict__ anno_buf,
-                                                         unsigned* __restrict__ anno_off, int* __restrict__ anno_cnt,
+                                                         unsigned char* __restrict__ hinge_flag, unsigned* __restrict__ anno_off,
+                                                         int* __restrict__ anno_cnt,
                                                          unsigned* __restrict__ counters /*[0]=anno alloc [1]=work count*/,
                                                          unsigned anno_cap, int* __restrict__ work_list, int* __restrict__ status) {
     extern __shared__ int lds[];
@@ -216,34 +321,51 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
     const int MIN_COV = *d_min_cov;
     const int reso = P.reso;
 
-    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+    int i = r_begin + wave;
+    int64_t s = 0, e = 0;
+    int rl = 0;
+    if (i <= r_end) { s = row_ptr[i]; e = row_ptr[i + 1]; rl = rlen[i]; }
+    while (i <= r_end) {
+        const int inext = i + nwaves;
+        int64_t sn = 0, en = 0;
+        int rln = 0;
+        if (inext <= r_end) { sn = row_ptr[inext]; en = row_ptr[inext + 1]; rln = rlen[inext]; }
         const int n = (int)(e - s);
+        // first chunk of the pile-up is requested before the histogram is cleared
+        int64_t k = s + lane;
+        int2 v = make_int2(0, 0);
+        if (k < e) v = a_span[k];
         // bins this read can touch: events are <= rlen + cut_off for well-formed input
-        int kb = bin_of(rlen[i] + max(P.cut_off, 0), reso) + 2;
+        int kb = bin_of<RESO>(rl + max(P.cut_off, 0), reso) + 2;
         kb = min(kb, kcap);
-        for (int k = lane; k < kb; k += WAVE) { h0[k] = 0; hc[k] = 0; }
+        for (int t = lane; t < kb; t += WAVE) { h0[t] = 0; hc[t] = 0; }
         int mx0 = INT_MIN, mxc = INT_MIN;
         bool oob = false;
-        for (int64_t k = s + lane; k < e; k += WAVE) {
-            const int2 v = a_span[k];
-            const int b0 = bin_of(v.x, reso), b1 = bin_of(v.y, reso);
-            const int c0 = bin_of(v.x + P.cut_off, reso), c1 = bin_of(v.y - P.cut_off, reso);
-            if (max(max(b0, b1), max(c0, c1)) >= kb) { oob = true; continue; }
-            atomicAdd(&h0[b0], 1);
-            atomicAdd(&h0[b1], -1);
-            atomicAdd(&hc[c0], 1);
-            atomicAdd(&hc[c1], -1);
-            mx0 = max(mx0, max(v.x, v.y));
-            mxc = max(mxc, max(v.x + P.cut_off, v.y - P.cut_off));
+        while (k < e) {
+            const int64_t kn = k + WAVE;
+            int2 vn = make_int2(0, 0);
+            if (kn < e) vn = a_span[kn];
+            const int b0 = bin_of<RESO>(v.x, reso), b1 = bin_of<RESO>(v.y, reso);
+            const int c0 = bin_of<RESO>(v.x + P.cut_off, reso), c1 = bin_of<RESO>(v.y - P.cut_off, reso);
+            if (max(max(b0, b1), max(c0, c1)) >= kb) {
+                oob = true;
+            } else {
+                atomicAdd(&h0[b0], 1);
+                atomicAdd(&h0[b1], -1);
+                atomicAdd(&hc[c0], 1);
+                atomicAdd(&hc[c1], -1);
+                mx0 = max(mx0, max(v.x, v.y));
+                mxc = max(mxc, max(v.x + P.cut_off, v.y - P.cut_off));
+            }
+            k = kn; v = vn;
         }
         if (__any(oob)) {
             if (lane == 0) atomicOr(status, ST_RANGE);
         }
         mx0 = wave_max(mx0);
         mxc = wave_max(mxc);
-        const int K0 = nbins_of(n, mx0, reso);
-        const int KC = nbins_of(n, mxc, reso);
+        const int K0 = nbins_of<RESO>(n, mx0, reso);
+        const int KC = nbins_of<RESO>(n, mxc, reso);
 
         // ---- coverage mask on the cutoff bins (filter.cpp:696-728) ------------------------------
         // scan hc in place; track, per bin, the last non-positive bin before it
@@ -253,30 +375,28 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         long long best = 0;   // (len << 32) | (0x7fffffff - j): first longest run wins
         for (int base = 0; base < KC; base += WAVE) {
             const int j = base + lane;
-            int v = j < KC ? hc[j] : 0;
-            v = wave_incl_scan(v, lane) + carry;
-            if (j < KC) hc[j] = v;
-            carry = __shfl(v, WAVE - 1);
-            const int pos = (j < KC) && (v > MIN_COV);   // c[j] > 0
+            int c = j < KC ? hc[j] : 0;
+            c = wave_incl_scan(c) + carry;
+            if (j < KC) hc[j] = c;
+            carry = wave_last(c);
+            const int pos = (j < KC) && (c > MIN_COV);   // c[j] > 0 after subtracting MIN_COV
             // last non-positive index strictly before j
-            int npi = ((j < KC) && !pos) ? j : -1;
-            int incl = wave_incl_max_scan(npi, lane);
-            int excl = __shfl_up(incl, 1);
-            if (lane == 0) excl = -1;
+            const int npi = ((j < KC) && !pos) ? j : INT_MIN;
+            const int incl = wave_incl_max_scan(npi);
+            int excl = shfl_up1(incl, INT_MIN);
             excl = max(excl, last_np);
-            int pp = __shfl_up(pos, 1);
-            if (lane == 0) pp = prev_pos;
+            const int pp = shfl_up1(pos, prev_pos);
             if ((j < KC) && !pos && pp) {
                 // run of positive bins (z, j-1] closed by bin j
                 const int z = excl;
                 const int len = reso * (j - 1) - reso * z - reso;
                 if (len > 0) {
-                    long long cand = ((long long)len << 32) | (unsigned)(0x7fffffff - j);
+                    const long long cand = ((long long)len << 32) | (unsigned)(0x7fffffff - j);
                     best = cand > best ? cand : best;
                 }
             }
-            last_np = max(last_np, __shfl(incl, WAVE - 1));
-            prev_pos = __shfl(pos, WAVE - 1);
+            last_np = max(last_np, wave_last(incl));
+            prev_pos = wave_last(pos);
         }
         best = wave_max64(best);
         int maxstart = 0, maxend = 0, msc = 0, mec = 0;
@@ -319,39 +439,39 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         carry = 0;
         int ncand = 0;
         int S = 0, nS = 0, E = 0, nE = 0;
-        int prev_cov = 0;   // cov0[j-1] carried across chunks (for the gradient at the chunk seam)
-        // gradient cg[j] = cov0[j+1] - cov0[j] needs the next bin: scan first, then a second sweep.
         for (int base = 0; base < K0; base += WAVE) {
             const int j = base + lane;
-            int v = j < K0 ? h0[j] : 0;
-            v = wave_incl_scan(v, lane) + carry;
-            if (j < K0) h0[j] = v;
-            carry = __shfl(v, WAVE - 1);
+            int c = j < K0 ? h0[j] : 0;
+            c = wave_incl_scan(c) + carry;
+            if (j < K0) h0[j] = c;
+            carry = wave_last(c);
             if (j < K0) {
                 const int pos = reso * j;
-                if ((pos <= mk.x + P.nhr) && (pos >= mk.x)) { S += v; nS++; }
-                if ((pos <= mk.y) && (pos >= mk.y - P.nhr)) { E += v; nE++; }
+                if ((pos <= mk.x + P.nhr) && (pos >= mk.x)) { S += c; nS++; }
+                if ((pos <= mk.y) && (pos >= mk.y - P.nhr)) { E += c; nE++; }
             }
         }
-        (void)prev_cov;
         S = wave_sum(S); nS = wave_sum(nS); E = wave_sum(E); nE = wave_sum(nE);
-        for (int base = 0; base < K0 - 2; base += WAVE) {
-            const int j = base + lane;
-            int code = 0;
-            if (j < K0 - 2) {
-                const int pos = reso * j;
-                if ((pos >= mk.x + P.nhr) && (pos <= mk.y - P.nhr)) {
+        // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
+        {
+            const int wlo = mk.x + P.nhr, whi = mk.y - P.nhr;
+            int jlo = wlo <= 0 ? 0 : (wlo + reso - 1) / reso;
+            int jhi = whi < 0 ? -1 : whi / reso;
+            jhi = min(jhi, K0 - 3);
+            for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
+                const int j = base + lane;
+                int code = -1;
+                if (j >= jlo && j <= jhi) {
                     const int c = h0[j];
                     const int g = h0[j + 1] - c;
                     const int thr = min(max((c + MIN_COV) / P.cov_frac, P.min_ra), P.max_ra);
-                    if (g > thr) code = (pos << 1) | 1;
-                    else if (g < -thr) code = (pos << 1) | 0;
-                    else code = -1;
-                } else code = -1;
-            } else code = -1;
-            const unsigned long long bal = __ballot(code != -1);
-            if (code != -1) cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = code;
-            ncand += __popcll(bal);
+                    if (g > thr) code = ((reso * j) << 1) | 1;
+                    else if (g < -thr) code = ((reso * j) << 1) | 0;
+                }
+                const unsigned long long bal = __ballot(code != -1);
+                if (code != -1) cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = code;
+                ncand += __popcll(bal);
+            }
         }
         // merge (filter.cpp:817-829) - sequential on a short list, in place
         int m = 0;
@@ -371,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             }
             cand[m++] = cur;
         }
-        m = __shfl(m, 0);
+        m = __builtin_amdgcn_readfirstlane(m);
         // gate: fp32, IEEE divide, NaN compares false (filter.cpp:861-865)
         bool gate_skip;
         {
@@ -392,53 +512,42 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
                 work_list[w] = i;
             }
         }
-        m = __shfl(m, 0);
-        off = __shfl(off, 0);
+        m = __builtin_amdgcn_readfirstlane(m);
+        off = __builtin_amdgcn_readfirstlane(off);
         for (int t = lane; t < m; t += WAVE) {
             const int c = cand[t];
             anno_buf[off + t] = make_int2(c >> 1, (c & 1) ? 1 : -1);
+            hinge_flag[off + t] = 0;
         }
+        i = inext; s = sn; e = en; rl = rln;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Hinge scan shared by the fast path (LDS lists, any tie order) and the exact path (global lists in
-// std::sort order).  f[] = other-end coordinate mapped so that ascending f is the scan order
-// (abpos for type -1, -aepos for type +1); m0 = mask.first resp. -mask.second.
-// Returns 1 = bridged, 0 = not bridged, 2 = outcome depends on the order inside a tie group
-// (only reported when detect_ties).   filter.cpp:920-963 / 1019-1062.
+// Hinge scan over the supporters in their final (std::sort) order.  f[] = other-end coordinate
+// mapped so that ascending f is the scan order (abpos for type -1, -aepos for type +1);
+// m0 = mask.first resp. -mask.second.  `ord` is an optional indirection (position -> element).
+// Returns 1 = bridged, 0 = not bridged.   filter.cpp:920-963 / 1019-1062.
 // ------------------------------------------------------------------------------------------------
-HINGE_HD inline int hinge_scan(const int* f, const int* sec, int s, int m0, int BIN, int TH, int UNB, int PIL, bool detect_ties) {
+HINGE_HD inline int hinge_scan(const int* f, const int* sec, const int* ord, int s, int m0, int BIN, int TH, int UNB, int PIL) {
     int considered = 0, to_end = 0;
+    const int f0 = f[ord ? ord[0] : 0];
     for (int id = 0; id < s; ++id) {
-        if (f[id] - m0 < BIN) {
+        const int x = ord ? ord[id] : id;
+        const int fx = f[x];
+        if (fx - m0 < BIN) {
             considered++;
             to_end++;
-            if ((to_end > UNB) || ((considered > UNB) && (f[id] - f[0] > BIN))) return 0;
-            continue;
-        }
-        if (detect_ties) {
-            // tie group of id (equal f): mixed categories make the outcome order-dependent
-            int g0 = id, g1 = id + 1;
-            while (g0 > 0 && f[g0 - 1] == f[id]) --g0;
-            while (g1 < s && f[g1] == f[id]) ++g1;
-            if (g1 - g0 > 1) {
-                const int c0 = sec[g0] < TH ? 0 : (sec[g0] > TH ? 1 : 2);
-                for (int t = g0 + 1; t < g1; ++t) {
-                    const int ct = sec[t] < TH ? 0 : (sec[t] > TH ? 1 : 2);
-                    if (ct != c0) return 2;
-                }
-            }
-        }
-        if (sec[id] < TH) {
+            if ((to_end > UNB) || ((considered > UNB) && (fx - f0 > BIN))) return 0;
+        } else if (sec[x] < TH) {
             considered++;
-            if ((to_end > UNB) || ((considered > UNB) && (f[id] - f[0] > BIN))) return 0;
-        } else if (sec[id] > TH) {
+            if ((to_end > UNB) || ((considered > UNB) && (fx - f0 > BIN))) return 0;
+        } else if (sec[x] > TH) {
             considered++;
             int id1 = id + 1;
             int pile = 1;
             while (id1 < s) {
-                if (f[id1] - f[id] < BIN) { pile++; id1++; }
+                if (f[ord ? ord[id1] : id1] - fx < BIN) { pile++; id1++; }
                 else break;
             }
             if (pile > PIL) return 1;
@@ -451,111 +560,6 @@ __device__ __forceinline__ void overhangs(int2 bs, int comp, int2 mb, int& L, in
     // filter.cpp:883-890: overhang of B past the alignment, inside B's mask, on A's left / right
     if (comp == 0) { R = max(mb.y - bs.y, 0); L = max(bs.x - mb.x, 0); }
     else { R = max(bs.x - mb.x, 0); L = max(mb.y - bs.y, 0); }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3 fast path: one wave per work-list read; per annotation gather supporters (A-side test first,
-// B-side fields and the mask[B] gather only for lanes that pass), bitonic-sort them by the other
-// end in LDS, run the scan.  Ties whose order could matter and oversize lists go to the exact queue.
-// hinge_flag[anno slot] = 1 emit / 0 no.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
-                                                      const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
-                                                      const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
-                                                      const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
-                                                      const int* __restrict__ work_list, const unsigned* __restrict__ counters,
-                                                      unsigned char* __restrict__ hinge_flag, int2* __restrict__ exact_queue,
-                                                      unsigned* __restrict__ exact_count, unsigned exact_cap, int force_exact,
-                                                      int* __restrict__ status) {
-    __shared__ int s_f[WAVES_PER_BLOCK][SUP_CAP];
-    __shared__ int s_s[WAVES_PER_BLOCK][SUP_CAP];
-    const int lane = lane_id();
-    const int wib = threadIdx.x >> 6;
-    int* F = s_f[wib];
-    int* Sx = s_s[wib];
-    const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-    const int nwaves = gridDim.x * WAVES_PER_BLOCK;
-    const unsigned nwork = counters[1];
-    for (unsigned w = wave; w < nwork; w += nwaves) {
-        const int i = work_list[w];
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        const int2 mk = mask[i];
-        const unsigned off = anno_off[i];
-        const int cnt = anno_cnt[i];
-        for (int a = 0; a < cnt; a++) {
-            const int2 an = anno_buf[off + a];
-            const int pos = an.x, type = an.y;
-            int support = 0;
-            for (int64_t k0 = s; k0 < e; k0 += WAVE) {
-                const int64_t k = k0 + lane;
-                bool sup = false;
-                int fo = 0, so = 0;
-                if (k < e) {
-                    const int2 av = a_span[k];
-                    const int near_c = type == -1 ? av.y : av.x;
-                    if ((near_c > pos - P.tol) && (near_c < pos + P.tol)) {
-                        const unsigned bf = b_flag[k];
-                        const int2 bs = b_span[k];
-                        const int2 mb = mask[bf & 0x7fffffffu];
-                        int L, R;
-                        overhangs(bs, (int)(bf >> 31), mb, L, R);
-                        if (type == -1) { sup = R > P.theta; fo = av.x; so = L; }
-                        else { sup = L > P.theta; fo = -av.y; so = R; }
-                    }
-                }
-                const unsigned long long bal = __ballot(sup);
-                if (sup) {
-                    const int slot = support + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (slot < SUP_CAP) { F[slot] = fo; Sx[slot] = so; }
-                }
-                support += __popcll(bal);
-            }
-            int result;   // 0 no hinge, 1 hinge, 2 -> exact path
-            if (support <= P.sup) {
-                result = 0;    // needs support >= SUP to be scanned and > SUP to be emitted
-            } else if (support > SUP_CAP || force_exact) {
-                result = 2;
-            } else {
-                // bitonic sort of (F, Sx) by F ascending over the next power of two
-                int np2 = 64;
-                while (np2 < support) np2 <<= 1;
-                for (int t = support + lane; t < np2; t += WAVE) { F[t] = INT_MAX; Sx[t] = 0; }
-                for (int kk = 2; kk <= np2; kk <<= 1) {
-                    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                        for (int t = lane; t < np2; t += WAVE) {
-                            const int p = t ^ jj;
-                            if (p > t) {
-                                const bool up = (t & kk) == 0;
-                                const int ft = F[t], fp = F[p];
-                                if ((ft > fp) == up) {
-                                    F[t] = fp; F[p] = ft;
-                                    const int st = Sx[t]; Sx[t] = Sx[p]; Sx[p] = st;
-                                }
-                            }
-                        }
-                        // a single wave executes in lockstep; LDS ops of one wave complete in order
-                    }
-                }
-                int r = 0;
-                if (lane == 0) {
-                    const int m0 = type == -1 ? mk.x : -mk.y;
-                    r = hinge_scan(F, Sx, support, m0, P.bin_len, P.theta, P.unb, P.pil, true);
-                }
-                r = __shfl(r, 0);
-                result = r == 2 ? 2 : (r == 0 ? 1 : 0);   // emit iff not bridged (support > SUP holds)
-            }
-            if (lane == 0) {
-                if (result == 2) {
-                    const unsigned q = atomicAdd(exact_count, 1u);
-                    if (q < exact_cap) exact_queue[q] = make_int2(i, a);
-                    else atomicOr(status, ST_QUEUE_CAP);
-                    hinge_flag[off + a] = 0;
-                } else {
-                    hinge_flag[off + a] = (unsigned char)result;
-                }
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -595,28 +599,28 @@ __global__ void k_hinge_exact(FilterDev P, const int64_t* __restrict__ row_ptr, 
         for (int t = 0; t < n; t++) {
             const int64_t k = s + perm[t];
             const int2 av = a_span[k];
+            const int near_c = type == -1 ? av.y : av.x;
+            if (!((near_c > pos - P.tol) && (near_c < pos + P.tol))) continue;
             const unsigned bf = b_flag[k];
             const int2 bs = b_span[k];
             const int2 mb = mask[bf & 0x7fffffffu];
             int L, R;
             overhangs(bs, (int)(bf >> 31), mb, L, R);
             if (type == -1) {
-                if (R > P.theta && (av.y > pos - P.tol) && (av.y < pos + P.tol)) { sf[support] = av.x; ss[support] = L; support++; }
+                if (R > P.theta) { sf[support] = av.x; ss[support] = L; support++; }
             } else {
-                if (L > P.theta && (av.x > pos - P.tol) && (av.x < pos + P.tol)) { sf[support] = -av.y; ss[support] = R; support++; }
+                if (L > P.theta) { sf[support] = -av.y; ss[support] = R; support++; }
             }
         }
         unsigned char res = 0;
-        if (support >= P.sup) {
+        if (support > P.sup) {
             for (int t = 0; t < support; t++) sidx[t] = t;
             // pairAscend on abpos == ascending f; pairDescend on aepos == ascending f = -aepos
             hinge_sort::std_sort(sidx, support, sf, 0);
-            // gather into sorted order (reuse perm/key as the sorted lists)
-            for (int t = 0; t < support; t++) { perm[t] = sf[sidx[t]]; key[t] = ss[sidx[t]]; }
             const int2 mk = mask[i];
             const int m0 = type == -1 ? mk.x : -mk.y;
-            const int r = hinge_scan(perm, key, support, m0, P.bin_len, P.theta, P.unb, P.pil, false);
-            res = (r == 0 && support > P.sup) ? 1 : 0;
+            const int r = hinge_scan(sf, ss, sidx, support, m0, P.bin_len, P.theta, P.unb, P.pil);
+            res = r == 0 ? 1 : 0;
         }
         hinge_flag[anno_off[i] + a] = res;
     }
@@ -643,24 +647,24 @@ __global__ __launch_bounds__(BLOCK) void k_coverage_bins(int r0, int r1, const i
             mx = max(mx, max(v.x + cutoff, v.y - cutoff));
         }
         mx = wave_max(mx);
-        const int K = nbins_of((int)(e - s), mx, reso);
+        const int K = nbins_of<0>((int)(e - s), mx, reso);
         if (lane == 0) nbins[i - r0] = K;
         if (cov == nullptr) continue;
         if (K > kcap) { if (lane == 0) atomicOr(status, ST_RANGE); continue; }
         for (int k = lane; k < K; k += WAVE) h[k] = 0;
         for (int64_t k = s + lane; k < e; k += WAVE) {
             const int2 v = a_span[k];
-            atomicAdd(&h[bin_of(v.x + cutoff, reso)], 1);
-            atomicAdd(&h[bin_of(v.y - cutoff, reso)], -1);
+            atomicAdd(&h[bin_of<0>(v.x + cutoff, reso)], 1);
+            atomicAdd(&h[bin_of<0>(v.y - cutoff, reso)], -1);
         }
         int carry = 0;
         const int64_t o = out_off[i - r0];
         for (int base = 0; base < K; base += WAVE) {
             const int j = base + lane;
             int v = j < K ? h[j] : 0;
-            v = wave_incl_scan(v, lane) + carry;
+            v = wave_incl_scan(v) + carry;
             if (j < K) cov[o + j] = v;
-            carry = __shfl(v, WAVE - 1);
+            carry = wave_last(v);
         }
     }
 }

@@ -1,0 +1,219 @@
+// K3 of `hinge filter`: hinge calling (src/filter/filter.cpp:867-1068), one workgroup per work-list read,
+// one pass over the pile-up per annotation of that read.
+//
+//   gather   all 256 threads stream (abpos, aepos); only overlaps whose near end falls in the annotation's
+//            +-HINGE_TOLERANCE window load their B-side fields and gather mask[B] (filter.cpp:877-908).
+//            Supporters are compacted into LDS in .las order.
+//   order    the reference collects supporters in the order of the std::sort-ed pile-up
+//            (filter.cpp:565-567).  For a short list with no confusable length tie that is simply
+//            (length desc, .las order).  Otherwise the exact pile-up order is computed ONCE per read by
+//            wave_std_sort_desc() and the supporters are compacted in that order.
+//   sort     std::sort(pairAscend / pairDescend) of the supporters is replayed by the same routine.
+//   scan     lane 0 walks the sorted list (it usually stops within the first ~10 elements).
+//
+// Pile-ups or supporter lists beyond PO_CAP go to k_hinge_exact (global scratch, serial).
+// hinge_flag[anno slot] = 1 emit / 0 no.
+#pragma once
+#include "filter_kernels.h"
+#include "pileup_order.h"
+
+namespace hinge {
+
+constexpr int HC_SMALL = 64;    // lists up to this size try the tie-free shortcut
+
+struct HingeCallLds {
+    WaveSortLds ws;
+    unsigned short ppos[PO_CAP];   // position of every overlap of the read in the sorted pile-up
+    int sF[PO_CAP];                // supporters in .las order: other end in scan-ascending form ...
+    int sS[PO_CAP];                // ... and the overhang on the far side; reused for the sorted lists
+    unsigned short sK[PO_CAP];     // ... and the local overlap index
+    int sL[HC_SMALL];              // length sums of the first HC_SMALL supporters
+    int wF[PO_CAP];                // supporters in pile-up order
+    int wS[PO_CAP];
+    int wcnt[2][WAVES_PER_BLOCK];
+    int cnt;
+    int need_order;
+    int near_end;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
+                                                      const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
+                                                      const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
+                                                      const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
+                                                      const int* __restrict__ work_list, const unsigned* __restrict__ counters,
+                                                      unsigned char* __restrict__ hinge_flag, int2* __restrict__ exact_queue,
+                                                      unsigned* __restrict__ exact_count, unsigned exact_cap, int force_exact,
+                                                      int* __restrict__ status) {
+    __shared__ HingeCallLds S;
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int wib = tid >> 6;
+    const unsigned long long lmask = (1ull << lane) - 1ull;
+    const unsigned nwork = counters[1];
+    for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int i = work_list[w];
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int n = (int)(e - s);
+        const int2 mk = mask[i];
+        const unsigned off = anno_off[i];
+        const int cnt = anno_cnt[i];
+        bool order_ready = false;   // block-uniform
+        for (int a = 0; a < cnt; a++) {
+            const int2 an = anno_buf[off + a];
+            const int pos = an.x, type = an.y;
+            __syncthreads();
+            if (tid == 0) { S.cnt = 0; S.need_order = 0; S.near_end = 0; }
+            const int m0 = type == -1 ? mk.x : -mk.y;
+            __syncthreads();
+            // ---- gather -----------------------------------------------------------------------------
+            int par = 0;
+            for (int64_t k0 = s; k0 < e; k0 += BLOCK, par ^= 1) {
+                const int64_t k = k0 + tid;
+                bool sup = false;
+                int f = 0, sec = 0, Lsum = 0;
+                if (k < e) {
+                    const int2 av = a_span[k];
+                    const int c = type == -1 ? av.y : av.x;
+                    if ((c > pos - P.tol) && (c < pos + P.tol)) {
+                        const unsigned bf = b_flag[k];
+                        const int2 bs = b_span[k];
+                        const int2 mb = mask[bf & 0x7fffffffu];
+                        int L, R;
+                        overhangs(bs, (int)(bf >> 31), mb, L, R);
+                        if (type == -1) { sup = R > P.theta; f = av.x; sec = L; }
+                        else { sup = L > P.theta; f = -av.y; sec = R; }
+                        Lsum = av.y - av.x + bs.y - bs.x;
+                    }
+                }
+                const unsigned long long bal = __ballot(sup);
+                const unsigned long long baln = __ballot(sup && (f - m0 < P.bin_len));
+                if (lane == 0) {
+                    S.wcnt[par][wib] = __popcll(bal);
+                    // supporters whose other end lies within HINGE_BIN_LENGTH of the mask end (scan branch 1)
+                    const int nn = __popcll(baln);
+                    if (nn) atomicAdd(&S.near_end, nn);
+                }
+                __syncthreads();
+                if (sup) {
+                    int slot = S.cnt + __popcll(bal & lmask);
+                    for (int ww = 0; ww < wib; ww++) slot += S.wcnt[par][ww];
+                    if (slot < PO_CAP) {
+                        S.sF[slot] = f;
+                        S.sS[slot] = sec;
+                        S.sK[slot] = (unsigned short)(k - s);
+                        if (slot < HC_SMALL) S.sL[slot] = Lsum;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) S.cnt += S.wcnt[par][0] + S.wcnt[par][1] + S.wcnt[par][2] + S.wcnt[par][3];
+                // the next chunk writes the other wcnt buffer and syncs before cnt is read again
+            }
+            __syncthreads();
+            const int sup = S.cnt;
+            // ---- decide the path (block-uniform) ----------------------------------------------------
+            int action;   // 0: result 0, 1: resolve in LDS, 2: k_hinge_exact, 3: result 1 without sorting
+            if (sup <= P.sup) action = 0;   // needs support >= SUP to be scanned and > SUP to be emitted
+            else if (force_exact == 0 && P.unb >= 0 && S.near_end > P.unb) {
+                // Sorted by the other end, the supporters with f - m0 < BIN form a prefix (the test is monotone
+                // in f) and every one of them takes the scan's first branch: to_end reaches UNB + 1 at element
+                // UNB and nothing can stop the scan earlier (considered == to_end <= UNB until then).  The hinge
+                // is unbridged whatever the order inside that prefix is (filter.cpp:920-931 / 1019-1030).
+                action = 3;
+            }
+            else if (sup > PO_CAP || force_exact == 1) action = 2;
+            else action = 1;
+            bool need_order = false;
+            if (action == 1) {
+                need_order = (force_exact == 2) || (sup > HC_SMALL);
+                if (!need_order) {
+                    // a length tie matters if the two could swap places in the final order: always when the
+                    // supporter sort is an introsort (sup > 16), only for equal f when it is a stable
+                    // insertion sort; never when the pile-up sort itself is stable (n <= 16)
+                    if (wib == 0 && n > 16) {
+                        bool tie = false;
+                        for (int t = lane; t < sup; t += WAVE) {
+                            const int Lt = S.sL[t], ft = S.sF[t];
+                            for (int u = 0; u < sup; u++)
+                                if (u != t && S.sL[u] == Lt && (sup > 16 || S.sF[u] == ft)) tie = true;
+                        }
+                        if (__any(tie) && lane == 0) S.need_order = 1;
+                    }
+                    __syncthreads();
+                    need_order = S.need_order != 0;
+                }
+                if (need_order && n > PO_CAP) action = 2;
+            }
+            if (action == 0 || action == 3) {
+                if (tid == 0) hinge_flag[off + a] = action == 3 ? 1 : 0;
+                continue;
+            }
+            if (action == 2) {
+                if (tid == 0) {
+                    const unsigned q = atomicAdd(exact_count, 1u);
+                    if (q < exact_cap) exact_queue[q] = make_int2(i, a);
+                    else atomicOr(status, ST_QUEUE_CAP);
+                }
+                continue;
+            }
+            // ---- exact pile-up order, once per read ---------------------------------------------
+            if (need_order && !order_ready) {
+                for (int64_t k = s + tid; k < e; k += BLOCK) {
+                    const int2 av = a_span[k];
+                    const int2 bs = b_span[k];
+                    S.ws.key[k - s] = av.y - av.x + bs.y - bs.x;   // compare_overlap key
+                }
+                __syncthreads();
+                if (wib == 0) {
+                    wave_std_sort_desc(S.ws, n, lane);
+                    for (int p = lane; p < n; p += WAVE) S.ppos[p] = S.ws.pl[p];
+                }
+                __syncthreads();
+                order_ready = true;
+            }
+            if (wib != 0) continue;   // the rest is one wave's work; the loop top re-synchronises
+            // ---- supporters in pile-up order -> wF / wS ---------------------------------------------
+            if (need_order) {
+                unsigned short* slot_of = S.ws.seglo;   // scratch: pile-up position -> supporter + 1
+                for (int p = lane; p < n; p += WAVE) slot_of[p] = 0;
+                for (int t = lane; t < sup; t += WAVE) slot_of[S.ppos[S.sK[t]]] = (unsigned short)(t + 1);
+                int r = 0;
+                for (int base = 0; base < n; base += WAVE) {
+                    const int p = base + lane;
+                    const int v = p < n ? slot_of[p] : 0;
+                    const unsigned long long bal = __ballot(v != 0);
+                    if (v) {
+                        const int dst = r + __popcll(bal & lmask);
+                        S.wF[dst] = S.sF[v - 1];
+                        S.wS[dst] = S.sS[v - 1];
+                    }
+                    r += __popcll(bal);
+                }
+            } else {
+                for (int t = lane; t < sup; t += WAVE) {
+                    const int Lt = S.sL[t];
+                    int rank = 0;
+                    for (int u = 0; u < sup; u++) {
+                        const int Lu = S.sL[u];
+                        rank += (Lu > Lt) || (Lu == Lt && u < t);   // .las order breaks (harmless) ties
+                    }
+                    S.wF[rank] = S.sF[t];
+                    S.wS[rank] = S.sS[t];
+                }
+            }
+            // ---- std::sort(pairAscend / pairDescend): ascending f == descending -f --------------------
+            for (int t = lane; t < sup; t += WAVE) S.ws.key[t] = -S.wF[t];
+            wave_std_sort_desc(S.ws, sup, lane);
+            for (int t = lane; t < sup; t += WAVE) {
+                const int p = S.ws.pl[t];
+                S.sF[p] = S.wF[t];
+                S.sS[p] = S.wS[t];
+            }
+            if (lane == 0) {
+                const int r = hinge_scan(S.sF, S.sS, nullptr, sup, m0, P.bin_len, P.theta, P.unb, P.pil);
+                hinge_flag[off + a] = r == 0 ? 1 : 0;   // emit iff not bridged (support > SUP holds)
+            }
+        }
+    }
+}
+
+}  // namespace hinge

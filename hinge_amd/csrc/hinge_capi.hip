@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/hinge_hip.h"
 #include "filter_kernels.h"
+#include "hinge_call_kernel.h"
 #include "align_kernels.h"
 
 using namespace hinge;
@@ -45,6 +47,8 @@ struct hinge_ctx {
     DevBuf arena;
     unsigned long long arena_cap = 0;
     DevBuf scalars;   // see Scalars
+    DevBuf med;       // median histogram scratch (k_median_hist)
+    size_t lds_attr_set = 0;
     int force_exact = 0;
 
     // trim / classify (maximal, layout)
@@ -84,14 +88,18 @@ struct ProfScope {
 
 // device scalars, one allocation
 struct Scalars {
+    // ---- cleared by ONE memset at the start of every pass (SCALARS_RESET_BYTES) ----
     unsigned long long totals[2];       // total_cov, num_slot
     unsigned long long arena_used;
     unsigned counters[2];               // annotation alloc, work count
     unsigned exact_count;
+    int status;
+    // ---- persistent across passes ----
     int est[2];                         // cov_est, n_long
     int min_cov;
-    int status;
+    int pad;
 };
+static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
 
 #define CK(call)                                                                                         \
     do {                                                                                                 \
@@ -159,6 +167,9 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (hipMalloc(&ctx->scalars.p, sizeof(Scalars)) != hipSuccess) { delete ctx; return HINGE_E_DEVICE; }
     ctx->scalars.bytes = sizeof(Scalars);
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
+    if (hipMalloc(&ctx->med.p, sizeof(unsigned) * (MED_BINS + 4)) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
+    ctx->med.bytes = sizeof(unsigned) * (MED_BINS + 4);
+    (void)hipMemset(ctx->med.p, 0, ctx->med.bytes);
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     *out = ctx;
@@ -170,7 +181,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->trace, &ctx->trace_off, &ctx->eff_reads,
+                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->trace, &ctx->trace_off, &ctx->eff_reads,
                      &ctx->pair_sel, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -290,7 +301,33 @@ int hinge_clear_masks(hinge_ctx* ctx) {
     return HINGE_OK;
 }
 
-// hidden knob for tests: route every scanned annotation through the exact path
+// test hook: std::sort(compare_overlap) order of n keys through the wavefront-parallel replay
+__global__ __launch_bounds__(64) void k_debug_pileup_order(const int* __restrict__ keys, int n, int* __restrict__ pos_out) {
+    __shared__ WaveSortLds po;
+    const int lane = threadIdx.x;
+    for (int k = lane; k < n; k += 64) po.key[k] = keys[k];
+    wave_std_sort_desc(po, n, lane);
+    for (int k = lane; k < n; k += 64) pos_out[k] = po.pl[k];
+}
+
+int hinge_debug_pileup_order(hinge_ctx* ctx, int32_t n, const int32_t* keys, int32_t* pos_out) {
+    if (!ctx || n < 0 || n > PO_CAP || !keys || !pos_out) return fail(ctx, HINGE_E_ARG, "hinge_debug_pileup_order: bad arguments");
+    CK(hipSetDevice(ctx->device));
+    int *dk = nullptr, *dp = nullptr;
+    CK(hipMalloc(&dk, sizeof(int) * (size_t)std::max(n, 1)));
+    CK(hipMalloc(&dp, sizeof(int) * (size_t)std::max(n, 1)));
+    CK(hipMemcpy(dk, keys, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_pileup_order, dim3(1), dim3(64), 0, ctx->stream, (const int*)dk, n, dp);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpy(pos_out, dp, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(dk);
+    (void)hipFree(dp);
+    return HINGE_OK;
+}
+
+// hidden knob for tests: 1 = route every scanned annotation through k_hinge_exact,
+// 2 = force the in-kernel exact pile-up order for every scanned annotation
 int hinge_debug_force_exact(hinge_ctx* ctx, int on) {
     if (!ctx) return HINGE_E_ARG;
     ctx->force_exact = on;
@@ -309,19 +346,33 @@ static int kcap_for(hinge_ctx* ctx, const hinge_filter_params* p) {
     return (k + 3) & ~3;
 }
 
+// one memset clears every per-pass device scalar (totals, counters, exact queue, arena, status)
+static int reset_pass(hinge_ctx* ctx) {
+    CK(hipMemsetAsync(ctx->scalars.p, 0, SCALARS_RESET_BYTES, ctx->stream));
+    return HINGE_OK;
+}
+
+static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
+    const int nr = ctx->r_end - ctx->r_begin + 1;
+    const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
+    ProfScope _ps(ctx, KID_STATS);
+    if (p->reso == 40)
+        hipLaunchKernelGGL(k_cov_stats<40>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, sc(ctx)->totals);
+    else
+        hipLaunchKernelGGL(k_cov_stats<0>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, sc(ctx)->totals);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
 int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     int rc = check_params(ctx, p);
     if (rc) return rc;
     if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
     CK(hipSetDevice(ctx->device));
-    CK(hipMemsetAsync(&sc(ctx)->totals[0], 0, 2 * sizeof(unsigned long long), ctx->stream));
-    const int nr = ctx->r_end - ctx->r_begin + 1;
-    const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
-    ProfScope _ps(ctx, KID_STATS);
-    hipLaunchKernelGGL(k_cov_stats, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
-                       (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, sc(ctx)->totals);
-    CK(hipGetLastError());
-    return HINGE_OK;
+    if ((rc = reset_pass(ctx))) return rc;   // a pass always starts here
+    return launch_stats(ctx, p);
 }
 
 int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out) {
@@ -329,9 +380,15 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
     if (rc) return rc;
     if (lo < 0 || hi >= ctx->n_reads || hi < lo) return fail(ctx, HINGE_E_ARG, "median range");
     CK(hipSetDevice(ctx->device));
-    { ProfScope _ps(ctx, KID_MEDIAN);
-    hipLaunchKernelGGL(k_median_select, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov, sc(ctx)->est,
-                       &sc(ctx)->min_cov, &sc(ctx)->status); }
+    {
+        ProfScope _ps(ctx, KID_MEDIAN);
+        const int n = hi - lo + 1;
+        const int grid = std::max(1, std::min((n + 2047) / 2048, ctx->n_cu));
+        hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
+                           (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status);
+        hipLaunchKernelGGL(k_median_select, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
+                           (const unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status);
+    }
     CK(hipGetLastError());
     if (out) {
         Scalars h;
@@ -358,20 +415,28 @@ int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* v) {
     return HINGE_OK;
 }
 
+#define LAUNCH_MASK_ANNOTATE(RESO)                                                                                           \
+    hipLaunchKernelGGL(k_mask_annotate<RESO>, dim3(grid), dim3(BLOCK), lds, ctx->stream, to_dev(p), ctx->r_begin, ctx->r_end,     \
+                       (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,                        \
+                       ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr, (const int*)&sc(ctx)->min_cov, kcap,      \
+                       ctx->mask, (int2*)ctx->cmask.p, (unsigned char*)ctx->rflags.p, (int2*)ctx->anno_buf.p,                      \
+                       (unsigned char*)ctx->hinge_flag.p, (unsigned*)ctx->anno_off.p, (int*)ctx->anno_cnt.p, sc(ctx)->counters,    \
+                       ctx->anno_cap, (int*)ctx->work_list.p, &sc(ctx)->status)
+
 static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int kcap = kcap_for(ctx, p);
     const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
     if (lds > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
-    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_mask_annotate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CK(hipMemsetAsync(sc(ctx)->counters, 0, 2 * sizeof(unsigned), ctx->stream));
+    if (lds > 48 * 1024 && lds > ctx->lds_attr_set) {
+        CK(hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute((const void*)k_mask_annotate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->lds_attr_set = lds;
+    }
     const int nr = ctx->r_end - ctx->r_begin + 1;
     const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
     ProfScope _ps(ctx, KID_MASK_ANNOTATE);
-    hipLaunchKernelGGL(k_mask_annotate, dim3(grid), dim3(BLOCK), lds, ctx->stream, to_dev(p), ctx->r_begin, ctx->r_end,
-                       (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
-                       ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr, (const int*)&sc(ctx)->min_cov, kcap, ctx->mask,
-                       (int2*)ctx->cmask.p, (unsigned char*)ctx->rflags.p, (int2*)ctx->anno_buf.p, (unsigned*)ctx->anno_off.p,
-                       (int*)ctx->anno_cnt.p, sc(ctx)->counters, ctx->anno_cap, (int*)ctx->work_list.p, &sc(ctx)->status);
+    if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40);
+    else LAUNCH_MASK_ANNOTATE(0);
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -383,6 +448,7 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 8; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+        CK(hipMemsetAsync(sc(ctx)->counters, 0, 2 * sizeof(unsigned), ctx->stream));
         if ((rc = launch_mask_annotate(ctx, p))) return rc;
         // the annotation buffer is sized optimistically; grow + rerun on overflow (rare)
         Scalars h;
@@ -398,9 +464,6 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
 }
 
 static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
-    CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, sizeof(unsigned), ctx->stream));
-    CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
-    CK(hipMemsetAsync(ctx->hinge_flag.p, 0, (size_t)ctx->anno_cap, ctx->stream));
     const int grid = ctx->n_cu * 2;
     { ProfScope _ps(ctx, KID_HINGE_CALL);
     hipLaunchKernelGGL(k_hinge_call, dim3(grid), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
@@ -445,6 +508,8 @@ int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 16; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
+        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, sizeof(unsigned), ctx->stream));
+        CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
         if ((rc = launch_hinges(ctx, p))) return rc;
         int rerun = 0;
         if ((rc = hinges_settle(ctx, &rerun))) return rc;
@@ -459,7 +524,6 @@ int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p) {
     if (rc) return rc;
     if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
     CK(hipSetDevice(ctx->device));
-    CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
     CK(hipMemsetD32Async((hipDeviceptr_t)&sc(ctx)->min_cov, p->min_cov, 1, ctx->stream));   // single part: MIN_COV starts at the ini value
     if ((rc = hinge_filter_stats(ctx, p))) return rc;
     if ((rc = hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, nullptr))) return rc;
@@ -585,12 +649,6 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
 
 // staged launches without the host round trip (multi-GPU pipeline: collectives sit between them);
 // capacity / range flags accumulate in the status word and are reported by hinge_filter_check.
-int hinge_filter_begin_async(hinge_ctx* ctx) {
-    if (!ctx) return HINGE_E_ARG;
-    CK(hipSetDevice(ctx->device));
-    CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-    return HINGE_OK;
-}
 int hinge_filter_mask_annotate_async(hinge_ctx* ctx, const hinge_filter_params* p) {
     int rc = check_params(ctx, p);
     if (rc) return rc;

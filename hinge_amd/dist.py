@@ -186,7 +186,6 @@ class HipBackend:
 
     def begin(self):
         self.ctx.set_min_cov(self.ini_min_cov)    # stream-ordered 4-byte set, no host sync
-        self.ctx.begin_async()
 
     def stats(self):
         self.ctx.filter_stats(self.p)

@@ -126,8 +126,8 @@ int hinge_filter_coverage_bins(hinge_ctx* ctx, int32_t r0, int32_t r1, int32_t r
 int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
 
 /* Staged launches with no host round trip, for pipelines that put a collective between the stages
- * (multi-GPU): begin clears the status word, check reports HINGE_E_* flags raised since begin.     */
-int hinge_filter_begin_async(hinge_ctx* ctx);
+ * (multi-GPU).  A pass starts at hinge_filter_stats (which clears the per-pass device scalars and is
+ * itself asynchronous); check reports the HINGE_E_* flags raised since then.                       */
 int hinge_filter_mask_annotate_async(hinge_ctx* ctx, const hinge_filter_params* p);
 int hinge_filter_hinges_async(hinge_ctx* ctx, const hinge_filter_params* p);
 int hinge_filter_check(hinge_ctx* ctx);

@@ -29,7 +29,7 @@ def _compare(wd_o, wd_h):
 
 @pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("tiny_mlas", True), ("tiny_mlas", False),
                                        ("ties", False), ("chimera", False)])
-@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("exact", [0, 1, 2])
 def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas, exact):
     src, _ = datasets(name)
     wd_o = clone_dataset(src, str(tmp_path / "oracle"))
@@ -54,3 +54,35 @@ def test_filter_ini_variants(datasets, oracle_lib, tmp_path, extra):
     assert _oracle_filter(oracle_lib, wd_o, False, "v.ini") == 0
     assert _hip_filter(wd_h, False, "v.ini") == 0
     _compare(wd_o, wd_h)
+
+
+def test_pileup_order_replays_std_sort(oracle_lib):
+    """wave_pileup_order (parallel Hoare partitions in LDS) == std::sort(compare_overlap) of libstdc++."""
+    import ctypes
+    from hinge_amd import capi
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(5)
+    ip = ctypes.POINTER(ctypes.c_int)
+    sizes = [0, 1, 2, 15, 16, 17, 18, 33, 64, 65, 100, 257, 1000, 2048, 4095, 4096] + [int(x) for x in rng.integers(17, 4096, size=40)]
+    for n in sizes:
+        for kind in range(6):
+            if kind == 0:
+                key = rng.integers(0, 4, size=n)
+            elif kind == 1:
+                key = rng.integers(0, max(1, n // 8) + 1, size=n)
+            elif kind == 2:
+                key = np.sort(rng.integers(0, 50, size=n))
+            elif kind == 3:
+                key = np.sort(rng.integers(0, 50, size=n))[::-1]
+            elif kind == 4:
+                key = rng.integers(0, 1 << 20, size=n)
+            else:
+                key = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]])
+            key = np.ascontiguousarray(key, dtype=np.int32)
+            perm = np.zeros(max(n, 1), np.int32)
+            oracle_lib.oracle_sort_perm(n, key.ctypes.data_as(ip), 0, perm.ctypes.data_as(ip))   # descending, like compare_overlap
+            pos = ctx.debug_pileup_order(key)
+            got = np.zeros(n, np.int32)
+            got[pos] = np.arange(n, dtype=np.int32)
+            assert np.array_equal(got, perm[:n]), (n, kind)
+    ctx.close()
