@@ -11,7 +11,7 @@ LIB  = hinge_amd/lib/libhinge_hip.so
 
 all: $(LIB) oracle
 
-$(LIB): $(CSRC)/hinge_capi.hip $(CSRC)/filter_kernels.h $(CSRC)/align_kernels.h $(CSRC)/align_capi.inc $(CSRC)/stdsort_emul.h include/hinge_hip.h
+$(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.inc) include/hinge_hip.h
 	mkdir -p hinge_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hinge_capi.hip
 

@@ -20,12 +20,13 @@
 namespace hinge {
 
 constexpr int HC_SMALL = 64;    // lists up to this size try the tie-free shortcut
+constexpr int SF_BINS = 2 * PO_CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
 
 struct HingeCallLds {
     WaveSortLds ws;
     unsigned short ppos[PO_CAP];   // position of every overlap of the read in the sorted pile-up
-    int sF[PO_CAP];                // supporters in .las order: other end in scan-ascending form ...
-    int sS[PO_CAP];                // ... and the overhang on the far side; reused for the sorted lists
+    alignas(16) int sF[PO_CAP];    // supporters in .las order: other end in scan-ascending form ...
+    alignas(16) int sS[PO_CAP];    // ... and the overhang on the far side; reused for the sorted lists
     unsigned short sK[PO_CAP];     // ... and the local overlap index
     int sL[HC_SMALL];              // length sums of the first HC_SMALL supporters
     int wF[PO_CAP];                // supporters in pile-up order
@@ -34,6 +35,10 @@ struct HingeCallLds {
     int cnt;
     int need_order;
     int near_end;
+    int ev_ucan, ev_bcan, ev_umust, ev_bmust, f0;   // sort-free scan: smallest f (bin) of a group with each property
+    int sf_over;
+    int wtot[2][WAVES_PER_BLOCK];
+    unsigned next_item;
 };
 
 __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
@@ -43,14 +48,21 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                                                       const int* __restrict__ work_list, const unsigned* __restrict__ counters,
                                                       unsigned char* __restrict__ hinge_flag, int2* __restrict__ exact_queue,
                                                       unsigned* __restrict__ exact_count, unsigned exact_cap, int force_exact,
-                                                      int* __restrict__ status) {
+                                                      int* __restrict__ status, unsigned* __restrict__ work_next,
+                                                      unsigned* __restrict__ dbg) {
     __shared__ HingeCallLds S;
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wib = tid >> 6;
     const unsigned long long lmask = (1ull << lane) - 1ull;
     const unsigned nwork = counters[1];
-    for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {
+    while (true) {
+        // dynamic work distribution: reads differ by orders of magnitude in cost
+        __syncthreads();
+        if (tid == 0) S.next_item = atomicAdd(work_next, 1u);
+        __syncthreads();
+        const unsigned w = S.next_item;
+        if (w >= nwork) break;
         const int i = work_list[w];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int n = (int)(e - s);
@@ -65,6 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             if (tid == 0) { S.cnt = 0; S.need_order = 0; S.near_end = 0; }
             const int m0 = type == -1 ? mk.x : -mk.y;
             __syncthreads();
+            long long T0 = clock64();
             // ---- gather -----------------------------------------------------------------------------
             int par = 0;
             for (int64_t k0 = s; k0 < e; k0 += BLOCK, par ^= 1) {
@@ -110,6 +123,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             }
             __syncthreads();
             const int sup = S.cnt;
+            long long T1 = clock64();
             // ---- decide the path (block-uniform) ----------------------------------------------------
             int action;   // 0: result 0, 1: resolve in LDS, 2: k_hinge_exact, 3: result 1 without sorting
             if (sup <= P.sup) action = 0;   // needs support >= SUP to be scanned and > SUP to be emitted
@@ -123,6 +137,106 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             else if (sup > PO_CAP || force_exact == 1) action = 2;
             else action = 1;
             bool need_order = false;
+            if (action == 1 && force_exact == 0 && sup <= PO_CAP) {
+                // ---- sort-free evaluation of the scan (filter.cpp:932-963 / 1031-1062) -----------------
+                // Past the first-branch prefix (c1 = near_end <= UNB elements) the scan walks the remaining
+                // supporters by ascending f.  With cat = 2 (sec < TH), 3 (sec > TH), 0 (sec == TH):
+                //   a cat-2 element stops it "unbridged" once considered > UNB and f - f[0] > BIN, where
+                //     considered = c1 + #(cat 2/3 elements up to and including it);
+                //   a cat-3 element stops it "bridged" when 1 + #(following elements with f' - f < BIN) > PIL.
+                // Take the group G of elements with one value f: g2/g3/g0 members per category, g = |G|,
+                // before = #(cat 2/3 elements with smaller f), W = #(f < f' < f + BIN), far = f - f[0] > BIN.
+                // Whatever order std::sort leaves INSIDE the group:
+                //   U_can  (an unbridged stop is possible)  = far, g2 >= 1, c1 + before + g2 + g3 > UNB
+                //   B_can  (a bridged stop is possible)     = g3 >= 1, g + W > PIL        (a cat-3 member first)
+                //   U_must (unbridged stop in every order)  = far, c1 + before + g2 > UNB (the last cat-2 member
+                //                                             has seen all g2 of them), and not B_can
+                //   B_must (bridged stop in every order)    = g3 >= 1, g3 + W > PIL (the first cat-3 member has at
+                //                                             least the other g3 - 1 behind it), and not U_can
+                // The scan's outcome is decided by the first group that stops it, so with F* = smallest f of a
+                // group with that property:  no U_can anywhere -> bridged;  F(B_must) < F(U_can) -> bridged;
+                // F(U_must) < F(B_can) -> unbridged.  Only otherwise does the tie order matter (exact replay).
+                // Groups are found by binning f - f[0] at 1 bp (SF_BINS bins in LDS scratch that is idle at this
+                // point); `before` and W are differences of prefix sums over the bins.  O(sup + SF_BINS).
+                // Supporters further than SF_BINS bp from f[0] are rare; such a list takes the exact replay.
+                if (tid == 0) { S.ev_ucan = INT_MAX; S.ev_bcan = INT_MAX; S.ev_umust = INT_MAX; S.ev_bmust = INT_MAX; S.f0 = INT_MAX; S.sf_over = 0; }
+                int* bin23 = S.wF;                                   // [SF_BINS] g2 | g3 << 16   (wF..wS are contiguous)
+                unsigned short* bin0 = reinterpret_cast<unsigned short*>(S.ws.key);    // [SF_BINS] g0
+                unsigned short* p23 = S.ws.pl;                       // [SF_BINS] inclusive prefix of g2 + g3 (pl..pr)
+                unsigned short* pall = S.ws.seglo;                   // [SF_BINS] inclusive prefix of g       (seglo..seghi)
+                for (int b = tid; b < SF_BINS; b += BLOCK) { bin23[b] = 0; bin0[b] = 0; }
+                __syncthreads();
+                {
+                    int fm = INT_MAX;
+                    for (int t = tid; t < sup; t += BLOCK) fm = min(fm, S.sF[t]);
+                    fm = -wave_max(-fm);
+                    if (lane == 0 && fm != INT_MAX) atomicMin(&S.f0, fm);
+                }
+                __syncthreads();
+                const int f0 = S.f0, c1 = S.near_end;
+                for (int t = tid; t < sup; t += BLOCK) {
+                    const int ft = S.sF[t];
+                    if (ft - m0 < P.bin_len) continue;   // first-branch prefix: never counted in `before` or W
+                    const int rel = ft - f0;
+                    if (rel >= SF_BINS) { S.sf_over = 1; continue; }
+                    const int st = S.sS[t];
+                    if (st < P.theta) atomicAdd(&bin23[rel], 1);
+                    else if (st > P.theta) atomicAdd(&bin23[rel], 1 << 16);
+                    else atomicAdd(reinterpret_cast<unsigned*>(&bin0[rel & ~1]), (rel & 1) ? (1u << 16) : 1u);
+                }
+                __syncthreads();
+                if (!S.sf_over) {
+                    // workgroup inclusive scan: each thread owns SF_BINS/BLOCK consecutive bins
+                    constexpr int PER = SF_BINS / BLOCK;
+                    const int b0 = tid * PER;
+                    int s23 = 0, sall = 0;
+                    for (int k = 0; k < PER; k++) {
+                        const int v = bin23[b0 + k];
+                        const int c23 = (v & 0xffff) + (v >> 16);
+                        s23 += c23;
+                        sall += c23 + bin0[b0 + k];
+                    }
+                    int i23 = wave_incl_scan(s23), iall = wave_incl_scan(sall);
+                    if (lane == WAVE - 1) { S.wtot[0][wib] = i23; S.wtot[1][wib] = iall; }
+                    __syncthreads();
+                    int off23 = 0, offall = 0;
+                    for (int ww = 0; ww < wib; ww++) { off23 += S.wtot[0][ww]; offall += S.wtot[1][ww]; }
+                    int run23 = off23 + i23 - s23, runall = offall + iall - sall;
+                    for (int k = 0; k < PER; k++) {
+                        const int v = bin23[b0 + k];
+                        const int c23 = (v & 0xffff) + (v >> 16);
+                        run23 += c23;
+                        runall += c23 + bin0[b0 + k];
+                        p23[b0 + k] = (unsigned short)run23;
+                        pall[b0 + k] = (unsigned short)runall;
+                    }
+                    __syncthreads();
+                    for (int b = tid; b < SF_BINS; b += BLOCK) {
+                        const int v = bin23[b];
+                        const int g2 = v & 0xffff, g3 = v >> 16;
+                        const int g = g2 + g3 + bin0[b];
+                        if (g == 0) continue;
+                        const int before = (int)p23[b] - (g2 + g3);
+                        const int W = (int)pall[min(b + P.bin_len - 1, SF_BINS - 1)] - (int)pall[b];
+                        const bool far = b > P.bin_len;          // f - f[0] > BIN
+                        const bool ucan = far && g2 >= 1 && (c1 + before + g2 + g3 > P.unb);
+                        const bool bcan = g3 >= 1 && (g + W > P.pil);
+                        const bool umust = far && g2 >= 1 && (c1 + before + g2 > P.unb) && !bcan;
+                        const bool bmust = g3 >= 1 && (g3 + W > P.pil) && !ucan;
+                        if (ucan) atomicMin(&S.ev_ucan, b);
+                        if (bcan) atomicMin(&S.ev_bcan, b);
+                        if (umust) atomicMin(&S.ev_umust, b);
+                        if (bmust) atomicMin(&S.ev_bmust, b);
+                    }
+                    __syncthreads();
+                    if (S.ev_ucan == INT_MAX) action = 0;
+                    else if (S.ev_bmust < S.ev_ucan) action = 0;
+                    else if (S.ev_umust < S.ev_bcan) action = 3;
+                }
+            }
+            long long T2 = clock64();
+            if (tid == 0 && dbg) { atomicAdd((unsigned long long*)&dbg[8], (unsigned long long)(T1 - T0)); atomicAdd((unsigned long long*)&dbg[10], (unsigned long long)(T2 - T1)); }
+            if (tid == 0 && dbg) { atomicAdd(&dbg[action], 1u); atomicMax(&dbg[6], (unsigned)sup); atomicMax(&dbg[7], (unsigned)cnt); }
             if (action == 1) {
                 need_order = (force_exact == 2) || (sup > HC_SMALL);
                 if (!need_order) {
@@ -157,60 +271,68 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             }
             // ---- exact pile-up order, once per read ---------------------------------------------
             if (need_order && !order_ready) {
+                if (tid == 0 && dbg) atomicAdd(&dbg[4], 1u);
                 for (int64_t k = s + tid; k < e; k += BLOCK) {
                     const int2 av = a_span[k];
                     const int2 bs = b_span[k];
                     S.ws.key[k - s] = av.y - av.x + bs.y - bs.x;   // compare_overlap key
                 }
                 __syncthreads();
-                if (wib == 0) {
-                    wave_std_sort_desc(S.ws, n, lane);
-                    for (int p = lane; p < n; p += WAVE) S.ppos[p] = S.ws.pl[p];
-                }
+                block_std_sort_desc(S.ws, n, tid);
+                for (int p = tid; p < n; p += BLOCK) S.ppos[p] = S.ws.pl[p];
                 __syncthreads();
                 order_ready = true;
             }
-            if (wib != 0) continue;   // the rest is one wave's work; the loop top re-synchronises
-            // ---- supporters in pile-up order -> wF / wS ---------------------------------------------
-            if (need_order) {
-                unsigned short* slot_of = S.ws.seglo;   // scratch: pile-up position -> supporter + 1
-                for (int p = lane; p < n; p += WAVE) slot_of[p] = 0;
-                for (int t = lane; t < sup; t += WAVE) slot_of[S.ppos[S.sK[t]]] = (unsigned short)(t + 1);
-                int r = 0;
-                for (int base = 0; base < n; base += WAVE) {
-                    const int p = base + lane;
-                    const int v = p < n ? slot_of[p] : 0;
-                    const unsigned long long bal = __ballot(v != 0);
-                    if (v) {
-                        const int dst = r + __popcll(bal & lmask);
-                        S.wF[dst] = S.sF[v - 1];
-                        S.wS[dst] = S.sS[v - 1];
+            if (tid == 0 && dbg && need_order) atomicAdd(&dbg[5], 1u);
+            long long T3 = clock64();
+            // ---- supporters in pile-up order -> wF / wS (one wave) --------------------------------
+            if (wib == 0) {
+                if (need_order) {
+                    unsigned short* slot_of = S.ws.seglo;   // scratch: pile-up position -> supporter + 1
+                    for (int p = lane; p < n; p += WAVE) slot_of[p] = 0;
+                    for (int t = lane; t < sup; t += WAVE) slot_of[S.ppos[S.sK[t]]] = (unsigned short)(t + 1);
+                    int r = 0;
+                    for (int base = 0; base < n; base += WAVE) {
+                        const int p = base + lane;
+                        const int v = p < n ? slot_of[p] : 0;
+                        const unsigned long long bal = __ballot(v != 0);
+                        if (v) {
+                            const int dst = r + __popcll(bal & lmask);
+                            S.wF[dst] = S.sF[v - 1];
+                            S.wS[dst] = S.sS[v - 1];
+                        }
+                        r += __popcll(bal);
                     }
-                    r += __popcll(bal);
-                }
-            } else {
-                for (int t = lane; t < sup; t += WAVE) {
-                    const int Lt = S.sL[t];
-                    int rank = 0;
-                    for (int u = 0; u < sup; u++) {
-                        const int Lu = S.sL[u];
-                        rank += (Lu > Lt) || (Lu == Lt && u < t);   // .las order breaks (harmless) ties
+                } else {
+                    for (int t = lane; t < sup; t += WAVE) {
+                        const int Lt = S.sL[t];
+                        int rank = 0;
+                        for (int u = 0; u < sup; u++) {
+                            const int Lu = S.sL[u];
+                            rank += (Lu > Lt) || (Lu == Lt && u < t);   // .las order breaks (harmless) ties
+                        }
+                        S.wF[rank] = S.sF[t];
+                        S.wS[rank] = S.sS[t];
                     }
-                    S.wF[rank] = S.sF[t];
-                    S.wS[rank] = S.sS[t];
                 }
             }
+            __syncthreads();
+            long long T4 = clock64();
             // ---- std::sort(pairAscend / pairDescend): ascending f == descending -f --------------------
-            for (int t = lane; t < sup; t += WAVE) S.ws.key[t] = -S.wF[t];
-            wave_std_sort_desc(S.ws, sup, lane);
-            for (int t = lane; t < sup; t += WAVE) {
+            for (int t = tid; t < sup; t += BLOCK) S.ws.key[t] = -S.wF[t];
+            __syncthreads();
+            block_std_sort_desc(S.ws, sup, tid);
+            for (int t = tid; t < sup; t += BLOCK) {
                 const int p = S.ws.pl[t];
                 S.sF[p] = S.wF[t];
                 S.sS[p] = S.wS[t];
             }
-            if (lane == 0) {
+            __syncthreads();
+            long long T5 = clock64();
+            if (tid == 0) {
                 const int r = hinge_scan(S.sF, S.sS, nullptr, sup, m0, P.bin_len, P.theta, P.unb, P.pil);
                 hinge_flag[off + a] = r == 0 ? 1 : 0;   // emit iff not bridged (support > SUP holds)
+                if (dbg) { long long T6 = clock64(); atomicAdd((unsigned long long*)&dbg[12], (unsigned long long)(T3 - T2)); atomicAdd((unsigned long long*)&dbg[14], (unsigned long long)(T4 - T3)); atomicAdd((unsigned long long*)&dbg[16], (unsigned long long)(T5 - T4)); atomicAdd((unsigned long long*)&dbg[18], (unsigned long long)(T6 - T5)); }
             }
         }
     }

@@ -93,11 +93,14 @@ struct Scalars {
     unsigned long long arena_used;
     unsigned counters[2];               // annotation alloc, work count
     unsigned exact_count;
+    unsigned work_next;                 // k_hinge_call's work-list cursor
     int status;
+    int pad0;
     // ---- persistent across passes ----
     int est[2];                         // cov_est, n_long
     int min_cov;
     int pad;
+    unsigned dbg[24];                   // k_hinge_call path counters + phase cycles (cumulative; diagnostics only)
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
 
@@ -302,12 +305,13 @@ int hinge_clear_masks(hinge_ctx* ctx) {
 }
 
 // test hook: std::sort(compare_overlap) order of n keys through the wavefront-parallel replay
-__global__ __launch_bounds__(64) void k_debug_pileup_order(const int* __restrict__ keys, int n, int* __restrict__ pos_out) {
+__global__ __launch_bounds__(256) void k_debug_pileup_order(const int* __restrict__ keys, int n, int* __restrict__ pos_out) {
     __shared__ WaveSortLds po;
-    const int lane = threadIdx.x;
-    for (int k = lane; k < n; k += 64) po.key[k] = keys[k];
-    wave_std_sort_desc(po, n, lane);
-    for (int k = lane; k < n; k += 64) pos_out[k] = po.pl[k];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += 256) po.key[k] = keys[k];
+    __syncthreads();
+    block_std_sort_desc(po, n, tid);
+    for (int k = tid; k < n; k += 256) pos_out[k] = po.pl[k];
 }
 
 int hinge_debug_pileup_order(hinge_ctx* ctx, int32_t n, const int32_t* keys, int32_t* pos_out) {
@@ -317,7 +321,7 @@ int hinge_debug_pileup_order(hinge_ctx* ctx, int32_t n, const int32_t* keys, int
     CK(hipMalloc(&dk, sizeof(int) * (size_t)std::max(n, 1)));
     CK(hipMalloc(&dp, sizeof(int) * (size_t)std::max(n, 1)));
     CK(hipMemcpy(dk, keys, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_debug_pileup_order, dim3(1), dim3(64), 0, ctx->stream, (const int*)dk, n, dp);
+    hipLaunchKernelGGL(k_debug_pileup_order, dim3(1), dim3(256), 0, ctx->stream, (const int*)dk, n, dp);
     CK(hipGetLastError());
     CK(hipStreamSynchronize(ctx->stream));
     CK(hipMemcpy(pos_out, dp, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
@@ -470,7 +474,8 @@ static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
                        (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
-                       (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status); }
+                       (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status,
+                       &sc(ctx)->work_next, sc(ctx)->dbg); }
     CK(hipGetLastError());
     ProfScope _ps2(ctx, KID_HINGE_EXACT);
     hipLaunchKernelGGL(k_hinge_exact, dim3(64), dim3(64), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
@@ -508,7 +513,7 @@ int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 16; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, sizeof(unsigned), ctx->stream));
+        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 2 * sizeof(unsigned), ctx->stream));   // + work_next
         CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
         if ((rc = launch_hinges(ctx, p))) return rc;
         int rerun = 0;
@@ -644,6 +649,14 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     int64_t nh = 0;
     for (unsigned char c : hf) nh += c;
     out[3] = nh;
+    if (getenv("HINGE_DEBUG_PATHS"))
+        fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u\n",
+                h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7]);
+    if (getenv("HINGE_DEBUG_PATHS")) {
+        const unsigned long long* t = (const unsigned long long*)&h.dbg[8];
+        fprintf(stderr, "[hinge] cumulative Mcycles: gather=%.1f pairwise=%.1f pilesort=%.1f compact=%.1f supsort=%.1f scan=%.1f\n",
+                t[0] / 1e6, t[1] / 1e6, t[2] / 1e6, t[3] / 1e6, t[4] / 1e6, t[5] / 1e6);
+    }
     return HINGE_OK;
 }
 

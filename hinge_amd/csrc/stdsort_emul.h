@@ -130,21 +130,19 @@ HINGE_HD inline void insertion_sort_(int* a, int first, int last, const KeyCmp& 
     }
 }
 
-// std::sort(idx, idx + n, comp).  The explicit stack replaces the recursion on the right part.
-HINGE_HD inline void std_sort(int* idx, int n, const int* key, int desc) {
-    if (n <= 0) return;
-    KeyCmp c{key, desc};
+// __introsort_loop(idx + first, idx + last, depth, comp).  The explicit stack replaces the recursion on
+// the right part: the recursive call on [cut,last) runs BEFORE the loop continues on [first,cut), but the
+// two ranges are disjoint, so deferring one of them performs the same operations on each range.
+template <int STACK>
+HINGE_HD inline void introsort_loop(int* idx, int first0, int last0, int depth0, const KeyCmp& c) {
     const int THRESH = 16;
-    int stack_first[64], stack_last[64], stack_depth[64];
+    int stack_first[STACK], stack_last[STACK], stack_depth[STACK];
     int sp = 0;
-    stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = floor_log2((unsigned)n) * 2;
+    stack_first[0] = first0; stack_last[0] = last0; stack_depth[0] = depth0;
     sp = 1;
     while (sp > 0) {
         --sp;
         int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
-        // __introsort_loop(first, last, depth): the recursive call on [cut,last) runs BEFORE the loop
-        // continues on [first,cut).  The two ranges are disjoint, so deferring the left part on the
-        // stack while the right part is processed first performs the same operations on each range.
         while (last - first > THRESH) {
             if (depth == 0) {
                 heapsort_(idx, first, last, c);
@@ -154,12 +152,20 @@ HINGE_HD inline void std_sort(int* idx, int n, const int* key, int desc) {
             int mid = first + (last - first) / 2;
             move_median_to_first_(idx, first, first + 1, mid, last - 1, c);
             int cut = unguarded_partition_(idx, first + 1, last, first, c);
-            // push left part for later, continue with the right part now
+            // defer the LARGER... no: defer the left part, continue with the right part (any order is exact)
             stack_first[sp] = first; stack_last[sp] = cut; stack_depth[sp] = depth;
             ++sp;
             first = cut;
         }
     }
+}
+
+// std::sort(idx, idx + n, comp)
+HINGE_HD inline void std_sort(int* idx, int n, const int* key, int desc) {
+    if (n <= 0) return;
+    KeyCmp c{key, desc};
+    const int THRESH = 16;
+    introsort_loop<64>(idx, 0, n, floor_log2((unsigned)n) * 2, c);
     // __final_insertion_sort
     if (n > THRESH) {
         insertion_sort_(idx, 0, THRESH, c);
