@@ -77,7 +77,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             if (tid == 0) { S.cnt = 0; S.need_order = 0; S.near_end = 0; }
             const int m0 = type == -1 ? mk.x : -mk.y;
             __syncthreads();
-            long long T0 = clock64();
             // ---- gather -----------------------------------------------------------------------------
             int par = 0;
             for (int64_t k0 = s; k0 < e; k0 += BLOCK, par ^= 1) {
@@ -123,7 +122,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             }
             __syncthreads();
             const int sup = S.cnt;
-            long long T1 = clock64();
             // ---- decide the path (block-uniform) ----------------------------------------------------
             int action;   // 0: result 0, 1: resolve in LDS, 2: k_hinge_exact, 3: result 1 without sorting
             if (sup <= P.sup) action = 0;   // needs support >= SUP to be scanned and > SUP to be emitted
@@ -234,8 +232,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                     else if (S.ev_umust < S.ev_bcan) action = 3;
                 }
             }
-            long long T2 = clock64();
-            if (tid == 0 && dbg) { atomicAdd((unsigned long long*)&dbg[8], (unsigned long long)(T1 - T0)); atomicAdd((unsigned long long*)&dbg[10], (unsigned long long)(T2 - T1)); }
             if (tid == 0 && dbg) { atomicAdd(&dbg[action], 1u); atomicMax(&dbg[6], (unsigned)sup); atomicMax(&dbg[7], (unsigned)cnt); }
             if (action == 1) {
                 need_order = (force_exact == 2) || (sup > HC_SMALL);
@@ -284,7 +280,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 order_ready = true;
             }
             if (tid == 0 && dbg && need_order) atomicAdd(&dbg[5], 1u);
-            long long T3 = clock64();
             // ---- supporters in pile-up order -> wF / wS (one wave) --------------------------------
             if (wib == 0) {
                 if (need_order) {
@@ -317,7 +312,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 }
             }
             __syncthreads();
-            long long T4 = clock64();
             // ---- std::sort(pairAscend / pairDescend): ascending f == descending -f --------------------
             for (int t = tid; t < sup; t += BLOCK) S.ws.key[t] = -S.wF[t];
             __syncthreads();
@@ -328,11 +322,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 S.sS[p] = S.wS[t];
             }
             __syncthreads();
-            long long T5 = clock64();
             if (tid == 0) {
                 const int r = hinge_scan(S.sF, S.sS, nullptr, sup, m0, P.bin_len, P.theta, P.unb, P.pil);
                 hinge_flag[off + a] = r == 0 ? 1 : 0;   // emit iff not bridged (support > SUP holds)
-                if (dbg) { long long T6 = clock64(); atomicAdd((unsigned long long*)&dbg[12], (unsigned long long)(T3 - T2)); atomicAdd((unsigned long long*)&dbg[14], (unsigned long long)(T4 - T3)); atomicAdd((unsigned long long*)&dbg[16], (unsigned long long)(T5 - T4)); atomicAdd((unsigned long long*)&dbg[18], (unsigned long long)(T6 - T5)); }
             }
         }
     }

@@ -100,7 +100,7 @@ struct Scalars {
     int est[2];                         // cov_est, n_long
     int min_cov;
     int pad;
-    unsigned dbg[24];                   // k_hinge_call path counters + phase cycles (cumulative; diagnostics only)
+    unsigned dbg[8];                    // k_hinge_call path counters (cumulative; diagnostics only)
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
 
@@ -652,11 +652,6 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     if (getenv("HINGE_DEBUG_PATHS"))
         fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u\n",
                 h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7]);
-    if (getenv("HINGE_DEBUG_PATHS")) {
-        const unsigned long long* t = (const unsigned long long*)&h.dbg[8];
-        fprintf(stderr, "[hinge] cumulative Mcycles: gather=%.1f pairwise=%.1f pilesort=%.1f compact=%.1f supsort=%.1f scan=%.1f\n",
-                t[0] / 1e6, t[1] / 1e6, t[2] / 1e6, t[3] / 1e6, t[4] / 1e6, t[5] / 1e6);
-    }
     return HINGE_OK;
 }
 

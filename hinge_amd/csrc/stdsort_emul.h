@@ -152,7 +152,7 @@ HINGE_HD inline void introsort_loop(int* idx, int first0, int last0, int depth0,
             int mid = first + (last - first) / 2;
             move_median_to_first_(idx, first, first + 1, mid, last - 1, c);
             int cut = unguarded_partition_(idx, first + 1, last, first, c);
-            // defer the LARGER... no: defer the left part, continue with the right part (any order is exact)
+            // defer the left part, continue with the right part (any order gives the same result)
             stack_first[sp] = first; stack_last[sp] = cut; stack_depth[sp] = depth;
             ++sp;
             first = cut;

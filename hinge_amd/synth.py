@@ -386,6 +386,8 @@ CONFIGS = {
     "ties": SynthSpec(genome_len=100_000, coverage=60, seed=10, tie_quantum=100, end_jitter=0, indel_max=0,
                       n_repeat_families=2, repeat_copies=(2, 3)),
     "chimera": SynthSpec(genome_len=150_000, coverage=40, seed=11, chimera_frac=0.05, n_repeat_families=2),
+    "long_repeat": SynthSpec(genome_len=150_000, coverage=80, len_min=3000, len_max=8000, repeat_len=(12000, 12000),
+                             repeat_copies=(2, 2), inverted_copies=False, seed=23),
     "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
                                  repeat_len=(1000, 5000), repeat_copies=(2, 3)),
     "cfg2_ecoli160": SynthSpec(genome_len=4_600_000, coverage=160, len_dist="lognormal", len_mean=8500,

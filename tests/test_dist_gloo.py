@@ -1,0 +1,154 @@
+"""The N > 1 path on CPU: world_size 2, gloo.  The exchange / orchestration layer (hinge_amd/dist.py) runs
+for real; the per-block compute is replaced by tables taken from a CPU-oracle run of the same data, so
+the test checks what the collectives must deliver: the global median / the --mlas running MIN_COV, the
+mask table every rank sees before hinge calling (all parts in "merged" mode, only parts <= own in
+"mlas" mode), and the assembled global hinge list."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import clone_dataset, run_in
+
+MEAN_SENTINEL = -(2 ** 31)
+
+
+def _mean_cov_from_coverage(path, rlen):
+    out = np.full(len(rlen), MEAN_SENTINEL, np.int64)
+    for line in open(path):
+        tok = line.split()
+        i = int(tok[1])
+        if rlen[i] < 5000:
+            continue
+        vals = [int(t.split(",")[1]) for t in tok[2:]]
+        s = sum(vals)
+        k = max(1, len(vals))
+        out[i] = int(s / k) if s >= 0 else -int(-s / k)
+    return out
+
+
+def _pairs(path):
+    rows = []
+    for line in open(path):
+        tok = line.split()
+        i = int(tok[0])
+        for j in range(1, len(tok) - 1, 2):
+            rows.append((i, int(tok[j]), int(tok[j + 1])))
+    return np.array(rows, np.int32).reshape(-1, 3)
+
+
+class TableBackend:
+    """Stands in for HipBackend: same methods, values from precomputed tables."""
+
+    def __init__(self, lo, hi, mean_all, mask_all, hinge_rows, expect_min_cov, expect_visible_mask, ini_min_cov=5):
+        self.lo, self.hi = lo, hi
+        self.mean_all, self.mask_all, self.rows = mean_all, mask_all, hinge_rows
+        self.expect_min_cov, self.expect_visible = expect_min_cov, expect_visible_mask
+        self.ini_min_cov, self.est_cov = ini_min_cov, 0
+        self.min_cov = ini_min_cov
+        self.checked = []
+
+    def attach(self, mean_cov, mask):
+        self.mean_cov, self.mask = mean_cov, mask
+
+    def begin(self):
+        self.min_cov = self.ini_min_cov
+
+    def stats(self):
+        self.mean_cov[self.lo:self.hi] = torch.from_numpy(self.mean_all[self.lo:self.hi].astype(np.int32))
+
+    def _median(self, lo, hi):
+        v = self.mean_cov[lo:hi + 1]
+        v = np.sort(v[v != MEAN_SENTINEL].numpy())
+        return int(v[len(v) // 2])
+
+    def median(self, lo, hi):
+        c = self._median(lo, hi)
+        self.min_cov = max(self.min_cov, int(c / 3))
+
+    def median_fetch(self, lo, hi):
+        return self._median(lo, hi)
+
+    def set_min_cov(self, v):
+        self.min_cov = v
+
+    def mask_annotate(self):
+        assert self.min_cov == self.expect_min_cov, (self.min_cov, self.expect_min_cov)
+        self.mask[self.lo:self.hi] = torch.from_numpy(self.mask_all[self.lo:self.hi])
+        self.checked.append("min_cov")
+
+    def hinges(self):
+        assert np.array_equal(self.mask.numpy(), self.expect_visible), "mask table seen by hinge calling is wrong"
+        self.checked.append("masks")
+
+    def hinge_rows(self):
+        sel = (self.rows[:, 0] >= self.lo) & (self.rows[:, 0] < self.hi)
+        t = torch.from_numpy(np.ascontiguousarray(self.rows[sel]))
+        return t, int(t.shape[0])
+
+
+def _worker(rank, world, port, mode, first, mean_all, mask_all, rows, expect_min_cov, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hinge_amd.dist import BlockTable, Exchange, ShardedFilter
+        blocks = BlockTable(first)
+        lo, hi = first[rank], first[rank + 1]
+        visible = mask_all.copy()
+        if mode == "mlas":
+            visible[hi:] = 0
+        be = TableBackend(lo, hi, mean_all, mask_all, rows, expect_min_cov[rank], visible)
+        job = ShardedFilter(be, Exchange(blocks, torch.device("cpu")), mode=mode)
+        got = job.step(fetch_hinges=True)
+        assert be.checked == ["min_cov", "masks"]
+        assert np.array_equal(job.mean_cov.numpy()[lo:hi], mean_all[lo:hi].astype(np.int32))
+        if mode == "merged":
+            assert np.array_equal(job.mean_cov.numpy(), mean_all.astype(np.int32)), "all-gather of mean coverage"
+        assert np.array_equal(got.numpy(), rows), "assembled hinge list"
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["merged", "mlas"])
+def test_sharded_filter_exchanges(oracle_lib, tmp_path, mode):
+    import dataclasses
+    from hinge_amd import synth
+    from hinge_amd.dist import mlas_min_cov
+    from conftest import write_ini
+    d = synth.generate(dataclasses.replace(synth.CONFIGS["tiny_mlas"], n_blocks=2))
+    wd = str(tmp_path / "data")
+    synth.write_dataset(d, wd, "G")
+    write_ini(os.path.join(wd, "nominal.ini"))
+    mlas = mode == "mlas"
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G" if mlas else b"G.las", int(mlas), b"G", b"nominal.ini", b"") == 0
+    first = d.block_first
+    mean_all = _mean_cov_from_coverage(os.path.join(wd, "G.coverage.txt"), d.rlen)
+    mask_all = np.loadtxt(os.path.join(wd, "G.mas"), dtype=np.int64)[:, 1:].astype(np.int32)
+    rows = _pairs(os.path.join(wd, "G.hinges.txt"))
+    # expected MIN_COV per rank from the path's own definition (filter.cpp:660-678)
+    def med(lo, hi):
+        v = np.sort(mean_all[lo:hi][mean_all[lo:hi] != MEAN_SENTINEL])
+        return int(v[len(v) // 2])
+    if mlas:
+        expect = mlas_min_cov(5, [med(first[k], first[k + 1]) for k in range(2)])
+    else:
+        expect = [max(5, int(med(0, d.n_reads) / 3))] * 2
+    port = 29500 + (os.getpid() % 2000) + (7 if mlas else 0)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, mode, first, mean_all, mask_all, rows, expect, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_mlas_min_cov_is_a_running_max():
+    from hinge_amd.dist import mlas_min_cov
+    assert mlas_min_cov(5, [30, 12, 60, 9]) == [10, 10, 20, 20]
+    assert mlas_min_cov(5, [3, 6]) == [5, 5]
+    assert mlas_min_cov(-1, [2, 0]) == [0, 0]
+    assert mlas_min_cov(5, [30, 90], est_cov_override=45) == [15, 15]

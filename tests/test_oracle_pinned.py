@@ -1,0 +1,154 @@
+"""The oracle's library-level functions against the REFERENCE's own compiled code:
+ * golden vectors captured from oracle/_ref (tests/golden/ref_vectors.npz, made by make_golden.py) - always run;
+ * the live oracle/_ref library when it is present (build container) - same calls, fresh random inputs."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden  # noqa: E402
+
+ip = ctypes.POINTER(ctypes.c_int)
+u16p = ctypes.POINTER(ctypes.c_uint16)
+P = lambda a: a.ctypes.data_as(ip)  # noqa: E731
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz"), allow_pickle=True)
+
+
+def _cov(lib, pre, n, ab, ae, cutoff):
+    buf = np.zeros(4096, np.int32)
+    K = getattr(lib, pre + "_profile_coverage")(n, P(np.ascontiguousarray(ab, np.int32)), P(np.ascontiguousarray(ae, np.int32)), 40, cutoff, P(buf), 4096)
+    return K, buf[:K].copy()
+
+
+def _pa(lib, pre, hdr, trace, aln_thr, theta, theta2):
+    res = np.zeros(10, np.int32)
+    hdr = np.ascontiguousarray(hdr, np.int32)
+    trace = np.ascontiguousarray(trace, np.uint16)
+    getattr(lib, pre + "_process_alignment")(P(hdr), trace.ctypes.data_as(u16p), len(trace), aln_thr, theta, theta2, P(res))
+    return res
+
+
+def _mp(lib, pre, hdr, trace, pos):
+    trace = np.ascontiguousarray(trace, np.uint16)
+    return getattr(lib, pre + "_matching_position")(int(hdr[0]), int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4]),
+                                                    trace.ctypes.data_as(u16p), len(trace), int(pos))
+
+
+def test_profile_coverage_golden(oracle_lib):
+    for cin, cout in zip(GOLD["cov_in"], GOLD["cov_out"]):
+        n, cutoff = int(cin[0]), int(cin[1])
+        K, cov = _cov(oracle_lib, "oracle", n, cin[2:2 + n], cin[2 + n:2 + 2 * n], cutoff)
+        assert K == cout[0] and np.array_equal(cov, cout[1:])
+
+
+def test_process_alignment_and_matching_position_golden(oracle_lib):
+    for hdr, trace, want, mp in zip(GOLD["pa_in"], GOLD["pa_trace"], GOLD["pa_out"], GOLD["mp"]):
+        got = _pa(oracle_lib, "oracle", hdr[:9], trace, int(hdr[9]), int(hdr[10]), int(hdr[11]))
+        assert np.array_equal(got, want), (hdr, got, want)
+        for pos, exp in zip(mp[:6], mp[6:]):
+            assert _mp(oracle_lib, "oracle", hdr, trace, pos) == exp
+    types = set(int(x[4]) for x in GOLD["pa_out"])
+    assert len(types) >= 6, "golden vectors should cover most match types, got %s" % types
+
+
+def test_sort_order_golden(oracle_lib):
+    """libstdc++ std::sort tie order with the reference's comparators."""
+    for sin, sout in zip(GOLD["sort_in"], GOLD["sort_out"]):
+        mode, key = int(sin[0]), np.ascontiguousarray(sin[1:], np.int32)
+        perm = np.zeros(max(len(key), 1), np.int32)
+        oracle_lib.oracle_sort_perm(len(key), P(key), 1 if mode == 1 else 0, P(perm))
+        assert np.array_equal(perm[:len(key)], sout), (mode, len(key))
+
+
+def test_las_parse_golden(oracle_lib, tmp_path):
+    from hinge_amd import formats, synth
+    g, cov, seed = (int(x) for x in GOLD["las_spec"])
+    d = synth.generate(synth.SynthSpec(genome_len=g, coverage=cov, seed=seed))
+    db = synth.write_dataset(d, str(tmp_path), "G")
+    want = GOLD["las_records"]
+    buf = np.zeros((d.novl, 8), np.int32)
+    n = oracle_lib.oracle_load_las(db.encode(), (db + ".las").encode(), P(buf), d.novl)
+    assert n == len(want) and np.array_equal(buf, want)
+    assert want[:, 6].sum() > 0, "needs complemented overlaps to exercise the strand flip"
+    # the Python-side reader used by the drivers agrees too
+    recs = formats.read_las(db + ".las")
+    pile = formats.pileups_from_las(recs, d.rlen)
+    keep = want[:, 0] != want[:, 1]
+    assert np.array_equal(pile.a_span, want[keep][:, 2:4]) and np.array_equal(pile.b_span, want[keep][:, 4:6])
+    assert np.array_equal(pile.b_flag & 0x7FFFFFFF, want[keep][:, 1].astype(np.uint32))
+    assert np.array_equal(pile.b_flag >> 31, want[keep][:, 6].astype(np.uint32))
+
+
+def test_ini_golden(oracle_lib, tmp_path):
+    from hinge_amd.config import IniFile
+    ini = str(tmp_path / "q.ini")
+    with open(ini, "w") as f:
+        f.write(make_golden.INI_TEXT)
+    py = IniFile(ini)
+    for (s, k, dflt), want in zip(make_golden.INI_QUERIES, GOLD["ini_int"]):
+        assert oracle_lib.oracle_ini_int(ini.encode(), s.encode(), k.encode(), dflt) == want
+        assert py.get_int(s, k, dflt) == want
+    for (s, k, dflt), want in zip(make_golden.INI_BOOLS, GOLD["ini_bool"]):
+        assert oracle_lib.oracle_ini_bool(ini.encode(), s.encode(), k.encode(), dflt) == want
+        assert int(py.get_bool(s, k, bool(dflt))) == want
+    assert oracle_lib.oracle_ini_real(ini.encode(), b"filter", b"quality_threshold", 0.0) == GOLD["ini_real"][0]
+    assert py.get_real("filter", "quality_threshold", 0.0) == GOLD["ini_real"][0]
+    assert oracle_lib.oracle_ini_error(ini.encode()) == GOLD["ini_error"][0]
+    assert oracle_lib.oracle_ini_error(b"/nonexistent.ini") == GOLD["ini_error"][1] == -1
+    assert IniFile("/nonexistent.ini").error == -1
+
+
+def test_live_reference_library(oracle_lib, ref_lib):
+    """Fresh random inputs through oracle/_ref (the reference's code) and the oracle."""
+    rng = np.random.default_rng(1234)
+    for _ in range(200):
+        n = int(rng.choice([0, 1, 3, 60, 500]))
+        ab = rng.integers(0, 20000, size=n).astype(np.int32)
+        ae = (ab + rng.integers(10, 4000, size=n)).astype(np.int32)
+        cutoff = int(rng.choice([0, 300, 5000]))
+        k1, c1 = _cov(oracle_lib, "oracle", n, ab, ae, cutoff)
+        k2, c2 = _cov(ref_lib, "ref", n, ab, ae, cutoff)
+        assert k1 == k2 and np.array_equal(c1, c2)
+    for _ in range(600):
+        hdr, trace = make_golden.random_overlap(rng)
+        a = _pa(oracle_lib, "oracle", hdr, trace, 1000, 300, 0)
+        b = _pa(ref_lib, "ref", hdr, trace, 1000, 300, 0)
+        assert np.array_equal(a, b)
+        for pos in rng.integers(hdr[0] - 20, hdr[1] + 20, size=4):
+            assert _mp(oracle_lib, "oracle", hdr, trace, pos) == _mp(ref_lib, "ref", hdr, trace, pos)
+    for _ in range(300):
+        n = int(rng.integers(0, 3000))
+        key = rng.integers(0, max(2, n // int(rng.integers(1, 40))), size=n).astype(np.int32)
+        for mode_o, mode_r in ((0, 0), (1, 1), (0, 2), (0, 3)):
+            p1 = np.zeros(max(n, 1), np.int32)
+            p2 = np.zeros(max(n, 1), np.int32)
+            oracle_lib.oracle_sort_perm(n, P(key), mode_o, P(p1))
+            ref_lib.ref_sort_perm(n, P(key), mode_r, P(p2))
+            assert np.array_equal(p1, p2)
+
+
+def test_live_reference_db_and_qv(oracle_lib, ref_lib, datasets):
+    """Open_DB/Trim_DB read lengths, getQV and getOverlap of the real reference on a written data set."""
+    from hinge_amd import formats
+    wd, d = datasets("tiny_qv")
+    db = os.path.join(wd, "G").encode()
+    out = np.zeros(d.n_reads, np.int32)
+    assert ref_lib.ref_read_lengths(db, P(out), d.n_reads) == d.n_reads
+    assert np.array_equal(out, d.rlen) and np.array_equal(formats.read_db_index(os.path.join(wd, "G"))["rlen"], d.rlen)
+    a = np.zeros((d.novl, 8), np.int32)
+    b = np.zeros((d.novl, 8), np.int32)
+    assert oracle_lib.oracle_load_las(db, db + b".las", P(a), d.novl) == d.novl
+    assert ref_lib.ref_load_las(db, db + b".las", P(b), d.novl) == d.novl
+    assert np.array_equal(a, b)
+    ref_lib.ref_qv.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_long), ip, ctypes.c_long]
+    ref_lib.ref_qv.restype = ctypes.c_long
+    offs = np.zeros(d.n_reads + 1, np.int64)
+    tot = sum(len(q) for q in d.qv)
+    vals = np.zeros(tot, np.int32)
+    assert ref_lib.ref_qv(db, offs.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), P(vals), tot) == tot
+    py = formats.read_qual_track(os.path.join(wd, "G"))
+    for i in range(d.n_reads):
+        assert np.array_equal(vals[offs[i]:offs[i + 1]], py[i].astype(np.int32))
