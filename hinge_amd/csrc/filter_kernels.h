@@ -26,6 +26,7 @@ constexpr int BLOCK = WAVE * WAVES_PER_BLOCK;
 constexpr int MEAN_SENTINEL = INT_MIN;  // mean_cov of reads that do not enter the median
 
 constexpr int MED_BINS = 4096;  // one-pass median histogram range
+constexpr int LOADS_IN_FLIGHT = 8;   // 8-byte pile-up loads a lane issues back to back (4 KiB per wave)
 
 // status word bits (device -> host)
 constexpr int ST_RANGE = 1;        // bin index beyond the LDS histogram
@@ -114,34 +115,31 @@ template <int RESO>
 __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                      const int2* __restrict__ a_span, const int* __restrict__ rlen, int reso,
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
-                                                     unsigned long long* __restrict__ totals) {
+                                                     unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/) {
     const int lane = lane_id();
     const int wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * BLOCK) >> 6;
     long long blk_cov = 0, blk_slot = 0;
-    int i = r_begin + wave;
-    int64_t s = 0, e = 0;
-    int rl = 0;
-    if (i <= r_end) { s = row_ptr[i]; e = row_ptr[i + 1]; rl = rlen[i]; }
-    while (i <= r_end) {
-        // prefetch the next read's row while this one streams
-        const int inext = i + nwaves;
-        int64_t sn = 0, en = 0;
-        int rln = 0;
-        if (inext <= r_end) { sn = row_ptr[inext]; en = row_ptr[inext + 1]; rln = rlen[inext]; }
+    // (no hand-written prefetch of the next row: measured 7x slower - it serialises the wave's loads)
+    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int rl = rlen[i];
         int sum = 0;
         int mx = INT_MIN;
-        int64_t k = s + lane;
-        for (; k + 3 * WAVE < e; k += 4 * WAVE) {   // four loads in flight per lane
-            const int2 v0 = a_span[k], v1 = a_span[k + WAVE], v2 = a_span[k + 2 * WAVE], v3 = a_span[k + 3 * WAVE];
-            sum += (bin_of<RESO>(v0.y, reso) - bin_of<RESO>(v0.x, reso)) + (bin_of<RESO>(v1.y, reso) - bin_of<RESO>(v1.x, reso)) +
-                   (bin_of<RESO>(v2.y, reso) - bin_of<RESO>(v2.x, reso)) + (bin_of<RESO>(v3.y, reso) - bin_of<RESO>(v3.x, reso));
-            mx = max(max(mx, max(max(v0.x, v0.y), max(v1.x, v1.y))), max(max(v2.x, v2.y), max(v3.x, v3.y)));
-        }
-        for (; k < e; k += WAVE) {
-            const int2 v0 = a_span[k];
-            sum += bin_of<RESO>(v0.y, reso) - bin_of<RESO>(v0.x, reso);
-            mx = max(mx, max(v0.x, v0.y));
+        for (int64_t base = s; base < e; base += LOADS_IN_FLIGHT * WAVE) {   // all loads of a batch are issued before the first use
+            int2 v[LOADS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                const int64_t k = base + u * WAVE + lane;
+                v[u] = k < e ? a_span[k] : make_int2(0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                if (base + u * WAVE + lane < e) {
+                    sum += bin_of<RESO>(v[u].y, reso) - bin_of<RESO>(v[u].x, reso);
+                    mx = max(mx, max(v[u].x, v[u].y));
+                }
+            }
         }
         // per-lane partial sums fit 32 bits (<= 2^31 / 64 bins*overlaps per lane); widen for the total
         const long long tot = wave_sum64((long long)sum);
@@ -158,11 +156,11 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
                 mean_cov[i] = MEAN_SENTINEL;
             }
         }
-        i = inext; s = sn; e = en; rl = rln;
     }
-    if (lane == 0 && (blk_cov != 0 || blk_slot != 0)) {
-        atomicAdd(&totals[0], (unsigned long long)blk_cov);
-        atomicAdd(&totals[1], (unsigned long long)blk_slot);
+    // one slot per wave: thousands of atomics on one address cost ~12 ns each (they would dominate the kernel)
+    if (lane == 0) {
+        wave_totals[2 * wave] = (unsigned long long)blk_cov;
+        wave_totals[2 * wave + 1] = (unsigned long long)blk_slot;
     }
 }
 
@@ -176,7 +174,8 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
                                                      unsigned* __restrict__ med, int* __restrict__ est, int* __restrict__ min_cov,
-                                                     int* __restrict__ status) {
+                                                     int* __restrict__ status, const unsigned long long* __restrict__ wave_totals,
+                                                     int n_wave_totals, unsigned long long* __restrict__ totals) {
     __shared__ unsigned hist[MED_BINS];
     __shared__ unsigned s_valid, s_oor, s_last;
     const int tid = threadIdx.x;
@@ -209,6 +208,12 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    {   // total_cov / num_slot of the part (only logged by the reference, filter.cpp:666,672): sum k_cov_stats' per-wave partials
+        unsigned long long tc = 0, ts = 0;
+        for (int w = tid; w < n_wave_totals; w += blockDim.x) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
+        if (tc) atomicAdd(&totals[0], tc);
+        if (ts) atomicAdd(&totals[1], ts);
+    }
     // last block: all merges are visible at device scope; read them back with agent-scope loads
     for (int b = tid; b < MED_BINS; b += blockDim.x) {
         hist[b] = __hip_atomic_load(&med[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -321,43 +326,64 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
     const int MIN_COV = *d_min_cov;
     const int reso = P.reso;
 
-    int i = r_begin + wave;
-    int64_t s = 0, e = 0;
-    int rl = 0;
-    if (i <= r_end) { s = row_ptr[i]; e = row_ptr[i + 1]; rl = rlen[i]; }
-    while (i <= r_end) {
-        const int inext = i + nwaves;
-        int64_t sn = 0, en = 0;
-        int rln = 0;
-        if (inext <= r_end) { sn = row_ptr[inext]; en = row_ptr[inext + 1]; rln = rlen[inext]; }
+    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int rl = rlen[i];
         const int n = (int)(e - s);
-        // first chunk of the pile-up is requested before the histogram is cleared
-        int64_t k = s + lane;
-        int2 v = make_int2(0, 0);
-        if (k < e) v = a_span[k];
         // bins this read can touch: events are <= rlen + cut_off for well-formed input
         int kb = bin_of<RESO>(rl + max(P.cut_off, 0), reso) + 2;
         kb = min(kb, kcap);
-        for (int t = lane; t < kb; t += WAVE) { h0[t] = 0; hc[t] = 0; }
         int mx0 = INT_MIN, mxc = INT_MIN;
         bool oob = false;
-        while (k < e) {
-            const int64_t kn = k + WAVE;
-            int2 vn = make_int2(0, 0);
-            if (kn < e) vn = a_span[kn];
-            const int b0 = bin_of<RESO>(v.x, reso), b1 = bin_of<RESO>(v.y, reso);
-            const int c0 = bin_of<RESO>(v.x + P.cut_off, reso), c1 = bin_of<RESO>(v.y - P.cut_off, reso);
-            if (max(max(b0, b1), max(c0, c1)) >= kb) {
-                oob = true;
-            } else {
-                atomicAdd(&h0[b0], 1);
-                atomicAdd(&h0[b1], -1);
-                atomicAdd(&hc[c0], 1);
-                atomicAdd(&hc[c1], -1);
-                mx0 = max(mx0, max(v.x, v.y));
-                mxc = max(mxc, max(v.x + P.cut_off, v.y - P.cut_off));
+        bool cleared = false;
+        // hot bins: starts at abpos ~ 0, ends at aepos ~ rlen (and the same shifted by cut_off)
+        const int hot_s = 1, hot_e = max(bin_of<RESO>(rl, reso), 2);
+        const int hot_cs = bin_of<RESO>(max(P.cut_off, 0), reso), hot_ce = max(bin_of<RESO>(rl - P.cut_off, reso), 2);
+        int n_s0 = 0, n_e0 = 0, n_cs0 = 0, n_ce0 = 0;
+        for (int64_t base = s; base < e || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
+            int2 v[LOADS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                const int64_t k = base + u * WAVE + lane;
+                v[u] = k < e ? a_span[k] : make_int2(0, 0);
             }
-            k = kn; v = vn;
+            if (!cleared) {   // the histogram is cleared while the first batch is in flight
+                for (int t = lane; t < kb; t += WAVE) { h0[t] = 0; hc[t] = 0; }
+                cleared = true;
+            }
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                const bool live = base + u * WAVE + lane < e;
+                const int2 w = v[u];
+                const int b0 = bin_of<RESO>(w.x, reso), b1 = bin_of<RESO>(w.y, reso);
+                const int c0 = bin_of<RESO>(w.x + P.cut_off, reso), c1 = bin_of<RESO>(w.y - P.cut_off, reso);
+                const bool bad = live && (max(max(b0, b1), max(c0, c1)) >= kb);
+                oob |= bad;
+                const bool ok = live && !bad;
+                // Alignments pile up at the two ends of the read (an overlap usually runs to the end of A), so a few
+                // bins take most of the events: count those with ballots (scalar adds) instead of 64-way conflicting
+                // LDS atomics, and let only the other lanes touch the histogram.
+                const bool s_hot = ok && b0 == hot_s, e_hot = ok && b1 == hot_e;
+                const bool cs_hot = ok && c0 == hot_cs, ce_hot = ok && c1 == hot_ce;
+                n_s0 += __popcll(__ballot(s_hot));
+                n_e0 += __popcll(__ballot(e_hot));
+                n_cs0 += __popcll(__ballot(cs_hot));
+                n_ce0 += __popcll(__ballot(ce_hot));
+                if (ok) {
+                    if (!s_hot) atomicAdd(&h0[b0], 1);
+                    if (!e_hot) atomicAdd(&h0[b1], -1);
+                    if (!cs_hot) atomicAdd(&hc[c0], 1);
+                    if (!ce_hot) atomicAdd(&hc[c1], -1);
+                    mx0 = max(mx0, max(w.x, w.y));
+                    mxc = max(mxc, max(w.x + P.cut_off, w.y - P.cut_off));
+                }
+            }
+        }
+        if (lane == 0) {   // hot bins are < kb by construction (hot_e/hot_ce come from rlen, the others are tiny)
+            if (n_s0) h0[hot_s] += n_s0;
+            if (n_e0) h0[hot_e] -= n_e0;
+            if (n_cs0) hc[hot_cs] += n_cs0;
+            if (n_ce0) hc[hot_ce] -= n_ce0;
         }
         if (__any(oob)) {
             if (lane == 0) atomicOr(status, ST_RANGE);
@@ -519,7 +545,6 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             anno_buf[off + t] = make_int2(c >> 1, (c & 1) ? 1 : -1);
             hinge_flag[off + t] = 0;
         }
-        i = inext; s = sn; e = en; rl = rln;
     }
 }
 

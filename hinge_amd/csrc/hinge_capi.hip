@@ -48,6 +48,8 @@ struct hinge_ctx {
     unsigned long long arena_cap = 0;
     DevBuf scalars;   // see Scalars
     DevBuf med;       // median histogram scratch (k_median_hist)
+    DevBuf wave_totals;   // k_cov_stats per-wave (total_cov, num_slot) partials
+    int n_wave_totals = 0;
     size_t lds_attr_set = 0;
     int force_exact = 0;
 
@@ -184,7 +186,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->trace, &ctx->trace_off, &ctx->eff_reads,
+                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->eff_reads,
                      &ctx->pair_sel, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -359,13 +361,18 @@ static int reset_pass(hinge_ctx* ctx) {
 static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int nr = ctx->r_end - ctx->r_begin + 1;
     const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
+    ctx->n_wave_totals = grid * WAVES_PER_BLOCK;
+    {
+        int rc = ensure(ctx, ctx->wave_totals, sizeof(unsigned long long) * 2 * (size_t)ctx->n_wave_totals);
+        if (rc) return rc;
+    }
     ProfScope _ps(ctx, KID_STATS);
     if (p->reso == 40)
         hipLaunchKernelGGL(k_cov_stats<40>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
-                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, sc(ctx)->totals);
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p);
     else
         hipLaunchKernelGGL(k_cov_stats<0>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
-                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, sc(ctx)->totals);
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p);
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -389,7 +396,8 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
         const int n = hi - lo + 1;
         const int grid = std::max(1, std::min((n + 2047) / 2048, ctx->n_cu));
         hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
-                           (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status);
+                           (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status,
+                           (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals);
         hipLaunchKernelGGL(k_median_select, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
                            (const unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status);
     }
