@@ -35,12 +35,19 @@ constexpr int ST_QUEUE_CAP = 4;    // exact queue full
 constexpr int ST_ARENA_CAP = 8;    // exact-path scratch arena full
 constexpr int ST_NO_LONG_READ = 16;
 
+#ifdef HINGE_ABLATE
+#define HINGE_ABLATE_POINT(k) if (P.ablate == (k)) continue;
+#else
+#define HINGE_ABLATE_POINT(k)
+#endif
+
 struct FilterDev {   // device copy of hinge_filter_params + derived values
     int reso, cut_off, theta;
     int cov_frac, min_ra, max_ra, ra_gap, nhr;
     int sup, pil, unb, tol, bin_len;
     int use_qv, use_cov, del_telo;
     int est_cov;
+    int ablate;   // scratch/ablation builds only (HINGE_ABLATE): stop k_mask_annotate after phase k
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
@@ -388,6 +395,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         if (__any(oob)) {
             if (lane == 0) atomicOr(status, ST_RANGE);
         }
+        HINGE_ABLATE_POINT(1)
         mx0 = wave_max(mx0);
         mxc = wave_max(mxc);
         const int K0 = nbins_of<RESO>(n, mx0, reso);
@@ -460,6 +468,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             rflags[i] = fl;
         }
 
+        HINGE_ABLATE_POINT(2)
         // ---- cutoff-0 coverage, gate sums, annotation candidates (filter.cpp:796-813,842-865) ---
         int* cand = hc;   // hc is dead now: packed candidates (pos << 1 | (type == +1))
         carry = 0;
@@ -478,6 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             }
         }
         S = wave_sum(S); nS = wave_sum(nS); E = wave_sum(E); nE = wave_sum(nE);
+        HINGE_ABLATE_POINT(3)
         // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
         {
             const int wlo = mk.x + P.nhr, whi = mk.y - P.nhr;
@@ -499,6 +509,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
                 ncand += __popcll(bal);
             }
         }
+        HINGE_ABLATE_POINT(4)
         // merge (filter.cpp:817-829) - sequential on a short list, in place
         int m = 0;
         if (lane == 0 && ncand > 0) {

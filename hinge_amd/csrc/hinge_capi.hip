@@ -147,6 +147,7 @@ static FilterDev to_dev(const hinge_filter_params* p) {
     d.bin_len = 2 * p->hinge_tolerance;   // filter.cpp:405
     d.use_qv = p->use_qv_mask; d.use_cov = p->use_coverage_mask; d.del_telo = p->delete_telomere;
     d.est_cov = p->est_cov;
+    d.ablate = 0;
     return d;
 }
 
