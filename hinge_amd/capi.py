@@ -61,6 +61,10 @@ SYMBOLS = [
     ("hinge_filter_get_annotations", C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     ("hinge_filter_coverage_bins", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
     ("hinge_filter_counters", C.c_int, [_VP, _VP]),
+    ("hinge_set_traces", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int, C.c_int]),
+    ("hinge_set_eff_reads", C.c_int, [_VP, _VP]),
+    ("hinge_trim_classify", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    ("hinge_matching_position", C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
     ("hinge_filter_mask_annotate_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_hinges_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_check", C.c_int, [_VP]),
@@ -239,6 +243,32 @@ class Context:
         out = np.zeros(4, np.int64)
         self._ck(self.lib.hinge_filter_counters(self.h, _ptr(out)))
         return out
+
+    # ---- maximal / layout ---------------------------------------------------------------------
+    def set_traces(self, trace: np.ndarray, trace_off: np.ndarray, tlen: np.ndarray, tbytes: int = 1):
+        trace = np.ascontiguousarray(trace, dtype=np.uint8)
+        trace_off = np.ascontiguousarray(trace_off, dtype=np.int64)
+        tlen = np.ascontiguousarray(tlen, dtype=np.int32)
+        self._keep_tr = [trace, trace_off, tlen]
+        self._ck(self.lib.hinge_set_traces(self.h, _ptr(trace), int(trace.shape[0]), _ptr(trace_off), _ptr(tlen), int(tbytes), 0))
+
+    def set_eff_reads(self, eff: np.ndarray):
+        eff = np.ascontiguousarray(eff, dtype=np.int32)
+        self._ck(self.lib.hinge_set_eff_reads(self.h, _ptr(eff)))
+
+    def trim_classify(self, sel: np.ndarray, a_of: np.ndarray, aln_threshold: int, theta: int, theta2: int) -> np.ndarray:
+        sel = np.ascontiguousarray(sel, dtype=np.int64)
+        a_of = np.ascontiguousarray(a_of, dtype=np.int32)
+        out = np.zeros((max(len(sel), 1), 10), np.int32)
+        self._ck(self.lib.hinge_trim_classify(self.h, len(sel), _ptr(sel), _ptr(a_of), aln_threshold, theta, theta2, _ptr(out)))
+        return out[:len(sel)]
+
+    def matching_position(self, q_ovl: np.ndarray, q_pos: np.ndarray) -> np.ndarray:
+        q_ovl = np.ascontiguousarray(q_ovl, dtype=np.int64)
+        q_pos = np.ascontiguousarray(q_pos, dtype=np.int32)
+        out = np.zeros(max(len(q_ovl), 1), np.int32)
+        self._ck(self.lib.hinge_matching_position(self.h, len(q_ovl), _ptr(q_ovl), _ptr(q_pos), _ptr(out)))
+        return out[:len(q_ovl)]
 
     def filter_mask_annotate_async(self, p: FilterParams):
         self._ck(self.lib.hinge_filter_mask_annotate_async(self.h, C.byref(p)))

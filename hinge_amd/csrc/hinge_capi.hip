@@ -54,8 +54,9 @@ struct hinge_ctx {
     int force_exact = 0;
 
     // trim / classify (maximal, layout)
-    DevBuf trace, trace_off, eff_reads, pair_sel, pair_out;
+    DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
     int64_t trace_bytes = 0;
+    int tbytes = 1;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -187,8 +188,8 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->eff_reads,
-                     &ctx->pair_sel, &ctx->pair_out};
+                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
+                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

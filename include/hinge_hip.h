@@ -125,6 +125,23 @@ int hinge_filter_coverage_bins(hinge_ctx* ctx, int32_t r0, int32_t r1, int32_t r
  * the exact (std::sort-replaying) path, [2] total annotations, [3] total hinges.                  */
 int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
 
+/* ---- maximal / layout: overlap trim + classify ------------------------------------------------- */
+/* Trace points of the pile-up overlaps set by hinge_set_pileups (same order): trace = concatenated
+ * trace bytes as they are in the .las (tbytes = 1 if tspace <= 125 else 2: LAInterface.cpp:607-614),
+ * trace_off[n_ovl] = byte offset of each overlap's trace, tlen[n_ovl] = Path.tlen (align.h:126-132).  */
+int hinge_set_traces(hinge_ctx* ctx, const uint8_t* trace, int64_t trace_bytes, const int64_t* trace_off, const int32_t* tlen, int tbytes,
+                     int on_device);
+/* effective_start / effective_end of every read (the .mas file: maximal.cpp:524-531, hinging.cpp:867-874) */
+int hinge_set_eff_reads(hinge_ctx* ctx, const int32_t* eff);
+/* ProcessAlignment(match, A, B, ALN_THRESHOLD, THETA, THETA2, trim=true) (maximal.cpp:65-134 ==
+ * hinging.cpp:78-147 -> LOverlap::trim_overlap LAInterface.cpp:4552-4683, AddTypesAsymmetric :4721-4806) for
+ * n_sel overlaps: sel[j] indexes the pile-up arrays, a_of[j] is its A read.  out[j][10] = eff_ab, eff_ae,
+ * eff_bb, eff_be, match type (enum of LAInterface.h:30-33), active, weight, length, start idx, end idx.       */
+int hinge_trim_classify(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel, const int32_t* a_of, int32_t aln_threshold, int32_t theta,
+                        int32_t theta2, int32_t* out);
+/* LOverlap::GetMatchingPosition (LAInterface.cpp:4498-4546) for nq (overlap, position on A) queries.        */
+int hinge_matching_position(hinge_ctx* ctx, int64_t nq, const int64_t* q_ovl, const int32_t* q_pos, int32_t* out);
+
 /* Staged launches with no host round trip, for pipelines that put a collective between the stages
  * (multi-GPU).  A pass starts at hinge_filter_stats (which clears the per-pass device scalars and is
  * itself asynchronous); check reports the HINGE_E_* flags raised since then.                       */

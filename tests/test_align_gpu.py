@@ -1,0 +1,72 @@
+"""GPU parity of the trim / classify kernels (ProcessAlignment, GetMatchingPosition) against the CPU
+oracle (which is itself pinned to the reference's compiled LOverlap methods), overlap by overlap."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import clone_dataset, run_in
+
+pytestmark = pytest.mark.gpu
+ip = ctypes.POINTER(ctypes.c_int)
+u16p = ctypes.POINTER(ctypes.c_uint16)
+
+
+def _setup(datasets, oracle_lib, tmp_path, name):
+    from hinge_amd import capi, formats
+    src, d = datasets(name)
+    wd = clone_dataset(src, str(tmp_path / "w"))
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G.las", 0, b"G", b"nominal.ini", b"") == 0
+    eff = np.loadtxt(os.path.join(wd, "G.mas"), dtype=np.int64)[:, 1:].astype(np.int32)
+    recs = formats.read_las(os.path.join(wd, "G.las"))
+    pile = formats.pileups_from_las(recs, d.rlen)
+    ctx = capi.Context(0)
+    ctx.set_reads(d.rlen, None)
+    ctx.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+    toff = recs.trace_off[:-1][pile.las_index]
+    tlen = recs.rec["tlen"][pile.las_index]
+    ctx.set_traces(recs.trace, toff, tlen, 1)
+    ctx.set_eff_reads(eff)
+    a_of = np.repeat(np.arange(d.n_reads, dtype=np.int32), np.diff(pile.row_ptr).astype(np.int64))
+    return ctx, recs, pile, eff, a_of, toff, tlen
+
+
+@pytest.mark.parametrize("name", ["tiny", "chimera"])
+@pytest.mark.parametrize("thr", [(1000, 300, 0), (2500, 50, 100)])
+def test_trim_classify_matches_oracle(datasets, oracle_lib, tmp_path, name, thr):
+    ctx, recs, pile, eff, a_of, toff, tlen = _setup(datasets, oracle_lib, tmp_path, name)
+    n = pile.n_ovl
+    sel = np.arange(n, dtype=np.int64)
+    got = ctx.trim_classify(sel, a_of, *thr)
+    rng = np.random.default_rng(0)
+    check = np.concatenate([np.arange(min(n, 3000)), rng.integers(0, n, size=6000)])
+    types = set()
+    for k in check:
+        b = int(pile.b_flag[k] & 0x7FFFFFFF)
+        comp = int(pile.b_flag[k] >> 31)
+        a = int(a_of[k])
+        hdr = np.array([pile.a_span[k, 0], pile.a_span[k, 1], pile.b_span[k, 0], pile.b_span[k, 1], comp,
+                        eff[a, 0], eff[a, 1], eff[b, 0], eff[b, 1]], np.int32)
+        tr = recs.trace[toff[k]:toff[k] + tlen[k]].astype(np.uint16)
+        want = np.zeros(10, np.int32)
+        oracle_lib.oracle_process_alignment(hdr.ctypes.data_as(ip), tr.ctypes.data_as(u16p), len(tr), thr[0], thr[1], thr[2], want.ctypes.data_as(ip))
+        assert np.array_equal(got[k], want), (k, got[k], want)
+        types.add(int(want[4]))
+    assert len(types) >= 5, types
+    ctx.close()
+
+
+def test_matching_position_matches_oracle(datasets, oracle_lib, tmp_path):
+    ctx, recs, pile, eff, a_of, toff, tlen = _setup(datasets, oracle_lib, tmp_path, "tiny")
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, pile.n_ovl, size=4000).astype(np.int64)
+    pos = (pile.a_span[q, 0] + rng.integers(-60, 60, size=len(q)) + (rng.random(len(q)) * (pile.a_span[q, 1] - pile.a_span[q, 0])).astype(np.int64)).astype(np.int32)
+    got = ctx.matching_position(q, pos)
+    for j, k in enumerate(q):
+        tr = recs.trace[toff[k]:toff[k] + tlen[k]].astype(np.uint16)
+        want = oracle_lib.oracle_matching_position(int(pile.a_span[k, 0]), int(pile.a_span[k, 1]), int(pile.b_span[k, 0]), int(pile.b_span[k, 1]),
+                                                   int(pile.b_flag[k] >> 31), tr.ctypes.data_as(u16p), len(tr), int(pos[j]))
+        assert got[j] == want, (k, pos[j], got[j], want)
+    assert (got == -1).any() and (got >= 0).any()
+    ctx.close()
