@@ -9,7 +9,29 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functio
 CSRC = hinge_amd/csrc
 LIB  = hinge_amd/lib/libhinge_hip.so
 
-all: $(LIB) oracle
+BIN  = hinge_amd/bin
+HOST = hinge_amd/host
+HOSTDEPS = $(wildcard $(HOST)/*.h) include/hinge_hip.h $(LIB)
+PROGS = $(BIN)/Reads_filter $(BIN)/get_maximal_reads $(BIN)/hinging $(BIN)/hinge
+
+all: $(LIB) $(PROGS) oracle
+
+$(BIN)/Reads_filter: $(HOST)/filter_main.cpp $(HOSTDEPS)
+	mkdir -p $(BIN)
+	$(HIPCC) -O2 -std=c++17 -w -o $@ $< -Lhinge_amd/lib -lhinge_hip -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(BIN)/get_maximal_reads: $(HOST)/maximal_main.cpp $(HOSTDEPS)
+	mkdir -p $(BIN)
+	$(HIPCC) -O2 -std=c++17 -w -o $@ $< -Lhinge_amd/lib -lhinge_hip -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(BIN)/hinging: $(HOST)/layout_main.cpp $(HOSTDEPS)
+	mkdir -p $(BIN)
+	$(HIPCC) -O2 -std=c++17 -w -o $@ $< -Lhinge_amd/lib -lhinge_hip -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(BIN)/hinge: $(HOST)/hinge
+	mkdir -p $(BIN)
+	cp $< $@
+	chmod +x $@
 
 $(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.inc) include/hinge_hip.h
 	mkdir -p hinge_amd/lib

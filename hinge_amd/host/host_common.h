@@ -1,0 +1,492 @@
+// Host side of the three stage programs (Reads_filter, get_maximal_reads, hinging): argv and nominal.ini
+// surface, DAZZ_DB / .las ingest into the SoA layout of include/hinge_hip.h, text writers.
+// All arithmetic on overlaps happens behind the C ABI (libhinge_hip.so); nothing here computes coverage,
+// masks, hinges or overlap types.
+//
+// Reference behaviour mirrored (file:line under /root/reference/src):
+//   cmdline flags            filter/filter.cpp:172-183, maximal/maximal.cpp:242-253, layout/hinging.cpp:621-640
+//   INI reader + quirks      lib/ini.c:43-165, lib/INIReader.cpp:23-80
+//   DB stub/index/trim       lib/DB.c:395-683;  qual track lib/DB.c:1080-1300, lib/LAInterface.cpp:4369-4494
+//   .las header/records      lib/LAInterface.cpp:595-621,1519-1634, lib/align.c:3042-3081
+#pragma once
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <map>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+
+#include "../../include/hinge_hip.h"
+
+namespace hh {
+
+// ---------------------------------------------------------------------------------------------------
+// logging: stdout + <log dir>/log.txt (the reference logs through spdlog; the text is not part of parity)
+// ---------------------------------------------------------------------------------------------------
+struct Log {
+    FILE* file = nullptr;
+    void open(const std::string& dir) {
+        mkdir(dir.c_str(), S_IRWXU | S_IRWXG | S_IROTH | S_IXOTH);
+        file = fopen((dir + "/log.txt").c_str(), "a");
+    }
+    void line(const char* level, const char* fmt, va_list ap) {
+        char buf[4096];
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        printf("[log] [%s] %s\n", level, buf);
+        if (file) { fprintf(file, "[log] [%s] %s\n", level, buf); fflush(file); }
+    }
+    void info(const char* fmt, ...) { va_list ap; va_start(ap, fmt); line("info", fmt, ap); va_end(ap); }
+    void warn(const char* fmt, ...) { va_list ap; va_start(ap, fmt); line("warning", fmt, ap); va_end(ap); }
+    void error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); line("error", fmt, ap); va_end(ap); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// argv: the subset of tanakh cmdline.h the three programs use
+// ---------------------------------------------------------------------------------------------------
+class CmdLine {
+public:
+    void add_string(const std::string& name, char shortn, const std::string& desc, bool need, const std::string& def) {
+        opts_.push_back({name, shortn, desc, need, true, def, false});
+    }
+    void add_flag(const std::string& name, char shortn, const std::string& desc) { opts_.push_back({name, shortn, desc, false, false, "", false}); }
+    std::string get(const std::string& name) const { for (auto& o : opts_) if (o.name == name) return o.value; return ""; }
+    bool exist(const std::string& name) const { for (auto& o : opts_) if (o.name == name) return o.set; return false; }
+
+    // parse_check: usage + exit(1) on any error, usage + exit(0) on --help
+    void parse_check(int argc, char** argv) {
+        prog_ = argc > 0 ? argv[0] : "prog";
+        std::vector<std::string> errors;
+        bool help = false;
+        for (int i = 1; i < argc; i++) {
+            std::string a = argv[i];
+            Opt* o = nullptr;
+            std::string val;
+            bool has_val = false;
+            if (a.rfind("--", 0) == 0) {
+                std::string name = a.substr(2);
+                size_t eq = name.find('=');
+                if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
+                if (name == "help") { help = true; continue; }
+                o = find_long(name);
+                if (!o) { errors.push_back("undefined option: --" + name); continue; }
+            } else if (a.size() >= 2 && a[0] == '-') {
+                if (a[1] == '?') { help = true; continue; }
+                o = find_short(a[a.size() - 1]);
+                if (!o) { errors.push_back(std::string("undefined short option: -") + a[a.size() - 1]); continue; }
+            } else {
+                rest_.push_back(a);
+                continue;
+            }
+            if (o->has_value) {
+                if (!has_val) {
+                    if (i + 1 >= argc) { errors.push_back("option needs value: --" + o->name); continue; }
+                    val = argv[++i];
+                }
+                o->value = val;
+            } else if (has_val) {
+                errors.push_back("option does not take a value: --" + o->name);
+            }
+            o->set = true;
+        }
+        if (help) { usage(stdout); exit(0); }
+        for (auto& o : opts_) if (o.need && !o.set) errors.push_back("need option: --" + o.name);
+        if (!errors.empty()) {
+            for (auto& e : errors) fprintf(stderr, "%s\n", e.c_str());
+            usage(stderr);
+            exit(1);
+        }
+    }
+
+private:
+    struct Opt { std::string name; char shortn; std::string desc; bool need; bool has_value; std::string value; bool set; };
+    std::vector<Opt> opts_;
+    std::vector<std::string> rest_;
+    std::string prog_;
+    Opt* find_long(const std::string& n) { for (auto& o : opts_) if (o.name == n) return &o; return nullptr; }
+    Opt* find_short(char c) { for (auto& o : opts_) if (o.shortn && o.shortn == c) return &o; return nullptr; }
+    void usage(FILE* f) const {
+        fprintf(f, "usage: %s", prog_.c_str());
+        for (auto& o : opts_) if (o.need) fprintf(f, " --%s=string", o.name.c_str());
+        fprintf(f, " [options] ...\noptions:\n");
+        for (auto& o : opts_) {
+            if (o.shortn) fprintf(f, "  -%c, ", o.shortn); else fprintf(f, "      ");
+            fprintf(f, "--%-16s %s%s\n", o.name.c_str(), o.desc.c_str(), o.has_value ? " (string)" : "");
+        }
+        fprintf(f, "  -?, --help             print this message\n");
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// nominal.ini
+// ---------------------------------------------------------------------------------------------------
+class Config {
+public:
+    int error = 0;   // 0 ok, -1 cannot open, >0 first bad line (inih); ParseError() < 0 is what the programs test
+    explicit Config(const std::string& path) {
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) { error = -1; return; }
+        char raw[200];             // INI_MAX_LINE: longer lines are split, as fgets does in the reference
+        std::string section, prev;
+        int lineno = 0;
+        while (fgets(raw, sizeof(raw), f)) {
+            lineno++;
+            std::string s(raw);
+            size_t p0 = 0;
+            if (lineno == 1 && s.size() >= 3 && (unsigned char)s[0] == 0xEF && (unsigned char)s[1] == 0xBB && (unsigned char)s[2] == 0xBF) p0 = 3;
+            size_t end = s.size();
+            while (end > p0 && isspace((unsigned char)s[end - 1])) end--;
+            size_t beg = p0;
+            while (beg < end && isspace((unsigned char)s[beg])) beg++;
+            const bool indented = beg > 0;     // "start > line" (also true after a BOM, like the original)
+            std::string body = s.substr(beg, end - beg);
+            if (body.empty()) continue;
+            if (body[0] == ';' || body[0] == '#') continue;
+            if (!prev.empty() && indented) { put(section, prev, body); continue; }
+            if (body[0] == '[') {
+                size_t c = cut(body, 1, ']');
+                if (c < body.size() && body[c] == ']') { section = body.substr(1, c - 1).substr(0, 49); prev.clear(); }
+                else if (!error) error = lineno;
+                continue;
+            }
+            size_t c = cut(body, 0, '=');
+            if (!(c < body.size() && body[c] == '=')) c = cut(body, 0, ':');
+            if (c < body.size() && (body[c] == '=' || body[c] == ':')) {
+                std::string name = rtrim(body.substr(0, c));
+                std::string value = ltrim(body.substr(c + 1));
+                size_t cc = cut(value, 0, '\0');
+                if (cc < value.size() && value[cc] == ';') value = value.substr(0, cc);
+                value = rtrim(value);
+                prev = name.substr(0, 49);
+                put(section, name, value);
+            } else if (!error) error = lineno;
+        }
+        fclose(f);
+    }
+    std::string get(const std::string& s, const std::string& n, const std::string& d) const {
+        auto it = kv_.find(key(s, n));
+        return it == kv_.end() ? d : it->second;
+    }
+    long get_int(const std::string& s, const std::string& n, long d) const {
+        std::string v = get(s, n, "");
+        const char* c = v.c_str();
+        char* e;
+        long r = strtol(c, &e, 0);      // prefix parse: "1000;" -> 1000, "0x10" -> 16
+        return e > c ? r : d;
+    }
+    bool get_bool(const std::string& s, const std::string& n, bool d) const {
+        std::string v = get(s, n, "");
+        std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+        if (v == "true" || v == "yes" || v == "on" || v == "1") return true;
+        if (v == "false" || v == "no" || v == "off" || v == "0") return false;
+        return d;                        // "true;" lands here
+    }
+
+private:
+    std::map<std::string, std::string> kv_;
+    static std::string key(const std::string& s, const std::string& n) {
+        std::string k = s + "=" + n;
+        std::transform(k.begin(), k.end(), k.begin(), ::tolower);
+        return k;
+    }
+    void put(const std::string& s, const std::string& n, const std::string& v) {
+        std::string& slot = kv_[key(s, n)];
+        if (!slot.empty()) slot += "\n";
+        slot += v;
+    }
+    static size_t cut(const std::string& s, size_t from, char c) {   // first `c` or whitespace-preceded ';'
+        bool ws = false;
+        size_t i = from;
+        while (i < s.size() && s[i] != c && !(ws && s[i] == ';')) { ws = isspace((unsigned char)s[i]); i++; }
+        return i;
+    }
+    static std::string rtrim(std::string s) { while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back(); return s; }
+    static std::string ltrim(const std::string& s) { size_t i = 0; while (i < s.size() && isspace((unsigned char)s[i])) i++; return s.substr(i); }
+};
+
+inline hinge_filter_params filter_params_from(const Config& c, bool has_qv) {   // filter.cpp:377-409
+    hinge_filter_params p;
+    p.reso = 40;
+    p.cut_off = (int)c.get_int("filter", "cut_off", -1);
+    p.min_cov = (int)c.get_int("filter", "min_cov", -1);
+    p.est_cov = (int)c.get_int("filter", "ec", 0);
+    p.theta = (int)c.get_int("filter", "theta", -1);
+    p.coverage_fraction = (int)c.get_int("filter", "coverage_frac_repeat_annotation", 3);
+    p.min_repeat_annotation = (int)c.get_int("filter", "min_repeat_annotation_threshold", 10);
+    p.max_repeat_annotation = (int)c.get_int("filter", "max_repeat_annotation_threshold", 20);
+    p.repeat_annotation_gap = (int)c.get_int("filter", "repeat_annotation_gap_threshold", 300);
+    p.no_hinge_region = (int)c.get_int("filter", "no_hinge_region", 500);
+    p.hinge_min_support = (int)c.get_int("filter", "hinge_min_support", 7);
+    p.hinge_bin_pileup = (int)c.get_int("filter", "hinge_min_pileup", 7);
+    p.hinge_unbridged = (int)c.get_int("filter", "hinge_unbridged", 6);
+    p.hinge_tolerance = (int)c.get_int("filter", "hinge_tolerance_length", 100);
+    p.use_qv_mask = (c.get_bool("filter", "use_qv", true) && has_qv) ? 1 : 0;
+    p.use_coverage_mask = c.get_bool("filter", "coverage", true) ? 1 : 0;
+    p.delete_telomere = ((int)c.get_int("layout", "del_telomere", 0)) != 0 ? 1 : 0;   // (sic) filter reads del_telomere
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// read-only memory map
+// ---------------------------------------------------------------------------------------------------
+struct Mapped {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    bool open(const std::string& path) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); return false; }
+        n = (size_t)st.st_size;
+        if (n == 0) { ::close(fd); p = nullptr; return true; }
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) { n = 0; return false; }
+        p = (const uint8_t*)m;
+        return true;
+    }
+    ~Mapped() { if (p) munmap((void*)p, n); }
+};
+
+template <typename T> inline T rd(const uint8_t* p) { T v; memcpy(&v, p, sizeof(T)); return v; }
+
+// ---------------------------------------------------------------------------------------------------
+// DAZZ_DB: trimmed read lengths + qual track
+// ---------------------------------------------------------------------------------------------------
+struct ReadDB {
+    int ureads = 0, treads = 0, cutoff = 0, all = 1;
+    std::vector<int32_t> rlen;        // trimmed order = the ids the .las uses
+    std::vector<uint8_t> keep;        // per untrimmed read
+    std::string dir, root;
+
+    static std::string dirname_of(const std::string& p) { size_t s = p.rfind('/'); return s == std::string::npos ? "." : p.substr(0, s); }
+    static std::string rootname_of(const std::string& p) {
+        size_t s = p.rfind('/');
+        std::string b = s == std::string::npos ? p : p.substr(s + 1);
+        if (b.size() > 3 && b.compare(b.size() - 3, 3, ".db") == 0) b.resize(b.size() - 3);
+        return b;
+    }
+    // Open_DB + Trim_DB: 0 ok, -1 = the reference would exit(1)
+    int open(const std::string& name) {
+        dir = dirname_of(name);
+        root = rootname_of(name);
+        FILE* stub = fopen((dir + "/" + root + ".db").c_str(), "r");
+        if (!stub) return -1;
+        int nfiles = 0;
+        bool ok = fscanf(stub, "files = %9d\n", &nfiles) == 1;
+        for (int i = 0; ok && i < nfiles; i++) {
+            int last;
+            char a[10000], b[10000];
+            ok = fscanf(stub, "  %9d %s %s\n", &last, a, b) == 3;
+        }
+        int nblocks = 0;
+        cutoff = 0; all = 1;
+        if (ok && fscanf(stub, "blocks = %9d\n", &nblocks) == 1) {
+            long long size;
+            ok = fscanf(stub, "size = %9lld cutoff = %9d all = %1d\n", &size, &cutoff, &all) == 3;
+        }
+        fclose(stub);
+        if (!ok) return -1;
+        Mapped idx;
+        if (!idx.open(dir + "/." + root + ".idx") || idx.n < 112) return -1;
+        ureads = rd<int32_t>(idx.p);
+        treads = rd<int32_t>(idx.p + 4);
+        if (idx.n < 112 + (size_t)ureads * 40) return -1;
+        const bool trim = !(cutoff <= 0 && all);
+        const int allflag = all ? 0 : 0x800;                 // DB_BEST
+        keep.assign(ureads, 1);
+        rlen.clear();
+        for (int i = 0; i < ureads; i++) {
+            const uint8_t* r = idx.p + 112 + (size_t)i * 40;
+            const int len = rd<int32_t>(r + 4), flags = rd<int32_t>(r + 32);
+            if (trim && !((flags & 0x800) >= allflag && len >= cutoff)) { keep[i] = 0; continue; }
+            rlen.push_back(len);
+        }
+        return 0;
+    }
+    // getQV: false = no usable qual track (has_qv = false in the programs)
+    bool load_qual(std::vector<std::vector<uint8_t>>& qv) const {
+        Mapped anno, data;
+        const std::string pre = dir + "/." + root + ".qual";
+        if (!anno.open(pre + ".anno") || anno.n < 8) return false;
+        const int tracklen = rd<int32_t>(anno.p);
+        const int n = (int)rlen.size();
+        if (tracklen != ureads && tracklen != treads) return false;
+        if (anno.n < 8 + 8 * ((size_t)tracklen + 1)) return false;
+        if (!data.open(pre + ".data")) return false;
+        const bool untrimmed = tracklen == ureads && ureads != n;
+        qv.clear();
+        for (int i = 0; i < tracklen; i++) {
+            if (untrimmed && !keep[i]) continue;
+            const int64_t a = rd<int64_t>(anno.p + 8 + 8 * (size_t)i), b = rd<int64_t>(anno.p + 8 + 8 * ((size_t)i + 1));
+            if (a < 0 || b < a || (size_t)b > data.n) return false;
+            qv.emplace_back(data.p + a, data.p + b);
+        }
+        return (int)qv.size() == n;
+    }
+};
+
+// QV mask, filter.cpp:309-312,340-369: longest run of good (< 40) segments; the last segment always breaks a run
+inline void qv_masks(const std::vector<std::vector<uint8_t>>& qv, int tspace, std::vector<int32_t>& out) {
+    out.assign(2 * qv.size(), 0);
+    for (size_t i = 0; i < qv.size(); i++) {
+        int s = 0, e = 0, mx = 0, maxs = 0, maxe = 0;
+        const size_t n = qv[i].size();
+        for (size_t j = 0; j < n; j++) {
+            if (qv[i][j] < 40 && j < n - 1) e++;
+            else {
+                if (e - s > mx) { maxe = e; maxs = s; mx = e - s; }
+                s = (int)j + 1;
+                e = (int)j + 1;
+            }
+        }
+        out[2 * i] = maxs * tspace;
+        out[2 * i + 1] = maxe * tspace;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// .las ingest: one header-hop pass over the mapped file, then a fill pass into the SoA arrays
+// ---------------------------------------------------------------------------------------------------
+struct LasPart {
+    Mapped file;
+    int64_t novl = 0;
+    int tspace = 0, tbytes = 1;
+    int r_begin = 0, r_end = -1;               // A read of the first / last record (filter.cpp:516-517)
+    // kept (non-self) overlaps in .las order
+    std::vector<int64_t> row_ptr;              // n_reads + 1
+    std::vector<int32_t> a_span, b_span;       // 2 per overlap
+    std::vector<uint32_t> b_flag;
+    std::vector<int64_t> trace_off;            // byte offset of the trace inside the mapped file
+    std::vector<int32_t> tlen;
+    // every record (self-overlaps included), for the (A, B) grouping of maximal / layout
+    std::vector<int64_t> rec_row_ptr;          // n_reads + 1 over records
+    std::vector<int32_t> rec_b;
+    std::vector<int64_t> rec_kept;             // index into the kept arrays, -1 for a self-overlap
+    // self-overlaps (filter.cpp:538-544)
+    std::vector<int32_t> self_a, self_span;    // self_span: abpos, aepos, bbpos', bepos'
+
+    int64_t n_kept() const { return (int64_t)b_flag.size(); }
+
+    static int header(const std::string& path, int64_t& novl, int& tspace) {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) return -1;
+        int ok = fread(&novl, 8, 1, f) == 1 && fread(&tspace, 4, 1, f) == 1;
+        fclose(f);
+        return ok ? 0 : -1;
+    }
+
+    // 0 ok; -1 cannot open / truncated (reference: exit(1)); -2 records not grouped by ascending A read
+    int load(const std::string& path, const std::vector<int32_t>& rlen) {
+        if (!file.open(path) || file.n < 12) return -1;
+        novl = rd<int64_t>(file.p);
+        tspace = rd<int32_t>(file.p + 8);
+        tbytes = tspace <= 125 ? 1 : 2;            // TRACE_XOVR
+        const int n_reads = (int)rlen.size();
+        std::vector<int64_t> off((size_t)novl);
+        size_t pos = 12;
+        for (int64_t j = 0; j < novl; j++) {
+            if (pos + 40 > file.n) return -1;
+            off[(size_t)j] = (int64_t)pos;
+            const int tl = rd<int32_t>(file.p + pos);
+            pos += 40 + (size_t)tl * tbytes;
+        }
+        if (pos > file.n) return -1;
+        row_ptr.assign((size_t)n_reads + 1, 0);
+        rec_row_ptr.assign((size_t)n_reads + 1, 0);
+        rec_b.resize((size_t)novl);
+        rec_kept.resize((size_t)novl);
+        int prev_a = -1;
+        int64_t kept = 0;
+        for (int64_t j = 0; j < novl; j++) {
+            const uint8_t* r = file.p + off[(size_t)j];
+            const int a = rd<int32_t>(r + 28), b = rd<int32_t>(r + 32);
+            if (a < 0 || a >= n_reads || b < 0 || b >= n_reads) return -1;
+            if (a < prev_a) return -2;
+            prev_a = a;
+            rec_row_ptr[(size_t)a + 1]++;
+            rec_b[(size_t)j] = b;
+            if (a != b) { row_ptr[(size_t)a + 1]++; rec_kept[(size_t)j] = kept++; }
+            else rec_kept[(size_t)j] = -1;
+        }
+        for (int i = 0; i < n_reads; i++) { row_ptr[(size_t)i + 1] += row_ptr[(size_t)i]; rec_row_ptr[(size_t)i + 1] += rec_row_ptr[(size_t)i]; }
+        a_span.resize((size_t)kept * 2);
+        b_span.resize((size_t)kept * 2);
+        b_flag.resize((size_t)kept);
+        trace_off.resize((size_t)kept);
+        tlen.resize((size_t)kept);
+        for (int64_t j = 0; j < novl; j++) {
+            const uint8_t* r = file.p + off[(size_t)j];
+            const int tl = rd<int32_t>(r), abpos = rd<int32_t>(r + 8), bbpos = rd<int32_t>(r + 12), aepos = rd<int32_t>(r + 16),
+                      bepos = rd<int32_t>(r + 20), a = rd<int32_t>(r + 28), b = rd<int32_t>(r + 32);
+            const uint32_t flags = rd<uint32_t>(r + 24);
+            const int comp = (int)(flags & 1u);                       // COMP()
+            int bb = bbpos, be = bepos;
+            if (comp) { bb = rlen[(size_t)b] - bepos; be = rlen[(size_t)b] - bbpos; }   // LAInterface.cpp:1619-1626
+            const int64_t k = rec_kept[(size_t)j];
+            if (k < 0) {
+                self_a.push_back(a);
+                self_span.push_back(abpos); self_span.push_back(aepos); self_span.push_back(bb); self_span.push_back(be);
+                continue;
+            }
+            a_span[(size_t)k * 2] = abpos; a_span[(size_t)k * 2 + 1] = aepos;
+            b_span[(size_t)k * 2] = bb; b_span[(size_t)k * 2 + 1] = be;
+            b_flag[(size_t)k] = (uint32_t)b | ((uint32_t)comp << 31);
+            trace_off[(size_t)k] = off[(size_t)j] + 40;
+            tlen[(size_t)k] = tl;
+        }
+        if (novl > 0) {
+            r_begin = rd<int32_t>(file.p + off[0] + 28);
+            r_end = rd<int32_t>(file.p + off[(size_t)novl - 1] + 28);
+        }
+        return 0;
+    }
+};
+
+inline std::string las_name(const std::string& base, bool mlas) {   // filter.cpp:228-241
+    if (mlas) return base;
+    if (base.size() >= 4 && base.compare(base.size() - 4, 4, ".las") == 0) return base;
+    return base + ".las";
+}
+inline std::vector<std::string> las_parts(const std::string& base) {   // glob(), filter.cpp:35-63
+    std::vector<std::string> out;
+    for (int i = 1;; i++) {
+        std::string p = base + "." + std::to_string(i) + ".las";
+        if (access(p.c_str(), F_OK) != 0) break;
+        out.push_back(p);
+    }
+    return out;
+}
+
+// .mas -> effective_start / effective_end (maximal.cpp:524-531, hinging.cpp:867-874)
+inline bool read_mas(const std::string& path, int n_reads, std::vector<int32_t>& eff, std::vector<uint8_t>& seen) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    eff.assign((size_t)n_reads * 2, 0);
+    seen.assign((size_t)n_reads, 0);
+    int r, s, e;
+    while (fscanf(f, "%d %d %d", &r, &s, &e) != EOF) {
+        if (r < 0 || r >= n_reads) continue;
+        eff[(size_t)r * 2] = s; eff[(size_t)r * 2 + 1] = e; seen[(size_t)r] = 1;
+    }
+    fclose(f);
+    return true;
+}
+
+#define HH_CHECK(ctx, call)                                                                   \
+    do {                                                                                      \
+        int _rc = (call);                                                                     \
+        if (_rc != HINGE_OK) {                                                                \
+            console.error("%s failed (%d): %s", #call, _rc, hinge_last_error(ctx));           \
+            return _rc == HINGE_E_UNDEFINED ? 1 : 2;                                          \
+        }                                                                                     \
+    } while (0)
+
+}  // namespace hh

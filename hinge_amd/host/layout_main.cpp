@@ -1,0 +1,475 @@
+// hinging  ==  `hinge layout --db DB --las LAS[.las] [--mlas] -x PREFIX -o OUT --config nominal.ini`
+// Same flags, inputs (.mas .max .repeat.txt .hinges.txt), outputs (.edges.hinges .edges.hinges2 .hinge.list
+// .deadends.txt .hgraph .killed.hinges .garbage.txt .edges.greedy .edges.1 .edges.2 .edges.skipped + the
+// debug dumps in the cwd) and exit codes as src/layout/hinging.cpp.
+//
+// GPU: ProcessAlignment of the best one/two overlaps of every maximal x maximal pair (k_trim_classify) and
+// GetMatchingPosition of every hinge through every match (k_matching_position).  Host: the (A, B) walk in
+// unordered_map order, the std::sort by weight, the hinge graph bookkeeping and the text writers - all on
+// the ~10^5 matches that survive, i.e. a few MB.
+#include <fstream>
+#include <set>
+#include <sstream>
+#include "pairs.h"
+
+using namespace hh;
+
+namespace {
+
+struct Match {
+    int a, b, comp;
+    int ab, ae, bb, be;          // raw coordinates (B on the forward strand)
+    int a_rs, a_re, b_rs, b_re;  // effective read bounds used for the trim
+    int64_t k;                   // index in the part's pile-up arrays
+    int part;
+    Classified c;
+};
+
+struct Hinge {
+    int pos, type;
+    bool active;
+};
+
+void print_overlap(FILE* f, const Match& m) {   // PrintOverlapToFile, hinging.cpp:188-248
+    const int t = m.c.type;
+    const int hinged = (t == MT_FORWARD || t == MT_BACKWARD) ? -1 : 1;
+    if (t == MT_FORWARD_INTERNAL || t == MT_FORWARD)
+        fprintf(f, "%d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d] [%d %d] [%d %d]\n", m.a, m.b, m.c.length, 0, m.comp, hinged, m.c.eff_ab,
+                m.c.eff_ae, m.c.eff_bb, m.c.eff_be, m.a_rs, m.a_re, m.b_rs, m.b_re, m.ab, m.ae, m.bb, m.be);
+    else if (t == MT_BACKWARD_INTERNAL || t == MT_BACKWARD)
+        fprintf(f, "%d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d] [%d %d] [%d %d]\n", m.b, m.a, m.c.length, m.comp, 0, hinged, m.c.eff_bb,
+                m.c.eff_be, m.c.eff_ab, m.c.eff_ae, m.b_rs, m.b_re, m.a_rs, m.a_re, m.ab, m.ae, m.bb, m.be);
+}
+
+void print_overlap2(FILE* f, const Match& m, int hinge_pos) {   // PrintOverlapToFile2, hinging.cpp:253-344
+    const int t = m.c.type;
+    if (t == MT_FORWARD || t == MT_FORWARD_INTERNAL)
+        fprintf(f, "%d %d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m.a, m.b, m.c.length, 0, m.comp, t == MT_FORWARD ? 0 : 1,
+                t == MT_FORWARD ? -1 : hinge_pos, m.c.eff_ab, m.c.eff_ae, m.c.eff_bb, m.c.eff_be, m.a_rs, m.a_re, m.b_rs, m.b_re);
+    else if (t == MT_BACKWARD || t == MT_BACKWARD_INTERNAL)
+        fprintf(f, "%d %d %d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m.b, m.a, m.c.length, m.comp, 0, t == MT_BACKWARD ? 0 : -1,
+                t == MT_BACKWARD ? -1 : hinge_pos, m.c.eff_bb, m.c.eff_be, m.c.eff_ab, m.c.eff_ae, m.b_rs, m.b_re, m.a_rs, m.a_re);
+}
+
+void print_dump(FILE* f, const Match& m) {   // the 13-field debug line, hinging.cpp:1080-1090 etc.
+    fprintf(f, "%d %d %d %d %d [%d %d] [%d %d] [%d %d] [%d %d] \n", m.a, m.b, m.c.length, m.comp, m.c.type, m.c.eff_ab, m.c.eff_ae, m.c.eff_bb,
+            m.c.eff_be, m.a_rs, m.a_re, m.b_rs, m.b_re);
+}
+
+void print_g(FILE* f, const char* fmt, int x, int y, const Match& m) {
+    fprintf(f, fmt, x, y, m.c.length, m.c.eff_ab, m.c.eff_ae, m.c.eff_bb, m.c.eff_be, m.a_rs, m.a_re, m.b_rs, m.b_re);
+}
+
+// "<id> <v1> <v2> <v1> <v2> ... \n" lines; pairs with v1 != 0 and v2 != 0 (hinging.cpp:887-936)
+void parse_pairs(const std::string& path, std::map<int, std::vector<std::pair<int, int>>>& m, std::vector<int>* order) {
+    std::ifstream f(path);
+    std::string line;
+    while (std::getline(f, line)) {
+        std::stringstream ss;
+        ss << line << "\n";
+        int num = 0;
+        ss >> num;
+        m[num] = std::vector<std::pair<int, int>>();
+        if (order) order->push_back(num);
+        while (!ss.eof()) {
+            int r1 = 0, r2 = 0;
+            ss >> r1 >> r2;
+            if (r1 != 0 && r2 != 0) m[num].push_back(std::make_pair(r1, r2));
+        }
+    }
+}
+
+// component sizes are all that reach the output (hinging.cpp:1644-1675): union-find instead of Boost.Graph
+std::vector<int> components(int n, const std::vector<std::pair<int, int>>& edges) {
+    std::vector<int> parent((size_t)n);
+    for (int i = 0; i < n; i++) parent[(size_t)i] = i;
+    auto find = [&](int x) { while (parent[(size_t)x] != x) { parent[(size_t)x] = parent[(size_t)parent[(size_t)x]]; x = parent[(size_t)x]; } return x; };
+    for (auto& e : edges) { const int a = find(e.first), b = find(e.second); if (a != b) parent[(size_t)a] = b; }
+    std::vector<int> comp((size_t)n);
+    for (int i = 0; i < n; i++) comp[(size_t)i] = find(i);
+    return comp;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    CmdLine cmdp;
+    cmdp.add_string("db", 'b', "db file name", false, "");
+    cmdp.add_string("las", 'l', "las file name", false, "");
+    cmdp.add_string("paf", 'p', "paf file name", false, "");
+    cmdp.add_string("config", 'c', "configuration file name", false, "");
+    cmdp.add_string("fasta", 'f', "fasta file name", false, "");
+    cmdp.add_string("prefix", 'x', "(intermediate output) input file prefix", true, "");
+    cmdp.add_string("out", 'o', "final output file name", true, "");
+    cmdp.add_string("log", 'g', "log folder name", false, "log");
+    cmdp.add_flag("debug", '\0', "debug mode");
+    cmdp.add_flag("mlas", '\0', "multiple las files");
+    cmdp.parse_check(argc, argv);
+
+    Log console;
+    console.open(cmdp.get("log"));
+    console.info("Hinging layout");
+    const std::string name_db = cmdp.get("db"), name_las_base = cmdp.get("las"), name_paf = cmdp.get("paf"), name_fasta = cmdp.get("fasta");
+    const std::string name_config = cmdp.get("config"), out = cmdp.get("prefix"), out_name = cmdp.get("out");
+    const bool mlas = cmdp.exist("mlas");
+    FILE* deadend_out = fopen((out_name + ".deadends.txt").c_str(), "w");
+    FILE* garbage_out = fopen((out + ".garbage.txt").c_str(), "w");
+    const bool db_and_las = !name_db.empty() && !name_las_base.empty(), db_or_las = !name_db.empty() || !name_las_base.empty();
+    const bool fa_and_paf = !name_fasta.empty() && !name_paf.empty(), fa_or_paf = !name_fasta.empty() || !name_paf.empty();
+    if (db_or_las && fa_or_paf) { console.error("Pass in either a db and a las or a fasta and a paf"); return 1; }
+    if (!fa_and_paf && !db_and_las) { console.error("Pass in at least one of the following two combinations: a db and a las or a fasta and a paf"); return 1; }
+    if (mlas && !db_and_las) { console.error("--mlas works only with db and las"); return 1; }
+    if (fa_and_paf) { console.error("fasta + paf input is not supported by this build (SURVEY 8f-3): use a db and a las"); return 1; }
+    if (!deadend_out || !garbage_out) { console.error("cannot open output files"); return 2; }
+
+    ReadDB db;
+    if (db.open(name_db) != 0) { fprintf(stderr, "hinging: Could not open database %s\n", name_db.c_str()); exit(1); }
+    const int n_read = (int)db.rlen.size();
+    console.info("# Reads: %d", n_read);
+
+    Config ini(name_config);
+    if (ini.error < 0) { console.warn("Can't load %s", name_config.c_str()); return 1; }
+    const int LENGTH_THRESHOLD = (int)ini.get_int("filter", "length_threshold", -1);
+    const int ALN_THRESHOLD = (int)ini.get_int("filter", "aln_threshold", -1);
+    const int THETA = (int)ini.get_int("filter", "theta", -1);
+    const int THETA2 = (int)ini.get_int("filter", "theta2", 0);
+    const int HINGE_SLACK = (int)ini.get_int("layout", "hinge_slack", 1000);
+    const int HINGE_TOLERANCE = (int)ini.get_int("layout", "hinge_tolerance", 150);
+    const int KILL_HINGE_OVERLAP_ALLOWANCE = (int)ini.get_int("layout", "kill_hinge_overlap", 300);
+    const int KILL_HINGE_INTERNAL_ALLOWANCE = (int)ini.get_int("layout", "kill_hinge_internal", 40);
+    const int MATCHING_HINGE_SLACK = (int)ini.get_int("layout", "matching_hinge_slack", 200);
+    const int NUM_EVENTS_TELOMERE = (int)ini.get_int("layout", "num_events_telomere", 7);
+    const int MIN_CONNECTED_COMPONENT_SIZE = (int)ini.get_int("layout", "min_connected_component_size", 8);
+    const bool USE_TWO_MATCHES = ((int)ini.get_int("layout", "use_two_matches", 1)) != 0;
+    const bool KEEP_ONLY_MAX = ((int)ini.get_int("layout", "keep_only_matches_between_maximal_reads", 1)) != 0;
+    const bool delete_telomere = ((int)ini.get_int("layout", "del_telomeres", 0)) != 0;   // (sic) layout reads del_telomeres
+    console.info("del_telomeres = %d", (int)delete_telomere);
+
+    std::vector<int32_t> eff;
+    std::vector<uint8_t> seen;
+    if (!read_mas(out + ".mas", n_read, eff, seen)) { console.error("cannot open %s.mas (run hinge filter first)", out.c_str()); return 2; }
+    for (int i = 0; i < n_read; i++)
+        if (!seen[(size_t)i]) { console.error("read %d has no line in %s.mas: the reference reads uninitialised memory here", i, out.c_str()); return 2; }
+    std::vector<uint8_t> active((size_t)n_read, 1);
+
+    std::map<int, std::vector<std::pair<int, int>>> marked_repeats, marked_hinges;
+    {
+        std::vector<int> order;
+        parse_pairs(out + ".repeat.txt", marked_repeats, &order);
+        for (int num : order)
+            if (delete_telomere && (int)marked_repeats[num].size() > NUM_EVENTS_TELOMERE && num >= 0 && num < n_read) active[(size_t)num] = 0;
+        parse_pairs(out + ".hinges.txt", marked_hinges, nullptr);
+    }
+    for (int i = 0; i < n_read; i++)
+        if (eff[(size_t)i * 2 + 1] - eff[(size_t)i * 2] < LENGTH_THRESHOLD) { active[(size_t)i] = 0; fprintf(garbage_out, "%d\n", i); }
+    fclose(garbage_out);
+
+    hinge_ctx* ctx = nullptr;
+    if (hinge_ctx_create(0, &ctx) != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), nullptr));
+    HH_CHECK(ctx, hinge_set_eff_reads(ctx, eff.data()));
+
+    // ---- GetAlignment, hinging.cpp:347-610 ---------------------------------------------------------------
+    {
+        std::vector<uint8_t> maximal((size_t)n_read, 0);
+        std::ifstream mf(out + ".max");
+        std::string line;
+        while (std::getline(mf, line)) { const int r = atoi(line.c_str()); if (r >= 0 && r < n_read) maximal[(size_t)r] = 1; }
+        for (int i = 0; i < n_read; i++) active[(size_t)i] = active[(size_t)i] && maximal[(size_t)i];
+    }
+    std::vector<std::vector<Match>> matches_forward((size_t)n_read), matches_backward((size_t)n_read);
+    const std::string name_las = las_name(name_las_base, mlas);
+    std::vector<std::string> las_list;
+    if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
+    std::vector<LasPart*> parts;   // kept mapped: GetMatchingPosition needs the traces again
+    for (size_t part = 0; part < las_list.size(); part++) {
+        LasPart* lp = new LasPart();
+        parts.push_back(lp);
+        LasPart& las = *lp;
+        const int lrc = las.load(las_list[part], db.rlen);
+        if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
+        if (lrc != 0) { fprintf(stderr, "hinging: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        if (las.novl == 0) { console.error("No alignments!"); return 2; }
+        const int r_begin = las.r_begin, r_end = las.r_end;
+        const size_t nr = (size_t)(r_end - r_begin + 1);
+        HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
+        HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
+        // pairs between reads that are active now (the map only ever receives active x active records, hinging.cpp:478-490)
+        std::vector<std::vector<PairPick>> picks(nr);
+        std::vector<int64_t> sel;
+        std::vector<int32_t> a_of;
+        for (int i = r_begin; i <= r_end; i++) {
+            if (!active[(size_t)i]) continue;
+            std::vector<PairPick>& pp = picks[(size_t)(i - r_begin)];
+            pick_pairs(las, i, USE_TWO_MATCHES, 1, [&](int b) { return active[(size_t)b] && KEEP_ONLY_MAX; }, pp);
+            for (auto& p : pp)
+                for (int w = 0; w < 2; w++)
+                    if (p.pick[w] >= 0) { sel.push_back(p.pick[w]); a_of.push_back(i); }
+        }
+        std::vector<Classified> cls(std::max<size_t>(sel.size(), 1));
+        HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
+        size_t c = 0;
+        for (int i = r_begin; i <= r_end; i++) {
+            // NOTE: `active` is the state BEFORE this loop for the pair filter above (the reference fills idx_ab for the
+            // whole part first, hinging.cpp:478-490), but a read dropped here is inactive for the reads after it.
+            if (picks[(size_t)(i - r_begin)].empty() && !active[(size_t)i]) continue;
+            if (!active[(size_t)i]) { for (auto& p : picks[(size_t)(i - r_begin)]) for (int w = 0; w < 2; w++) if (p.pick[w] >= 0) c++; continue; }
+            bool contained = false;
+            for (auto& p : picks[(size_t)(i - r_begin)])
+                for (int w = 0; w < 2; w++) {
+                    if (p.pick[w] < 0) continue;
+                    const Classified& r = cls[c++];
+                    const int64_t k = p.pick[w];
+                    Match m;
+                    m.a = i; m.b = p.b; m.comp = (int)(las.b_flag[(size_t)k] >> 31);
+                    m.ab = las.a_span[(size_t)k * 2]; m.ae = las.a_span[(size_t)k * 2 + 1];
+                    m.bb = las.b_span[(size_t)k * 2]; m.be = las.b_span[(size_t)k * 2 + 1];
+                    m.a_rs = eff[(size_t)i * 2]; m.a_re = eff[(size_t)i * 2 + 1];
+                    m.b_rs = eff[(size_t)p.b * 2]; m.b_re = eff[(size_t)p.b * 2 + 1];
+                    m.k = k; m.part = (int)part; m.c = r;
+                    if (active[(size_t)p.b]) contained = contained || (r.type == MT_BCOVERA);
+                    if (r.type == MT_FORWARD || r.type == MT_FORWARD_INTERNAL) matches_forward[(size_t)i].push_back(m);
+                    else if (r.type == MT_BACKWARD || r.type == MT_BACKWARD_INTERNAL) matches_backward[(size_t)i].push_back(m);
+                }
+            if (contained) active[(size_t)i] = 0;   // "[contained] Should not happen"
+        }
+    }
+
+    auto by_weight = [](const Match& x, const Match& y) { return x.c.weight > y.c.weight; };   // compare_overlap_weight
+    for (int i = 0; i < n_read; i++)
+        if (active[(size_t)i]) {
+            std::sort(matches_forward[(size_t)i].begin(), matches_forward[(size_t)i].end(), by_weight);
+            std::sort(matches_backward[(size_t)i].begin(), matches_backward[(size_t)i].end(), by_weight);
+        }
+
+    // debug dumps in the cwd, hinging.cpp:1074-1150
+    {
+        FILE* g = fopen("edges.g_out.txt", "w");
+        for (int i = 0; i < n_read; i++)
+            if (active[(size_t)i])
+                for (auto& m : matches_forward[(size_t)i]) if (active[(size_t)m.b]) { print_dump(g, m); break; }
+        fprintf(g, "bkw\n");
+        for (int i = 0; i < n_read; i++)
+            if (active[(size_t)i])
+                for (auto& m : matches_backward[(size_t)i]) if (active[(size_t)m.b]) { print_dump(g, m); break; }
+        fclose(g);
+        FILE* ob = fopen("edges.fwd.backup.txt", "w");
+        for (int i = 0; i < n_read; i++)
+            if (active[(size_t)i]) for (auto& m : matches_forward[(size_t)i]) if (active[(size_t)m.b]) print_dump(ob, m);
+        fclose(ob);
+        ob = fopen("edges.bkw.backup.txt", "w");
+        for (int i = 0; i < n_read; i++)
+            if (active[(size_t)i]) for (auto& m : matches_backward[(size_t)i]) if (active[(size_t)m.b]) print_dump(ob, m);
+        fclose(ob);
+    }
+
+    FILE* out_g1 = fopen((out_name + ".edges.1").c_str(), "w");
+    FILE* out_g2 = fopen((out_name + ".edges.2").c_str(), "w");
+    FILE* out_hg = fopen((out_name + ".edges.hinges").c_str(), "w");
+    FILE* out_hg2 = fopen((out_name + ".edges.hinges2").c_str(), "w");
+    FILE* out_greedy = fopen((out_name + ".edges.greedy").c_str(), "w");
+    FILE* out_skipped = fopen((out_name + ".edges.skipped").c_str(), "w");
+
+    std::vector<std::vector<Hinge>> hinges_vec((size_t)n_read), killed_hinges_vec((size_t)n_read), new_killed_hinges_vec((size_t)n_read);
+    for (int i = 0; i < n_read; i++) {
+        auto& mh = marked_hinges[i];
+        std::set<std::pair<int, int>> surviving(mh.begin(), mh.end());
+        for (auto& h : mh) hinges_vec[(size_t)i].push_back(Hinge{h.first, h.second, true});
+        for (auto& r : marked_repeats[i])
+            if (surviving.find(r) == surviving.end()) killed_hinges_vec[(size_t)i].push_back(Hinge{r.first, r.second, false});
+    }
+    {
+        FILE* ko = fopen((out + ".killed.hinges").c_str(), "w");
+        for (int i = 0; i < n_read; i++) {
+            fprintf(ko, "%d ", i);
+            for (auto& h : killed_hinges_vec[(size_t)i]) fprintf(ko, "%d %d ", h.type, h.pos);
+            fprintf(ko, "\n");
+        }
+        fclose(ko);
+    }
+
+    // hinges bridged by a match, hinging.cpp:1262-1321
+    for (int i = 0; i < n_read; i++) {
+        if (!active[(size_t)i]) continue;
+        for (auto& m : matches_forward[(size_t)i])
+            if (m.c.active && active[(size_t)m.b])
+                for (auto& h : hinges_vec[(size_t)i])
+                    if ((((m.c.eff_ab < h.pos + KILL_HINGE_INTERNAL_ALLOWANCE) && (m.c.type == MT_FORWARD_INTERNAL)) ||
+                         ((m.c.eff_ab < h.pos - KILL_HINGE_OVERLAP_ALLOWANCE) && (m.c.type == MT_FORWARD))) && (h.type == 1))
+                        h.active = false;
+        for (auto& m : matches_backward[(size_t)i])
+            if (m.c.active && active[(size_t)m.b])
+                for (auto& h : hinges_vec[(size_t)i])
+                    if ((((m.c.eff_ae > h.pos - KILL_HINGE_INTERNAL_ALLOWANCE) && (m.c.type == MT_BACKWARD_INTERNAL)) ||
+                         ((m.c.eff_ae > h.pos + KILL_HINGE_OVERLAP_ALLOWANCE) && (m.c.type == MT_BACKWARD))) && (h.type == -1))
+                        h.active = false;
+    }
+
+    // ---- hinge graph, hinging.cpp:1325-1640 ------------------------------------------------------------------
+    // GetMatchingPosition of every hinge through every live match: batched per .las part on the GPU, consumed in loop order
+    std::vector<std::vector<int>> pos_of_query(parts.size());
+    {
+        std::vector<std::vector<int64_t>> q_ovl(parts.size());
+        std::vector<std::vector<int32_t>> q_pos(parts.size());
+        for (int i = 0; i < n_read; i++) {
+            if (!active[(size_t)i]) continue;
+            for (auto& h : hinges_vec[(size_t)i])
+                for (int dirn = 0; dirn < 2; dirn++)
+                    for (auto& m : (dirn == 0 ? matches_forward : matches_backward)[(size_t)i])
+                        if (m.c.active && active[(size_t)m.b]) { q_ovl[(size_t)m.part].push_back(m.k); q_pos[(size_t)m.part].push_back(h.pos); }
+        }
+        for (size_t p = 0; p < parts.size(); p++) {
+            pos_of_query[p].assign(std::max<size_t>(q_ovl[p].size(), 1), 0);
+            if (q_ovl[p].empty()) continue;
+            LasPart& las = *parts[p];
+            if (parts.size() > 1 || p != parts.size() - 1) {   // the last loaded part is still resident
+                HH_CHECK(ctx, hinge_set_pileups(ctx, las.r_begin, las.r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
+                HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
+            }
+            HH_CHECK(ctx, hinge_matching_position(ctx, (int64_t)q_ovl[p].size(), q_ovl[p].data(), q_pos[p].data(), pos_of_query[p].data()));
+        }
+    }
+    int num_hinges = 0;
+    std::vector<int> node_base((size_t)n_read + 1, 0);
+    for (int i = 0; i < n_read; i++) { node_base[(size_t)i] = num_hinges; num_hinges += (int)hinges_vec[(size_t)i].size(); }
+    std::vector<std::pair<int, int>> graph_edges;
+    FILE* out_hgraph = fopen((out_name + ".hgraph").c_str(), "w");
+    FILE* out_debug = fopen((out_name + ".debug").c_str(), "w");
+    fclose(fopen("overlap_debug.txt", "w"));
+    {
+        std::vector<size_t> cursor(parts.size(), 0);
+        for (int i = 0; i < n_read; i++) {
+            if (!active[(size_t)i]) continue;
+            for (int k = 0; k < (int)hinges_vec[(size_t)i].size(); k++) {
+                const Hinge hk = hinges_vec[(size_t)i][(size_t)k];
+                for (int dirn = 0; dirn < 2; dirn++) {
+                    const int own_type = dirn == 0 ? 1 : -1;   // hinge type whose line is written (i, b) in this direction
+                    for (auto& m : (dirn == 0 ? matches_forward : matches_backward)[(size_t)i]) {
+                        if (!(m.c.active && active[(size_t)m.b])) continue;
+                        const int pos_B = pos_of_query[(size_t)m.part][cursor[(size_t)m.part]++];
+                        const int rev_int = m.comp == 1 ? 1 : 0;
+                        const int req_type = m.comp == 1 ? -hk.type : hk.type;
+                        const int b_id = m.b;
+                        for (int l = 0; l < (int)hinges_vec[(size_t)b_id].size(); l++) {
+                            const Hinge& hb = hinges_vec[(size_t)b_id][(size_t)l];
+                            if ((hb.pos < pos_B + MATCHING_HINGE_SLACK) && (hb.pos > pos_B - MATCHING_HINGE_SLACK) && req_type == hb.type) {
+                                if (hk.type == own_type) {
+                                    graph_edges.push_back(std::make_pair(node_base[(size_t)i] + k, node_base[(size_t)b_id] + l));
+                                    fprintf(out_hgraph, "%d %d %d %d %d %d\n", i, b_id, hk.pos, hb.pos, 1, rev_int);
+                                } else {
+                                    graph_edges.push_back(std::make_pair(node_base[(size_t)b_id] + l, node_base[(size_t)i] + k));
+                                    fprintf(out_hgraph, "%d %d %d %d %d %d\n", b_id, i, hb.pos, hk.pos, 1, rev_int);
+                                }
+                            }
+                        }
+                        for (auto& kb : killed_hinges_vec[(size_t)b_id]) {
+                            if (!((kb.pos < pos_B + MATCHING_HINGE_SLACK) && (kb.pos > pos_B - MATCHING_HINGE_SLACK))) continue;
+                            const bool type_ok = req_type == kb.type;
+                            if (type_ok) {
+                                if (hk.type == own_type) fprintf(out_hgraph, "%d %d %d %d %d %d\n", i, b_id, hk.pos, kb.pos, 0, rev_int);
+                                else fprintf(out_hgraph, "%d %d %d %d %d %d\n", b_id, i, kb.pos, hk.pos, 0, rev_int);
+                            }
+                            if (dirn == 0) {   // forward: inside the type test (hinging.cpp:1467-1493)
+                                if (type_ok && m.c.type == MT_FORWARD) {
+                                    new_killed_hinges_vec[(size_t)i].push_back(Hinge{hk.pos, hk.type, false});
+                                    if (hk.type == -1) {
+                                        print_dump(out_debug, m);
+                                        fprintf(out_debug, "%d %d %d %d\n", hk.pos, hk.type, kb.pos, kb.type);
+                                    }
+                                }
+                            } else if (m.c.type == MT_BACKWARD) {   // backward: OUTSIDE the type test (hinging.cpp:1612-1622)
+                                new_killed_hinges_vec[(size_t)i].push_back(Hinge{hk.pos, hk.type, false});
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    fclose(out_hgraph);
+    fclose(out_debug);
+    {
+        std::vector<int> comp = components(num_hinges, graph_edges);
+        std::map<int, int> size;
+        for (int v : comp) size[v] += 1;
+        int node = 0;
+        for (int i = 0; i < n_read; i++)
+            for (auto& h : hinges_vec[(size_t)i]) { if (size[comp[(size_t)node]] < MIN_CONNECTED_COMPONENT_SIZE) h.active = false; node++; }
+    }
+    {
+        FILE* hl = fopen((out_name + ".hinge.list").c_str(), "w");
+        int n = 0;
+        for (int i = 0; i < n_read; i++)
+            for (size_t j = 0; j < hinges_vec[(size_t)i].size(); j++)
+                if (active[(size_t)i] && hinges_vec[(size_t)i][j].active) { fprintf(hl, "%d %d %d\n", i, marked_hinges[i][j].first, marked_hinges[i][j].second); n++; }
+        fclose(hl);
+        console.info("after filter %d active hinges", n);
+    }
+
+    // pure greedy graph, hinging.cpp:1724-1860
+    for (int i = 0; i < n_read; i++) {
+        if (!active[(size_t)i]) continue;
+        for (int dirn = 0; dirn < 2; dirn++) {
+            int cnt = 0;
+            for (auto& m : (dirn == 0 ? matches_forward : matches_backward)[(size_t)i]) {
+                if (!(m.c.active && m.c.type == (dirn == 0 ? MT_FORWARD : MT_BACKWARD) && active[(size_t)m.b])) continue;
+                if (cnt < 1) {
+                    print_overlap(out_greedy, m);
+                    if (m.comp == 0) print_g(out_g1, "%d %d %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m.a, m.b, m);
+                    else print_g(out_g1, "%d %d' %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m.a, m.b, m);
+                    if (m.comp == 0) print_g(out_g2, "%d' %d' %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m.b, m.a, m);
+                    else print_g(out_g2, "%d %d' %d [%d %d] [%d %d] [%d %d] [%d %d]\n", m.b, m.a, m);
+                }
+                cnt++;
+            }
+        }
+    }
+
+    fclose(fopen("hinge_debug.txt", "w"));
+    // best-overlap selection, hinging.cpp:1911-2148
+    int hinge_pos = -1;
+    for (int i = 0; i < n_read; i++) {
+        if (!active[(size_t)i]) continue;
+        const Match* chosen = nullptr;
+        for (int dirn = 0; dirn < 2; dirn++) {
+            std::vector<Match>& ms = (dirn == 0 ? matches_forward : matches_backward)[(size_t)i];
+            int plain = 0, internal = 0;
+            for (auto& m : ms) {
+                if (!m.c.active || !active[(size_t)m.b]) continue;
+                if (m.c.type == (dirn == 0 ? MT_FORWARD : MT_BACKWARD) && plain == 0) {
+                    bool poisoned = false;
+                    for (auto& nk : new_killed_hinges_vec[(size_t)i]) {
+                        bool hit;
+                        if (dirn == 0)
+                            hit = ((m.comp != 1) && (nk.type == -1) && (nk.pos > m.c.eff_be)) || ((m.comp == 1) && (nk.type == 1) && (nk.pos < m.c.eff_bb));
+                        else
+                            hit = ((m.comp != 1) && (nk.type == 1) && (nk.pos < m.c.eff_bb)) || ((m.comp == 1) && (nk.type == -1) && (nk.pos > m.c.eff_be));
+                        if (hit) { print_overlap(out_skipped, m); poisoned = true; }
+                    }
+                    if (!poisoned) { chosen = &m; hinge_pos = -1; plain = 1; }
+                } else if (m.c.type == (dirn == 0 ? MT_FORWARD_INTERNAL : MT_BACKWARD_INTERNAL) && !hinges_vec[(size_t)m.b].empty() && internal == 0) {
+                    int anchor, want;
+                    if (dirn == 0) { anchor = m.comp == 1 ? m.be : m.bb; want = 1 - 2 * m.comp; }
+                    else { anchor = m.comp == 1 ? m.bb : m.be; want = -1 + 2 * m.comp; }
+                    for (auto& hb : hinges_vec[(size_t)m.b])
+                        if ((anchor > hb.pos - HINGE_TOLERANCE) && (anchor < hb.pos + HINGE_TOLERANCE) && hb.type == want && hb.active) {
+                            if (plain == 0 || m.c.weight > chosen->c.weight - 2 * HINGE_SLACK) { chosen = &m; plain = 1; internal = 1; hinge_pos = hb.pos; }
+                            break;
+                        }
+                }
+            }
+            if (chosen) {
+                print_overlap(out_hg, *chosen);
+                print_overlap2(out_hg2, *chosen, hinge_pos);
+                if (dirn == 0) chosen = nullptr;   // reset only after the forward pass (hinging.cpp:2026)
+            } else {
+                fprintf(deadend_out, "%d\t matches_%s size: %d\n", i, dirn == 0 ? "forward" : "backward", (int)ms.size());
+            }
+        }
+    }
+    fclose(out_g1); fclose(out_g2); fclose(out_hg); fclose(out_hg2); fclose(out_greedy); fclose(out_skipped); fclose(deadend_out);
+    for (auto* p : parts) delete p;
+    hinge_ctx_destroy(ctx);
+    console.info("sort and output finished");
+    return 0;
+}

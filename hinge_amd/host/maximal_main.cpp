@@ -1,0 +1,148 @@
+// get_maximal_reads  ==  `hinge maximal --db DB --las LAS[.las] [--mlas] -x PREFIX --config nominal.ini`
+// Same flags, inputs, outputs (.max, .contained.txt, rewritten .coverage.txt, emptied .homologous.txt /
+// .filtered.fasta) and exit codes as src/maximal/maximal.cpp.  ProcessAlignment of every (A, B) pair's
+// best one or two overlaps (maximal.cpp:780-850) runs in k_trim_classify; the order-dependent containment
+// resolution (maximal.cpp:805-857: a read is dropped only if its container is still active) stays a
+// sequential host pass over 10 ints per classified overlap.
+#include "pairs.h"
+
+using namespace hh;
+
+int main(int argc, char* argv[]) {
+    CmdLine cmdp;
+    cmdp.add_string("db", 'b', "db file name", false, "");
+    cmdp.add_string("las", 'l', "las file name", false, "");
+    cmdp.add_string("paf", 'p', "paf file name", false, "");
+    cmdp.add_string("config", 'c', "configuration file name", false, "");
+    cmdp.add_string("fasta", 'f', "fasta file name", false, "");
+    cmdp.add_string("prefix", 'x', "prefix of (intermediate) output", false, "out");
+    cmdp.add_string("restrictreads", 'r', "restrict to reads in the file", false, "");
+    cmdp.add_string("log", 'g', "log folder name", false, "log");
+    cmdp.add_flag("mlas", '\0', "multiple las files");
+    cmdp.add_flag("debug", '\0', "debug mode");
+    cmdp.parse_check(argc, argv);
+
+    Log console;
+    console.open(cmdp.get("log"));
+    console.info("Getting maximal reads");
+    const std::string name_db = cmdp.get("db"), name_las_base = cmdp.get("las"), name_paf = cmdp.get("paf"), name_fasta = cmdp.get("fasta");
+    const std::string name_config = cmdp.get("config"), out = cmdp.get("prefix");
+    const bool db_and_las = !name_db.empty() && !name_las_base.empty(), db_or_las = !name_db.empty() || !name_las_base.empty();
+    const bool fa_and_paf = !name_fasta.empty() && !name_paf.empty(), fa_or_paf = !name_fasta.empty() || !name_paf.empty();
+    if (db_or_las && fa_or_paf) { console.error("Pass in either a db and a las or a fasta and a paf"); return 1; }
+    if (!fa_and_paf && !db_and_las) { console.error("Pass in at least one of the following two combinations: a db and a las or a fasta and a paf"); return 1; }
+    const bool mlas = cmdp.exist("mlas");
+    if (mlas && !db_and_las) { console.error("--mlas works only with db and las"); return 1; }
+    if (fa_and_paf) { console.error("fasta + paf input is not supported by this build (SURVEY 8f-3): use a db and a las"); return 1; }
+
+    ReadDB db;
+    if (db.open(name_db) != 0) { fprintf(stderr, "get_maximal_reads: Could not open database %s\n", name_db.c_str()); exit(1); }
+    const int n_read = (int)db.rlen.size();
+    console.info("# Reads: %d", n_read);
+    const std::string name_las = las_name(name_las_base, mlas);
+    std::vector<std::string> las_list;
+    if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
+
+    Config ini(name_config);
+    if (ini.error < 0) { console.warn("Can't load %s", name_config.c_str()); return 1; }
+    const int LENGTH_THRESHOLD = (int)ini.get_int("filter", "length_threshold", -1);
+    const int ALN_THRESHOLD = (int)ini.get_int("filter", "aln_threshold", -1);
+    const int THETA = (int)ini.get_int("filter", "theta", -1);
+    const int THETA2 = (int)ini.get_int("filter", "theta2", 0);
+    const bool USE_TWO_MATCHES = ((int)ini.get_int("layout", "use_two_matches", 1)) != 0;
+    const int reso = 40;
+
+    FILE* f_cov = fopen((out + ".coverage.txt").c_str(), "w");
+    fclose(fopen((out + ".homologous.txt").c_str(), "w"));
+    fclose(fopen((out + ".filtered.fasta").c_str(), "w"));
+    FILE* f_contained = fopen((out + ".contained.txt").c_str(), "w");
+    FILE* f_max = fopen((out + ".max").c_str(), "w");
+    if (!f_cov || !f_contained || !f_max) { console.error("cannot open output files with prefix %s", out.c_str()); return 2; }
+
+    std::vector<int32_t> eff;
+    std::vector<uint8_t> seen;
+    if (!read_mas(out + ".mas", n_read, eff, seen)) { console.error("cannot open %s.mas (run hinge filter first)", out.c_str()); return 2; }
+    for (int i = 0; i < n_read; i++)
+        if (!seen[(size_t)i]) { console.error("read %d has no line in %s.mas: the reference reads uninitialised memory here", i, out.c_str()); return 2; }
+    std::vector<uint8_t> active((size_t)n_read, 1);
+    for (int i = 0; i < n_read; i++)
+        if (eff[(size_t)i * 2 + 1] - eff[(size_t)i * 2] < LENGTH_THRESHOLD) active[(size_t)i] = 0;
+
+    hinge_ctx* ctx = nullptr;
+    if (hinge_ctx_create(0, &ctx) != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), nullptr));
+    HH_CHECK(ctx, hinge_set_eff_reads(ctx, eff.data()));
+
+    for (size_t part = 0; part < las_list.size(); part++) {
+        console.info("name of las: %s", las_list[part].c_str());
+        LasPart las;
+        const int lrc = las.load(las_list[part], db.rlen);
+        if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
+        if (lrc != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        if (las.novl == 0) { console.error("No alignments!"); return 1; }
+        const int r_begin = las.r_begin, r_end = las.r_end;
+        const size_t nr = (size_t)(r_end - r_begin + 1);
+        HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
+        HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
+
+        // .coverage.txt is truncated and rewritten with the same content (maximal.cpp:517,659-685)
+        {
+            std::vector<int32_t> nb(nr);
+            HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, reso, 0, nb.data(), nullptr, 0));
+            int64_t tot = 0;
+            for (size_t k = 0; k < nr; k++) tot += nb[k];
+            std::vector<int32_t> cov((size_t)std::max<int64_t>(tot, 1));
+            HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, reso, 0, nb.data(), cov.data(), tot));
+            int64_t o = 0;
+            for (size_t k = 0; k < nr; k++) {
+                fprintf(f_cov, "read %d ", r_begin + (int)k);
+                for (int j = 0; j < nb[k]; j++) fprintf(f_cov, "%d,%d ", reso * j, cov[(size_t)(o + j)]);
+                fprintf(f_cov, "\n");
+                o += nb[k];
+            }
+        }
+
+        // pairs of every read that is active when its turn comes (activity only changes at a read's own turn)
+        std::vector<std::vector<PairPick>> picks(nr);
+        std::vector<int64_t> sel;
+        std::vector<int32_t> a_of;
+        for (int i = r_begin; i <= r_end; i++) {
+            if (!active[(size_t)i]) continue;
+            std::vector<PairPick>& pp = picks[(size_t)(i - r_begin)];
+            pick_pairs(las, i, USE_TWO_MATCHES, 2, [](int) { return true; }, pp);
+            for (auto& p : pp)
+                for (int w = 0; w < 2; w++)
+                    if (p.pick[w] >= 0) { sel.push_back(p.pick[w]); a_of.push_back(i); }
+        }
+        std::vector<Classified> cls(std::max<size_t>(sel.size(), 1));
+        HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
+
+        // sequential containment resolution, maximal.cpp:780-858
+        size_t c = 0;
+        int64_t n_classified = 0;
+        for (int i = r_begin; i <= r_end; i++) {
+            if (!active[(size_t)i]) continue;
+            bool contained = false;
+            int containing_read = 0;
+            for (auto& p : picks[(size_t)(i - r_begin)])
+                for (int w = 0; w < 2; w++) {
+                    if (p.pick[w] < 0) continue;
+                    const bool ca = cls[c++].type == MT_BCOVERA;
+                    n_classified++;
+                    if (ca) containing_read = p.b;
+                    if (active[(size_t)p.b]) contained = contained || ca;
+                }
+            if (contained) {
+                active[(size_t)i] = 0;
+                fprintf(f_contained, "%d\t%d\n", i, containing_read);
+            }
+        }
+        int n_active = 0;
+        for (int i = r_begin; i <= r_end; i++)
+            if (active[(size_t)i]) { n_active++; fprintf(f_max, "%d\n", i); }
+        console.info("classified %lld overlaps; removed contained reads, active reads: %d / %zu", (long long)n_classified, n_active, nr);
+    }
+    fclose(f_cov); fclose(f_contained); fclose(f_max);
+    hinge_ctx_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,69 @@
+"""GPU parity of the installed command-line tools (hinge filter / maximal / layout = Reads_filter,
+get_maximal_reads, hinging over libhinge_hip) against the CPU oracle: every output file, byte for byte."""
+import filecmp
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, clone_dataset, run_in, write_ini
+
+pytestmark = pytest.mark.gpu
+HINGE = os.path.join(ROOT, "hinge_amd", "bin", "hinge")
+
+FILES = ["G.mas", "G.cmas", "G.repeat.txt", "G.hinges.txt", "G.coverage.txt", "G.cov.flag", "G.self.flag", "G.homologous.txt",
+         "G.filtered.fasta", "G.max", "G.contained.txt", "G.garbage.txt", "G.killed.hinges", "G.edges.hinges", "G.edges.hinges2",
+         "G.hinge.list", "G.deadends.txt", "G.hgraph", "G.debug", "G.edges.greedy", "G.edges.1", "G.edges.2", "G.edges.skipped",
+         "edges.g_out.txt", "edges.fwd.backup.txt", "edges.bkw.backup.txt"]
+
+
+def _oracle(lib, wd, mlas, ini):
+    las = b"G" if mlas else b"G.las"
+    return [run_in(wd, lib.oracle_filter, b"G", las, int(mlas), b"G", ini.encode(), b""),
+            run_in(wd, lib.oracle_maximal, b"G", las, int(mlas), b"G", ini.encode()),
+            run_in(wd, lib.oracle_layout, b"G", las, int(mlas), b"G", b"G", ini.encode())]
+
+
+def _cli(wd, mlas, ini):
+    las = ["--las", "G", "--mlas"] if mlas else ["--las", "G.las"]
+    rcs = []
+    for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+        r = subprocess.run([HINGE, sub, "--db", "G"] + las + ["-x", "G", "--config", ini] + extra, cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        rcs.append(r.returncode)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return rcs
+
+
+CASES = [("tiny", False, "", ""), ("tiny_qv", False, "", ""), ("tiny_mlas", True, "", ""), ("tiny_mlas", False, "", ""), ("ties", False, "", ""),
+         ("chimera", False, "", ""), ("long_repeat", False, "", ""),
+         ("tiny", False, "", "min_connected_component_size = 2\n"),
+         ("tiny_qv", False, "ec = 60\nhinge_min_support = 3\nhinge_unbridged = 2\nhinge_min_pileup = 3\n", "del_telomere = 1\ndel_telomeres = 1\nuse_two_matches = 0\n"),
+         ("long_repeat", False, "theta2 = 100\naln_threshold = 2500\n", "hinge_tolerance = 400\nmatching_hinge_slack = 500\nmin_connected_component_size = 1\nhinge_slack = 10\n")]
+
+
+@pytest.mark.parametrize("name,mlas,extra_filter,extra_layout", CASES)
+def test_cli_pipeline_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas, extra_filter, extra_layout):
+    src, _ = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    for wd in (wd_o, wd_h):
+        write_ini(os.path.join(wd, "v.ini"), extra_filter=extra_filter, extra_layout=extra_layout)
+    assert _oracle(oracle_lib, wd_o, mlas, "v.ini") == [0, 0, 0]
+    assert _cli(wd_h, mlas, "v.ini") == [0, 0, 0]
+    bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
+    assert os.path.getsize(os.path.join(wd_h, "G.edges.hinges")) > 0 and os.path.getsize(os.path.join(wd_h, "G.max")) > 0
+
+
+def test_cli_error_behaviour(datasets, tmp_path):
+    """Exit codes of the reference's argument / config error paths (filter.cpp:218-226,372-375, hinging.cpp required flags)."""
+    src, _ = datasets("tiny")
+    wd = clone_dataset(src, str(tmp_path / "w"))
+    run = lambda *a: subprocess.run([HINGE] + list(a), cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode  # noqa: E731
+    assert run("filter", "--db", "G", "--las", "G.las", "--paf", "x.paf", "-x", "G", "--config", "nominal.ini") == 1
+    assert run("filter", "-x", "G", "--config", "nominal.ini") == 1
+    assert run("filter", "--db", "G", "--las", "G.las", "-x", "G", "--config", "missing.ini") == 1
+    assert run("filter", "--db", "nope", "--las", "G.las", "-x", "G", "--config", "nominal.ini") == 1
+    assert run("layout", "--db", "G", "--las", "G.las", "--config", "nominal.ini") == 1          # -x / -o are required
+    assert run("filter", "--db", "G", "--las", "G.las", "--bogus", "-x", "G", "--config", "nominal.ini") == 1
+    assert run("nosuchcommand") == 1
