@@ -337,82 +337,70 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];
         const int n = (int)(e - s);
+        const int2* __restrict__ row = a_span + s;
         // bins this read can touch: events are <= rlen + cut_off for well-formed input
         int kb = bin_of<RESO>(rl + max(P.cut_off, 0), reso) + 2;
         kb = min(kb, kcap);
+        const int kclamp = kb - 1;
         int mx0 = INT_MIN, mxc = INT_MIN;
-        bool oob = false;
         bool cleared = false;
-        // hot bins: starts at abpos ~ 0, ends at aepos ~ rlen (and the same shifted by cut_off)
-        const int hot_s = 1, hot_e = max(bin_of<RESO>(rl, reso), 2);
-        const int hot_cs = bin_of<RESO>(max(P.cut_off, 0), reso), hot_ce = max(bin_of<RESO>(rl - P.cut_off, reso), 2);
-        int n_s0 = 0, n_e0 = 0, n_cs0 = 0, n_ce0 = 0;
-        for (int64_t base = s; base < e || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
+        for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
             int2 v[LOADS_IN_FLIGHT];
 #pragma unroll
             for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
-                const int64_t k = base + u * WAVE + lane;
-                v[u] = k < e ? a_span[k] : make_int2(0, 0);
+                const int k = base + u * WAVE + lane;
+                v[u] = k < n ? row[k] : make_int2(0, 0);
             }
-            if (!cleared) {   // the histogram is cleared while the first batch is in flight
-                for (int t = lane; t < kb; t += WAVE) { h0[t] = 0; hc[t] = 0; }
+            if (!cleared) {   // the histograms are cleared (16 bytes per lane and store) while the first batch is in flight
+                int4* z0 = reinterpret_cast<int4*>(h0);
+                int4* zc = reinterpret_cast<int4*>(hc);
+                for (int t = lane; t < (kb + 3) / 4; t += WAVE) { z0[t] = make_int4(0, 0, 0, 0); zc[t] = make_int4(0, 0, 0, 0); }
                 cleared = true;
             }
 #pragma unroll
             for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
-                const bool live = base + u * WAVE + lane < e;
-                const int2 w = v[u];
-                const int b0 = bin_of<RESO>(w.x, reso), b1 = bin_of<RESO>(w.y, reso);
-                const int c0 = bin_of<RESO>(w.x + P.cut_off, reso), c1 = bin_of<RESO>(w.y - P.cut_off, reso);
-                const bool bad = live && (max(max(b0, b1), max(c0, c1)) >= kb);
-                oob |= bad;
-                const bool ok = live && !bad;
-                // Alignments pile up at the two ends of the read (an overlap usually runs to the end of A), so a few
-                // bins take most of the events: count those with ballots (scalar adds) instead of 64-way conflicting
-                // LDS atomics, and let only the other lanes touch the histogram.
-                const bool s_hot = ok && b0 == hot_s, e_hot = ok && b1 == hot_e;
-                const bool cs_hot = ok && c0 == hot_cs, ce_hot = ok && c1 == hot_ce;
-                n_s0 += __popcll(__ballot(s_hot));
-                n_e0 += __popcll(__ballot(e_hot));
-                n_cs0 += __popcll(__ballot(cs_hot));
-                n_ce0 += __popcll(__ballot(ce_hot));
-                if (ok) {
-                    if (!s_hot) atomicAdd(&h0[b0], 1);
-                    if (!e_hot) atomicAdd(&h0[b1], -1);
-                    if (!cs_hot) atomicAdd(&hc[c0], 1);
-                    if (!ce_hot) atomicAdd(&hc[c1], -1);
+                if (base + u * WAVE >= n) break;   // wave-uniform: dead slots of the last batch cost nothing
+                if (base + u * WAVE + lane < n) {
+                    const int2 w = v[u];
+                    // an event past rlen + cut_off is malformed input: clamp keeps the LDS write in range, the
+                    // maxima below flag it
+                    atomicAdd(&h0[min(bin_of<RESO>(w.x, reso), kclamp)], 1);
+                    atomicAdd(&h0[min(bin_of<RESO>(w.y, reso), kclamp)], -1);
+                    atomicAdd(&hc[min(bin_of<RESO>(w.x + P.cut_off, reso), kclamp)], 1);
+                    atomicAdd(&hc[min(bin_of<RESO>(w.y - P.cut_off, reso), kclamp)], -1);
                     mx0 = max(mx0, max(w.x, w.y));
                     mxc = max(mxc, max(w.x + P.cut_off, w.y - P.cut_off));
                 }
             }
-        }
-        if (lane == 0) {   // hot bins are < kb by construction (hot_e/hot_ce come from rlen, the others are tiny)
-            if (n_s0) h0[hot_s] += n_s0;
-            if (n_e0) h0[hot_e] -= n_e0;
-            if (n_cs0) hc[hot_cs] += n_cs0;
-            if (n_ce0) hc[hot_ce] -= n_ce0;
-        }
-        if (__any(oob)) {
-            if (lane == 0) atomicOr(status, ST_RANGE);
         }
         HINGE_ABLATE_POINT(1)
         mx0 = wave_max(mx0);
         mxc = wave_max(mxc);
         const int K0 = nbins_of<RESO>(n, mx0, reso);
         const int KC = nbins_of<RESO>(n, mxc, reso);
+        if (max(K0, KC) > kb) {
+            if (lane == 0) atomicOr(status, ST_RANGE);
+            continue;
+        }
 
-        // ---- coverage mask on the cutoff bins (filter.cpp:696-728) ------------------------------
-        // scan hc in place; track, per bin, the last non-positive bin before it
-        int carry = 0;        // running coverage
+        // ---- both prefix scans in one sweep; coverage mask on the cutoff bins (filter.cpp:696-728) ----
+        // track, per cutoff bin, the last non-positive bin before it
+        int carry = 0, carry0 = 0;   // running coverage (cutoff / cutoff-0)
         int last_np = 0;      // index of the last bin with c <= 0 seen so far (0 before any: start = 0)
         int prev_pos = 0;     // was bin j-1 positive?
         long long best = 0;   // (len << 32) | (0x7fffffff - j): first longest run wins
-        for (int base = 0; base < KC; base += WAVE) {
+        const int Kmax = max(K0, KC);
+        for (int base = 0; base < Kmax; base += WAVE) {
             const int j = base + lane;
             int c = j < KC ? hc[j] : 0;
+            int z = j < K0 ? h0[j] : 0;
             c = wave_incl_scan(c) + carry;
+            z = wave_incl_scan(z) + carry0;
             if (j < KC) hc[j] = c;
+            if (j < K0) h0[j] = z;
             carry = wave_last(c);
+            carry0 = wave_last(z);
+            if (base >= KC) continue;   // wave-uniform
             const int pos = (j < KC) && (c > MIN_COV);   // c[j] > 0 after subtracting MIN_COV
             // last non-positive index strictly before j
             const int npi = ((j < KC) && !pos) ? j : INT_MIN;
@@ -422,8 +410,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             const int pp = shfl_up1(pos, prev_pos);
             if ((j < KC) && !pos && pp) {
                 // run of positive bins (z, j-1] closed by bin j
-                const int z = excl;
-                const int len = reso * (j - 1) - reso * z - reso;
+                const int zb = excl;
+                const int len = reso * (j - 1) - reso * zb - reso;
                 if (len > 0) {
                     const long long cand = ((long long)len << 32) | (unsigned)(0x7fffffff - j);
                     best = cand > best ? cand : best;
@@ -469,22 +457,18 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         }
 
         HINGE_ABLATE_POINT(2)
-        // ---- cutoff-0 coverage, gate sums, annotation candidates (filter.cpp:796-813,842-865) ---
+        // ---- gate sums over the two NO_HINGE_REGION windows only (filter.cpp:842-865) -----------------
         int* cand = hc;   // hc is dead now: packed candidates (pos << 1 | (type == +1))
-        carry = 0;
         int ncand = 0;
         int S = 0, nS = 0, E = 0, nE = 0;
-        for (int base = 0; base < K0; base += WAVE) {
-            const int j = base + lane;
-            int c = j < K0 ? h0[j] : 0;
-            c = wave_incl_scan(c) + carry;
-            if (j < K0) h0[j] = c;
-            carry = wave_last(c);
-            if (j < K0) {
-                const int pos = reso * j;
-                if ((pos <= mk.x + P.nhr) && (pos >= mk.x)) { S += c; nS++; }
-                if ((pos <= mk.y) && (pos >= mk.y - P.nhr)) { E += c; nE++; }
-            }
+        {
+            // bins j with lo <= reso*j <= hi, clipped to [0, K0)
+            auto jfirst = [&](int lo) { return lo <= 0 ? 0 : (lo + reso - 1) / reso; };
+            auto jlast = [&](int hi) { return hi < 0 ? -1 : min(hi / reso, K0 - 1); };
+            const int s0 = jfirst(mk.x), s1 = jlast(mk.x + P.nhr);
+            for (int j = s0 + lane; j <= s1; j += WAVE) { S += h0[j]; nS++; }
+            const int e0 = jfirst(mk.y - P.nhr), e1 = jlast(mk.y);
+            for (int j = e0 + lane; j <= e1; j += WAVE) { E += h0[j]; nE++; }
         }
         S = wave_sum(S); nS = wave_sum(nS); E = wave_sum(E); nE = wave_sum(nE);
         HINGE_ABLATE_POINT(3)
