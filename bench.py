@@ -29,9 +29,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 PATH_BYTES_PER_OVERLAP = 40    # pass 1 = 8 B, pass 2 = 24 B + one 8 B mask gather
 # algorithmic bytes of each kernel per overlap it streams (DESIGN.md "Kernels")
-KERNEL_BYTES_PER_OVERLAP = {"k_cov_stats": 8, "k_mask_annotate": 8, "k_hinge_call": 32, "k_hinge_exact": 32}
+KERNEL_BYTES_PER_OVERLAP = {"k_cov_stats": 8, "k_mask_annotate": 8}
 # per-read side traffic of each kernel: row_ptr 8 + rlen 4 + outputs
-KERNEL_BYTES_PER_READ = {"k_cov_stats": 8 + 4 + 4 + 4, "k_mask_annotate": 8 + 4 + 8 + 8 + 1 + 4 + 4, "k_hinge_call": 0, "k_hinge_exact": 0}
+KERNEL_BYTES_PER_READ = {"k_cov_stats": 8 + 4 + 4 + 4, "k_mask_annotate": 8 + 4 + 8 + 8 + 1 + 4 + 4}
 
 
 def parse_args():
@@ -101,8 +101,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or ("RANK" in os.environ and os.environ.get("HINGE_FORCE_COLLECTIVES", "0") == "1")
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload: every rank generates its own block (seed offset by rank) ---------------------
@@ -116,7 +118,7 @@ def main():
 
     # block table over ranks (block sizes differ slightly only through the seed)
     sizes = [d.n_reads]
-    if world > 1:
+    if use_pg:
         t = torch.tensor([d.n_reads], dtype=torch.int64, device=dev)
         out = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(out, t)
@@ -130,7 +132,7 @@ def main():
 
     # global-id views of this rank's block: rlen table of ALL reads, row_ptr with empty rows elsewhere
     rlen_all = np.zeros(n_total, np.int32)
-    if world > 1:
+    if use_pg:
         t = torch.zeros(n_total, dtype=torch.int32, device=dev)
         t[lo:hi] = torch.from_numpy(d.rlen).to(dev)
         dist.all_reduce(t)
@@ -156,17 +158,17 @@ def main():
     job = ShardedFilter(backend, xch, mode="merged")
 
     def sync():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
     # ---- warmup (also sizes the library's annotation buffers) ------------------------------------
     ctx.filter_stats(P)
-    if world > 1:
+    if use_pg:
         xch.all_gather_rows(job.mean_cov)
     ctx.filter_median(P, 0, n_total - 1, fetch=True)
     ctx.filter_mask_annotate(P)          # synchronous variant: regrows the annotation buffer if needed
-    if world > 1:
+    if use_pg:
         xch.all_gather_rows(job.mask)
     ctx.filter_hinges(P)                 # synchronous variant: regrows the exact-path buffers if needed
     for _ in range(args.warmup):
@@ -188,7 +190,7 @@ def main():
     n_hinges = int(hinges.shape[0])
     counters = ctx.counters()
 
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -204,7 +206,7 @@ def main():
         # dominant kernel of rank 0 by total HIP-event time
         kname, (kms, kcnt) = max(((k, v) for k, v in prof.items() if v[1] > 0), key=lambda kv: kv[1][0])
         avg_ms = kms / kcnt
-        if kname in ("k_hinge_call", "k_hinge_exact"):
+        if kname not in KERNEL_BYTES_PER_OVERLAP:
             alg_bytes = None   # sparse kernel: touches only the work-list reads; no per-launch algorithmic figure
             achieved = None
         else:
@@ -256,7 +258,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -20,6 +20,7 @@
 namespace hinge {
 
 constexpr int HC_SMALL = 64;    // lists up to this size try the tie-free shortcut
+constexpr int PRE_MAXA = 4;     // annotations covered by the count-only sweep
 constexpr int SF_BINS = 2 * PO_CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
 
 struct HingeCallLds {
@@ -36,16 +37,91 @@ struct HingeCallLds {
     int need_order;
     int near_end;
     int ev_ucan, ev_bcan, ev_umust, ev_bmust, f0;   // sort-free scan: smallest f (bin) of a group with each property
-    int sf_over;
+    int sf_over, fmax;
     int wtot[2][WAVES_PER_BLOCK];
     unsigned next_item;
 };
+
+// ------------------------------------------------------------------------------------------------
+// K3a: count-only sweep, one wavefront per work-list read, no LDS.  For every annotation: support and the
+// number of supporters that take the scan's first branch.  These two numbers decide most annotations
+// (support <= SUP: no hinge;  first-branch count > UNB: unbridged whatever the order, filter.cpp:920-931).
+// Undecided annotations get hinge_flag = 2 and their read goes to the heavy list for k_hinge_call.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
+                                                       const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
+                                                       const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
+                                                       const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
+                                                       const int* __restrict__ work_list, const unsigned* __restrict__ counters,
+                                                       unsigned char* __restrict__ hinge_flag, int* __restrict__ heavy_list,
+                                                       unsigned* __restrict__ heavy_count, int force_exact, unsigned* __restrict__ dbg) {
+    const int lane = lane_id();
+    const unsigned wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * BLOCK) >> 6;
+    const unsigned nwork = counters[1];
+    for (unsigned w = wave; w < nwork; w += nwaves) {
+        const int i = work_list[w];
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int2 mk = mask[i];
+        const unsigned off = anno_off[i];
+        const int cnt = anno_cnt[i];
+        bool heavy = false;
+        for (int a0 = 0; a0 < cnt; a0 += PRE_MAXA) {
+            const int na = min(PRE_MAXA, cnt - a0);
+            int apos[PRE_MAXA], atype[PRE_MAXA], csup[PRE_MAXA], cnear[PRE_MAXA];
+#pragma unroll
+            for (int a = 0; a < PRE_MAXA; a++) {
+                const int2 an = a < na ? anno_buf[off + a0 + a] : make_int2(0, 0);
+                apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0;
+            }
+            for (int64_t k = s + lane; k < e; k += WAVE) {
+                const int2 av = a_span[k];
+                bool loaded = false;
+                int L = 0, R = 0;
+#pragma unroll
+                for (int a = 0; a < PRE_MAXA; a++) {
+                    if (a >= na) break;
+                    const int c = atype[a] == -1 ? av.y : av.x;
+                    if ((c > apos[a] - P.tol) && (c < apos[a] + P.tol)) {
+                        if (!loaded) {
+                            const unsigned bf = b_flag[k];
+                            const int2 bs = b_span[k];
+                            const int2 mb = mask[bf & 0x7fffffffu];
+                            overhangs(bs, (int)(bf >> 31), mb, L, R);
+                            loaded = true;
+                        }
+                        const bool sup = atype[a] == -1 ? (R > P.theta) : (L > P.theta);
+                        if (sup) {
+                            csup[a]++;
+                            const int f = atype[a] == -1 ? av.x : -av.y;
+                            const int m0 = atype[a] == -1 ? mk.x : -mk.y;
+                            cnear[a] += (f - m0 < P.bin_len);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < PRE_MAXA; a++) {
+                if (a >= na) break;
+                const int psup = wave_sum(csup[a]), pnear = wave_sum(cnear[a]);
+                int quick = 2;
+                if (force_exact == 0) {
+                    if (psup <= P.sup) quick = 0;                      // needs support >= SUP to be scanned and > SUP to be emitted
+                    else if (P.unb >= 0 && pnear > P.unb) quick = 1;   // the first UNB+1 sorted supporters all take branch 1
+                }
+                if (quick == 2) heavy = true;
+                if (lane == 0) { hinge_flag[off + a0 + a] = (unsigned char)quick; if (dbg && quick != 2) atomicAdd(&dbg[quick ? 3 : 0], 1u); }
+            }
+        }
+        if (heavy && lane == 0) heavy_list[atomicAdd(heavy_count, 1u)] = i;
+    }
+}
 
 __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
                                                       const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
                                                       const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
                                                       const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
-                                                      const int* __restrict__ work_list, const unsigned* __restrict__ counters,
+                                                      const int* __restrict__ heavy_list, const unsigned* __restrict__ heavy_count,
                                                       unsigned char* __restrict__ hinge_flag, int2* __restrict__ exact_queue,
                                                       unsigned* __restrict__ exact_count, unsigned exact_cap, int force_exact,
                                                       int* __restrict__ status, unsigned* __restrict__ work_next,
@@ -55,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
     const int lane = lane_id();
     const int wib = tid >> 6;
     const unsigned long long lmask = (1ull << lane) - 1ull;
-    const unsigned nwork = counters[1];
+    const unsigned nwork = *heavy_count;
     while (true) {
         // dynamic work distribution: reads differ by orders of magnitude in cost
         __syncthreads();
@@ -63,7 +139,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
         __syncthreads();
         const unsigned w = S.next_item;
         if (w >= nwork) break;
-        const int i = work_list[w];
+        const int i = heavy_list[w];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int n = (int)(e - s);
         const int2 mk = mask[i];
@@ -71,6 +147,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
         const int cnt = anno_cnt[i];
         bool order_ready = false;   // block-uniform
         for (int a = 0; a < cnt; a++) {
+            if (hinge_flag[off + a] != 2 && force_exact == 0) continue;   // decided by k_hinge_count (block-uniform)
             const int2 an = anno_buf[off + a];
             const int pos = an.x, type = an.y;
             __syncthreads();
@@ -157,26 +234,32 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 // Groups are found by binning f - f[0] at 1 bp (SF_BINS bins in LDS scratch that is idle at this
                 // point); `before` and W are differences of prefix sums over the bins.  O(sup + SF_BINS).
                 // Supporters further than SF_BINS bp from f[0] are rare; such a list takes the exact replay.
-                if (tid == 0) { S.ev_ucan = INT_MAX; S.ev_bcan = INT_MAX; S.ev_umust = INT_MAX; S.ev_bmust = INT_MAX; S.f0 = INT_MAX; S.sf_over = 0; }
+                if (tid == 0) { S.ev_ucan = INT_MAX; S.ev_bcan = INT_MAX; S.ev_umust = INT_MAX; S.ev_bmust = INT_MAX; S.f0 = INT_MAX; S.fmax = INT_MIN; S.sf_over = 0; }
                 int* bin23 = S.wF;                                   // [SF_BINS] g2 | g3 << 16   (wF..wS are contiguous)
                 unsigned short* bin0 = reinterpret_cast<unsigned short*>(S.ws.key);    // [SF_BINS] g0
                 unsigned short* p23 = S.ws.pl;                       // [SF_BINS] inclusive prefix of g2 + g3 (pl..pr)
                 unsigned short* pall = S.ws.seglo;                   // [SF_BINS] inclusive prefix of g       (seglo..seghi)
-                for (int b = tid; b < SF_BINS; b += BLOCK) { bin23[b] = 0; bin0[b] = 0; }
                 __syncthreads();
                 {
-                    int fm = INT_MAX;
-                    for (int t = tid; t < sup; t += BLOCK) fm = min(fm, S.sF[t]);
+                    int fm = INT_MAX, fx = INT_MIN;
+                    for (int t = tid; t < sup; t += BLOCK) { const int v = S.sF[t]; fm = min(fm, v); fx = max(fx, v); }
                     fm = -wave_max(-fm);
-                    if (lane == 0 && fm != INT_MAX) atomicMin(&S.f0, fm);
+                    fx = wave_max(fx);
+                    if (lane == 0 && fm != INT_MAX) { atomicMin(&S.f0, fm); atomicMax(&S.fmax, fx); }
                 }
                 __syncthreads();
                 const int f0 = S.f0, c1 = S.near_end;
+                // only the bins the supporters actually span (rounded to the workgroup size) are touched
+                const long long span = (long long)S.fmax - f0 + 1;
+                const int nb = span > SF_BINS ? SF_BINS : (int)((span + BLOCK - 1) / BLOCK) * BLOCK;
+                if (span > SF_BINS && tid == 0) S.sf_over = 1;
+                for (int b = tid; b < nb; b += BLOCK) { bin23[b] = 0; bin0[b] = 0; }
+                __syncthreads();
                 for (int t = tid; t < sup; t += BLOCK) {
                     const int ft = S.sF[t];
                     if (ft - m0 < P.bin_len) continue;   // first-branch prefix: never counted in `before` or W
                     const int rel = ft - f0;
-                    if (rel >= SF_BINS) { S.sf_over = 1; continue; }
+                    if (rel >= nb) continue;             // only when sf_over
                     const int st = S.sS[t];
                     if (st < P.theta) atomicAdd(&bin23[rel], 1);
                     else if (st > P.theta) atomicAdd(&bin23[rel], 1 << 16);
@@ -184,8 +267,8 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 }
                 __syncthreads();
                 if (!S.sf_over) {
-                    // workgroup inclusive scan: each thread owns SF_BINS/BLOCK consecutive bins
-                    constexpr int PER = SF_BINS / BLOCK;
+                    // workgroup inclusive scan: each thread owns nb/BLOCK consecutive bins
+                    const int PER = nb / BLOCK;
                     const int b0 = tid * PER;
                     int s23 = 0, sall = 0;
                     for (int k = 0; k < PER; k++) {
@@ -209,13 +292,13 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                         pall[b0 + k] = (unsigned short)runall;
                     }
                     __syncthreads();
-                    for (int b = tid; b < SF_BINS; b += BLOCK) {
+                    for (int b = tid; b < nb; b += BLOCK) {
                         const int v = bin23[b];
                         const int g2 = v & 0xffff, g3 = v >> 16;
                         const int g = g2 + g3 + bin0[b];
                         if (g == 0) continue;
                         const int before = (int)p23[b] - (g2 + g3);
-                        const int W = (int)pall[min(b + P.bin_len - 1, SF_BINS - 1)] - (int)pall[b];
+                        const int W = (int)pall[min(b + P.bin_len - 1, nb - 1)] - (int)pall[b];
                         const bool far = b > P.bin_len;          // f - f[0] > BIN
                         const bool ucan = far && g2 >= 1 && (c1 + before + g2 + g3 > P.unb);
                         const bool bcan = g3 >= 1 && (g + W > P.pil);

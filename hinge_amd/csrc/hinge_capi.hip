@@ -40,7 +40,7 @@ struct hinge_ctx {
     DevBuf mean_own;
     int* mean_cov = nullptr;
     DevBuf cmask, rflags, nbins0;
-    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list;
+    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list;
     unsigned anno_cap = 0;
     DevBuf exact_queue;
     unsigned exact_cap = 0;
@@ -67,8 +67,8 @@ struct hinge_ctx {
     std::vector<int> prof_kid;
 };
 
-enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY, KID_COUNT };
-static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_select", "k_mask_annotate", "k_hinge_call", "k_hinge_exact",
+enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY, KID_COUNT };
+static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_select", "k_mask_annotate", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
                                                      "k_coverage_bins", "k_trim_classify"};
 
 struct ProfScope {
@@ -97,8 +97,8 @@ struct Scalars {
     unsigned counters[2];               // annotation alloc, work count
     unsigned exact_count;
     unsigned work_next;                 // k_hinge_call's work-list cursor
+    unsigned heavy_count;               // reads with annotations the count-only sweep could not decide
     int status;
-    int pad0;
     // ---- persistent across passes ----
     int est[2];                         // cov_est, n_long
     int min_cov;
@@ -188,7 +188,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
+                     &ctx->work_list, &ctx->heavy_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -233,6 +233,7 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->anno_off, sizeof(unsigned) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->work_list, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->heavy_list, sizeof(int) * n))) return rc;
     if (!ctx->mask) ctx->mask = (int2*)ctx->mask_own.p;
     if (!ctx->mean_cov) ctx->mean_cov = (int*)ctx->mean_own.p;
     CK(hipMemsetAsync(ctx->mask_own.p, 0, sizeof(int2) * n, ctx->stream));
@@ -478,12 +479,19 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
 }
 
 static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
-    const int grid = ctx->n_cu * 2;
+    const int grid = ctx->n_cu;   // 145 KB of LDS: one workgroup per CU
+    { ProfScope _ps(ctx, KID_HINGE_COUNT);
+    hipLaunchKernelGGL(k_hinge_count, dim3(ctx->n_cu * 4), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
+                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
+                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
+                       (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
+                       (int*)ctx->heavy_list.p, &sc(ctx)->heavy_count, ctx->force_exact, sc(ctx)->dbg); }
+    CK(hipGetLastError());
     { ProfScope _ps(ctx, KID_HINGE_CALL);
     hipLaunchKernelGGL(k_hinge_call, dim3(grid), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
-                       (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
+                       (const int*)ctx->heavy_list.p, (const unsigned*)&sc(ctx)->heavy_count, (unsigned char*)ctx->hinge_flag.p,
                        (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status,
                        &sc(ctx)->work_next, sc(ctx)->dbg); }
     CK(hipGetLastError());
@@ -523,7 +531,7 @@ int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 16; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 2 * sizeof(unsigned), ctx->stream));   // + work_next
+        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 3 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count
         CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
         if ((rc = launch_hinges(ctx, p))) return rc;
         int rerun = 0;

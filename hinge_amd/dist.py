@@ -22,6 +22,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -62,6 +64,8 @@ class Exchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         assert blocks.n_blocks == self.world, "one block per rank"
         self.S = blocks.max_size
+        # HINGE_FORCE_COLLECTIVES=1 runs the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.force = dist.is_initialized() and os.environ.get("HINGE_FORCE_COLLECTIVES", "0") == "1"
 
     @property
     def my_range(self) -> Tuple[int, int]:
@@ -70,7 +74,7 @@ class Exchange:
     def all_gather_rows(self, table: torch.Tensor) -> None:
         """table[n_reads, ...]: every rank has filled the rows of its own block; on return every rank
         holds all rows.  One all_gather_into_tensor of world x S padded rows."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         lo, hi = self.my_range
         tail = table.shape[1:]
@@ -84,7 +88,7 @@ class Exchange:
                 table[a:b] = recv[k * self.S: k * self.S + (b - a)]
 
     def all_gather_scalar(self, v: int) -> List[int]:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return [int(v)]
         t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
         out = torch.empty(self.world, dtype=torch.int64, device=self.device)
@@ -94,7 +98,7 @@ class Exchange:
     def gather_lists(self, rows: torch.Tensor, count: int) -> Optional[torch.Tensor]:
         """Variable-length int32 row lists (e.g. (read, pos, type) hinges) -> concatenated in rank order
         on every rank: counts all-gather, then one padded all-gather."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return rows[:count]
         counts = self.all_gather_scalar(count)
         cap = max(max(counts), 1)
