@@ -55,9 +55,9 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 template <int RESO>
 __device__ __forceinline__ int bin_of(int v, int reso) {
     // index of the first bin k with v < k*reso  (profileCoverage consumes events `< i*reso`)
-    if (v < 0) return 0;
-    if constexpr (RESO > 0) return v / RESO + 1;   // reso is 40 in the reference (filter.cpp:386): constant division
-    else return v / reso + 1;
+    // reso is 40 in the reference (filter.cpp:386): constant division, branch-free ((v + R) / R is 0 on [-R, -1])
+    if constexpr (RESO > 0) return (int)((unsigned)(max(v, -RESO) + RESO) / (unsigned)RESO);
+    else return v < 0 ? 0 : v / reso + 1;
 }
 
 // ---- wavefront primitives on DPP (no LDS round trips) ------------------------------------------
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
                                                      unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/) {
     const int lane = lane_id();
-    const int wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);   // tell the compiler it is wave-uniform: row bounds become scalar loads
     const int nwaves = (gridDim.x * BLOCK) >> 6;
     long long blk_cov = 0, blk_slot = 0;
     // (no hand-written prefetch of the next row: measured 7x slower - it serialises the wave's loads)
@@ -325,13 +325,13 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
                                                          unsigned anno_cap, int* __restrict__ work_list, int* __restrict__ status) {
     extern __shared__ int lds[];
     const int lane = lane_id();
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; lets the per-read control flow go scalar
     int* h0 = lds + (size_t)wib * 2 * kcap;
     int* hc = h0 + kcap;
     const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
     const int nwaves = gridDim.x * WAVES_PER_BLOCK;
     const int MIN_COV = *d_min_cov;
-    const int reso = P.reso;
+    const int reso = RESO > 0 ? RESO : P.reso;   // compile-time 40 in the shipped configuration: no runtime divisions
 
     for (int i = r_begin + wave; i <= r_end; i += nwaves) {
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
@@ -344,6 +344,17 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         const int kclamp = kb - 1;
         int mx0 = INT_MIN, mxc = INT_MIN;
         bool cleared = false;
+        // Hot bins.  Pile-up events are concentrated where overlaps reach the read's ends: about half of all
+        // begins fall in the first bin and half of all ends in the last one or two, and 32 lanes adding to one
+        // LDS word serialise.  Events in these seven bins are counted in registers (two 16-bit counters per
+        // VGPR; pile-ups of 65536+ overlaps take the plain path) and added once per read; integer adds
+        // commute, so the histogram is the one a per-event update would give.
+        const bool hot = n < 65536;
+        const int g0b = hot ? bin_of<RESO>(0, reso) : -1;
+        const int g0e = hot ? min(bin_of<RESO>(rl, reso), kclamp) : -1, g0e1 = hot ? g0e - 1 : -1;
+        const int gcb = hot ? min(bin_of<RESO>(P.cut_off, reso), kclamp) : -1, gcb1 = hot ? gcb + 1 : -1;
+        const int gce = hot ? min(bin_of<RESO>(rl - P.cut_off, reso), kclamp) : -1, gce1 = hot ? gce - 1 : -1;
+        int c_b0_e0 = 0, c_e01_bc = 0, c_bc1_ec = 0, c_ec1 = 0;
         for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
             int2 v[LOADS_IN_FLIGHT];
 #pragma unroll
@@ -364,14 +375,31 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
                     const int2 w = v[u];
                     // an event past rlen + cut_off is malformed input: clamp keeps the LDS write in range, the
                     // maxima below flag it
-                    atomicAdd(&h0[min(bin_of<RESO>(w.x, reso), kclamp)], 1);
-                    atomicAdd(&h0[min(bin_of<RESO>(w.y, reso), kclamp)], -1);
-                    atomicAdd(&hc[min(bin_of<RESO>(w.x + P.cut_off, reso), kclamp)], 1);
-                    atomicAdd(&hc[min(bin_of<RESO>(w.y - P.cut_off, reso), kclamp)], -1);
+                    const int b0 = min(bin_of<RESO>(w.x, reso), kclamp), e0 = min(bin_of<RESO>(w.y, reso), kclamp);
+                    const int bc = min(bin_of<RESO>(w.x + P.cut_off, reso), kclamp), ec = min(bin_of<RESO>(w.y - P.cut_off, reso), kclamp);
+                    if (b0 == g0b) c_b0_e0 += 1; else atomicAdd(&h0[b0], 1);
+                    if (e0 == g0e) c_b0_e0 += 0x10000; else if (e0 == g0e1) c_e01_bc += 1; else atomicAdd(&h0[e0], -1);
+                    if (bc == gcb) c_e01_bc += 0x10000; else if (bc == gcb1) c_bc1_ec += 1; else atomicAdd(&hc[bc], 1);
+                    if (ec == gce) c_bc1_ec += 0x10000; else if (ec == gce1) c_ec1 += 1; else atomicAdd(&hc[ec], -1);
                     mx0 = max(mx0, max(w.x, w.y));
                     mxc = max(mxc, max(w.x + P.cut_off, w.y - P.cut_off));
                 }
             }
+        }
+        if (hot) {   // wave-uniform; wave totals are < 65536 each, so the packed halves cannot carry into each other
+            c_b0_e0 = wave_sum(c_b0_e0); c_e01_bc = wave_sum(c_e01_bc); c_bc1_ec = wave_sum(c_bc1_ec); c_ec1 = wave_sum(c_ec1);
+            int* hh = nullptr; int idx = -1, val = 0;
+            switch (lane) {
+                case 0: hh = h0; idx = g0b; val = c_b0_e0 & 0xffff; break;
+                case 1: hh = h0; idx = g0e; val = -(int)((unsigned)c_b0_e0 >> 16); break;
+                case 2: hh = h0; idx = g0e1; val = -(c_e01_bc & 0xffff); break;
+                case 3: hh = hc; idx = gcb; val = (int)((unsigned)c_e01_bc >> 16); break;
+                case 4: hh = hc; idx = gcb1; val = c_bc1_ec & 0xffff; break;
+                case 5: hh = hc; idx = gce; val = -(int)((unsigned)c_bc1_ec >> 16); break;
+                case 6: hh = hc; idx = gce1; val = -(c_ec1 & 0xffff); break;
+                default: break;
+            }
+            if (val != 0) atomicAdd(&hh[idx], val);   // a counter is non-zero only if some event had that (valid) bin
         }
         HINGE_ABLATE_POINT(1)
         mx0 = wave_max(mx0);
@@ -384,50 +412,53 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         }
 
         // ---- both prefix scans in one sweep; coverage mask on the cutoff bins (filter.cpp:696-728) ----
-        // track, per cutoff bin, the last non-positive bin before it
+        // The run bookkeeping is scalar: a ballot of "coverage > MIN_COV" per 64 bins, runs closed by the
+        // set bits of C below (a handful per read), all on the SALU.
         int carry = 0, carry0 = 0;   // running coverage (cutoff / cutoff-0)
-        int last_np = 0;      // index of the last bin with c <= 0 seen so far (0 before any: start = 0)
-        int prev_pos = 0;     // was bin j-1 positive?
-        long long best = 0;   // (len << 32) | (0x7fffffff - j): first longest run wins
+        int last_np = 0;             // index of the last bin with c <= MIN_COV seen so far (0 before any: start = 0)
+        unsigned long long prev_pos = 0;   // was the previous bin positive?
+        int best_len = 0, best_j = 0;      // first longest run wins (strict > in ascending j)
         const int Kmax = max(K0, KC);
+        const bool packed = n < 32768;     // cutoff-0 prefix in [0, n], cutoff prefix in [-n, n]: one 16|16 scan does both
         for (int base = 0; base < Kmax; base += WAVE) {
             const int j = base + lane;
             int c = j < KC ? hc[j] : 0;
             int z = j < K0 ? h0[j] : 0;
-            c = wave_incl_scan(c) + carry;
-            z = wave_incl_scan(z) + carry0;
+            if (packed) {
+                const int pk = wave_incl_scan(z + c * 65536) + carry;
+                carry = wave_last(pk);
+                z = pk & 0xffff;
+                c = pk >> 16;
+            } else {
+                c = wave_incl_scan(c) + carry;
+                z = wave_incl_scan(z) + carry0;
+                carry = wave_last(c);
+                carry0 = wave_last(z);
+            }
             if (j < KC) hc[j] = c;
             if (j < K0) h0[j] = z;
-            carry = wave_last(c);
-            carry0 = wave_last(z);
             if (base >= KC) continue;   // wave-uniform
-            const int pos = (j < KC) && (c > MIN_COV);   // c[j] > 0 after subtracting MIN_COV
-            // last non-positive index strictly before j
-            const int npi = ((j < KC) && !pos) ? j : INT_MIN;
-            const int incl = wave_incl_max_scan(npi);
-            int excl = shfl_up1(incl, INT_MIN);
-            excl = max(excl, last_np);
-            const int pp = shfl_up1(pos, prev_pos);
-            if ((j < KC) && !pos && pp) {
-                // run of positive bins (z, j-1] closed by bin j
-                const int zb = excl;
-                const int len = reso * (j - 1) - reso * zb - reso;
-                if (len > 0) {
-                    const long long cand = ((long long)len << 32) | (unsigned)(0x7fffffff - j);
-                    best = cand > best ? cand : best;
-                }
+            const int left = KC - base;
+            const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            const unsigned long long M = __ballot(c > MIN_COV) & V;   // c[j] > 0 after subtracting MIN_COV
+            const unsigned long long N = ~M & V;
+            unsigned long long C = N & ((M << 1) | prev_pos);          // non-positive bins that close a positive run
+            while (C) {
+                const int jj = __ffsll((long long)C) - 1;
+                C &= C - 1ull;
+                const unsigned long long below = N & ((1ull << jj) - 1ull);
+                const int zb = below ? base + 63 - __clzll((long long)below) : last_np;   // last non-positive bin before the run
+                const int len = reso * (base + jj - 1) - reso * zb - reso;
+                if (len > best_len) { best_len = len; best_j = base + jj; }
             }
-            last_np = max(last_np, wave_last(incl));
-            prev_pos = wave_last(pos);
+            if (N) last_np = base + 63 - __clzll((long long)N);
+            prev_pos = M >> 63;
         }
-        best = wave_max64(best);
         int maxstart = 0, maxend = 0, msc = 0, mec = 0;
-        if (best != 0) {
-            const int jclose = 0x7fffffff - (int)(best & 0xffffffffLL);
-            const int len = (int)(best >> 32);
-            mec = jclose - 1;
+        if (best_len > 0) {
+            mec = best_j - 1;
             maxend = reso * mec;
-            maxstart = maxend - len;          // = reso*z + reso
+            maxstart = maxend - best_len;     // = reso*z + reso
             msc = maxstart / reso;            // = z + 1
         }
         unsigned char fl = 0;
@@ -466,11 +497,13 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             auto jfirst = [&](int lo) { return lo <= 0 ? 0 : (lo + reso - 1) / reso; };
             auto jlast = [&](int hi) { return hi < 0 ? -1 : min(hi / reso, K0 - 1); };
             const int s0 = jfirst(mk.x), s1 = jlast(mk.x + P.nhr);
-            for (int j = s0 + lane; j <= s1; j += WAVE) { S += h0[j]; nS++; }
+            for (int j = s0 + lane; j <= s1; j += WAVE) S += h0[j];
             const int e0 = jfirst(mk.y - P.nhr), e1 = jlast(mk.y);
-            for (int j = e0 + lane; j <= e1; j += WAVE) { E += h0[j]; nE++; }
+            for (int j = e0 + lane; j <= e1; j += WAVE) E += h0[j];
+            nS = max(s1 - s0 + 1, 0);
+            nE = max(e1 - e0 + 1, 0);
         }
-        S = wave_sum(S); nS = wave_sum(nS); E = wave_sum(E); nE = wave_sum(nE);
+        S = wave_sum(S); E = wave_sum(E);
         HINGE_ABLATE_POINT(3)
         // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
         {
@@ -478,15 +511,24 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             int jlo = wlo <= 0 ? 0 : (wlo + reso - 1) / reso;
             int jhi = whi < 0 ? -1 : whi / reso;
             jhi = min(jhi, K0 - 3);
+            // |g| > min(max(x / F, lo), hi) with x = c + MIN_COV  <=>  |g| > hi  ||  (|g| > lo && |g| > x / F), and for
+            // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
+            const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
             for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
                 const int j = base + lane;
                 int code = -1;
                 if (j >= jlo && j <= jhi) {
                     const int c = h0[j];
                     const int g = h0[j + 1] - c;
-                    const int thr = min(max((c + MIN_COV) / P.cov_frac, P.min_ra), P.max_ra);
-                    if (g > thr) code = ((reso * j) << 1) | 1;
-                    else if (g < -thr) code = ((reso * j) << 1) | 0;
+                    const int x = c + MIN_COV;
+                    const int G = g < 0 ? -g : g;
+                    if (mulpath && x >= 0 && (unsigned)G < 131072u) {   // thr >= 0 here: the sign of g picks the type, g == 0 never passes
+                        if ((G > P.max_ra) || ((G > P.min_ra) && (G * P.cov_frac > x))) code = ((reso * j) << 1) | (g > 0 ? 1 : 0);
+                    } else {
+                        const int thr = min(max(x / P.cov_frac, P.min_ra), P.max_ra);
+                        if (g > thr) code = ((reso * j) << 1) | 1;
+                        else if (g < -thr) code = ((reso * j) << 1) | 0;
+                    }
                 }
                 const unsigned long long bal = __ballot(code != -1);
                 if (code != -1) cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = code;
@@ -655,7 +697,7 @@ __global__ __launch_bounds__(BLOCK) void k_coverage_bins(int r0, int r1, const i
                                                          const int64_t* __restrict__ out_off, int* __restrict__ cov, int* __restrict__ status) {
     extern __shared__ int lds[];
     const int lane = lane_id();
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; lets the per-read control flow go scalar
     int* h = lds + (size_t)wib * kcap;
     const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
     const int nwaves = gridDim.x * WAVES_PER_BLOCK;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
                                                        unsigned char* __restrict__ hinge_flag, int* __restrict__ heavy_list,
                                                        unsigned* __restrict__ heavy_count, int force_exact, unsigned* __restrict__ dbg) {
     const int lane = lane_id();
-    const unsigned wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
     const unsigned nwaves = (gridDim.x * BLOCK) >> 6;
     const unsigned nwork = counters[1];
     for (unsigned w = wave; w < nwork; w += nwaves) {

