@@ -45,6 +45,34 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(kname):
+    """HBM bytes per launch of `kname` from the newest committed PMC summary (profiles/*_pmc_summary.csv).
+
+    The counters come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same
+    command (they cannot share a pass with timing); on gfx950 FETCH_SIZE reports half the bytes of a wide
+    coalesced read, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (None, None) without a file.
+    """
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_summary.csv")))
+    if not files:
+        return None, None
+    fetch = write = None
+    with open(files[-1], newline="") as f:
+        for row in csv.DictReader(f):
+            if row["kernel"].split("::")[-1].split("<")[0] != kname:
+                continue
+            v = float(row.get("mean_value_KB") or row.get("mean_value"))
+            if row["counter"] == "FETCH_SIZE":
+                fetch = v
+            elif row["counter"] == "WRITE_SIZE":
+                write = v
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, "profiles/" + os.path.basename(files[-1]) + " (2*FETCH_SIZE + WRITE_SIZE, KB)"
+
+
+
 def cpu_baseline(workload: str, sample_genome: int):
     """Time the CPU oracle (single thread, a statement-level port of filter.cpp) on a bounded sample of
     the same workload: same coverage / read-length / repeat model, smaller genome."""
@@ -212,6 +240,7 @@ def main():
         else:
             alg_bytes = KERNEL_BYTES_PER_OVERLAP[kname] * n_ovl + KERNEL_BYTES_PER_READ[kname] * (hi - lo)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(kname)
         roofline = {
             "bound": "hbm",
             "kernel": kname,
@@ -219,7 +248,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "avg_launch_ms": avg_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernels_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in prof.items() if v[1] > 0},
