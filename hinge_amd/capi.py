@@ -69,6 +69,7 @@ SYMBOLS = [
     ("hinge_filter_hinges_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_check", C.c_int, [_VP]),
     ("hinge_profile_enable", C.c_int, [_VP, C.c_int]),
+    ("hinge_profile_select", C.c_int, [_VP, C.c_uint32]),
     ("hinge_profile_kernels", C.c_int, []),
     ("hinge_profile_kernel_name", C.c_char_p, [C.c_int]),
     ("hinge_profile_report", C.c_int, [_VP, _VP, _VP]),
@@ -97,6 +98,7 @@ def load_library() -> C.CDLL:
 
 EXTRA_SYMBOLS = [
     ("hinge_debug_force_exact", C.c_int, [_VP, C.c_int]),
+    ("hinge_debug_force_general_mask", C.c_int, [_VP, C.c_int]),
     ("hinge_debug_pileup_order", C.c_int, [_VP, C.c_int32, _VP, _VP]),
 ]
 
@@ -178,6 +180,10 @@ class Context:
     def force_exact(self, mode):
         """0 normal, 1 everything through k_hinge_exact, 2 always use the in-kernel exact pile-up order."""
         self._ck(self.lib.hinge_debug_force_exact(self.h, int(mode)))
+
+    def force_general_mask(self, on):
+        """Run the general mask/annotate kernel even where the 20-bp fast kernel applies (tests)."""
+        self._ck(self.lib.hinge_debug_force_general_mask(self.h, int(on)))
 
     def debug_pileup_order(self, keys: np.ndarray) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.int32)
@@ -281,6 +287,15 @@ class Context:
 
     def profile_enable(self, max_launches: int):
         self._ck(self.lib.hinge_profile_enable(self.h, int(max_launches)))
+
+    def profile_select(self, names=None):
+        """Record events only for the named kernels (None = all)."""
+        k = self.lib.hinge_profile_kernels()
+        mask = 0
+        for i in range(k):
+            if names is None or self.lib.hinge_profile_kernel_name(i).decode() in names:
+                mask |= 1 << i
+        self._ck(self.lib.hinge_profile_select(self.h, mask))
 
     def profile_report(self):
         k = self.lib.hinge_profile_kernels()

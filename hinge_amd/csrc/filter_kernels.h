@@ -37,8 +37,10 @@ constexpr int ST_NO_LONG_READ = 16;
 
 #ifdef HINGE_ABLATE
 #define HINGE_ABLATE_POINT(k) if (P.ablate == (k)) continue;
+#define HINGE_ABLATE_RETURN(k) if (P.ablate == (k)) return;
 #else
 #define HINGE_ABLATE_POINT(k)
+#define HINGE_ABLATE_RETURN(k)
 #endif
 
 struct FilterDev {   // device copy of hinge_filter_params + derived values
@@ -309,20 +311,192 @@ __global__ __launch_bounds__(1024) void k_median_select(const int* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: coverage mask + repeat annotation + gate.
-// LDS per wave: h0[kcap] (cutoff-0 difference histogram -> coverage), hc[kcap] (cutoff CUT_OFF;
-// reused as the candidate-annotation list once the mask is known).
+// K2: coverage mask + repeat annotation + gate.  Two kernels share everything after the binning:
+//   k_mask_annotate_q20  the shipped configuration (reso 40, cut_off a multiple of 20): ONE 20-bp
+//                        begin|end histogram per read from which both 40-bp profiles derive
+//   k_mask_annotate      any reso / cut_off / pile-up size: two 40-bp difference histograms; also runs
+//                        the reads the fast kernel hands back (fallback list)
 // ------------------------------------------------------------------------------------------------
+struct AnnoOut {   // per-part outputs of K2
+    const int2* qv_mask;
+    int2* mask;
+    int2* cmask;
+    unsigned char* rflags;
+    int2* anno_buf;
+    unsigned char* hinge_flag;
+    unsigned* anno_off;
+    int* anno_cnt;
+    unsigned* counters;   // [0] = annotation allocator, [1] = work-list length
+    unsigned anno_cap;
+    int* work_list;
+    int* status;
+};
+
+// Longest run of bins with coverage > MIN_COV (filter.cpp:696-728), fed 64 bins at a time as a ballot.
+// All of it is scalar: runs are closed by the set bits of C below (a handful per read).
+struct RunState {
+    int last_np;                   // index of the last bin with c <= MIN_COV seen so far (0 before any: start = 0)
+    unsigned long long prev_pos;   // was the previous bin positive?
+    int best_len, best_j;          // first longest run wins (strict > in ascending j)
+};
+__device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long long M /*positive bins*/, unsigned long long V /*valid bins*/,
+                                         int reso) {
+    const unsigned long long N = ~M & V;
+    unsigned long long C = N & ((M << 1) | r.prev_pos);   // non-positive bins that close a positive run
+    while (C) {
+        const int jj = __ffsll((long long)C) - 1;
+        C &= C - 1ull;
+        const unsigned long long below = N & ((1ull << jj) - 1ull);
+        const int zb = below ? base + 63 - __clzll((long long)below) : r.last_np;   // last non-positive bin before the run
+        const int len = reso * (base + jj - 1) - reso * zb - reso;
+        if (len > r.best_len) { r.best_len = len; r.best_j = base + jj; }
+    }
+    if (N) r.last_np = base + 63 - __clzll((long long)N);
+    r.prev_pos = M >> 63;
+}
+
+// Everything after the coverage profiles exist: mask, telomere flag, gate sums, annotation candidates, merge,
+// outputs.  z(j) = cutoff-0 coverage of bin j (j < K0), c(j) = cutoff coverage; cand = LDS scratch for the
+// packed candidates (pos << 1 | (type == +1)): slot t is written only after z(j) was read for every j <= t.
+template <typename ZF, typename CF>
+__device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
+                                                   const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o) {
+    int maxstart = 0, maxend = 0, msc = 0, mec = 0;
+    if (run.best_len > 0) {
+        mec = run.best_j - 1;
+        maxend = reso * mec;
+        maxstart = maxend - run.best_len;   // = reso*z + reso
+        msc = maxstart / reso;              // = z + 1
+    }
+    unsigned char fl = 0;
+    if (P.del_telo && lane == 0) {   // filter.cpp:731-760 on cutoff_cov + MIN_COV = max(cov, MIN_COV)
+        int sc = 0, ec = 0;
+        if (mec - msc + 1 > 20) {
+            for (int d = 0; d < 10; d++) { sc += max(c(msc + d), MIN_COV); ec += max(c(mec - d), MIN_COV); }
+            sc /= 10; ec /= 10;
+        } else {
+            const int limit = (mec - msc) / 2;
+            for (int d = 0; d < limit; d++) { sc += max(c(msc + d), MIN_COV); ec += max(c(mec - d), MIN_COV); }
+            if (limit == 0) { sc = 0; ec = 0; } else { sc /= limit; ec /= limit; }
+        }
+        if ((sc >= 10 * ec) || (ec >= 10 * sc)) fl |= 1;
+    }
+    int2 mk;
+    {
+        const int2 q = o.qv_mask ? o.qv_mask[i] : make_int2(0, 0);
+        if (P.use_qv && P.use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
+        else if (P.use_cov && !P.use_qv) mk = make_int2(maxstart, maxend);
+        else mk = q;
+    }
+    if (lane == 0) {
+        o.mask[i] = mk;
+        o.cmask[i] = make_int2(msc, mec);
+        o.rflags[i] = fl;
+    }
+    HINGE_ABLATE_RETURN(2)
+    // ---- gate sums over the two NO_HINGE_REGION windows only (filter.cpp:842-865) -----------------
+    int ncand = 0;
+    int S = 0, nS = 0, E = 0, nE = 0;
+    {
+        // bins j with lo <= reso*j <= hi, clipped to [0, K0)
+        auto jfirst = [&](int lo) { return lo <= 0 ? 0 : (lo + reso - 1) / reso; };
+        auto jlast = [&](int hi) { return hi < 0 ? -1 : min(hi / reso, K0 - 1); };
+        const int s0 = jfirst(mk.x), s1 = jlast(mk.x + P.nhr);
+        for (int j = s0 + lane; j <= s1; j += WAVE) S += z(j);
+        const int e0 = jfirst(mk.y - P.nhr), e1 = jlast(mk.y);
+        for (int j = e0 + lane; j <= e1; j += WAVE) E += z(j);
+        nS = max(s1 - s0 + 1, 0);
+        nE = max(e1 - e0 + 1, 0);
+    }
+    S = wave_sum(S); E = wave_sum(E);
+    HINGE_ABLATE_RETURN(3)
+    // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
+    {
+        const int wlo = mk.x + P.nhr, whi = mk.y - P.nhr;
+        int jlo = wlo <= 0 ? 0 : (wlo + reso - 1) / reso;
+        int jhi = whi < 0 ? -1 : whi / reso;
+        jhi = min(jhi, K0 - 3);
+        // |g| > min(max(x / F, lo), hi) with x = c + MIN_COV  <=>  |g| > hi  ||  (|g| > lo && |g| > x / F), and for
+        // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
+        const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
+        for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
+            const int j = base + lane;
+            int code = -1;
+            if (j >= jlo && j <= jhi) {
+                const int cv = z(j);
+                const int g = z(j + 1) - cv;
+                const int x = cv + MIN_COV;
+                const int G = g < 0 ? -g : g;
+                if (mulpath && x >= 0 && (unsigned)G < 131072u) {   // thr >= 0 here: the sign of g picks the type, g == 0 never passes
+                    if ((G > P.max_ra) || ((G > P.min_ra) && (G * P.cov_frac > x))) code = ((reso * j) << 1) | (g > 0 ? 1 : 0);
+                } else {
+                    const int thr = min(max(x / P.cov_frac, P.min_ra), P.max_ra);
+                    if (g > thr) code = ((reso * j) << 1) | 1;
+                    else if (g < -thr) code = ((reso * j) << 1) | 0;
+                }
+            }
+            const unsigned long long bal = __ballot(code != -1);
+            if (code != -1) cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = code;
+            ncand += __popcll(bal);
+        }
+    }
+    HINGE_ABLATE_RETURN(4)
+    // merge (filter.cpp:817-829) - sequential on a short list, in place
+    int m = 0;
+    if (lane == 0 && ncand > 0) {
+        int cur = cand[0];
+        for (int t = 1; t < ncand; t++) {
+            const int nx = cand[t];
+            const bool close = ((nx >> 1) - (cur >> 1)) < P.ra_gap;
+            if ((cur & 1) && (nx & 1) && close) {
+                // (+,+): drop the later one
+            } else if (!(cur & 1) && !(nx & 1) && close) {
+                cur = nx;   // (-,-): drop the earlier one
+            } else {
+                cand[m++] = cur;
+                cur = nx;
+            }
+        }
+        cand[m++] = cur;
+    }
+    m = __builtin_amdgcn_readfirstlane(m);
+    // gate: fp32, IEEE divide, NaN compares false (filter.cpp:861-865)
+    bool gate_skip;
+    {
+        const float avg_end = __fdiv_rn((float)E, (float)nE);
+        const float avg_start = __fdiv_rn((float)S, (float)nS);
+        gate_skip = fabsf(avg_end - avg_start) < 10.0f;
+    }
+    unsigned off = 0;
+    if (lane == 0) {
+        if (m > 0) {
+            off = atomicAdd(&o.counters[0], (unsigned)m);
+            if (off + (unsigned)m > o.anno_cap) { atomicOr(o.status, ST_ANNO_CAP); m = 0; }
+        }
+        o.anno_off[i] = off;
+        o.anno_cnt[i] = m;
+        if (m > 0 && !gate_skip) {
+            const unsigned w = atomicAdd(&o.counters[1], 1u);
+            o.work_list[w] = i;
+        }
+    }
+    m = __builtin_amdgcn_readfirstlane(m);
+    off = __builtin_amdgcn_readfirstlane(off);
+    for (int t = lane; t < m; t += WAVE) {
+        const int cd = cand[t];
+        o.anno_buf[off + t] = make_int2(cd >> 1, (cd & 1) ? 1 : -1);
+        o.hinge_flag[off + t] = 0;
+    }
+}
+
+// General kernel.  LDS per wave: h0[kcap] (cutoff-0 difference histogram -> coverage), hc[kcap] (cutoff
+// CUT_OFF; reused as the candidate list once the mask is known).  With read_list != nullptr it runs the
+// *list_count reads of that list (the fast kernel's hand-backs) instead of [r_begin, r_end].
 template <int RESO>
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                          const int2* __restrict__ a_span, const int* __restrict__ rlen,
-                                                         const int2* __restrict__ qv_mask, const int* __restrict__ d_min_cov, int kcap,
-                                                         int2* __restrict__ mask, int2* __restrict__ cmask,
-                                                         unsigned char* __restrict__ rflags, int2* __restrict__ anno_buf,
-                                                         unsigned char* __restrict__ hinge_flag, unsigned* __restrict__ anno_off,
-                                                         int* __restrict__ anno_cnt,
-                                                         unsigned* __restrict__ counters /*[0]=anno alloc [1]=work count*/,
-                                                         unsigned anno_cap, int* __restrict__ work_list, int* __restrict__ status) {
+                                                         const int* __restrict__ d_min_cov, int kcap, AnnoOut o,
+                                                         const int* __restrict__ read_list, const unsigned* __restrict__ list_count) {
     extern __shared__ int lds[];
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; lets the per-read control flow go scalar
@@ -332,8 +506,10 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
     const int nwaves = gridDim.x * WAVES_PER_BLOCK;
     const int MIN_COV = *d_min_cov;
     const int reso = RESO > 0 ? RESO : P.reso;   // compile-time 40 in the shipped configuration: no runtime divisions
+    const int n_items = read_list ? (int)*list_count : r_end - r_begin + 1;
 
-    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
+    for (int item = wave; item < n_items; item += nwaves) {
+        const int i = read_list ? read_list[item] : r_begin + item;
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];
         const int n = (int)(e - s);
@@ -407,17 +583,13 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         const int K0 = nbins_of<RESO>(n, mx0, reso);
         const int KC = nbins_of<RESO>(n, mxc, reso);
         if (max(K0, KC) > kb) {
-            if (lane == 0) atomicOr(status, ST_RANGE);
+            if (lane == 0) atomicOr(o.status, ST_RANGE);
             continue;
         }
 
         // ---- both prefix scans in one sweep; coverage mask on the cutoff bins (filter.cpp:696-728) ----
-        // The run bookkeeping is scalar: a ballot of "coverage > MIN_COV" per 64 bins, runs closed by the
-        // set bits of C below (a handful per read), all on the SALU.
         int carry = 0, carry0 = 0;   // running coverage (cutoff / cutoff-0)
-        int last_np = 0;             // index of the last bin with c <= MIN_COV seen so far (0 before any: start = 0)
-        unsigned long long prev_pos = 0;   // was the previous bin positive?
-        int best_len = 0, best_j = 0;      // first longest run wins (strict > in ascending j)
+        RunState run{0, 0ull, 0, 0};
         const int Kmax = max(K0, KC);
         const bool packed = n < 32768;     // cutoff-0 prefix in [0, n], cutoff prefix in [-n, n]: one 16|16 scan does both
         for (int base = 0; base < Kmax; base += WAVE) {
@@ -440,148 +612,143 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             if (base >= KC) continue;   // wave-uniform
             const int left = KC - base;
             const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-            const unsigned long long M = __ballot(c > MIN_COV) & V;   // c[j] > 0 after subtracting MIN_COV
-            const unsigned long long N = ~M & V;
-            unsigned long long C = N & ((M << 1) | prev_pos);          // non-positive bins that close a positive run
-            while (C) {
-                const int jj = __ffsll((long long)C) - 1;
-                C &= C - 1ull;
-                const unsigned long long below = N & ((1ull << jj) - 1ull);
-                const int zb = below ? base + 63 - __clzll((long long)below) : last_np;   // last non-positive bin before the run
-                const int len = reso * (base + jj - 1) - reso * zb - reso;
-                if (len > best_len) { best_len = len; best_j = base + jj; }
-            }
-            if (N) last_np = base + 63 - __clzll((long long)N);
-            prev_pos = M >> 63;
+            run_feed(run, base, __ballot(c > MIN_COV) & V, V, reso);   // c[j] > 0 after subtracting MIN_COV
         }
-        int maxstart = 0, maxend = 0, msc = 0, mec = 0;
-        if (best_len > 0) {
-            mec = best_j - 1;
-            maxend = reso * mec;
-            maxstart = maxend - best_len;     // = reso*z + reso
-            msc = maxstart / reso;            // = z + 1
-        }
-        unsigned char fl = 0;
-        if (P.del_telo && lane == 0) {   // filter.cpp:731-760 on cutoff_cov + MIN_COV = max(cov, MIN_COV)
-            int sc = 0, ec = 0;
-            if (mec - msc + 1 > 20) {
-                for (int d = 0; d < 10; d++) { sc += max(hc[msc + d], MIN_COV); ec += max(hc[mec - d], MIN_COV); }
-                sc /= 10; ec /= 10;
-            } else {
-                const int limit = (mec - msc) / 2;
-                for (int d = 0; d < limit; d++) { sc += max(hc[msc + d], MIN_COV); ec += max(hc[mec - d], MIN_COV); }
-                if (limit == 0) { sc = 0; ec = 0; } else { sc /= limit; ec /= limit; }
-            }
-            if ((sc >= 10 * ec) || (ec >= 10 * sc)) fl |= 1;
-        }
-        int2 mk;
-        {
-            const int2 q = qv_mask ? qv_mask[i] : make_int2(0, 0);
-            if (P.use_qv && P.use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
-            else if (P.use_cov && !P.use_qv) mk = make_int2(maxstart, maxend);
-            else mk = q;
-        }
-        if (lane == 0) {
-            mask[i] = mk;
-            cmask[i] = make_int2(msc, mec);
-            rflags[i] = fl;
-        }
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, [&](int j) { return h0[j]; }, [&](int j) { return hc[j]; }, hc, o);
+    }
+}
 
-        HINGE_ABLATE_POINT(2)
-        // ---- gate sums over the two NO_HINGE_REGION windows only (filter.cpp:842-865) -----------------
-        int* cand = hc;   // hc is dead now: packed candidates (pos << 1 | (type == +1))
-        int ncand = 0;
-        int S = 0, nS = 0, E = 0, nE = 0;
-        {
-            // bins j with lo <= reso*j <= hi, clipped to [0, K0)
-            auto jfirst = [&](int lo) { return lo <= 0 ? 0 : (lo + reso - 1) / reso; };
-            auto jlast = [&](int hi) { return hi < 0 ? -1 : min(hi / reso, K0 - 1); };
-            const int s0 = jfirst(mk.x), s1 = jlast(mk.x + P.nhr);
-            for (int j = s0 + lane; j <= s1; j += WAVE) S += h0[j];
-            const int e0 = jfirst(mk.y - P.nhr), e1 = jlast(mk.y);
-            for (int j = e0 + lane; j <= e1; j += WAVE) E += h0[j];
-            nS = max(s1 - s0 + 1, 0);
-            nE = max(e1 - e0 + 1, 0);
+// Fast kernel for reso = 40 and cut_off = 20 * SH >= 0.  Per wave: Pq[qcap] = begin|end counts per 20-bp bin
+// (begins in the low 16 bits, ends in the high 16), then their inclusive prefixes PB|PE.  From those
+//     cov0[k] = PB[2k-1] - PE[2k-1]               (bin_of(v) <= k  <=>  v/20 <= 2k-1)
+//     covc[k] = PB[2k-1-SH] - PE[2k-1+SH]         ((v +- cut_off)/20 = v/20 +- SH exactly)
+// with PB[<0] = 0 and P[> last] = P[last]: 2 bin computations and 2 LDS adds per overlap instead of 4 + 4.
+// Events in the five hot bins (begins in bins 0-1, ends in the read's last three) go to lane-private LDS
+// words (hot[5][64]) so they never collide; they are summed once per read.
+// A read goes to the fallback list (run by k_mask_annotate afterwards) when its pile-up has 65536+ overlaps
+// or any coordinate lies outside [0, rlen].  The host launches it once per length bucket (read_list), so that
+// the LDS of a launch is sized by ITS longest read.
+__global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n_items, const int64_t* __restrict__ row_ptr,
+                                                             const int2* __restrict__ a_span, const int* __restrict__ rlen,
+                                                             const int* __restrict__ d_min_cov, int qcap, AnnoOut o,
+                                                             int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count) {
+    extern __shared__ int lds[];
+    constexpr int HOT = 5;
+    const int lane = lane_id();
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int* Pq = lds + (size_t)wib * (qcap + HOT * WAVE);
+    int* hot = Pq + qcap;
+    const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
+    const int nwaves = gridDim.x * WAVES_PER_BLOCK;
+    const int MIN_COV = *d_min_cov;
+    constexpr int reso = 40;
+    const int SH = P.cut_off / 20;
+#pragma unroll
+    for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
+    int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
+    int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1, 2}
+
+    for (int item = wave; item < n_items; item += nwaves) {
+        const int i = read_list[item];
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int rl = rlen[i];
+        const int64_t n64 = e - s;
+        if (n64 >= 65536 || rl < 0) {   // 16-bit counts would overflow: general kernel
+            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
+            continue;
         }
-        S = wave_sum(S); E = wave_sum(E);
-        HINGE_ABLATE_POINT(3)
-        // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
-        {
-            const int wlo = mk.x + P.nhr, whi = mk.y - P.nhr;
-            int jlo = wlo <= 0 ? 0 : (wlo + reso - 1) / reso;
-            int jhi = whi < 0 ? -1 : whi / reso;
-            jhi = min(jhi, K0 - 3);
-            // |g| > min(max(x / F, lo), hi) with x = c + MIN_COV  <=>  |g| > hi  ||  (|g| > lo && |g| > x / F), and for
-            // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
-            const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
-            for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
-                const int j = base + lane;
-                int code = -1;
-                if (j >= jlo && j <= jhi) {
-                    const int c = h0[j];
-                    const int g = h0[j + 1] - c;
-                    const int x = c + MIN_COV;
-                    const int G = g < 0 ? -g : g;
-                    if (mulpath && x >= 0 && (unsigned)G < 131072u) {   // thr >= 0 here: the sign of g picks the type, g == 0 never passes
-                        if ((G > P.max_ra) || ((G > P.min_ra) && (G * P.cov_frac > x))) code = ((reso * j) << 1) | (g > 0 ? 1 : 0);
-                    } else {
-                        const int thr = min(max(x / P.cov_frac, P.min_ra), P.max_ra);
-                        if (g > thr) code = ((reso * j) << 1) | 1;
-                        else if (g < -thr) code = ((reso * j) << 1) | 0;
-                    }
+        const int n = (int)n64;
+        const int2* __restrict__ row = a_span + s;
+        const int qe = rl / 20;                       // last bin a well-formed event can fall in
+        const int Qn = min(qe + 1, qcap);             // bins in use; qcap >= max_rlen / 20 + 1 by construction
+        const unsigned qclamp = (unsigned)(Qn - 1);
+        unsigned mxb = 0, mxe = 0;                    // maxima as unsigned: a negative coordinate shows up as > rl
+        bool cleared = false;
+        for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
+            int2 v[LOADS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                const int k = base + u * WAVE + lane;
+                v[u] = k < n ? row[k] : make_int2(0, 0);
+            }
+            if (!cleared) {   // cleared while the first batch is in flight
+                int4* z4 = reinterpret_cast<int4*>(Pq);
+                for (int t = lane; t < (Qn + 3) / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
+                cleared = true;
+            }
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                if (base + u * WAVE >= n) break;   // wave-uniform
+                if (base + u * WAVE + lane < n) {
+                    const int2 w = v[u];
+                    const unsigned qb = min((unsigned)w.x / 20u, qclamp), qd = min((unsigned)w.y / 20u, qclamp);
+                    const unsigned de = (unsigned)qe - qd;
+                    int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;
+                    int* pe = de < 3u ? hot_e + de * WAVE : Pq + qd;
+                    atomicAdd(pb, 1);
+                    atomicAdd(pe, 0x10000);
+                    mxb = max(mxb, (unsigned)w.x);
+                    mxe = max(mxe, (unsigned)w.y);
                 }
-                const unsigned long long bal = __ballot(code != -1);
-                if (code != -1) cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = code;
-                ncand += __popcll(bal);
             }
         }
-        HINGE_ABLATE_POINT(4)
-        // merge (filter.cpp:817-829) - sequential on a short list, in place
-        int m = 0;
-        if (lane == 0 && ncand > 0) {
-            int cur = cand[0];
-            for (int t = 1; t < ncand; t++) {
-                const int nx = cand[t];
-                const bool close = ((nx >> 1) - (cur >> 1)) < P.ra_gap;
-                if ((cur & 1) && (nx & 1) && close) {
-                    // (+,+): drop the later one
-                } else if (!(cur & 1) && !(nx & 1) && close) {
-                    cur = nx;   // (-,-): drop the earlier one
-                } else {
-                    cand[m++] = cur;
-                    cur = nx;
-                }
+        {   // fold the lane-private hot words into their bins (and zero them for the next read)
+            int hv[HOT];
+#pragma unroll
+            for (int h = 0; h < HOT; h++) { hv[h] = hot[h * WAVE + lane]; hot[h * WAVE + lane] = 0; }
+            // per-lane counts are < 65536, wave totals too (n < 65536): pack two per scan
+            const int sb = wave_sum(hv[0] | (hv[1] << 16));                                  // B0 | B1 << 16
+            const int se = wave_sum((int)((unsigned)hv[2] >> 16) | (hv[3] & (int)0xffff0000));   // E0 | E1 << 16
+            const int s2 = wave_sum((int)((unsigned)hv[4] >> 16));                             // E2
+            int idx = -1, val = 0;
+            switch (lane) {
+                case 0: idx = 0; val = sb & 0xffff; break;
+                case 1: idx = 1; val = (int)((unsigned)sb >> 16); break;
+                case 2: idx = qe; val = (se & 0xffff) << 16; break;
+                case 3: idx = qe - 1; val = se & (int)0xffff0000; break;
+                case 4: idx = qe - 2; val = s2 << 16; break;
+                default: break;
             }
-            cand[m++] = cur;
+            if (val != 0) atomicAdd(&Pq[min((unsigned)idx, qclamp)], val);   // non-zero only if some event had that bin
         }
-        m = __builtin_amdgcn_readfirstlane(m);
-        // gate: fp32, IEEE divide, NaN compares false (filter.cpp:861-865)
-        bool gate_skip;
-        {
-            const float avg_end = __fdiv_rn((float)E, (float)nE);
-            const float avg_start = __fdiv_rn((float)S, (float)nS);
-            gate_skip = fabsf(avg_end - avg_start) < 10.0f;
+        HINGE_ABLATE_POINT(1)
+        mxb = (unsigned)wave_max((int)min(mxb, 0x7fffffffu));
+        mxe = (unsigned)wave_max((int)min(mxe, 0x7fffffffu));
+        if (mxb > (unsigned)rl || mxe > (unsigned)rl || qe >= qcap) {   // malformed or out of range: the general kernel decides
+            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
+            continue;
         }
-        unsigned off = 0;
-        if (lane == 0) {
-            if (m > 0) {
-                off = atomicAdd(&counters[0], (unsigned)m);
-                if (off + (unsigned)m > anno_cap) { atomicOr(status, ST_ANNO_CAP); m = 0; }
-            }
-            anno_off[i] = off;
-            anno_cnt[i] = m;
-            if (m > 0 && !gate_skip) {
-                const unsigned w = atomicAdd(&counters[1], 1u);
-                work_list[w] = i;
-            }
+        const int mx0 = (int)max(mxb, mxe);
+        const int mxc = max((int)mxb + P.cut_off, (int)mxe - P.cut_off);
+        const int K0 = nbins_of<40>(n, mx0, reso);
+        const int KC = nbins_of<40>(n, mxc, reso);
+
+        // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
+        int carry = 0;
+        for (int base = 0; base < Qn; base += 4 * WAVE) {
+            const int t = base + 4 * lane;
+            int4 v = t < Qn ? *reinterpret_cast<const int4*>(Pq + t) : make_int4(0, 0, 0, 0);
+            v.y += v.x; v.z += v.y; v.w += v.z;
+            const int incl = wave_incl_scan(v.w);
+            const int excl = incl - v.w + carry;
+            v.x += excl; v.y += excl; v.z += excl; v.w += excl;
+            if (t < Qn) *reinterpret_cast<int4*>(Pq + t) = v;
+            carry += wave_last(incl);
         }
-        m = __builtin_amdgcn_readfirstlane(m);
-        off = __builtin_amdgcn_readfirstlane(off);
-        for (int t = lane; t < m; t += WAVE) {
-            const int c = cand[t];
-            anno_buf[off + t] = make_int2(c >> 1, (c & 1) ? 1 : -1);
-            hinge_flag[off + t] = 0;
+        const int qlast = Qn - 1;
+        auto PB = [&](int q) { return q < 0 ? 0 : (Pq[min(q, qlast)] & 0xffff); };
+        auto PE = [&](int q) { return q < 0 ? 0 : (int)((unsigned)Pq[min(q, qlast)] >> 16); };
+        auto cov0 = [&](int k) { const int q = 2 * k - 1; if (q < 0) return 0; const int p = Pq[min(q, qlast)]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
+        auto covc = [&](int k) { return PB(2 * k - 1 - SH) - PE(2 * k - 1 + SH); };
+
+        // ---- coverage mask on the cutoff profile ------------------------------------------------------
+        RunState run{0, 0ull, 0, 0};
+        for (int base = 0; base < KC; base += WAVE) {
+            const int left = KC - base;
+            const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            run_feed(run, base, __ballot(covc(base + lane) > MIN_COV) & V, V, reso);
         }
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o);
     }
 }
 

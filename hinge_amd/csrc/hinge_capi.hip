@@ -40,7 +40,7 @@ struct hinge_ctx {
     DevBuf mean_own;
     int* mean_cov = nullptr;
     DevBuf cmask, rflags, nbins0;
-    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list;
+    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list;
     unsigned anno_cap = 0;
     DevBuf exact_queue;
     unsigned exact_cap = 0;
@@ -50,8 +50,12 @@ struct hinge_ctx {
     DevBuf med;       // median histogram scratch (k_median_hist)
     DevBuf wave_totals;   // k_cov_stats per-wave (total_cov, num_slot) partials
     int n_wave_totals = 0;
-    size_t lds_attr_set = 0;
+    size_t lds_attr_set = 0, lds20_attr_set = 0;
     int force_exact = 0;
+    int force_general_mask = 0;
+    std::vector<int> h_rlen;      // host copy of the read lengths (length buckets of K2)
+    int n_short = 0, n_long = 0;  // bucket_list = [short reads | long reads] of the current part
+    int short_max_rlen = 0;   // tests: run the general K2 kernel where the q20 kernel would be chosen
 
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
@@ -62,32 +66,37 @@ struct hinge_ctx {
 
     // per-kernel HIP-event timing (bench.py roofline): pairs recorded around every launch
     bool prof_on = false;
+    uint32_t prof_mask = 0xffffffffu;   // kernel ids that get events (hinge_profile_select)
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
     std::vector<int> prof_kid;
 };
 
-enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY, KID_COUNT };
-static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_select", "k_mask_annotate", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
+enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY, KID_COUNT };
+static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_select", "k_mask_annotate", "k_mask_annotate_fallback", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
                                                      "k_coverage_bins", "k_trim_classify"};
 
 struct ProfScope {
     hinge_ctx* c;
     bool on;
     ProfScope(hinge_ctx* ctx, int kid) : c(ctx), on(false) {
-        if (c->prof_on && c->prof_used + 2 <= c->prof_pool.size()) {
+        if (c->prof_on && ((c->prof_mask >> kid) & 1u) && c->prof_used + 2 <= c->prof_pool.size()) {
             on = true;
             c->prof_kid.push_back(kid);
             (void)hipEventRecord(c->prof_pool[c->prof_used], c->stream);
         }
     }
-    ~ProfScope() {
+    void stop() {
         if (on) {
             (void)hipEventRecord(c->prof_pool[c->prof_used + 1], c->stream);
             c->prof_used += 2;
+            on = false;
         }
     }
+    ~ProfScope() { stop(); }
 };
+
+static const int K2_SHORT_RLEN = 18000;   // (18000 / 20 + 8 + 5 * 64) ints * 4 waves = 19.6 KiB per workgroup: 8 workgroups per CU
 
 // device scalars, one allocation
 struct Scalars {
@@ -95,6 +104,7 @@ struct Scalars {
     unsigned long long totals[2];       // total_cov, num_slot
     unsigned long long arena_used;
     unsigned counters[2];               // annotation alloc, work count
+    unsigned fallback_count;            // reads k_mask_annotate_q20 handed back to the general kernel (directly after counters)
     unsigned exact_count;
     unsigned work_next;                 // k_hinge_call's work-list cursor
     unsigned heavy_count;               // reads with annotations the count-only sweep could not decide
@@ -188,7 +198,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->heavy_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
+                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -224,6 +234,7 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     else CK(hipMemsetAsync(ctx->qv_mask.p, 0, sizeof(int2) * (size_t)n_reads, ctx->stream));
     ctx->max_rlen = 0;
     for (int i = 0; i < n_reads; i++) ctx->max_rlen = std::max(ctx->max_rlen, rlen[i]);
+    ctx->h_rlen.assign(rlen, rlen + n_reads);
     size_t n = (size_t)n_reads;
     if ((rc = ensure(ctx, ctx->mask_own, sizeof(int2) * n))) return rc;
     if ((rc = ensure(ctx, ctx->mean_own, sizeof(int) * n))) return rc;
@@ -234,6 +245,7 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->work_list, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->heavy_list, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->fallback_list, sizeof(int) * n))) return rc;
     if (!ctx->mask) ctx->mask = (int2*)ctx->mask_own.p;
     if (!ctx->mean_cov) ctx->mean_cov = (int*)ctx->mean_own.p;
     CK(hipMemsetAsync(ctx->mask_own.p, 0, sizeof(int2) * n, ctx->stream));
@@ -289,6 +301,20 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         ctx->arena_cap = 1ull << 22;   // ints
         if ((rc = ensure(ctx, ctx->arena, sizeof(int) * (size_t)ctx->arena_cap))) return rc;
     }
+    {   // K2 length buckets: LDS per wavefront is sized by the longest read of a launch, so the few long reads of a
+        // part would cost every read its occupancy; reads up to K2_SHORT_RLEN run in their own launch
+        const int nr = r_end - r_begin + 1;
+        std::vector<int> lst((size_t)nr);
+        int ns = 0, nl = 0, smax = 0;
+        for (int i = r_begin; i <= r_end; i++)
+            if (ctx->h_rlen[(size_t)i] <= K2_SHORT_RLEN) { lst[(size_t)ns++] = i; smax = std::max(smax, ctx->h_rlen[(size_t)i]); }
+        for (int i = r_begin; i <= r_end; i++)
+            if (ctx->h_rlen[(size_t)i] > K2_SHORT_RLEN) lst[(size_t)ns + (size_t)nl++] = i;
+        ctx->n_short = ns; ctx->n_long = nl; ctx->short_max_rlen = smax;
+        if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)nr))) return rc;
+        CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+    }
     if (!on_device) CK(hipStreamSynchronize(ctx->stream));
     return HINGE_OK;
 }
@@ -332,6 +358,13 @@ int hinge_debug_pileup_order(hinge_ctx* ctx, int32_t n, const int32_t* keys, int
     CK(hipMemcpy(pos_out, dp, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(dk);
     (void)hipFree(dp);
+    return HINGE_OK;
+}
+
+// hidden knob for tests: run the general K2 kernel even where k_mask_annotate_q20 applies
+int hinge_debug_force_general_mask(hinge_ctx* ctx, int on) {
+    if (!ctx) return HINGE_E_ARG;
+    ctx->force_general_mask = on;
     return HINGE_OK;
 }
 
@@ -430,13 +463,27 @@ int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* v) {
     return HINGE_OK;
 }
 
-#define LAUNCH_MASK_ANNOTATE(RESO)                                                                                           \
-    hipLaunchKernelGGL(k_mask_annotate<RESO>, dim3(grid), dim3(BLOCK), lds, ctx->stream, to_dev(p), ctx->r_begin, ctx->r_end,     \
-                       (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,                        \
-                       ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr, (const int*)&sc(ctx)->min_cov, kcap,      \
-                       ctx->mask, (int2*)ctx->cmask.p, (unsigned char*)ctx->rflags.p, (int2*)ctx->anno_buf.p,                      \
-                       (unsigned char*)ctx->hinge_flag.p, (unsigned*)ctx->anno_off.p, (int*)ctx->anno_cnt.p, sc(ctx)->counters,    \
-                       ctx->anno_cap, (int*)ctx->work_list.p, &sc(ctx)->status)
+static AnnoOut anno_out(hinge_ctx* ctx) {
+    AnnoOut o;
+    o.qv_mask = ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr;
+    o.mask = ctx->mask;
+    o.cmask = (int2*)ctx->cmask.p;
+    o.rflags = (unsigned char*)ctx->rflags.p;
+    o.anno_buf = (int2*)ctx->anno_buf.p;
+    o.hinge_flag = (unsigned char*)ctx->hinge_flag.p;
+    o.anno_off = (unsigned*)ctx->anno_off.p;
+    o.anno_cnt = (int*)ctx->anno_cnt.p;
+    o.counters = sc(ctx)->counters;
+    o.anno_cap = ctx->anno_cap;
+    o.work_list = (int*)ctx->work_list.p;
+    o.status = &sc(ctx)->status;
+    return o;
+}
+
+#define LAUNCH_MASK_ANNOTATE(RESO, GRID, LIST, COUNT)                                                                         \
+    hipLaunchKernelGGL(k_mask_annotate<RESO>, dim3(GRID), dim3(BLOCK), lds, ctx->stream, to_dev(p), ctx->r_begin, ctx->r_end,  \
+                       (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,                     \
+                       (const int*)&sc(ctx)->min_cov, kcap, anno_out(ctx), LIST, COUNT)
 
 static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int kcap = kcap_for(ctx, p);
@@ -451,9 +498,40 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     // one read per wavefront, no grid cap: the hardware dispatcher balances uneven pile-ups better than a
     // grid-stride loop does (measured 137 -> 119 us at 87 k reads)
     const int grid = std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
+    // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
+    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && ctx->force_general_mask == 0;
+    if (q20) {
+        auto qcap_of = [](int max_rlen) { return ((max_rlen / 20 + 1 + 3) & ~3) + 4; };
+        const size_t lds_max = (size_t)WAVES_PER_BLOCK * (qcap_of(ctx->max_rlen) + 5 * WAVE) * sizeof(int);
+        if (lds_max > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
+        if (lds_max > 48 * 1024 && lds_max > ctx->lds20_attr_set) {
+            CK(hipFuncSetAttribute((const void*)k_mask_annotate_q20, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            ctx->lds20_attr_set = lds_max;
+        }
+        ProfScope _ps(ctx, KID_MASK_ANNOTATE);
+        const int* lst = (const int*)ctx->bucket_list.p;
+        const int n_items[2] = {ctx->n_short, ctx->n_long};
+        const int max_len[2] = {ctx->short_max_rlen, ctx->max_rlen};
+        for (int b = 0; b < 2; b++) {
+            if (n_items[b] == 0) continue;
+            const int qcap = qcap_of(max_len[b]);
+            const size_t lds20 = (size_t)WAVES_PER_BLOCK * (qcap + 5 * WAVE) * sizeof(int);
+            const int g = std::max(1, std::min((n_items[b] + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
+            hipLaunchKernelGGL(k_mask_annotate_q20, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), lst + (b ? ctx->n_short : 0), n_items[b],
+                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
+                               (const int*)&sc(ctx)->min_cov, qcap, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
+        }
+        CK(hipGetLastError());
+        _ps.stop();
+        // reads handed back (65536+ overlaps, coordinates outside [0, rlen]): normally none, the launch is then ~3 us
+        ProfScope _ps2(ctx, KID_MASK_FALLBACK);
+        LAUNCH_MASK_ANNOTATE(40, std::min(grid, 64), (const int*)ctx->fallback_list.p, (const unsigned*)&sc(ctx)->fallback_count);
+        CK(hipGetLastError());
+        return HINGE_OK;
+    }
     ProfScope _ps(ctx, KID_MASK_ANNOTATE);
-    if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40);
-    else LAUNCH_MASK_ANNOTATE(0);
+    if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40, grid, (const int*)nullptr, (const unsigned*)nullptr);
+    else LAUNCH_MASK_ANNOTATE(0, grid, (const int*)nullptr, (const unsigned*)nullptr);
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -465,7 +543,7 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 8; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(sc(ctx)->counters, 0, 2 * sizeof(unsigned), ctx->stream));
+        CK(hipMemsetAsync(sc(ctx)->counters, 0, 3 * sizeof(unsigned), ctx->stream));   // + fallback_count
         if ((rc = launch_mask_annotate(ctx, p))) return rc;
         // the annotation buffer is sized optimistically; grow + rerun on overflow (rare)
         Scalars h;
@@ -706,6 +784,12 @@ int hinge_profile_enable(hinge_ctx* ctx, int max_launches) {
     return HINGE_OK;
 }
 // total milliseconds and launch count per kernel since hinge_profile_enable; arrays of hinge_profile_kernels() entries
+int hinge_profile_select(hinge_ctx* ctx, uint32_t kernel_mask) {
+    if (!ctx) return HINGE_E_ARG;
+    ctx->prof_mask = kernel_mask;
+    return HINGE_OK;
+}
+
 int hinge_profile_kernels(void) { return KID_COUNT; }
 const char* hinge_profile_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? KERNEL_NAMES[id] : ""; }
 int hinge_profile_report(hinge_ctx* ctx, double* total_ms, int64_t* count) {

@@ -151,8 +151,11 @@ int hinge_filter_check(hinge_ctx* ctx);
 
 /* Per-kernel timing with HIP events recorded around every launch on the context's stream.
  * enable(max_launches > 0) starts a fresh recording; report() synchronises and returns total ms and
- * launch count per kernel id in [0, hinge_profile_kernels()).                                     */
+ * launch count per kernel id in [0, hinge_profile_kernels()).  select() restricts the events to the
+ * kernel ids whose bit is set (default: all); two events per launch cost a few microseconds of stream
+ * time each, so a timed region brackets only the kernel it prices.                                 */
 int hinge_profile_enable(hinge_ctx* ctx, int max_launches);
+int hinge_profile_select(hinge_ctx* ctx, uint32_t kernel_mask);
 int hinge_profile_kernels(void);
 const char* hinge_profile_kernel_name(int id);
 int hinge_profile_report(hinge_ctx* ctx, double* total_ms, int64_t* count);

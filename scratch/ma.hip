@@ -53,21 +53,25 @@ int main() {
     FilterDev P{}; P.reso = 40; P.cut_off = 300; P.theta = 300; P.cov_frac = 3; P.min_ra = 10; P.max_ra = 20; P.ra_gap = 300; P.nhr = 500;
     P.sup = 7; P.pil = 7; P.unb = 6; P.tol = 100; P.bin_len = 200; P.use_qv = 0; P.use_cov = 1; P.del_telo = 0;
     const int kcap = ((maxrl + 300) / 40 + 4 + 3) & ~3;
-    (void)hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * kcap * 4);
     const size_t lds = 4 * 2 * kcap * 4;
+    (void)hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int qcap = ((maxrl / 20 + 1 + 3) & ~3) + 4;
+    const size_t lds20 = 4 * (qcap + 5 * 64) * 4;
+    (void)hipFuncSetAttribute((const void*)k_mask_annotate_q20, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds20);
+    int* fb; (void)hipMalloc(&fb, nr * 4);
+    int* ids; (void)hipMalloc(&ids, nr * 4);
+    { std::vector<int> hi(nr); for (int i = 0; i < nr; i++) hi[i] = i; (void)hipMemcpy(ids, hi.data(), nr * 4, hipMemcpyHostToDevice); }
+    AnnoOut o{nullptr, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * (unsigned)nr, wl, st};
+    const int grid = (nr + 3) / 4;
     for (int mode = 1; mode <= 5; mode++) {
         P.ablate = mode;
         float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
-            hipLaunchKernelGGL(k_mask_annotate<40>, dim3(2048), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, (const int2*)nullptr, mc, kcap, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * nr, wl, st); });
-        printf("stop after phase %d: %7.1f us   (1 histogram, 2 +mask, 3 +cov0 scan/gate, 4 +candidates, 5 all)\n", mode, t * 1e3);
+            hipLaunchKernelGGL(k_mask_annotate<40>, dim3(grid), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, mc, kcap, o, (const int*)nullptr, (const unsigned*)nullptr); });
+        float t2 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
+            hipLaunchKernelGGL(k_mask_annotate_q20, dim3(grid), dim3(256), lds20, 0, P, ids, nr, rp, a, rl, mc, qcap, o, fb, cnt + 2); });
+        printf("stop after phase %d: general %7.1f us   q20 %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all)\n", mode, t * 1e3, t2 * 1e3);
     }
-    P.ablate = 5;
-    for (int kc : {kcap, 1500}) {
-        const size_t l2 = 4 * 2 * kc * 4;
-        (void)hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-        float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
-            hipLaunchKernelGGL(k_mask_annotate<40>, dim3(21850), dim3(256), l2, 0, P, 0, nr - 1, rp, a, rl, (const int2*)nullptr, mc, kc, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * nr, wl, st); });
-        printf("kcap %5d (LDS %zu B/block): %7.1f us\n", kc, l2, t * 1e3);
-    }
+    unsigned hc[4]; (void)hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost);
+    printf("counters: anno %u work %u fallback %u\n", hc[0], hc[1], hc[2]);
     return 0;
 }
