@@ -99,6 +99,7 @@ def load_library() -> C.CDLL:
 EXTRA_SYMBOLS = [
     ("hinge_debug_force_exact", C.c_int, [_VP, C.c_int]),
     ("hinge_debug_force_general_mask", C.c_int, [_VP, C.c_int]),
+    ("hinge_debug_fallback_reads", C.c_int, [_VP, _VP]),
     ("hinge_debug_pileup_order", C.c_int, [_VP, C.c_int32, _VP, _VP]),
 ]
 
@@ -184,6 +185,12 @@ class Context:
     def force_general_mask(self, on):
         """Run the general mask/annotate kernel even where the 20-bp fast kernel applies (tests)."""
         self._ck(self.lib.hinge_debug_force_general_mask(self.h, int(on)))
+
+    def fallback_reads(self) -> int:
+        """Reads the last mask/annotate pass handed from the 20-bp fast kernel back to the general one."""
+        out = np.zeros(1, np.int64)
+        self._ck(self.lib.hinge_debug_fallback_reads(self.h, _ptr(out)))
+        return int(out[0])
 
     def debug_pileup_order(self, keys: np.ndarray) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.int32)

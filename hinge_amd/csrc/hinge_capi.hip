@@ -184,6 +184,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (hipMalloc(&ctx->scalars.p, sizeof(Scalars)) != hipSuccess) { delete ctx; return HINGE_E_DEVICE; }
     ctx->scalars.bytes = sizeof(Scalars);
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
+    if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * (MED_BINS + 4)) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
     ctx->med.bytes = sizeof(unsigned) * (MED_BINS + 4);
     (void)hipMemset(ctx->med.p, 0, ctx->med.bytes);
@@ -362,9 +363,20 @@ int hinge_debug_pileup_order(hinge_ctx* ctx, int32_t n, const int32_t* keys, int
 }
 
 // hidden knob for tests: run the general K2 kernel even where k_mask_annotate_q20 applies
+// (also: environment HINGE_DEBUG_GENERAL_MASK=1 when the context is created, for the executables)
 int hinge_debug_force_general_mask(hinge_ctx* ctx, int on) {
     if (!ctx) return HINGE_E_ARG;
     ctx->force_general_mask = on;
+    return HINGE_OK;
+}
+
+// hidden: reads the last K2 pass handed from k_mask_annotate_q20 back to the general kernel
+int hinge_debug_fallback_reads(hinge_ctx* ctx, int64_t* out) {
+    if (!ctx || !out) return HINGE_E_ARG;
+    unsigned v = 0;
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpy(&v, &sc(ctx)->fallback_count, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *out = v;
     return HINGE_OK;
 }
 

@@ -86,3 +86,77 @@ def test_pileup_order_replays_std_sort(oracle_lib):
             got[pos] = np.arange(n, dtype=np.int32)
             assert np.array_equal(got, perm[:n]), (n, kind)
     ctx.close()
+
+
+# ---- K2 kernel selection: 20-bp fast kernel, general kernel, and the hand-back between them -----------------
+@pytest.mark.parametrize("name", ["tiny_qv", "long_repeat"])
+def test_filter_general_mask_kernel_matches_oracle(datasets, oracle_lib, tmp_path, name):
+    """The general two-histogram kernel (any reso / cut_off) forced where the fast kernel would run."""
+    from hinge_amd import capi
+    src, _ = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, False) == 0
+    ctx = capi.Context(0)
+    ctx.force_general_mask(1)
+    from hinge_amd import stages
+    assert run_in(wd_h, stages.run_filter, "G", "G.las", "G", "nominal.ini", False, 0, True, False, ctx) == 0
+    _compare(wd_o, wd_h)
+
+
+@pytest.mark.parametrize("cut_off", [0, 20, 100, 290, 305, 400, 1000])
+def test_filter_cut_off_values(datasets, oracle_lib, tmp_path, cut_off):
+    """cut_off % 20 == 0 runs the 20-bp kernel with another shift, anything else the general kernel."""
+    src, _ = datasets("long_repeat")
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    for wd in (wd_o, wd_h):
+        txt = open(os.path.join(wd, "nominal.ini")).read().replace("cut_off = 300;", "cut_off = %d;" % cut_off)
+        assert "cut_off = %d;" % cut_off in txt
+        open(os.path.join(wd, "c.ini"), "w").write(txt)
+    assert _oracle_filter(oracle_lib, wd_o, False, "c.ini") == 0
+    assert _hip_filter(wd_h, False, "c.ini") == 0
+    _compare(wd_o, wd_h)
+
+
+def _bloated_dataset(datasets, tmp_path, mode):
+    """`tiny` with one read's pile-up blown up to 66 000 overlaps (mode 'huge') or with a few alignments that run
+    past the end of the A read (mode 'past_end'): both must leave the fast kernel through the fallback list."""
+    import copy
+    from hinge_amd import synth
+    _, d0 = datasets("tiny")
+    d = copy.copy(d0)
+    rng = np.random.default_rng(11)
+    counts = np.bincount(d.aread[d.aread != d.bread], minlength=d.n_reads)
+    victim = int(np.argmax(counts))
+    rows = np.nonzero((d.aread == victim) & (d.bread != victim))[0]
+    cols = {k: getattr(d, k).copy() for k in ("aread", "bread", "comp", "ab", "ae", "bb", "be")}
+    if mode == "huge":
+        extra = rng.choice(rows, size=66000 - len(rows), replace=True)
+        for k in cols:
+            cols[k] = np.concatenate([cols[k], cols[k][extra]])
+    else:
+        hit = rows[:: max(1, len(rows) // 5)][:5]
+        new_ae = d.rlen[victim] + np.array([1, 40, 120, 250, 300])[: len(hit)]
+        cols["be"][hit] += new_ae - cols["ae"][hit]     # keep the B span as long as the A span (trace generator)
+        cols["ae"][hit] = new_ae
+    order = np.lexsort((cols["ab"], cols["comp"], cols["bread"], cols["aread"]))   # LAsort order
+    for k in cols:
+        setattr(d, k, cols[k][order])
+    wd = str(tmp_path / ("src_" + mode))
+    synth.write_dataset(d, wd, "G")
+    write_ini(os.path.join(wd, "nominal.ini"))
+    return wd, victim
+
+
+@pytest.mark.parametrize("mode", ["huge", "past_end"])
+def test_filter_fallback_reads(datasets, oracle_lib, tmp_path, mode):
+    from hinge_amd import capi, stages
+    src, _ = _bloated_dataset(datasets, tmp_path, mode)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, False) == 0
+    ctx = capi.Context(0)
+    assert run_in(wd_h, stages.run_filter, "G", "G.las", "G", "nominal.ini", False, 0, True, False, ctx) == 0
+    assert ctx.fallback_reads() == 1
+    _compare(wd_o, wd_h)
