@@ -5,8 +5,7 @@
 //
 // Reference semantics restated per kernel (file:line under /root/reference/src):
 //   k_cov_stats       profileCoverage(cutoff 0) sums as used by filter/filter.cpp:642-656
-//   k_median_hist /   nth_element median + MIN_COV update, filter/filter.cpp:660-678
-//   k_median_select
+//   k_median_hist     nth_element median + MIN_COV update, filter/filter.cpp:660-678
 //   k_mask_annotate   filter/filter.cpp:696-829 and the gate of :842-865
 //   k_hinge_call      filter/filter.cpp:867-1068, tie order of std::sort replayed in LDS
 //   k_hinge_exact     the same for the rare cases that need the whole pile-up's std::sort order
@@ -173,95 +172,10 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Median, fast path: one multi-block pass.  Every block histograms its slice of mean_cov into LDS
-// (values 0..MED_BINS-1), merges into a global histogram, and the last block to finish walks the
-// histogram to the element of rank n/2, applies the MIN_COV update and clears the scratch for the
-// next launch.  Values outside the range set med[MED_BINS+2] and leave the job to k_median_select.
-// med layout: [0..MED_BINS) histogram, [MED_BINS] valid count, [MED_BINS+1] blocks done,
-//             [MED_BINS+2] out-of-range flag, [MED_BINS+3] "median already written" flag
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
-                                                     unsigned* __restrict__ med, int* __restrict__ est, int* __restrict__ min_cov,
-                                                     int* __restrict__ status, const unsigned long long* __restrict__ wave_totals,
-                                                     int n_wave_totals, unsigned long long* __restrict__ totals) {
-    __shared__ unsigned hist[MED_BINS];
-    __shared__ unsigned s_valid, s_oor, s_last;
-    const int tid = threadIdx.x;
-    for (int b = tid; b < MED_BINS; b += blockDim.x) hist[b] = 0;
-    if (tid == 0) { s_valid = 0; s_oor = 0; s_last = 0; }
-    __syncthreads();
-    unsigned nv = 0, oor = 0;
-    for (int i = lo + blockIdx.x * blockDim.x + tid; i <= hi; i += gridDim.x * blockDim.x) {
-        const int v = mean_cov[i];
-        if (v == MEAN_SENTINEL) continue;
-        nv++;
-        if (v >= 0 && v < MED_BINS) atomicAdd(&hist[v], 1u);
-        else oor = 1;
-    }
-    if (nv) atomicAdd(&s_valid, nv);
-    if (oor) atomicOr(&s_oor, 1u);
-    __syncthreads();
-    for (int b = tid; b < MED_BINS; b += blockDim.x)
-        if (hist[b]) atomicAdd(&med[b], hist[b]);
-    if (tid == 0) {
-        if (s_valid) atomicAdd(&med[MED_BINS], s_valid);
-        if (s_oor) atomicOr(&med[MED_BINS + 2], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        const unsigned t = atomicAdd(&med[MED_BINS + 1], 1u);
-        s_last = (t == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    {   // total_cov / num_slot of the part (only logged by the reference, filter.cpp:666,672): sum k_cov_stats' per-wave partials
-        unsigned long long tc = 0, ts = 0;
-        for (int w = tid; w < n_wave_totals; w += blockDim.x) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
-        if (tc) atomicAdd(&totals[0], tc);
-        if (ts) atomicAdd(&totals[1], ts);
-    }
-    // last block: all merges are visible at device scope; read them back with agent-scope loads
-    for (int b = tid; b < MED_BINS; b += blockDim.x) {
-        hist[b] = __hip_atomic_load(&med[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        med[b] = 0;   // clean for the next launch
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned nvalid = __hip_atomic_load(&med[MED_BINS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned bad = __hip_atomic_load(&med[MED_BINS + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        med[MED_BINS] = 0; med[MED_BINS + 1] = 0; med[MED_BINS + 2] = 0;
-        if (nvalid == 0) {
-            est[0] = 0; est[1] = 0;
-            atomicOr(status, ST_NO_LONG_READ);
-            med[MED_BINS + 3] = 1;
-        } else if (bad) {
-            med[MED_BINS + 3] = 0;   // k_median_select does the general case
-        } else {
-            unsigned r = nvalid / 2;   // median_id = size/2, filter.cpp:660
-            int b = 0;
-            for (; b < MED_BINS; ++b) {
-                if (r < hist[b]) break;
-                r -= hist[b];
-            }
-            int cov_est = b;
-            est[0] = cov_est;
-            est[1] = (int)nvalid;
-            if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
-            if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;       // filter.cpp:677-678
-            med[MED_BINS + 3] = 1;
-        }
-    }
-}
-
-// General median (any int32 values): one workgroup, 4-pass 8-bit radix select.  Returns at once
-// when k_median_hist already produced the answer.
-__global__ __launch_bounds__(1024) void k_median_select(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
-                                                        const unsigned* __restrict__ med, int* __restrict__ est,
-                                                        int* __restrict__ min_cov, int* __restrict__ status) {
-    if (med[MED_BINS + 3] != 0) return;
+// General median (any int32 values): one workgroup, 4-pass 8-bit radix select.  Run by the last block of
+// k_median_hist when some mean coverage falls outside [0, MED_BINS).
+__device__ void median_radix_select(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override, int* __restrict__ est,
+                                    int* __restrict__ min_cov, int* __restrict__ status) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_rank, s_nvalid;
     const int tid = threadIdx.x;
@@ -308,6 +222,111 @@ __global__ __launch_bounds__(1024) void k_median_select(const int* __restrict__ 
         if (est_cov_override != 0) cov_est = est_cov_override;
         if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Median, fast path: one multi-block pass.  Every block histograms its slice of mean_cov into LDS
+// (values 0..MED_BINS-1), merges into a global histogram, and the last block to finish walks the
+// histogram to the element of rank n/2, applies the MIN_COV update and clears the scratch for the
+// next launch.  If a value lies outside the range (med[MED_BINS+2]) the last block runs the radix select.
+// med layout: [0..MED_BINS) histogram, [MED_BINS] valid count, [MED_BINS+1] blocks done,
+//             [MED_BINS+2] out-of-range flag,
+//             [MED_BINS+4] MED_BINS-1-min value, [MED_BINS+5] max value (occupied range of the histogram)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
+                                                     unsigned* __restrict__ med, int* __restrict__ est, int* __restrict__ min_cov,
+                                                     int* __restrict__ status, const unsigned long long* __restrict__ wave_totals,
+                                                     int n_wave_totals, unsigned long long* __restrict__ totals) {
+    __shared__ unsigned hist[MED_BINS];
+    __shared__ unsigned s_valid, s_oor, s_last, s_lo, s_hi, s_general;
+    __shared__ unsigned long long s_tc, s_ts;
+    const int tid = threadIdx.x;
+    for (int b = tid; b < MED_BINS; b += blockDim.x) hist[b] = 0;
+    if (tid == 0) { s_valid = 0; s_oor = 0; s_last = 0; s_lo = MED_BINS - 1; s_hi = 0; s_tc = 0; s_ts = 0; s_general = 0; }
+    __syncthreads();
+    // mean coverages cluster in a few dozen values: only the occupied range [vlo, vhi] is merged and read back
+    unsigned nv = 0, oor = 0, vlo = MED_BINS - 1, vhi = 0;
+    for (int i = lo + blockIdx.x * blockDim.x + tid; i <= hi; i += gridDim.x * blockDim.x) {
+        const int v = mean_cov[i];
+        if (v == MEAN_SENTINEL) continue;
+        nv++;
+        if (v >= 0 && v < MED_BINS) {
+            atomicAdd(&hist[v], 1u);
+            vlo = min(vlo, (unsigned)v);
+            vhi = max(vhi, (unsigned)v);
+        } else oor = 1;
+    }
+    {   // total_cov / num_slot of the part (only logged by the reference, filter.cpp:666,672): every block sums a slice of
+        // k_cov_stats' per-wave partials
+        unsigned long long tc = 0, ts = 0;
+        for (int w = blockIdx.x * blockDim.x + tid; w < n_wave_totals; w += gridDim.x * blockDim.x) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
+        if (tc) atomicAdd(&s_tc, tc);
+        if (ts) atomicAdd(&s_ts, ts);
+    }
+    if (nv) {
+        atomicAdd(&s_valid, nv);
+        atomicMin(&s_lo, vlo);
+        atomicMax(&s_hi, vhi);
+    }
+    if (oor) atomicOr(&s_oor, 1u);
+    __syncthreads();
+    for (unsigned b = s_lo + tid; b <= s_hi; b += blockDim.x)
+        if (hist[b]) atomicAdd(&med[b], hist[b]);
+    // one global atomic per lane (fire and forget), one fence, one ticket: a single round trip instead of seven
+    switch (tid) {
+        case 0: if (s_valid) atomicAdd(&med[MED_BINS], s_valid); break;
+        case 1: if (s_valid) atomicMax(&med[MED_BINS + 4], (unsigned)(MED_BINS - 1) - s_lo); break;   // stored reversed: zero means "nothing yet"
+        case 2: if (s_valid) atomicMax(&med[MED_BINS + 5], s_hi); break;
+        case 3: if (s_oor) atomicOr(&med[MED_BINS + 2], 1u); break;
+        case 4: if (s_tc) atomicAdd(&totals[0], s_tc); break;
+        case 5: if (s_ts) atomicAdd(&totals[1], s_ts); break;
+        default: break;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(&med[MED_BINS + 1], 1u);
+        s_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // last block: all merges are visible at device scope; read them back with agent-scope loads
+    __shared__ unsigned s_hdr[8];
+    if (tid < 8) s_hdr[tid] = __hip_atomic_load(&med[MED_BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned glo = (unsigned)(MED_BINS - 1) - s_hdr[4];
+    const unsigned ghi = s_hdr[5];
+    for (unsigned b = glo + tid; b <= ghi; b += blockDim.x) {
+        hist[b] = __hip_atomic_load(&med[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        med[b] = 0;   // clean for the next launch
+    }
+    if (tid < 8) med[MED_BINS + tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned nvalid = s_hdr[0];
+        const unsigned bad = s_hdr[2];
+        if (nvalid == 0) {
+            est[0] = 0; est[1] = 0;
+            atomicOr(status, ST_NO_LONG_READ);
+        } else if (bad) {
+            s_general = 1;
+        } else {
+            unsigned r = nvalid / 2;   // median_id = size/2, filter.cpp:660
+            unsigned b = glo;
+            for (; b <= ghi; ++b) {
+                if (r < hist[b]) break;
+                r -= hist[b];
+            }
+            int cov_est = (int)b;
+            est[0] = cov_est;
+            est[1] = (int)nvalid;
+            if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
+            if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;       // filter.cpp:677-678
+        }
+    }
+    __syncthreads();
+    if (s_general) median_radix_select(mean_cov, lo, hi, est_cov_override, est, min_cov, status);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -22,6 +22,23 @@ namespace hinge {
 constexpr int HC_SMALL = 64;    // lists up to this size try the tie-free shortcut
 constexpr int PRE_MAXA = 4;     // annotations covered by the count-only sweep
 constexpr int SF_BINS = 2 * PO_CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
+constexpr int GATHER_LOADS = 8;       // pile-up loads a lane of k_hinge_call keeps in flight
+
+// One undecided annotation, produced by k_hinge_count for k_hinge_call.  Both kernels cut a pile-up into the
+// same four contiguous slices (one per wavefront), so the count sweep can hand the gather the slot at which
+// every wavefront starts writing its supporters: the gather then needs no workgroup barrier per chunk.
+struct alignas(16) HeavyItem {   // everything k_hinge_call needs, so that it starts streaming after ONE dependent load
+    int read, anno;      // read id, annotation index within the read
+    int base[3];         // supporters in slices 0, 0-1, 0-2 (slice 0 starts at slot 0)
+    int sup, near_end;   // support; supporters that take the scan's first branch
+    int n;               // pile-up size
+    long long row;       // row_ptr[read]
+    int mask_lo, mask_hi;
+    int pos, type;       // the annotation
+    unsigned slot;       // anno_off[read] + anno: index into hinge_flag
+    int pad;
+};
+__device__ __forceinline__ int slice_len(int n) { return ((n + 4 * WAVE - 1) / (4 * WAVE)) * WAVE; }
 
 struct HingeCallLds {
     WaveSortLds ws;
@@ -43,7 +60,7 @@ struct HingeCallLds {
 };
 
 // ------------------------------------------------------------------------------------------------
-// K3a: count-only sweep, one wavefront per work-list read, no LDS.  For every annotation: support and the
+// K3a: count-only sweep, one workgroup per work-list read, 40 bytes of LDS.  For every annotation: support and the
 // number of supporters that take the scan's first branch.  These two numbers decide most annotations
 // (support <= SUP: no hinge;  first-branch count > UNB: unbridged whatever the order, filter.cpp:920-931).
 // Undecided annotations get hinge_flag = 2 and their read goes to the heavy list for k_hinge_call.
@@ -53,19 +70,21 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
                                                        const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
                                                        const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
                                                        const int* __restrict__ work_list, const unsigned* __restrict__ counters,
-                                                       unsigned char* __restrict__ hinge_flag, int* __restrict__ heavy_list,
+                                                       unsigned char* __restrict__ hinge_flag, HeavyItem* __restrict__ heavy,
                                                        unsigned* __restrict__ heavy_count, int force_exact, unsigned* __restrict__ dbg) {
+    __shared__ int s_sup[PRE_MAXA][WAVES_PER_BLOCK], s_near[PRE_MAXA][WAVES_PER_BLOCK];
+    const int tid = threadIdx.x;
     const int lane = lane_id();
-    const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
-    const unsigned nwaves = (gridDim.x * BLOCK) >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned nwork = counters[1];
-    for (unsigned w = wave; w < nwork; w += nwaves) {
+    for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {   // one workgroup per work-list read
         const int i = work_list[w];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int2 mk = mask[i];
         const unsigned off = anno_off[i];
         const int cnt = anno_cnt[i];
-        bool heavy = false;
+        const int q = slice_len((int)(e - s));
+        const int64_t k_lo = s + (int64_t)wib * q, k_hi = min(e, k_lo + q);   // this wavefront's slice
         for (int a0 = 0; a0 < cnt; a0 += PRE_MAXA) {
             const int na = min(PRE_MAXA, cnt - a0);
             int apos[PRE_MAXA], atype[PRE_MAXA], csup[PRE_MAXA], cnear[PRE_MAXA];
@@ -74,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
                 const int2 an = a < na ? anno_buf[off + a0 + a] : make_int2(0, 0);
                 apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0;
             }
-            for (int64_t k = s + lane; k < e; k += WAVE) {
+            for (int64_t k = k_lo + lane; k < k_hi; k += WAVE) {
                 const int2 av = a_span[k];
                 bool loaded = false;
                 int L = 0, R = 0;
@@ -104,24 +123,43 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
             for (int a = 0; a < PRE_MAXA; a++) {
                 if (a >= na) break;
                 const int psup = wave_sum(csup[a]), pnear = wave_sum(cnear[a]);
+                if (lane == 0) { s_sup[a][wib] = psup; s_near[a][wib] = pnear; }
+            }
+            __syncthreads();
+            if (tid < na) {
+                const int b1 = s_sup[tid][0], b2 = b1 + s_sup[tid][1], b3 = b2 + s_sup[tid][2];
+                const int psup = b3 + s_sup[tid][3];
+                const int pnear = s_near[tid][0] + s_near[tid][1] + s_near[tid][2] + s_near[tid][3];
                 int quick = 2;
                 if (force_exact == 0) {
                     if (psup <= P.sup) quick = 0;                      // needs support >= SUP to be scanned and > SUP to be emitted
                     else if (P.unb >= 0 && pnear > P.unb) quick = 1;   // the first UNB+1 sorted supporters all take branch 1
                 }
-                if (quick == 2) heavy = true;
-                if (lane == 0) { hinge_flag[off + a0 + a] = (unsigned char)quick; if (dbg && quick != 2) atomicAdd(&dbg[quick ? 3 : 0], 1u); }
+                hinge_flag[off + a0 + tid] = (unsigned char)quick;
+                if (quick == 2) {
+                    HeavyItem it;
+                    it.read = i; it.anno = a0 + tid;
+                    it.base[0] = b1; it.base[1] = b2; it.base[2] = b3;
+                    it.sup = psup; it.near_end = pnear; it.pad = 0;
+                    it.n = (int)(e - s); it.row = s; it.mask_lo = mk.x; it.mask_hi = mk.y;
+                    {
+                        const int2 an = anno_buf[off + a0 + tid];
+                        it.pos = an.x; it.type = an.y;
+                    }
+                    it.slot = off + a0 + tid;
+                    heavy[atomicAdd(heavy_count, 1u)] = it;
+                } else if (dbg) atomicAdd(&dbg[quick ? 3 : 0], 1u);
             }
+            __syncthreads();
         }
-        if (heavy && lane == 0) heavy_list[atomicAdd(heavy_count, 1u)] = i;
     }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
                                                       const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
                                                       const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
-                                                      const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
-                                                      const int* __restrict__ heavy_list, const unsigned* __restrict__ heavy_count,
+                                                      const unsigned* __restrict__ anno_off,
+                                                      const HeavyItem* __restrict__ heavy, const unsigned* __restrict__ heavy_count,
                                                       unsigned char* __restrict__ hinge_flag, int2* __restrict__ exact_queue,
                                                       unsigned* __restrict__ exact_count, unsigned exact_cap, int force_exact,
                                                       int* __restrict__ status, unsigned* __restrict__ work_next,
@@ -129,75 +167,111 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
     __shared__ HingeCallLds S;
     const int tid = threadIdx.x;
     const int lane = lane_id();
-    const int wib = tid >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long lmask = (1ull << lane) - 1ull;
     const unsigned nwork = *heavy_count;
     while (true) {
-        // dynamic work distribution: reads differ by orders of magnitude in cost
+        // dynamic work distribution: annotations differ by orders of magnitude in cost
         __syncthreads();
         if (tid == 0) S.next_item = atomicAdd(work_next, 1u);
         __syncthreads();
         const unsigned w = S.next_item;
         if (w >= nwork) break;
-        const int i = heavy_list[w];
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        const int n = (int)(e - s);
-        const int2 mk = mask[i];
-        const unsigned off = anno_off[i];
-        const int cnt = anno_cnt[i];
-        bool order_ready = false;   // block-uniform
-        for (int a = 0; a < cnt; a++) {
-            if (hinge_flag[off + a] != 2 && force_exact == 0) continue;   // decided by k_hinge_count (block-uniform)
-            const int2 an = anno_buf[off + a];
-            const int pos = an.x, type = an.y;
-            __syncthreads();
-            if (tid == 0) { S.cnt = 0; S.need_order = 0; S.near_end = 0; }
-            const int m0 = type == -1 ? mk.x : -mk.y;
-            __syncthreads();
-            // ---- gather -----------------------------------------------------------------------------
-            int par = 0;
-            for (int64_t k0 = s; k0 < e; k0 += BLOCK, par ^= 1) {
-                const int64_t k = k0 + tid;
-                bool sup = false;
-                int f = 0, sec = 0, Lsum = 0;
-                if (k < e) {
-                    const int2 av = a_span[k];
-                    const int c = type == -1 ? av.y : av.x;
-                    if ((c > pos - P.tol) && (c < pos + P.tol)) {
-                        const unsigned bf = b_flag[k];
-                        const int2 bs = b_span[k];
-                        const int2 mb = mask[bf & 0x7fffffffu];
-                        int L, R;
-                        overhangs(bs, (int)(bf >> 31), mb, L, R);
-                        if (type == -1) { sup = R > P.theta; f = av.x; sec = L; }
-                        else { sup = L > P.theta; f = -av.y; sec = R; }
-                        Lsum = av.y - av.x + bs.y - bs.x;
-                    }
-                }
-                const unsigned long long bal = __ballot(sup);
-                const unsigned long long baln = __ballot(sup && (f - m0 < P.bin_len));
-                if (lane == 0) {
-                    S.wcnt[par][wib] = __popcll(bal);
-                    // supporters whose other end lies within HINGE_BIN_LENGTH of the mask end (scan branch 1)
-                    const int nn = __popcll(baln);
-                    if (nn) atomicAdd(&S.near_end, nn);
-                }
-                __syncthreads();
-                if (sup) {
-                    int slot = S.cnt + __popcll(bal & lmask);
-                    for (int ww = 0; ww < wib; ww++) slot += S.wcnt[par][ww];
-                    if (slot < PO_CAP) {
-                        S.sF[slot] = f;
-                        S.sS[slot] = sec;
-                        S.sK[slot] = (unsigned short)(k - s);
-                        if (slot < HC_SMALL) S.sL[slot] = Lsum;
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) S.cnt += S.wcnt[par][0] + S.wcnt[par][1] + S.wcnt[par][2] + S.wcnt[par][3];
-                // the next chunk writes the other wcnt buffer and syncs before cnt is read again
+#ifdef HINGE_TIMING
+        const unsigned long long tm0 = wall_clock64();
+#endif
+        const HeavyItem item = heavy[w];
+        const int i = item.read, a = item.anno;
+        const int64_t s = item.row;
+        const int n = item.n;
+        const int64_t e = s + n;
+        const int2 mk = make_int2(item.mask_lo, item.mask_hi);
+        {
+            const int pos = item.pos, type = item.type;
+            if (tid == 0) {
+                S.cnt = item.sup; S.need_order = 0; S.near_end = item.near_end;
+                S.ev_ucan = INT_MAX; S.ev_bcan = INT_MAX; S.ev_umust = INT_MAX; S.ev_bmust = INT_MAX; S.f0 = INT_MAX; S.fmax = INT_MIN; S.sf_over = 0;
             }
             __syncthreads();
+            const int m0 = type == -1 ? mk.x : -mk.y;
+            int* bin23 = S.wF;                                   // [SF_BINS] g2 | g3 << 16   (wF..wS are contiguous)
+            unsigned short* bin0 = reinterpret_cast<unsigned short*>(S.ws.key);    // [SF_BINS] g0
+            unsigned short* p23 = S.ws.pl;                       // [SF_BINS] inclusive prefix of g2 + g3 (pl..pr)
+            unsigned short* pall = S.ws.seglo;                   // [SF_BINS] inclusive prefix of g       (seglo..seghi)
+            int fmin_w = INT_MAX, fmax_w = INT_MIN;              // range of the supporters' other ends (this wavefront's slice)
+            // ---- gather: every wavefront streams its own slice and writes from the slot k_hinge_count computed ----
+            {
+                const int q = slice_len(n);
+                const int64_t k_lo = s + (int64_t)wib * q, k_hi = min(e, k_lo + q);
+                int slot0 = wib == 0 ? 0 : item.base[wib - 1];   // wave-uniform
+                for (int64_t k0 = k_lo; k0 < k_hi; k0 += GATHER_LOADS * WAVE) {
+                    // three dependent round trips per GATHER_LOADS * 64 overlaps: spans, B-side fields, mask[B]
+                    int2 av[GATHER_LOADS], bs[GATHER_LOADS], mb[GATHER_LOADS];
+                    unsigned bf[GATHER_LOADS];
+                    bool nearw[GATHER_LOADS];
+#pragma unroll
+                    for (int u = 0; u < GATHER_LOADS; u++) {
+                        const int64_t k = k0 + u * WAVE + lane;
+                        av[u] = k < k_hi ? a_span[k] : make_int2(0, 0);
+                    }
+                    if (k0 == k_lo) {   // the sort-free evaluation's bins are cleared while the first loads are in flight
+                        int4* z23 = reinterpret_cast<int4*>(bin23);
+                        int4* z0 = reinterpret_cast<int4*>(bin0);
+                        for (int b = tid; b < SF_BINS / 4; b += BLOCK) z23[b] = make_int4(0, 0, 0, 0);
+                        for (int b = tid; b < SF_BINS / 8; b += BLOCK) z0[b] = make_int4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < GATHER_LOADS; u++) {
+                        const int64_t k = k0 + u * WAVE + lane;
+                        const int c = type == -1 ? av[u].y : av[u].x;
+                        nearw[u] = k < k_hi && (c > pos - P.tol) && (c < pos + P.tol);
+                        bf[u] = nearw[u] ? b_flag[k] : 0u;
+                        bs[u] = nearw[u] ? b_span[k] : make_int2(0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < GATHER_LOADS; u++) mb[u] = nearw[u] ? mask[bf[u] & 0x7fffffffu] : make_int2(0, 0);
+#pragma unroll
+                    for (int u = 0; u < GATHER_LOADS; u++) {
+                        if (k0 + u * WAVE >= k_hi) break;   // wave-uniform
+                        const int64_t k = k0 + u * WAVE + lane;
+                        bool sup = false;
+                        int f = 0, sec = 0;
+                        if (nearw[u]) {
+                            int L, R;
+                            overhangs(bs[u], (int)(bf[u] >> 31), mb[u], L, R);
+                            if (type == -1) { sup = R > P.theta; f = av[u].x; sec = L; }
+                            else { sup = L > P.theta; f = -av[u].y; sec = R; }
+                        }
+                        const unsigned long long bal = __ballot(sup);
+                        if (sup) {
+                            fmin_w = min(fmin_w, f);
+                            fmax_w = max(fmax_w, f);
+                            const int slot = slot0 + __popcll(bal & lmask);
+                            if (slot < PO_CAP) {
+                                S.sF[slot] = f;
+                                S.sS[slot] = sec;
+                                S.sK[slot] = (unsigned short)(k - s);
+                                if (slot < HC_SMALL) S.sL[slot] = av[u].y - av[u].x + bs[u].y - bs[u].x;
+                            }
+                        }
+                        slot0 += __popcll(bal);
+                    }
+                }
+                if (k_lo >= k_hi) {   // an empty slice still clears its share of the bins
+                    int4* z23 = reinterpret_cast<int4*>(bin23);
+                    int4* z0 = reinterpret_cast<int4*>(bin0);
+                    for (int b = tid; b < SF_BINS / 4; b += BLOCK) z23[b] = make_int4(0, 0, 0, 0);
+                    for (int b = tid; b < SF_BINS / 8; b += BLOCK) z0[b] = make_int4(0, 0, 0, 0);
+                }
+                fmin_w = -wave_max(-fmin_w);
+                fmax_w = wave_max(fmax_w);
+                if (lane == 0 && fmin_w != INT_MAX) { atomicMin(&S.f0, fmin_w); atomicMax(&S.fmax, fmax_w); }
+            }
+            __syncthreads();
+#ifdef HINGE_TIMING
+            const unsigned long long tm1 = wall_clock64();
+            if (tid == 0) { atomicAdd(&dbg[8], (unsigned)(tm1 - tm0)); atomicAdd(&dbg[9], (unsigned)n); atomicAdd(&dbg[10], 1u); }
+#endif
             const int sup = S.cnt;
             // ---- decide the path (block-uniform) ----------------------------------------------------
             int action;   // 0: result 0, 1: resolve in LDS, 2: k_hinge_exact, 3: result 1 without sorting
@@ -234,27 +308,11 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 // Groups are found by binning f - f[0] at 1 bp (SF_BINS bins in LDS scratch that is idle at this
                 // point); `before` and W are differences of prefix sums over the bins.  O(sup + SF_BINS).
                 // Supporters further than SF_BINS bp from f[0] are rare; such a list takes the exact replay.
-                if (tid == 0) { S.ev_ucan = INT_MAX; S.ev_bcan = INT_MAX; S.ev_umust = INT_MAX; S.ev_bmust = INT_MAX; S.f0 = INT_MAX; S.fmax = INT_MIN; S.sf_over = 0; }
-                int* bin23 = S.wF;                                   // [SF_BINS] g2 | g3 << 16   (wF..wS are contiguous)
-                unsigned short* bin0 = reinterpret_cast<unsigned short*>(S.ws.key);    // [SF_BINS] g0
-                unsigned short* p23 = S.ws.pl;                       // [SF_BINS] inclusive prefix of g2 + g3 (pl..pr)
-                unsigned short* pall = S.ws.seglo;                   // [SF_BINS] inclusive prefix of g       (seglo..seghi)
-                __syncthreads();
-                {
-                    int fm = INT_MAX, fx = INT_MIN;
-                    for (int t = tid; t < sup; t += BLOCK) { const int v = S.sF[t]; fm = min(fm, v); fx = max(fx, v); }
-                    fm = -wave_max(-fm);
-                    fx = wave_max(fx);
-                    if (lane == 0 && fm != INT_MAX) { atomicMin(&S.f0, fm); atomicMax(&S.fmax, fx); }
-                }
-                __syncthreads();
                 const int f0 = S.f0, c1 = S.near_end;
-                // only the bins the supporters actually span (rounded to the workgroup size) are touched
+                // only the bins the supporters actually span (rounded to the workgroup size) are scanned
                 const long long span = (long long)S.fmax - f0 + 1;
                 const int nb = span > SF_BINS ? SF_BINS : (int)((span + BLOCK - 1) / BLOCK) * BLOCK;
                 if (span > SF_BINS && tid == 0) S.sf_over = 1;
-                for (int b = tid; b < nb; b += BLOCK) { bin23[b] = 0; bin0[b] = 0; }
-                __syncthreads();
                 for (int t = tid; t < sup; t += BLOCK) {
                     const int ft = S.sF[t];
                     if (ft - m0 < P.bin_len) continue;   // first-branch prefix: never counted in `before` or W
@@ -266,48 +324,62 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                     else atomicAdd(reinterpret_cast<unsigned*>(&bin0[rel & ~1]), (rel & 1) ? (1u << 16) : 1u);
                 }
                 __syncthreads();
+#ifdef HINGE_TIMING
+                const unsigned long long tm2 = wall_clock64();
+                if (tid == 0) atomicAdd(&dbg[13], (unsigned)(tm2 - tm1));
+#endif
                 if (!S.sf_over) {
-                    // workgroup inclusive scan: each thread owns nb/BLOCK consecutive bins
-                    const int PER = nb / BLOCK;
-                    const int b0 = tid * PER;
-                    int s23 = 0, sall = 0;
-                    for (int k = 0; k < PER; k++) {
-                        const int v = bin23[b0 + k];
-                        const int c23 = (v & 0xffff) + (v >> 16);
-                        s23 += c23;
-                        sall += c23 + bin0[b0 + k];
-                    }
-                    int i23 = wave_incl_scan(s23), iall = wave_incl_scan(sall);
-                    if (lane == WAVE - 1) { S.wtot[0][wib] = i23; S.wtot[1][wib] = iall; }
-                    __syncthreads();
-                    int off23 = 0, offall = 0;
-                    for (int ww = 0; ww < wib; ww++) { off23 += S.wtot[0][ww]; offall += S.wtot[1][ww]; }
-                    int run23 = off23 + i23 - s23, runall = offall + iall - sall;
-                    for (int k = 0; k < PER; k++) {
-                        const int v = bin23[b0 + k];
-                        const int c23 = (v & 0xffff) + (v >> 16);
-                        run23 += c23;
-                        runall += c23 + bin0[b0 + k];
-                        p23[b0 + k] = (unsigned short)run23;
-                        pall[b0 + k] = (unsigned short)runall;
+                    // workgroup inclusive scan: every wavefront owns nb/4 consecutive bins and walks them 64 at a time
+                    // (stride-1 LDS accesses, DPP scan, carry in a register); the three cross-wave offsets are added at use
+                    const int QW = nb / WAVES_PER_BLOCK;   // multiple of 64
+                    {
+                        int run = 0;   // packed carry: low 16 bits prefix of g2 + g3, high 16 bits prefix of g (both <= sup <= PO_CAP)
+                        for (int b = wib * QW + lane; b < (wib + 1) * QW; b += WAVE) {
+                            const int v = bin23[b];
+                            const int c23 = (v & 0xffff) + (v >> 16);
+                            const int pk = wave_incl_scan(c23 | ((c23 + bin0[b]) << 16)) + run;
+                            p23[b] = (unsigned short)(pk & 0xffff);
+                            pall[b] = (unsigned short)((unsigned)pk >> 16);
+                            run = wave_last(pk);
+                        }
+                        if (lane == 0) { S.wtot[0][wib] = run & 0xffff; S.wtot[1][wib] = (int)((unsigned)run >> 16); }
                     }
                     __syncthreads();
-                    for (int b = tid; b < nb; b += BLOCK) {
+#ifdef HINGE_TIMING
+                    if (tid == 0) atomicAdd(&dbg[14], (unsigned)(wall_clock64() - tm2));
+#endif
+                    const int o23_1 = S.wtot[0][0], o23_2 = o23_1 + S.wtot[0][1], o23_3 = o23_2 + S.wtot[0][2];
+                    const int oal_1 = S.wtot[1][0], oal_2 = oal_1 + S.wtot[1][1], oal_3 = oal_2 + S.wtot[1][2];
+                    auto full23 = [&](int x) { return (int)p23[x] + (x >= 3 * QW ? o23_3 : x >= 2 * QW ? o23_2 : x >= QW ? o23_1 : 0); };
+                    auto fullall = [&](int x) { return (int)pall[x] + (x >= 3 * QW ? oal_3 : x >= 2 * QW ? oal_2 : x >= QW ? oal_1 : 0); };
+                    int m_ucan = INT_MAX, m_bcan = INT_MAX, m_umust = INT_MAX, m_bmust = INT_MAX;   // per-lane minima, one LDS atomic per wave
+                    // every supporter evaluates ITS group (members of one group compute the same thing; the minima do not care):
+                    // sup / 256 iterations instead of nb / 256
+                    for (int t = tid; t < sup; t += BLOCK) {
+                        const int ft = S.sF[t];
+                        if (ft - m0 < P.bin_len) continue;   // first-branch prefix: not a group of the walk
+                        const int b = ft - f0;
                         const int v = bin23[b];
                         const int g2 = v & 0xffff, g3 = v >> 16;
                         const int g = g2 + g3 + bin0[b];
-                        if (g == 0) continue;
-                        const int before = (int)p23[b] - (g2 + g3);
-                        const int W = (int)pall[min(b + P.bin_len - 1, nb - 1)] - (int)pall[b];
+                        const int before = full23(b) - (g2 + g3);
+                        const int W = fullall(min(b + P.bin_len - 1, nb - 1)) - fullall(b);
                         const bool far = b > P.bin_len;          // f - f[0] > BIN
                         const bool ucan = far && g2 >= 1 && (c1 + before + g2 + g3 > P.unb);
                         const bool bcan = g3 >= 1 && (g + W > P.pil);
                         const bool umust = far && g2 >= 1 && (c1 + before + g2 > P.unb) && !bcan;
                         const bool bmust = g3 >= 1 && (g3 + W > P.pil) && !ucan;
-                        if (ucan) atomicMin(&S.ev_ucan, b);
-                        if (bcan) atomicMin(&S.ev_bcan, b);
-                        if (umust) atomicMin(&S.ev_umust, b);
-                        if (bmust) atomicMin(&S.ev_bmust, b);
+                        if (ucan) m_ucan = min(m_ucan, b);
+                        if (bcan) m_bcan = min(m_bcan, b);
+                        if (umust) m_umust = min(m_umust, b);
+                        if (bmust) m_bmust = min(m_bmust, b);
+                    }
+                    m_ucan = -wave_max(-m_ucan); m_bcan = -wave_max(-m_bcan); m_umust = -wave_max(-m_umust); m_bmust = -wave_max(-m_bmust);
+                    if (lane == 0) {
+                        if (m_ucan != INT_MAX) atomicMin(&S.ev_ucan, m_ucan);
+                        if (m_bcan != INT_MAX) atomicMin(&S.ev_bcan, m_bcan);
+                        if (m_umust != INT_MAX) atomicMin(&S.ev_umust, m_umust);
+                        if (m_bmust != INT_MAX) atomicMin(&S.ev_bmust, m_bmust);
                     }
                     __syncthreads();
                     if (S.ev_ucan == INT_MAX) action = 0;
@@ -315,7 +387,10 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                     else if (S.ev_umust < S.ev_bcan) action = 3;
                 }
             }
-            if (tid == 0 && dbg) { atomicAdd(&dbg[action], 1u); atomicMax(&dbg[6], (unsigned)sup); atomicMax(&dbg[7], (unsigned)cnt); }
+            if (tid == 0 && dbg) { atomicAdd(&dbg[action], 1u); atomicMax(&dbg[6], (unsigned)sup); }
+#ifdef HINGE_TIMING
+            if (tid == 0) { atomicAdd(&dbg[11], (unsigned)(wall_clock64() - tm1)); atomicAdd(&dbg[12], (unsigned)sup); }
+#endif
             if (action == 1) {
                 need_order = (force_exact == 2) || (sup > HC_SMALL);
                 if (!need_order) {
@@ -337,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 if (need_order && n > PO_CAP) action = 2;
             }
             if (action == 0 || action == 3) {
-                if (tid == 0) hinge_flag[off + a] = action == 3 ? 1 : 0;
+                if (tid == 0) hinge_flag[item.slot] = action == 3 ? 1 : 0;
                 continue;
             }
             if (action == 2) {
@@ -349,7 +424,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 continue;
             }
             // ---- exact pile-up order, once per read ---------------------------------------------
-            if (need_order && !order_ready) {
+            if (need_order) {
                 if (tid == 0 && dbg) atomicAdd(&dbg[4], 1u);
                 for (int64_t k = s + tid; k < e; k += BLOCK) {
                     const int2 av = a_span[k];
@@ -360,7 +435,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 block_std_sort_desc(S.ws, n, tid);
                 for (int p = tid; p < n; p += BLOCK) S.ppos[p] = S.ws.pl[p];
                 __syncthreads();
-                order_ready = true;
             }
             if (tid == 0 && dbg && need_order) atomicAdd(&dbg[5], 1u);
             // ---- supporters in pile-up order -> wF / wS (one wave) --------------------------------
@@ -407,7 +481,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             __syncthreads();
             if (tid == 0) {
                 const int r = hinge_scan(S.sF, S.sS, nullptr, sup, m0, P.bin_len, P.theta, P.unb, P.pil);
-                hinge_flag[off + a] = r == 0 ? 1 : 0;   // emit iff not bridged (support > SUP holds)
+                hinge_flag[item.slot] = r == 0 ? 1 : 0;   // emit iff not bridged (support > SUP holds)
             }
         }
     }

@@ -73,7 +73,7 @@ struct hinge_ctx {
 };
 
 enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY, KID_COUNT };
-static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_select", "k_mask_annotate", "k_mask_annotate_fallback", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
+static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_hist", "k_mask_annotate", "k_mask_annotate_fallback", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
                                                      "k_coverage_bins", "k_trim_classify"};
 
 struct ProfScope {
@@ -113,7 +113,7 @@ struct Scalars {
     int est[2];                         // cov_est, n_long
     int min_cov;
     int pad;
-    unsigned dbg[8];                    // k_hinge_call path counters (cumulative; diagnostics only)
+    unsigned dbg[16];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
 
@@ -185,8 +185,8 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->scalars.bytes = sizeof(Scalars);
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
-    if (hipMalloc(&ctx->med.p, sizeof(unsigned) * (MED_BINS + 4)) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
-    ctx->med.bytes = sizeof(unsigned) * (MED_BINS + 4);
+    if (hipMalloc(&ctx->med.p, sizeof(unsigned) * (MED_BINS + 8)) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
+    ctx->med.bytes = sizeof(unsigned) * (MED_BINS + 8);
     (void)hipMemset(ctx->med.p, 0, ctx->med.bytes);
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
@@ -245,7 +245,6 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->anno_off, sizeof(unsigned) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->work_list, sizeof(int) * n))) return rc;
-    if ((rc = ensure(ctx, ctx->heavy_list, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->fallback_list, sizeof(int) * n))) return rc;
     if (!ctx->mask) ctx->mask = (int2*)ctx->mask_own.p;
     if (!ctx->mean_cov) ctx->mean_cov = (int*)ctx->mean_own.p;
@@ -293,6 +292,7 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         ctx->anno_cap = (unsigned)std::max<int64_t>(1024, 4LL * (r_end - r_begin + 1));
         if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
     }
     if (ctx->exact_cap == 0) {
         ctx->exact_cap = 4096;
@@ -442,12 +442,10 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
     {
         ProfScope _ps(ctx, KID_MEDIAN);
         const int n = hi - lo + 1;
-        const int grid = std::max(1, std::min((n + 2047) / 2048, ctx->n_cu));
+        const int grid = std::max(1, std::min((n + 511) / 512, 4 * ctx->n_cu));
         hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
                            (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status,
                            (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals);
-        hipLaunchKernelGGL(k_median_select, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
-                           (const unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status);
     }
     CK(hipGetLastError());
     if (out) {
@@ -566,6 +564,7 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         ctx->anno_cap = std::max(ctx->anno_cap * 2, h.counters[0] + 1024);
         if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
     }
     return fail(ctx, HINGE_E_CAPACITY, "annotation buffer kept overflowing");
 }
@@ -573,17 +572,17 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
 static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int grid = ctx->n_cu;   // 145 KB of LDS: one workgroup per CU
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
-    hipLaunchKernelGGL(k_hinge_count, dim3(ctx->n_cu * 4), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
+    hipLaunchKernelGGL(k_hinge_count, dim3(ctx->n_cu * 8), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
                        (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
-                       (int*)ctx->heavy_list.p, &sc(ctx)->heavy_count, ctx->force_exact, sc(ctx)->dbg); }
+                       (HeavyItem*)ctx->heavy_list.p, &sc(ctx)->heavy_count, ctx->force_exact, sc(ctx)->dbg); }
     CK(hipGetLastError());
     { ProfScope _ps(ctx, KID_HINGE_CALL);
     hipLaunchKernelGGL(k_hinge_call, dim3(grid), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
-                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
-                       (const int*)ctx->heavy_list.p, (const unsigned*)&sc(ctx)->heavy_count, (unsigned char*)ctx->hinge_flag.p,
+                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p,
+                       (const HeavyItem*)ctx->heavy_list.p, (const unsigned*)&sc(ctx)->heavy_count, (unsigned char*)ctx->hinge_flag.p,
                        (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status,
                        &sc(ctx)->work_next, sc(ctx)->dbg); }
     CK(hipGetLastError());
@@ -762,6 +761,9 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     if (getenv("HINGE_DEBUG_PATHS"))
         fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u\n",
                 h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7]);
+    if (getenv("HINGE_DEBUG_PATHS") && h.dbg[10])
+        fprintf(stderr, "[hinge] timing (10 ns ticks, cumulative): items=%u gather=%u (mean %.1f us) eval=%u (mean %.1f us) mean_n=%.0f mean_sup=%.0f | bin %.1f us scan %.1f us\n", h.dbg[10],
+                h.dbg[8], h.dbg[8] * 0.01 / h.dbg[10], h.dbg[11], h.dbg[11] * 0.01 / h.dbg[10], (double)h.dbg[9] / h.dbg[10], (double)h.dbg[12] / h.dbg[10], h.dbg[13] * 0.01 / h.dbg[10], h.dbg[14] * 0.01 / h.dbg[10]);
     return HINGE_OK;
 }
 

@@ -160,3 +160,41 @@ def test_filter_fallback_reads(datasets, oracle_lib, tmp_path, mode):
     assert run_in(wd_h, stages.run_filter, "G", "G.las", "G", "nominal.ini", False, 0, True, False, ctx) == 0
     assert ctx.fallback_reads() == 1
     _compare(wd_o, wd_h)
+
+
+@pytest.mark.parametrize("kind", ["clustered", "wide", "out_of_range", "negative", "sentinels", "single"])
+def test_median_kernel_matches_nth_element(kind):
+    """k_median_hist (histogram walk, radix-select tail) == sorted(values)[n / 2] as filter.cpp:660-678 uses it."""
+    import torch
+    from hinge_amd import capi
+    from hinge_amd.config import default_filter_params
+    rng = np.random.default_rng(3)
+    n = 50_000
+    sentinel = np.iinfo(np.int32).min
+    if kind == "clustered":
+        v = rng.integers(140, 180, size=n)
+    elif kind == "wide":
+        v = rng.integers(0, 4096, size=n)
+    elif kind == "out_of_range":
+        v = rng.integers(0, 200_000, size=n)
+    elif kind == "negative":
+        v = rng.integers(-5000, 5000, size=n)
+    elif kind == "sentinels":
+        v = rng.integers(100, 300, size=n)
+        v[rng.random(n) < 0.7] = sentinel
+    else:
+        v = np.full(n, sentinel, np.int64)
+        v[1234] = 77
+    v = v.astype(np.int32)
+    ctx = capi.Context(0)
+    ctx.set_reads(np.full(n, 6000, np.int32), None)
+    t = torch.from_numpy(v).cuda()
+    ctx.attach_mean_cov(t.data_ptr())
+    P = default_filter_params()
+    ctx.set_min_cov(5)
+    for _ in range(2):   # twice: the kernel must leave its scratch clean
+        est = ctx.filter_median(P, 0, n - 1, fetch=True)
+        valid = np.sort(v[v != sentinel])
+        assert est.n_long == len(valid)
+        assert est.cov_est == int(valid[len(valid) // 2])
+    assert ctx.get_min_cov() == max(5, int(valid[len(valid) // 2]) // 3)
