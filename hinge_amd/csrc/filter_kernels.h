@@ -123,7 +123,15 @@ template <int RESO>
 __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                      const int2* __restrict__ a_span, const int* __restrict__ rlen, int reso,
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
-                                                     unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/) {
+                                                     unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/,
+                                                     int* __restrict__ pass_scalars, int n_pass_scalars, int* __restrict__ d_min_cov,
+                                                     int set_min_cov, int min_cov_value) {
+    // This is the first kernel of a pass and touches none of the pass scalars itself, so workgroup 0 clears
+    // them (and applies a pending MIN_COV) instead of two 4-us memset launches in front of it.
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < n_pass_scalars; t += BLOCK) pass_scalars[t] = 0;
+        if (threadIdx.x == 0 && set_min_cov) *d_min_cov = min_cov_value;
+    }
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);   // tell the compiler it is wave-uniform: row bounds become scalar loads
     const int nwaves = (gridDim.x * BLOCK) >> 6;

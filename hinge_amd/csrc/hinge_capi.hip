@@ -53,6 +53,8 @@ struct hinge_ctx {
     size_t lds_attr_set = 0, lds20_attr_set = 0;
     int force_exact = 0;
     int force_general_mask = 0;
+    bool min_cov_pending = false;   // hinge_filter_set_min_cov is applied by the next launch that needs it
+    int min_cov_value = 0;
     std::vector<int> h_rlen;      // host copy of the read lengths (length buckets of K2)
     int n_short = 0, n_long = 0;  // bucket_list = [short reads | long reads] of the current part
     int short_max_rlen = 0;   // tests: run the general K2 kernel where the q20 kernel would be chosen
@@ -401,8 +403,12 @@ static int kcap_for(hinge_ctx* ctx, const hinge_filter_params* p) {
 }
 
 // one memset clears every per-pass device scalar (totals, counters, exact queue, arena, status)
-static int reset_pass(hinge_ctx* ctx) {
-    CK(hipMemsetAsync(ctx->scalars.p, 0, SCALARS_RESET_BYTES, ctx->stream));
+// a pending hinge_filter_set_min_cov becomes a stream-ordered 4-byte set (k_cov_stats applies it for free)
+static int flush_min_cov(hinge_ctx* ctx) {
+    if (ctx->min_cov_pending) {
+        CK(hipMemsetD32Async((hipDeviceptr_t)&sc(ctx)->min_cov, ctx->min_cov_value, 1, ctx->stream));
+        ctx->min_cov_pending = false;
+    }
     return HINGE_OK;
 }
 
@@ -414,13 +420,20 @@ static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
         int rc = ensure(ctx, ctx->wave_totals, sizeof(unsigned long long) * 2 * (size_t)ctx->n_wave_totals);
         if (rc) return rc;
     }
+    // the kernel also clears the pass scalars and applies a pending MIN_COV (a pass always starts here)
+    static_assert(SCALARS_RESET_BYTES % sizeof(int) == 0, "reset region is whole ints");
+    const int n_reset = (int)(SCALARS_RESET_BYTES / sizeof(int));
+    const int set_mc = ctx->min_cov_pending ? 1 : 0, mc = ctx->min_cov_value;
+    ctx->min_cov_pending = false;
     ProfScope _ps(ctx, KID_STATS);
     if (p->reso == 40)
         hipLaunchKernelGGL(k_cov_stats<40>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
-                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p);
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p,
+                           (int*)ctx->scalars.p, n_reset, &sc(ctx)->min_cov, set_mc, mc);
     else
         hipLaunchKernelGGL(k_cov_stats<0>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
-                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p);
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p,
+                           (int*)ctx->scalars.p, n_reset, &sc(ctx)->min_cov, set_mc, mc);
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -430,8 +443,7 @@ int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     if (rc) return rc;
     if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
     CK(hipSetDevice(ctx->device));
-    if ((rc = reset_pass(ctx))) return rc;   // a pass always starts here
-    return launch_stats(ctx, p);
+    return launch_stats(ctx, p);   // a pass always starts here: the kernel clears the pass scalars
 }
 
 int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out) {
@@ -439,6 +451,7 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
     if (rc) return rc;
     if (lo < 0 || hi >= ctx->n_reads || hi < lo) return fail(ctx, HINGE_E_ARG, "median range");
     CK(hipSetDevice(ctx->device));
+    if ((rc = flush_min_cov(ctx))) return rc;
     {
         ProfScope _ps(ctx, KID_MEDIAN);
         const int n = hi - lo + 1;
@@ -463,11 +476,14 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
 
 int hinge_filter_set_min_cov(hinge_ctx* ctx, int32_t v) {
     if (!ctx) return HINGE_E_ARG;
-    CK(hipMemsetD32Async((hipDeviceptr_t)&sc(ctx)->min_cov, v, 1, ctx->stream));   // stream-ordered, no sync
+    ctx->min_cov_pending = true;   // applied, in stream order, by the next launch that reads or updates MIN_COV
+    ctx->min_cov_value = v;
     return HINGE_OK;
 }
 int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* v) {
     if (!ctx || !v) return HINGE_E_ARG;
+    int rc0 = flush_min_cov(ctx);
+    if (rc0) return rc0;
     CK(hipMemcpyAsync(v, &sc(ctx)->min_cov, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     return HINGE_OK;
@@ -496,6 +512,10 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
                        (const int*)&sc(ctx)->min_cov, kcap, anno_out(ctx), LIST, COUNT)
 
 static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
+    {
+        int rc = flush_min_cov(ctx);
+        if (rc) return rc;
+    }
     const int kcap = kcap_for(ctx, p);
     const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
     if (lds > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
@@ -638,7 +658,8 @@ int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p) {
     if (rc) return rc;
     if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
     CK(hipSetDevice(ctx->device));
-    CK(hipMemsetD32Async((hipDeviceptr_t)&sc(ctx)->min_cov, p->min_cov, 1, ctx->stream));   // single part: MIN_COV starts at the ini value
+    ctx->min_cov_pending = true;   // single part: MIN_COV starts at the ini value (applied by k_cov_stats)
+    ctx->min_cov_value = p->min_cov;
     if ((rc = hinge_filter_stats(ctx, p))) return rc;
     if ((rc = hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, nullptr))) return rc;
     if ((rc = launch_mask_annotate(ctx, p))) return rc;
