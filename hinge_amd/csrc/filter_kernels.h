@@ -234,107 +234,165 @@ __device__ void median_radix_select(const int* __restrict__ mean_cov, int lo, in
 
 // ------------------------------------------------------------------------------------------------
 // Median, fast path: one multi-block pass.  Every block histograms its slice of mean_cov into LDS
-// (values 0..MED_BINS-1), merges into a global histogram, and the last block to finish walks the
-// histogram to the element of rank n/2, applies the MIN_COV update and clears the scratch for the
-// next launch.  If a value lies outside the range (med[MED_BINS+2]) the last block runs the radix select.
-// med layout: [0..MED_BINS) histogram, [MED_BINS] valid count, [MED_BINS+1] blocks done,
-//             [MED_BINS+2] out-of-range flag,
-//             [MED_BINS+4] MED_BINS-1-min value, [MED_BINS+5] max value (occupied range of the histogram)
+// (values 0..MED_BINS-1) and merges the occupied range into one of MED_REPLICAS global histograms; the
+// last block to finish sums the replicas, walks to the element of rank n/2, applies the MIN_COV update
+// and clears the scratch for the next launch.  If a value lies outside the range the last block runs
+// the radix select instead.
+// Same-cache-line global atomics cost ~12 ns each and serialise (a first version with 169 blocks adding
+// ~40 bins each to ONE histogram spent 27 us doing only that), hence few fat blocks, replicated
+// histograms 16 KiB apart and one header word per 128-byte line.
+// med layout: [MED_REPLICAS][MED_BINS] histograms, then one 64-bit word at MED_HDR: valid values (bits 0-39),
+//   blocks done (40-51), blocks that saw an out-of-range value (52-63)
 // ------------------------------------------------------------------------------------------------
+constexpr int MED_REPLICAS = 8;
+constexpr int MED_HDR = MED_REPLICAS * MED_BINS;
+constexpr int MED_WORDS = MED_HDR + 32;
+constexpr int MED_MAX_BLOCKS = 64;
+
 __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
                                                      unsigned* __restrict__ med, int* __restrict__ est, int* __restrict__ min_cov,
                                                      int* __restrict__ status, const unsigned long long* __restrict__ wave_totals,
                                                      int n_wave_totals, unsigned long long* __restrict__ totals) {
     __shared__ unsigned hist[MED_BINS];
     __shared__ unsigned s_valid, s_oor, s_last, s_lo, s_hi, s_general;
-    __shared__ unsigned long long s_tc, s_ts;
+    __shared__ unsigned long long s_tc, s_ts, s_ticket;
     const int tid = threadIdx.x;
+#ifdef HINGE_TIMING
+    const unsigned long long tq0 = wall_clock64();
+#endif
     for (int b = tid; b < MED_BINS; b += blockDim.x) hist[b] = 0;
     if (tid == 0) { s_valid = 0; s_oor = 0; s_last = 0; s_lo = MED_BINS - 1; s_hi = 0; s_tc = 0; s_ts = 0; s_general = 0; }
     __syncthreads();
     // mean coverages cluster in a few dozen values: only the occupied range [vlo, vhi] is merged and read back
     unsigned nv = 0, oor = 0, vlo = MED_BINS - 1, vhi = 0;
-    for (int i = lo + blockIdx.x * blockDim.x + tid; i <= hi; i += gridDim.x * blockDim.x) {
-        const int v = mean_cov[i];
-        if (v == MEAN_SENTINEL) continue;
-        nv++;
-        if (v >= 0 && v < MED_BINS) {
-            atomicAdd(&hist[v], 1u);
-            vlo = min(vlo, (unsigned)v);
-            vhi = max(vhi, (unsigned)v);
-        } else oor = 1;
+    unsigned long long tc = 0, ts = 0;
+    {
+        constexpr int U = 8;   // independent loads in flight per thread: one memory round trip per 8 values
+        const int stride = gridDim.x * blockDim.x;
+        // total_cov / num_slot of the part (only logged by the reference, filter.cpp:666,672): every block sums a slice of
+        // k_cov_stats' per-wave partials; loaded together with the first batch of values
+        for (int w = blockIdx.x * blockDim.x + tid; w < n_wave_totals; w += stride) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
+        for (int i0 = lo + blockIdx.x * blockDim.x + tid; i0 <= hi; i0 += U * stride) {
+            int vv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const long long i = (long long)i0 + (long long)u * stride;
+                vv[u] = i <= hi ? mean_cov[i] : MEAN_SENTINEL;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int v = vv[u];
+                if (v == MEAN_SENTINEL) continue;
+                nv++;
+                if (v >= 0 && v < MED_BINS) {
+                    atomicAdd(&hist[v], 1u);
+                    vlo = min(vlo, (unsigned)v);
+                    vhi = max(vhi, (unsigned)v);
+                } else oor = 1;
+            }
+        }
     }
-    {   // total_cov / num_slot of the part (only logged by the reference, filter.cpp:666,672): every block sums a slice of
-        // k_cov_stats' per-wave partials
-        unsigned long long tc = 0, ts = 0;
-        for (int w = blockIdx.x * blockDim.x + tid; w < n_wave_totals; w += gridDim.x * blockDim.x) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
-        if (tc) atomicAdd(&s_tc, tc);
-        if (ts) atomicAdd(&s_ts, ts);
+    {   // one LDS atomic per wavefront and quantity, not one per thread
+        const int lane = lane_id();
+        nv = (unsigned)wave_sum((int)nv);
+        vlo = (unsigned)(MED_BINS - 1) - (unsigned)wave_max((int)((unsigned)(MED_BINS - 1) - vlo));
+        vhi = (unsigned)wave_max((int)vhi);
+        oor = __ballot(oor != 0) != 0ull;
+        tc = (unsigned long long)wave_sum64((long long)tc);
+        ts = (unsigned long long)wave_sum64((long long)ts);
+        if (lane == 0) {
+            if (nv) { atomicAdd(&s_valid, nv); atomicMin(&s_lo, vlo); atomicMax(&s_hi, vhi); }
+            if (oor) atomicOr(&s_oor, 1u);
+            if (tc) atomicAdd(&s_tc, tc);
+            if (ts) atomicAdd(&s_ts, ts);
+        }
     }
-    if (nv) {
-        atomicAdd(&s_valid, nv);
-        atomicMin(&s_lo, vlo);
-        atomicMax(&s_hi, vhi);
-    }
-    if (oor) atomicOr(&s_oor, 1u);
     __syncthreads();
+#ifdef HINGE_TIMING
+    const unsigned long long tq1 = wall_clock64();
+#endif
+    unsigned* my_hist = med + (size_t)(blockIdx.x % MED_REPLICAS) * MED_BINS;
     for (unsigned b = s_lo + tid; b <= s_hi; b += blockDim.x)
-        if (hist[b]) atomicAdd(&med[b], hist[b]);
-    // one global atomic per lane (fire and forget), one fence, one ticket: a single round trip instead of seven
-    switch (tid) {
-        case 0: if (s_valid) atomicAdd(&med[MED_BINS], s_valid); break;
-        case 1: if (s_valid) atomicMax(&med[MED_BINS + 4], (unsigned)(MED_BINS - 1) - s_lo); break;   // stored reversed: zero means "nothing yet"
-        case 2: if (s_valid) atomicMax(&med[MED_BINS + 5], s_hi); break;
-        case 3: if (s_oor) atomicOr(&med[MED_BINS + 2], 1u); break;
+        if (hist[b]) atomicAdd(&my_hist[b], hist[b]);
+    switch (tid) {   // fire-and-forget
         case 4: if (s_tc) atomicAdd(&totals[0], s_tc); break;
         case 5: if (s_ts) atomicAdd(&totals[1], s_ts); break;
         default: break;
     }
     __threadfence();
     __syncthreads();
-    if (tid == 0) {
-        const unsigned t = atomicAdd(&med[MED_BINS + 1], 1u);
-        s_last = (t == gridDim.x - 1);
+    if (tid == 0) {   // ONE returning atomic publishes this block and tells the last one everything it needs:
+                      // bits 0-39 valid values, 40-51 blocks done, 52-63 blocks that saw an out-of-range value
+        const unsigned long long mine = (unsigned long long)s_valid + (1ull << 40) + (s_oor ? (1ull << 52) : 0ull);
+        const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&med[MED_HDR]), mine);
+        s_ticket = t + mine;
+        s_last = (((t >> 40) & 0xfffull) == gridDim.x - 1);
     }
     __syncthreads();
+#ifdef HINGE_TIMING
+    const unsigned long long tq2 = wall_clock64();
+#endif
     if (!s_last) return;
-    __threadfence();
-    // last block: all merges are visible at device scope; read them back with agent-scope loads
-    __shared__ unsigned s_hdr[8];
-    if (tid < 8) s_hdr[tid] = __hip_atomic_load(&med[MED_BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned glo = (unsigned)(MED_BINS - 1) - s_hdr[4];
-    const unsigned ghi = s_hdr[5];
-    for (unsigned b = glo + tid; b <= ghi; b += blockDim.x) {
-        hist[b] = __hip_atomic_load(&med[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        med[b] = 0;   // clean for the next launch
+    __threadfence();   // acquire: the loads below must not be served from a stale vector L1 line
+    // last block: sum the replicas, 16 consecutive bins per thread, all loads independent (one memory round trip),
+    // and leave the scratch clean for the next launch
+    {
+        int acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = 0;
+#pragma unroll
+        for (int r = 0; r < MED_REPLICAS; r++) {
+            int4* src = reinterpret_cast<int4*>(med + (size_t)r * MED_BINS + (size_t)tid * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int4 v = src[q];
+                acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+                src[q] = make_int4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) hist[tid * 16 + k] = (unsigned)acc[k];
     }
-    if (tid < 8) med[MED_BINS + tid] = 0;
-    __syncthreads();
+    if (tid == 0) { med[MED_HDR] = 0; med[MED_HDR + 1] = 0; }
+    const unsigned glo = 0, ghi = MED_BINS - 1;
     if (tid == 0) {
-        const unsigned nvalid = s_hdr[0];
-        const unsigned bad = s_hdr[2];
+        const unsigned nvalid = (unsigned)(s_ticket & ((1ull << 40) - 1ull));
+        const unsigned bad = (unsigned)(s_ticket >> 52);
         if (nvalid == 0) {
             est[0] = 0; est[1] = 0;
             atomicOr(status, ST_NO_LONG_READ);
         } else if (bad) {
             s_general = 1;
         } else {
-            unsigned r = nvalid / 2;   // median_id = size/2, filter.cpp:660
-            unsigned b = glo;
-            for (; b <= ghi; ++b) {
-                if (r < hist[b]) break;
-                r -= hist[b];
-            }
-            int cov_est = (int)b;
-            est[0] = cov_est;
-            est[1] = (int)nvalid;
-            if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
-            if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;       // filter.cpp:677-678
+            s_general = 2;   // in range: wavefront 0 walks the histogram below
         }
     }
     __syncthreads();
-    if (s_general) median_radix_select(mean_cov, lo, hi, est_cov_override, est, min_cov, status);
+    if (s_general == 2 && tid < WAVE) {
+        // element of rank n/2 (median_id = size/2, filter.cpp:660): first bin whose inclusive prefix exceeds it
+        const unsigned nvalid = (unsigned)(s_ticket & ((1ull << 40) - 1ull));
+        const int r = (int)(nvalid / 2);
+        int carry = 0, found = -1;
+        for (unsigned base = glo; base <= ghi && found < 0; base += WAVE) {
+            const unsigned b = base + tid;
+            const int incl = wave_incl_scan(b <= ghi ? (int)hist[b] : 0) + carry;
+            const unsigned long long hit = __ballot(incl > r);
+            if (hit) found = (int)base + __ffsll((long long)hit) - 1;
+            carry = wave_last(incl);
+        }
+        if (tid == 0) {
+            int cov_est = found;
+            est[0] = cov_est;
+            est[1] = (int)nvalid;
+            if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
+            atomicMax(min_cov, cov_est / 3);                          // filter.cpp:677-678: if (MIN_COV < cov_est/3) MIN_COV = cov_est/3
+        }
+    }
+#ifdef HINGE_TIMING
+    if (tid == 0) { est[4 + 4] += (int)(tq1 - tq0); est[4 + 5] += (int)(tq2 - tq1); est[4 + 15] += (int)(wall_clock64() - tq2); }   // Scalars::dbg[4], [5], [15]
+#endif
+    __syncthreads();
+    if (s_general == 1) median_radix_select(mean_cov, lo, hi, est_cov_override, est, min_cov, status);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -187,8 +187,8 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->scalars.bytes = sizeof(Scalars);
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
-    if (hipMalloc(&ctx->med.p, sizeof(unsigned) * (MED_BINS + 8)) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
-    ctx->med.bytes = sizeof(unsigned) * (MED_BINS + 8);
+    if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
+    ctx->med.bytes = sizeof(unsigned) * MED_WORDS;
     (void)hipMemset(ctx->med.p, 0, ctx->med.bytes);
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
@@ -455,7 +455,7 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
     {
         ProfScope _ps(ctx, KID_MEDIAN);
         const int n = hi - lo + 1;
-        const int grid = std::max(1, std::min((n + 511) / 512, 4 * ctx->n_cu));
+        const int grid = std::max(1, std::min((n + 1023) / 1024, MED_MAX_BLOCKS));
         hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
                            (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status,
                            (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals);
@@ -782,6 +782,8 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     if (getenv("HINGE_DEBUG_PATHS"))
         fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u\n",
                 h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7]);
+    if (getenv("HINGE_DEBUG_PATHS") && h.dbg[15])
+        fprintf(stderr, "[hinge] median last-block timing (10 ns ticks, cumulative): hist=%u merge+ticket=%u tail=%u\n", h.dbg[4], h.dbg[5], h.dbg[15]);
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[10])
         fprintf(stderr, "[hinge] timing (10 ns ticks, cumulative): items=%u gather=%u (mean %.1f us) eval=%u (mean %.1f us) mean_n=%.0f mean_sup=%.0f | bin %.1f us scan %.1f us\n", h.dbg[10],
                 h.dbg[8], h.dbg[8] * 0.01 / h.dbg[10], h.dbg[11], h.dbg[11] * 0.01 / h.dbg[10], (double)h.dbg[9] / h.dbg[10], (double)h.dbg[12] / h.dbg[10], h.dbg[13] * 0.01 / h.dbg[10], h.dbg[14] * 0.01 / h.dbg[10]);
