@@ -711,20 +711,28 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
 // Events in the five hot bins (begins in bins 0-1, ends in the read's last three) go to lane-private LDS
 // words (hot[5][64]) so they never collide; they are summed once per read.
 // A read goes to the fallback list (run by k_mask_annotate afterwards) when its pile-up has 65536+ overlaps
-// or any coordinate lies outside [0, rlen].  The host launches it once per length bucket (read_list), so that
-// the LDS of a launch is sized by ITS longest read.
-__global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n_items, const int64_t* __restrict__ row_ptr,
+// or any coordinate lies outside [0, rlen], or the read is too long even for a whole workgroup's LDS.
+__global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
+                                                             const int64_t* __restrict__ row_ptr,
                                                              const int2* __restrict__ a_span, const int* __restrict__ rlen,
-                                                             const int* __restrict__ d_min_cov, int qcap, AnnoOut o,
+                                                             const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count) {
     extern __shared__ int lds[];
     constexpr int HOT = 5;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int* Pq = lds + (size_t)wib * (qcap + HOT * WAVE);
+    // A workgroup has four LDS slots of slot_ints words.  read_list = [n1 reads that fit one slot | n2 reads that need two |
+    // n4 reads that need all four]; the first ceil(n1/4) workgroups run four reads, the next ceil(n2/2) two (wavefronts 0
+    // and 2, each over two slots), the last n4 one.  One launch, LDS sized for the common short read, and the few long
+    // reads of a part overlap with everything else instead of costing every read its occupancy.
+    const int g1 = (n1 + 3) / 4, g2 = (n2 + 1) / 2;
+    int width, item;
+    if ((int)blockIdx.x < g1) { width = 1; item = (int)blockIdx.x * 4 + wib; if (item >= n1) return; }
+    else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g1) * 2 + (wib >> 1); if (item >= n2) return; item += n1; }
+    else { width = 4; if (wib != 0) return; item = n1 + n2 + ((int)blockIdx.x - g1 - g2); }
+    const int qcap = width * slot_ints - HOT * WAVE;
+    int* Pq = lds + (size_t)wib * slot_ints;
     int* hot = Pq + qcap;
-    const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-    const int nwaves = gridDim.x * WAVES_PER_BLOCK;
     const int MIN_COV = *d_min_cov;
     constexpr int reso = 40;
     const int SH = P.cut_off / 20;
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
     int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
     int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1, 2}
 
-    for (int item = wave; item < n_items; item += nwaves) {
+    for (int once = 0; once < 1; once++) {         // one read per wavefront; `continue` leaves
         const int i = read_list[item];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];

@@ -50,14 +50,13 @@ struct hinge_ctx {
     DevBuf med;       // median histogram scratch (k_median_hist)
     DevBuf wave_totals;   // k_cov_stats per-wave (total_cov, num_slot) partials
     int n_wave_totals = 0;
-    size_t lds_attr_set = 0, lds20_attr_set = 0;
+    size_t lds_attr_set = 0;
     int force_exact = 0;
     int force_general_mask = 0;
     bool min_cov_pending = false;   // hinge_filter_set_min_cov is applied by the next launch that needs it
     int min_cov_value = 0;
     std::vector<int> h_rlen;      // host copy of the read lengths (length buckets of K2)
-    int n_short = 0, n_long = 0;  // bucket_list = [short reads | long reads] of the current part
-    int short_max_rlen = 0;   // tests: run the general K2 kernel where the q20 kernel would be chosen
+    int n_class[3] = {0, 0, 0};   // bucket_list = [reads needing 1 | 2 | 4 LDS slots of a K2 workgroup] of the current part   // tests: run the general K2 kernel where the q20 kernel would be chosen
 
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
@@ -99,6 +98,12 @@ struct ProfScope {
 };
 
 static const int K2_SHORT_RLEN = 18000;   // (18000 / 20 + 8 + 5 * 64) ints * 4 waves = 19.6 KiB per workgroup: 8 workgroups per CU
+
+// words of LDS per wavefront slot of k_mask_annotate_q20: 20-bp bins of the longest "short" read + the hot words
+static int k2_slot_ints(const hinge_ctx* ctx) {
+    const int len = std::min(ctx->max_rlen, K2_SHORT_RLEN);
+    return (((len / 20 + 1 + 3) & ~3) + 4) + 5 * WAVE;
+}
 
 // device scalars, one allocation
 struct Scalars {
@@ -304,16 +309,20 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         ctx->arena_cap = 1ull << 22;   // ints
         if ((rc = ensure(ctx, ctx->arena, sizeof(int) * (size_t)ctx->arena_cap))) return rc;
     }
-    {   // K2 length buckets: LDS per wavefront is sized by the longest read of a launch, so the few long reads of a
-        // part would cost every read its occupancy; reads up to K2_SHORT_RLEN run in their own launch
+    {   // K2 length classes: reads that fit one, two or four LDS slots of a workgroup (see k_mask_annotate_q20)
         const int nr = r_end - r_begin + 1;
+        const int slot = k2_slot_ints(ctx);
+        const int len1 = (slot - 5 * WAVE - 1) * 20 + 19, len2 = (2 * slot - 5 * WAVE - 1) * 20 + 19;   // longest read per class
         std::vector<int> lst((size_t)nr);
-        int ns = 0, nl = 0, smax = 0;
-        for (int i = r_begin; i <= r_end; i++)
-            if (ctx->h_rlen[(size_t)i] <= K2_SHORT_RLEN) { lst[(size_t)ns++] = i; smax = std::max(smax, ctx->h_rlen[(size_t)i]); }
-        for (int i = r_begin; i <= r_end; i++)
-            if (ctx->h_rlen[(size_t)i] > K2_SHORT_RLEN) lst[(size_t)ns + (size_t)nl++] = i;
-        ctx->n_short = ns; ctx->n_long = nl; ctx->short_max_rlen = smax;
+        int n1 = 0, n2 = 0, n4 = 0;
+        for (int i = r_begin; i <= r_end; i++) { const int l = ctx->h_rlen[(size_t)i]; n1 += l <= len1; n2 += l > len1 && l <= len2; }
+        n4 = nr - n1 - n2;
+        int p1 = 0, p2 = n1, p4 = n1 + n2;
+        for (int i = r_begin; i <= r_end; i++) {
+            const int l = ctx->h_rlen[(size_t)i];
+            if (l <= len1) lst[(size_t)p1++] = i; else if (l <= len2) lst[(size_t)p2++] = i; else lst[(size_t)p4++] = i;
+        }
+        ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
         if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)nr))) return rc;
         CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
@@ -531,26 +540,14 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
     const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && ctx->force_general_mask == 0;
     if (q20) {
-        auto qcap_of = [](int max_rlen) { return ((max_rlen / 20 + 1 + 3) & ~3) + 4; };
-        const size_t lds_max = (size_t)WAVES_PER_BLOCK * (qcap_of(ctx->max_rlen) + 5 * WAVE) * sizeof(int);
-        if (lds_max > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
-        if (lds_max > 48 * 1024 && lds_max > ctx->lds20_attr_set) {
-            CK(hipFuncSetAttribute((const void*)k_mask_annotate_q20, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-            ctx->lds20_attr_set = lds_max;
-        }
+        const int slot = k2_slot_ints(ctx);
+        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // <= 20 KiB: eight workgroups per CU
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
-        const int* lst = (const int*)ctx->bucket_list.p;
-        const int n_items[2] = {ctx->n_short, ctx->n_long};
-        const int max_len[2] = {ctx->short_max_rlen, ctx->max_rlen};
-        for (int b = 0; b < 2; b++) {
-            if (n_items[b] == 0) continue;
-            const int qcap = qcap_of(max_len[b]);
-            const size_t lds20 = (size_t)WAVES_PER_BLOCK * (qcap + 5 * WAVE) * sizeof(int);
-            const int g = std::max(1, std::min((n_items[b] + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
-            hipLaunchKernelGGL(k_mask_annotate_q20, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), lst + (b ? ctx->n_short : 0), n_items[b],
-                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
-                               (const int*)&sc(ctx)->min_cov, qcap, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
-        }
+        const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
+        const int g = std::max(1, (n1 + 3) / 4 + (n2 + 1) / 2 + n4);
+        hipLaunchKernelGGL(k_mask_annotate_q20, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
+                           (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen]): normally none, the launch is then ~3 us
