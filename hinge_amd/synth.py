@@ -388,6 +388,9 @@ CONFIGS = {
     "chimera": SynthSpec(genome_len=150_000, coverage=40, seed=11, chimera_frac=0.05, n_repeat_families=2),
     "long_repeat": SynthSpec(genome_len=150_000, coverage=80, len_min=3000, len_max=8000, repeat_len=(12000, 12000),
                              repeat_copies=(2, 2), inverted_copies=False, seed=23),
+    # reads from 4 kb to 120 kb: every LDS-slot class of the mask/annotate kernel (1, 2, 4 slots, and > 91 kb: general kernel)
+    "long_reads": SynthSpec(genome_len=400_000, coverage=40, len_dist="lognormal", len_mean=25000, len_sigma=0.7, len_min=4000,
+                            len_max=120000, repeat_len=(9000, 9000), repeat_copies=(3, 3), seed=31),
     "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
                                  repeat_len=(1000, 5000), repeat_copies=(2, 3)),
     "cfg2_ecoli160": SynthSpec(genome_len=4_600_000, coverage=160, len_dist="lognormal", len_mean=8500,

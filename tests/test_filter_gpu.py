@@ -198,3 +198,19 @@ def test_median_kernel_matches_nth_element(kind):
         assert est.n_long == len(valid)
         assert est.cov_est == int(valid[len(valid) // 2])
     assert ctx.get_min_cov() == max(5, int(valid[len(valid) // 2]) // 3)
+
+
+def test_filter_long_reads_all_lds_classes(datasets, oracle_lib, tmp_path):
+    """Reads of 4 kb .. 120 kb: one, two and four LDS slots per read, and reads too long for a workgroup's LDS."""
+    from hinge_amd import capi, stages
+    src, d = datasets("long_reads")
+    assert (d.rlen <= 18000).any() and ((d.rlen > 18000) & (d.rlen <= 42000)).any() and ((d.rlen > 43000) & (d.rlen <= 91000)).any()
+    n_too_long = int((d.rlen // 20 >= 4 * 1228 - 320).sum())   # 20-bp bins beyond four 1228-word slots minus the hot words
+    assert n_too_long > 0
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, False) == 0
+    ctx = capi.Context(0)
+    assert run_in(wd_h, stages.run_filter, "G", "G.las", "G", "nominal.ini", False, 0, True, False, ctx) == 0
+    assert ctx.fallback_reads() == n_too_long
+    _compare(wd_o, wd_h)
