@@ -389,10 +389,34 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
         }
     }
 #ifdef HINGE_TIMING
-    if (tid == 0) { est[4 + 4] += (int)(tq1 - tq0); est[4 + 5] += (int)(tq2 - tq1); est[4 + 15] += (int)(wall_clock64() - tq2); }   // Scalars::dbg[4], [5], [15]
 #endif
     __syncthreads();
     if (s_general == 1) median_radix_select(mean_cov, lo, hi, est_cov_override, est, min_cov, status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Facts about a part's pile-ups that stay true for every pass over it (run once by hinge_set_pileups):
+// facts[0] = largest pile-up, facts[1] = 1 if some coordinate lies outside [0, rlen].  With them the host
+// knows when the hand-back launch of K2 and the serial exact-path kernel of K3 cannot have work.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pileup_facts(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+                                                        const int2* __restrict__ a_span, const int* __restrict__ rlen,
+                                                        unsigned* __restrict__ facts) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * BLOCK) >> 6;
+    unsigned max_pile = 0, bad = 0;
+    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const unsigned rl = (unsigned)max(rlen[i], 0);
+        max_pile = max(max_pile, (unsigned)min<int64_t>(e - s, 0x7fffffff));
+        for (int64_t k = s + lane; k < e; k += WAVE) {
+            const int2 v = a_span[k];
+            bad |= ((unsigned)v.x > rl) || ((unsigned)v.y > rl);   // unsigned: negative coordinates are "too large"
+        }
+    }
+    if (__ballot(bad != 0) && lane == 0) atomicOr(&facts[1], 1u);
+    if (lane == 0 && max_pile) atomicMax(&facts[0], max_pile);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -78,6 +78,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned nwork = counters[1];
     for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {   // one workgroup per work-list read
+#ifdef HINGE_TIMING
+        const unsigned long long tc0 = wall_clock64();
+#endif
         const int i = work_list[w];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int2 mk = mask[i];
@@ -93,28 +96,49 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
                 const int2 an = a < na ? anno_buf[off + a0 + a] : make_int2(0, 0);
                 apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0;
             }
-            for (int64_t k = k_lo + lane; k < k_hi; k += WAVE) {
-                const int2 av = a_span[k];
-                bool loaded = false;
-                int L = 0, R = 0;
+            for (int64_t k0 = k_lo; k0 < k_hi; k0 += GATHER_LOADS * WAVE) {
+                // three dependent round trips per GATHER_LOADS * 64 overlaps (spans, B-side fields, mask[B]) instead of per 64
+                int2 av[GATHER_LOADS], bs[GATHER_LOADS], mb[GATHER_LOADS];
+                unsigned bf[GATHER_LOADS];
+                bool nearw[GATHER_LOADS];
 #pragma unroll
-                for (int a = 0; a < PRE_MAXA; a++) {
-                    if (a >= na) break;
-                    const int c = atype[a] == -1 ? av.y : av.x;
-                    if ((c > apos[a] - P.tol) && (c < apos[a] + P.tol)) {
-                        if (!loaded) {
-                            const unsigned bf = b_flag[k];
-                            const int2 bs = b_span[k];
-                            const int2 mb = mask[bf & 0x7fffffffu];
-                            overhangs(bs, (int)(bf >> 31), mb, L, R);
-                            loaded = true;
-                        }
-                        const bool sup = atype[a] == -1 ? (R > P.theta) : (L > P.theta);
-                        if (sup) {
-                            csup[a]++;
-                            const int f = atype[a] == -1 ? av.x : -av.y;
-                            const int m0 = atype[a] == -1 ? mk.x : -mk.y;
-                            cnear[a] += (f - m0 < P.bin_len);
+                for (int u = 0; u < GATHER_LOADS; u++) {
+                    const int64_t k = k0 + u * WAVE + lane;
+                    av[u] = k < k_hi ? a_span[k] : make_int2(0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < GATHER_LOADS; u++) {
+                    const int64_t k = k0 + u * WAVE + lane;
+                    bool nr = false;
+#pragma unroll
+                    for (int a = 0; a < PRE_MAXA; a++) {
+                        if (a >= na) break;
+                        const int c = atype[a] == -1 ? av[u].y : av[u].x;
+                        nr = nr || ((c > apos[a] - P.tol) && (c < apos[a] + P.tol));
+                    }
+                    nearw[u] = nr && k < k_hi;
+                    bf[u] = nearw[u] ? b_flag[k] : 0u;
+                    bs[u] = nearw[u] ? b_span[k] : make_int2(0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < GATHER_LOADS; u++) mb[u] = nearw[u] ? mask[bf[u] & 0x7fffffffu] : make_int2(0, 0);
+#pragma unroll
+                for (int u = 0; u < GATHER_LOADS; u++) {
+                    if (!nearw[u]) continue;
+                    int L, R;
+                    overhangs(bs[u], (int)(bf[u] >> 31), mb[u], L, R);
+#pragma unroll
+                    for (int a = 0; a < PRE_MAXA; a++) {
+                        if (a >= na) break;
+                        const int c = atype[a] == -1 ? av[u].y : av[u].x;
+                        if ((c > apos[a] - P.tol) && (c < apos[a] + P.tol)) {
+                            const bool sup = atype[a] == -1 ? (R > P.theta) : (L > P.theta);
+                            if (sup) {
+                                csup[a]++;
+                                const int f = atype[a] == -1 ? av[u].x : -av[u].y;
+                                const int m0 = atype[a] == -1 ? mk.x : -mk.y;
+                                cnear[a] += (f - m0 < P.bin_len);
+                            }
                         }
                     }
                 }
@@ -152,6 +176,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
             }
             __syncthreads();
         }
+#ifdef HINGE_TIMING
+        if (tid == 0 && dbg) { const unsigned dt = (unsigned)(wall_clock64() - tc0); atomicAdd(&dbg[4], dt); atomicAdd(&dbg[5], 1u); atomicMax(&dbg[15], dt); atomicMax(&dbg[7], (unsigned)(e - s)); }
+#endif
     }
 }
 
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             __syncthreads();
 #ifdef HINGE_TIMING
             const unsigned long long tm1 = wall_clock64();
-            if (tid == 0) { atomicAdd(&dbg[8], (unsigned)(tm1 - tm0)); atomicAdd(&dbg[9], (unsigned)n); atomicAdd(&dbg[10], 1u); }
+            if (tid == 0 && dbg) { atomicAdd(&dbg[8], (unsigned)(tm1 - tm0)); atomicAdd(&dbg[9], (unsigned)n); atomicAdd(&dbg[10], 1u); }
 #endif
             const int sup = S.cnt;
             // ---- decide the path (block-uniform) ----------------------------------------------------
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 __syncthreads();
 #ifdef HINGE_TIMING
                 const unsigned long long tm2 = wall_clock64();
-                if (tid == 0) atomicAdd(&dbg[13], (unsigned)(tm2 - tm1));
+                if (tid == 0 && dbg) atomicAdd(&dbg[13], (unsigned)(tm2 - tm1));
 #endif
                 if (!S.sf_over) {
                     // workgroup inclusive scan: every wavefront owns nb/4 consecutive bins and walks them 64 at a time
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                     }
                     __syncthreads();
 #ifdef HINGE_TIMING
-                    if (tid == 0) atomicAdd(&dbg[14], (unsigned)(wall_clock64() - tm2));
+                    if (tid == 0 && dbg) atomicAdd(&dbg[14], (unsigned)(wall_clock64() - tm2));
 #endif
                     const int o23_1 = S.wtot[0][0], o23_2 = o23_1 + S.wtot[0][1], o23_3 = o23_2 + S.wtot[0][2];
                     const int oal_1 = S.wtot[1][0], oal_2 = oal_1 + S.wtot[1][1], oal_3 = oal_2 + S.wtot[1][2];
@@ -389,7 +416,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
             }
             if (tid == 0 && dbg) { atomicAdd(&dbg[action], 1u); atomicMax(&dbg[6], (unsigned)sup); }
 #ifdef HINGE_TIMING
-            if (tid == 0) { atomicAdd(&dbg[11], (unsigned)(wall_clock64() - tm1)); atomicAdd(&dbg[12], (unsigned)sup); }
+            if (tid == 0 && dbg) { atomicAdd(&dbg[11], (unsigned)(wall_clock64() - tm1)); atomicAdd(&dbg[12], (unsigned)sup); }
 #endif
             if (action == 1) {
                 need_order = (force_exact == 2) || (sup > HC_SMALL);

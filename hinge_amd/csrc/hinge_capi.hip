@@ -53,9 +53,12 @@ struct hinge_ctx {
     size_t lds_attr_set = 0;
     int force_exact = 0;
     int force_general_mask = 0;
+    bool debug_paths = false;     // HINGE_DEBUG_PATHS: path counters (same-line global atomics, ~12 ns each: off by default)
     bool min_cov_pending = false;   // hinge_filter_set_min_cov is applied by the next launch that needs it
     int min_cov_value = 0;
     std::vector<int> h_rlen;      // host copy of the read lengths (length buckets of K2)
+    unsigned max_pile = 0;        // facts about the current part's pile-ups (k_pileup_facts)
+    bool spans_in_range = false;
     int n_class[3] = {0, 0, 0};   // bucket_list = [reads needing 1 | 2 | 4 LDS slots of a K2 workgroup] of the current part   // tests: run the general K2 kernel where the q20 kernel would be chosen
 
     // trim / classify (maximal, layout)
@@ -120,6 +123,7 @@ struct Scalars {
     int est[2];                         // cov_est, n_long
     int min_cov;
     int pad;
+    unsigned facts[2];                  // k_pileup_facts: largest pile-up, out-of-range flag
     unsigned dbg[16];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
@@ -192,6 +196,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->scalars.bytes = sizeof(Scalars);
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
+    ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
     ctx->med.bytes = sizeof(unsigned) * MED_WORDS;
     (void)hipMemset(ctx->med.p, 0, ctx->med.bytes);
@@ -325,7 +330,17 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
         if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)nr))) return rc;
         CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
+        // one sweep over the spans, once per part: largest pile-up, any coordinate outside [0, rlen]
+        unsigned* facts = sc(ctx)->facts;
+        CK(hipMemsetAsync(facts, 0, 2 * sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(k_pileup_facts, dim3(std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->n_cu * 8))), dim3(BLOCK), 0, ctx->stream, r_begin, r_end,
+                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts);
+        CK(hipGetLastError());
+        unsigned h[2] = {0, 0};
+        CK(hipMemcpyAsync(h, facts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
+        ctx->max_pile = h[0];
+        ctx->spans_in_range = h[1] == 0;
     }
     if (!on_device) CK(hipStreamSynchronize(ctx->stream));
     return HINGE_OK;
@@ -550,7 +565,10 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
                            (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
         CK(hipGetLastError());
         _ps.stop();
-        // reads handed back (65536+ overlaps, coordinates outside [0, rlen]): normally none, the launch is then ~3 us
+        // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is
+        // skipped when the part's facts rule all three out
+        const bool no_handback = ctx->max_pile < 65536u && ctx->spans_in_range && ctx->max_rlen / 20 < WAVES_PER_BLOCK * slot - 5 * WAVE;
+        if (no_handback) return HINGE_OK;
         ProfScope _ps2(ctx, KID_MASK_FALLBACK);
         LAUNCH_MASK_ANNOTATE(40, std::min(grid, 64), (const int*)ctx->fallback_list.p, (const unsigned*)&sc(ctx)->fallback_count);
         CK(hipGetLastError());
@@ -593,7 +611,7 @@ static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
                        (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
-                       (HeavyItem*)ctx->heavy_list.p, &sc(ctx)->heavy_count, ctx->force_exact, sc(ctx)->dbg); }
+                       (HeavyItem*)ctx->heavy_list.p, &sc(ctx)->heavy_count, ctx->force_exact, ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr); }
     CK(hipGetLastError());
     { ProfScope _ps(ctx, KID_HINGE_CALL);
     hipLaunchKernelGGL(k_hinge_call, dim3(grid), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
@@ -601,8 +619,10 @@ static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p,
                        (const HeavyItem*)ctx->heavy_list.p, (const unsigned*)&sc(ctx)->heavy_count, (unsigned char*)ctx->hinge_flag.p,
                        (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status,
-                       &sc(ctx)->work_next, sc(ctx)->dbg); }
+                       &sc(ctx)->work_next, ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr); }
     CK(hipGetLastError());
+    // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1)
+    if (ctx->max_pile <= (unsigned)PO_CAP && ctx->force_exact != 1) return HINGE_OK;
     ProfScope _ps2(ctx, KID_HINGE_EXACT);
     hipLaunchKernelGGL(k_hinge_exact, dim3(64), dim3(64), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
@@ -780,7 +800,7 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
         fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u\n",
                 h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7]);
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[15])
-        fprintf(stderr, "[hinge] median last-block timing (10 ns ticks, cumulative): hist=%u merge+ticket=%u tail=%u\n", h.dbg[4], h.dbg[5], h.dbg[15]);
+        fprintf(stderr, "[hinge] k_hinge_count per read (HINGE_TIMING builds): reads=%u mean %.1f us max %.1f us, largest pile-up %u\n", h.dbg[5], h.dbg[4] * 0.01 / std::max(1u, h.dbg[5]), h.dbg[15] * 0.01, h.dbg[7]);
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[10])
         fprintf(stderr, "[hinge] timing (10 ns ticks, cumulative): items=%u gather=%u (mean %.1f us) eval=%u (mean %.1f us) mean_n=%.0f mean_sup=%.0f | bin %.1f us scan %.1f us\n", h.dbg[10],
                 h.dbg[8], h.dbg[8] * 0.01 / h.dbg[10], h.dbg[11], h.dbg[11] * 0.01 / h.dbg[10], (double)h.dbg[9] / h.dbg[10], (double)h.dbg[12] / h.dbg[10], h.dbg[13] * 0.01 / h.dbg[10], h.dbg[14] * 0.01 / h.dbg[10]);
