@@ -60,13 +60,13 @@ def pmc_traffic(kname):
     fetch = write = None
     with open(files[-1], newline="") as f:
         for row in csv.DictReader(f):
-            if row["kernel"].split("::")[-1].split("<")[0] != kname:
-                continue
+            if not row["kernel"].split("::")[-1].split("<")[0].startswith(kname):
+                continue   # k_mask_annotate covers k_mask_annotate_q20 and the general k_mask_annotate<RESO>
             v = float(row.get("mean_value_KB") or row.get("mean_value"))
             if row["counter"] == "FETCH_SIZE":
-                fetch = v
+                fetch = (fetch or 0.0) + v
             elif row["counter"] == "WRITE_SIZE":
-                write = v
+                write = (write or 0.0) + v
     if fetch is None or write is None:
         return None, None
     return (2.0 * fetch + write) * 1024.0, "profiles/" + os.path.basename(files[-1]) + " (2*FETCH_SIZE + WRITE_SIZE, KB)"

@@ -55,20 +55,26 @@ int main() {
     const int kcap = ((maxrl + 300) / 40 + 4 + 3) & ~3;
     const size_t lds = 4 * 2 * kcap * 4;
     (void)hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int qcap = ((maxrl / 20 + 1 + 3) & ~3) + 4;
-    const size_t lds20 = 4 * (qcap + 5 * 64) * 4;
-    (void)hipFuncSetAttribute((const void*)k_mask_annotate_q20, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds20);
+    const int slot = ((((std::min(maxrl, 18000)) / 20 + 1 + 3) & ~3) + 4) + 5 * 64;
+    const size_t lds20 = 4 * (size_t)slot * 4;
+    const int len1 = (slot - 5 * 64 - 1) * 20 + 19, len2 = (2 * slot - 5 * 64 - 1) * 20 + 19;
+    std::vector<int> l1, l2, l4;
+    for (int i = 0; i < nr; i++) (hl[i] <= len1 ? l1 : hl[i] <= len2 ? l2 : l4).push_back(i);
+    std::vector<int> lst(l1); lst.insert(lst.end(), l2.begin(), l2.end()); lst.insert(lst.end(), l4.begin(), l4.end());
+    const int n1 = (int)l1.size(), n2 = (int)l2.size(), n4 = (int)l4.size();
+    printf("classes: %d / %d / %d, slot %d ints, LDS %zu B per workgroup\n", n1, n2, n4, slot, lds20);
     int* fb; (void)hipMalloc(&fb, nr * 4);
     int* ids; (void)hipMalloc(&ids, nr * 4);
-    { std::vector<int> hi(nr); for (int i = 0; i < nr; i++) hi[i] = i; (void)hipMemcpy(ids, hi.data(), nr * 4, hipMemcpyHostToDevice); }
+    (void)hipMemcpy(ids, lst.data(), nr * 4, hipMemcpyHostToDevice);
     AnnoOut o{nullptr, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * (unsigned)nr, wl, st};
     const int grid = (nr + 3) / 4;
+    const int grid20 = (n1 + 3) / 4 + (n2 + 1) / 2 + n4;
     for (int mode = 1; mode <= 5; mode++) {
         P.ablate = mode;
         float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
             hipLaunchKernelGGL(k_mask_annotate<40>, dim3(grid), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, mc, kcap, o, (const int*)nullptr, (const unsigned*)nullptr); });
         float t2 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
-            hipLaunchKernelGGL(k_mask_annotate_q20, dim3(grid), dim3(256), lds20, 0, P, ids, nr, rp, a, rl, mc, qcap, o, fb, cnt + 2); });
+            hipLaunchKernelGGL(k_mask_annotate_q20, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, mc, slot, o, fb, cnt + 2); });
         printf("stop after phase %d: general %7.1f us   q20 %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all)\n", mode, t * 1e3, t2 * 1e3);
     }
     unsigned hc[4]; (void)hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost);
