@@ -20,6 +20,9 @@ int main(int argc, char* argv[]) {
     cmdp.add_flag("debug", '\0', "debug mode");
     cmdp.parse_check(argc, argv);
 
+    PhaseTimer tm("filter");
+    CtxInit gpu;
+    gpu.start();
     Log console;
     console.open(cmdp.get("log"));
     console.info("Reads filtering");
@@ -57,11 +60,16 @@ int main(int argc, char* argv[]) {
     console.info("use_qv_mask set to %d", P.use_qv_mask);
     console.info("MIN_COV = %d CUT_OFF = %d THETA = %d EST_COV = %d", P.min_cov, P.cut_off, P.theta, P.est_cov);
 
-    hinge_ctx* ctx = nullptr;
-    if (hinge_ctx_create(0, &ctx) != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    tm.mark("db + qual + ini");
+    PartLoader loader;
+    if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
+    tm.mark("las ingest (part 1) || HIP init");
+    if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    hinge_ctx* ctx = gpu.ctx;
     HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), has_qv ? qvm.data() : nullptr));
     HH_CHECK(ctx, hinge_filter_set_min_cov(ctx, P.min_cov));
 
+    tm.mark("ctx_create + set_reads");
     FILE* f_cov = fopen((out + ".coverage.txt").c_str(), "w");
     fclose(fopen((out + ".homologous.txt").c_str(), "w"));
     FILE* f_rep = fopen((out + ".repeat.txt").c_str(), "w");
@@ -75,16 +83,19 @@ int main(int argc, char* argv[]) {
 
     for (size_t part = 0; part < las_list.size(); part++) {
         console.info("part: %zu  name of las: %s", part, las_list[part].c_str());
-        LasPart las;
-        const int lrc = las.load(las_list[part], db.rlen);
+        int lrc = 0;
+        std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
+        LasPart& las = *las_owner;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
         if (lrc != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        tm.mark("las ingest");
         console.info("# Alignments: %lld", (long long)las.novl);
         if (las.novl == 0) { console.error("No alignments!"); return 1; }
         const int r_begin = las.r_begin, r_end = las.r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
         HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
 
+        tm.mark("set_pileups (H2D)");
         // self_match_reads, filter.cpp:552-561 (float accumulation in record order)
         std::set<int> self_match;
         if (P.delete_telomere) {
@@ -100,6 +111,7 @@ int main(int argc, char* argv[]) {
             }
         }
 
+        tm.mark("self matches");
         hinge_cov_estimate est;
         HH_CHECK(ctx, hinge_filter_stats(ctx, &P));
         HH_CHECK(ctx, hinge_filter_median(ctx, &P, r_begin, r_end, &est));
@@ -108,6 +120,7 @@ int main(int argc, char* argv[]) {
         HH_CHECK(ctx, hinge_filter_mask_annotate(ctx, &P));
         HH_CHECK(ctx, hinge_filter_hinges(ctx, &P));
 
+        tm.mark("kernels (4 passes)");
         // .coverage.txt, filter.cpp:599-602
         {
             std::vector<int32_t> nb(nr);
@@ -116,14 +129,9 @@ int main(int argc, char* argv[]) {
             for (size_t k = 0; k < nr; k++) tot += nb[k];
             std::vector<int32_t> cov((size_t)std::max<int64_t>(tot, 1));
             HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, P.reso, 0, nb.data(), cov.data(), tot));
-            int64_t o = 0;
-            for (size_t k = 0; k < nr; k++) {
-                fprintf(f_cov, "read %d ", r_begin + (int)k);
-                for (int j = 0; j < nb[k]; j++) fprintf(f_cov, "%d,%d ", P.reso * j, cov[(size_t)(o + j)]);
-                fprintf(f_cov, "\n");
-                o += nb[k];
-            }
+            write_coverage_txt(f_cov, r_begin, nb, cov, P.reso);
         }
+        tm.mark("coverage.txt");
         std::vector<int32_t> mask(2 * nr), cmask(2 * nr);
         std::vector<uint8_t> flags(nr);
         HH_CHECK(ctx, hinge_filter_get_masks(ctx, mask.data(), cmask.data(), flags.data()));
@@ -160,6 +168,7 @@ int main(int argc, char* argv[]) {
                 if (is_hinge[(size_t)t]) { fprintf(f_hg, "%d %d ", pos[(size_t)t], type[(size_t)t]); hg_cnt++; }
             fprintf(f_hg, "\n");
         }
+        tm.mark("mas/cmas/repeat/hinges txt");
         console.info("Number of hinges before filtering: %lld", (long long)off[nr]);
         console.info("Number of hinges: %d", hg_cnt);
     }

@@ -18,9 +18,13 @@
 #include <cstring>
 #include <fcntl.h>
 #include <map>
+#include <memory>
+#include <chrono>
 #include <string>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <atomic>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
@@ -46,6 +50,23 @@ struct Log {
     void info(const char* fmt, ...) { va_list ap; va_start(ap, fmt); line("info", fmt, ap); va_end(ap); }
     void warn(const char* fmt, ...) { va_list ap; va_start(ap, fmt); line("warning", fmt, ap); va_end(ap); }
     void error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); line("error", fmt, ap); va_end(ap); }
+};
+
+// wall-clock marks of the host phases on stderr when HINGE_HOST_TIMING is set (tools/e2e_bench.py reads them)
+struct PhaseTimer {
+    bool on;
+    const char* prog;
+    std::chrono::steady_clock::time_point t0, last;
+    explicit PhaseTimer(const char* p) : on(getenv("HINGE_HOST_TIMING") != nullptr), prog(p), t0(std::chrono::steady_clock::now()), last(t0) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] %s %-28s %8.1f ms\n", prog, what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+    ~PhaseTimer() {
+        if (on) fprintf(stderr, "[timing] %s %-28s %8.1f ms\n", prog, "TOTAL", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -236,6 +257,68 @@ inline hinge_filter_params filter_params_from(const Config& c, bool has_qv) {   
 // ---------------------------------------------------------------------------------------------------
 // read-only memory map
 // ---------------------------------------------------------------------------------------------------
+// Host threads for the ingest / grouping / formatting loops.  HINGE_THREADS overrides; the loops are written so
+// that the result does not depend on the number of threads (outputs are per item or per chunk, stitched in order).
+inline int host_threads() {
+    static int n = [] {
+        if (const char* e = getenv("HINGE_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 256); }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(std::max<unsigned>(hw, 1u), 32u);
+    }();
+    return n;
+}
+// fn(chunk, begin, end) over [0, n) cut into `chunks` contiguous pieces, one thread each
+template <typename F>
+inline void parallel_chunks(int64_t n, int chunks, F fn) {
+    chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, n));
+    if (chunks == 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)chunks);
+    for (int c = 0; c < chunks; c++) {
+        const int64_t b = n * c / chunks, e = n * (c + 1) / chunks;
+        th.emplace_back([=, &fn] { fn(c, b, e); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// fn(begin, end) over [0, n) in pieces of `grain` items handed out dynamically to host_threads() threads
+template <typename F>
+inline void parallel_dynamic(int64_t n, int64_t grain, F fn) {
+    grain = std::max<int64_t>(1, grain);
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n + grain - 1) / grain));
+    if (T == 1) { if (n > 0) fn((int64_t)0, n); return; }
+    std::atomic<int64_t> next(0);
+    std::vector<std::thread> th;
+    th.reserve((size_t)T);
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&] {
+            for (;;) {
+                const int64_t b = next.fetch_add(grain);
+                if (b >= n) break;
+                fn(b, std::min(n, b + grain));
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+// uninitialised array for the big SoA columns: std::vector would zero (and page-fault) hundreds of MB on one thread
+// before the parallel fill writes every element anyway
+template <typename T>
+struct UVec {
+    T* p = nullptr;
+    size_t n = 0;
+    UVec() = default;
+    UVec(const UVec&) = delete;
+    UVec& operator=(const UVec&) = delete;
+    ~UVec() { free(p); }
+    void resize(size_t m) { free(p); p = m ? (T*)malloc(m * sizeof(T)) : nullptr; n = p ? m : 0; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct Mapped {
     const uint8_t* p = nullptr;
     size_t n = 0;
@@ -251,6 +334,20 @@ struct Mapped {
         if (m == MAP_FAILED) { n = 0; return false; }
         p = (const uint8_t*)m;
         return true;
+    }
+    // fault the pages in from host_threads() threads (one thread walking a 5 GB mapping pays ~0.5 us per 4 KiB page)
+    void prefault() const {
+        if (!p || n < (64u << 20)) return;
+        const size_t page = 4096, pages = (n + page - 1) / page;
+        parallel_dynamic((int64_t)pages, 4096, [&](int64_t b, int64_t e) {
+            const size_t o = (size_t)b * page, len = std::min(n, (size_t)e * page) - o;
+#ifdef MADV_POPULATE_READ
+            if (madvise((void*)(p + o), len, MADV_POPULATE_READ) == 0) return;
+#endif
+            volatile uint8_t sink = 0;
+            for (size_t q = o; q < o + len; q += page) sink += p[q];
+            (void)sink;
+        });
     }
     ~Mapped() { if (p) munmap((void*)p, n); }
 };
@@ -362,14 +459,14 @@ struct LasPart {
     int r_begin = 0, r_end = -1;               // A read of the first / last record (filter.cpp:516-517)
     // kept (non-self) overlaps in .las order
     std::vector<int64_t> row_ptr;              // n_reads + 1
-    std::vector<int32_t> a_span, b_span;       // 2 per overlap
-    std::vector<uint32_t> b_flag;
-    std::vector<int64_t> trace_off;            // byte offset of the trace inside the mapped file
-    std::vector<int32_t> tlen;
+    UVec<int32_t> a_span, b_span;              // 2 per overlap
+    UVec<uint32_t> b_flag;
+    UVec<int64_t> trace_off;                   // byte offset of the trace inside the mapped file
+    UVec<int32_t> tlen;
     // every record (self-overlaps included), for the (A, B) grouping of maximal / layout
     std::vector<int64_t> rec_row_ptr;          // n_reads + 1 over records
-    std::vector<int32_t> rec_b;
-    std::vector<int64_t> rec_kept;             // index into the kept arrays, -1 for a self-overlap
+    UVec<int32_t> rec_b;
+    UVec<int64_t> rec_kept;                    // index into the kept arrays, -1 for a self-overlap
     // self-overlaps (filter.cpp:538-544)
     std::vector<int32_t> self_a, self_span;    // self_span: abpos, aepos, bbpos', bepos'
 
@@ -384,69 +481,188 @@ struct LasPart {
     }
 
     // 0 ok; -1 cannot open / truncated (reference: exit(1)); -2 records not grouped by ascending A read
+    // The record chain (every record's position depends on the previous tlen) is walked once; everything else -
+    // validation, the strand flip of LAInterface.cpp:1619-1626, the SoA fill, both CSR row tables - runs on
+    // host_threads() threads over contiguous record ranges.
     int load(const std::string& path, const std::vector<int32_t>& rlen) {
+        PhaseTimer lt("  las.load");
         if (!file.open(path) || file.n < 12) return -1;
+        file.prefault();
+        lt.mark("prefault");
         novl = rd<int64_t>(file.p);
         tspace = rd<int32_t>(file.p + 8);
         tbytes = tspace <= 125 ? 1 : 2;            // TRACE_XOVR
+        if (novl < 0 || (uint64_t)novl > file.n / 40) return -1;
         const int n_reads = (int)rlen.size();
-        std::vector<int64_t> off((size_t)novl);
-        size_t pos = 12;
-        for (int64_t j = 0; j < novl; j++) {
-            if (pos + 40 > file.n) return -1;
-            off[(size_t)j] = (int64_t)pos;
-            const int tl = rd<int32_t>(file.p + pos);
-            pos += 40 + (size_t)tl * tbytes;
+        UVec<int64_t> off;
+        off.resize((size_t)novl);
+        if (novl > 0 && !off.data()) return -1;
+        {
+            size_t pos = 12;
+            const size_t fn = file.n;
+            for (int64_t j = 0; j < novl; j++) {
+                if (pos + 40 > fn) return -1;
+                off[(size_t)j] = (int64_t)pos;
+                const int tl = rd<int32_t>(file.p + pos);
+                if (tl < 0) return -1;
+                pos += 40 + (size_t)tl * tbytes;
+            }
+            if (pos > fn) return -1;
         }
-        if (pos > file.n) return -1;
+        lt.mark("record chain");
         row_ptr.assign((size_t)n_reads + 1, 0);
         rec_row_ptr.assign((size_t)n_reads + 1, 0);
         rec_b.resize((size_t)novl);
         rec_kept.resize((size_t)novl);
-        int prev_a = -1;
-        int64_t kept = 0;
-        for (int64_t j = 0; j < novl; j++) {
-            const uint8_t* r = file.p + off[(size_t)j];
-            const int a = rd<int32_t>(r + 28), b = rd<int32_t>(r + 32);
-            if (a < 0 || a >= n_reads || b < 0 || b >= n_reads) return -1;
-            if (a < prev_a) return -2;
-            prev_a = a;
-            rec_row_ptr[(size_t)a + 1]++;
-            rec_b[(size_t)j] = b;
-            if (a != b) { row_ptr[(size_t)a + 1]++; rec_kept[(size_t)j] = kept++; }
-            else rec_kept[(size_t)j] = -1;
-        }
-        for (int i = 0; i < n_reads; i++) { row_ptr[(size_t)i + 1] += row_ptr[(size_t)i]; rec_row_ptr[(size_t)i + 1] += rec_row_ptr[(size_t)i]; }
+        const int T = host_threads();
+        std::vector<int64_t> self_cnt((size_t)T + 1, 0);
+        std::vector<int> err((size_t)T, 0);
+        auto a_of = [&](int64_t j) { return rd<int32_t>(file.p + off[(size_t)j] + 28); };
+        // phase A: validate, count self-overlaps per chunk
+        int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(T, novl));
+        parallel_chunks(novl, chunks, [&](int c, int64_t j0, int64_t j1) {
+            int prev_a = j0 > 0 ? a_of(j0 - 1) : -1;
+            int64_t ns = 0;
+            for (int64_t j = j0; j < j1; j++) {
+                const uint8_t* r = file.p + off[(size_t)j];
+                const int a = rd<int32_t>(r + 28), b = rd<int32_t>(r + 32);
+                if (a < 0 || a >= n_reads || b < 0 || b >= n_reads) { err[(size_t)c] = -1; return; }
+                if (a < prev_a) { if (err[(size_t)c] == 0) err[(size_t)c] = -2; }
+                prev_a = a;
+                ns += a == b;
+            }
+            self_cnt[(size_t)c + 1] = ns;
+        });
+        for (int c = 0; c < chunks; c++) if (err[(size_t)c] == -1) return -1;
+        for (int c = 0; c < chunks; c++) if (err[(size_t)c] == -2) return -2;
+        for (int c = 0; c < chunks; c++) self_cnt[(size_t)c + 1] += self_cnt[(size_t)c];
+        lt.mark("validate");
+        const int64_t n_self = self_cnt[(size_t)chunks], kept = novl - n_self;
         a_span.resize((size_t)kept * 2);
         b_span.resize((size_t)kept * 2);
         b_flag.resize((size_t)kept);
         trace_off.resize((size_t)kept);
         tlen.resize((size_t)kept);
-        for (int64_t j = 0; j < novl; j++) {
-            const uint8_t* r = file.p + off[(size_t)j];
-            const int tl = rd<int32_t>(r), abpos = rd<int32_t>(r + 8), bbpos = rd<int32_t>(r + 12), aepos = rd<int32_t>(r + 16),
-                      bepos = rd<int32_t>(r + 20), a = rd<int32_t>(r + 28), b = rd<int32_t>(r + 32);
-            const uint32_t flags = rd<uint32_t>(r + 24);
-            const int comp = (int)(flags & 1u);                       // COMP()
-            int bb = bbpos, be = bepos;
-            if (comp) { bb = rlen[(size_t)b] - bepos; be = rlen[(size_t)b] - bbpos; }   // LAInterface.cpp:1619-1626
-            const int64_t k = rec_kept[(size_t)j];
-            if (k < 0) {
-                self_a.push_back(a);
-                self_span.push_back(abpos); self_span.push_back(aepos); self_span.push_back(bb); self_span.push_back(be);
-                continue;
+        self_a.resize((size_t)n_self);
+        self_span.resize((size_t)n_self * 4);
+        lt.mark("allocate");
+        // phase B: fill.  Records are sorted by A, so row tables are written at the A boundaries:
+        // row_ptr[r] = kept records with aread < r, rec_row_ptr[r] = records with aread < r
+        parallel_chunks(novl, chunks, [&](int c, int64_t j0, int64_t j1) {
+            int64_t si = self_cnt[(size_t)c];
+            int64_t k = j0 - si;
+            int prev_a = j0 > 0 ? a_of(j0 - 1) : -1;
+            for (int64_t j = j0; j < j1; j++) {
+                const uint8_t* r = file.p + off[(size_t)j];
+                const int tl = rd<int32_t>(r), abpos = rd<int32_t>(r + 8), bbpos = rd<int32_t>(r + 12), aepos = rd<int32_t>(r + 16),
+                          bepos = rd<int32_t>(r + 20), a = rd<int32_t>(r + 28), b = rd<int32_t>(r + 32);
+                const uint32_t flags = rd<uint32_t>(r + 24);
+                if (a != prev_a) {
+                    for (int q = prev_a + 1; q <= a; q++) { rec_row_ptr[(size_t)q] = j; row_ptr[(size_t)q] = k; }
+                    prev_a = a;
+                }
+                const int comp = (int)(flags & 1u);                       // COMP()
+                int bb = bbpos, be = bepos;
+                if (comp) { bb = rlen[(size_t)b] - bepos; be = rlen[(size_t)b] - bbpos; }   // LAInterface.cpp:1619-1626
+                rec_b[(size_t)j] = b;
+                if (a == b) {
+                    rec_kept[(size_t)j] = -1;
+                    self_a[(size_t)si] = a;
+                    self_span[(size_t)si * 4] = abpos; self_span[(size_t)si * 4 + 1] = aepos; self_span[(size_t)si * 4 + 2] = bb; self_span[(size_t)si * 4 + 3] = be;
+                    si++;
+                    continue;
+                }
+                rec_kept[(size_t)j] = k;
+                a_span[(size_t)k * 2] = abpos; a_span[(size_t)k * 2 + 1] = aepos;
+                b_span[(size_t)k * 2] = bb; b_span[(size_t)k * 2 + 1] = be;
+                b_flag[(size_t)k] = (uint32_t)b | ((uint32_t)comp << 31);
+                trace_off[(size_t)k] = off[(size_t)j] + 40;
+                tlen[(size_t)k] = tl;
+                k++;
             }
-            a_span[(size_t)k * 2] = abpos; a_span[(size_t)k * 2 + 1] = aepos;
-            b_span[(size_t)k * 2] = bb; b_span[(size_t)k * 2 + 1] = be;
-            b_flag[(size_t)k] = (uint32_t)b | ((uint32_t)comp << 31);
-            trace_off[(size_t)k] = off[(size_t)j] + 40;
-            tlen[(size_t)k] = tl;
+        });
+        lt.mark("fill");
+        {
+            const int last_a = novl > 0 ? a_of(novl - 1) : -1;
+            for (int q = last_a + 1; q <= n_reads; q++) { rec_row_ptr[(size_t)q] = novl; row_ptr[(size_t)q] = kept; }
         }
         if (novl > 0) {
-            r_begin = rd<int32_t>(file.p + off[0] + 28);
-            r_end = rd<int32_t>(file.p + off[(size_t)novl - 1] + 28);
+            r_begin = a_of(0);
+            r_end = a_of(novl - 1);
         }
         return 0;
+    }
+};
+
+// decimal text of v appended at p (no terminator); returns the new end
+inline char* put_int(char* p, long long v) {
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    if (v < 0) *p++ = '-';
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+// `.coverage.txt`: "read i p,c p,c ...\n" per read (filter.cpp:599-602, maximal.cpp:659-685).  nb[k] bins of read
+// r_begin + k start at cov[sum(nb[<k])].  Formatted by host_threads() threads in windows, written in read order.
+inline void write_coverage_txt(FILE* f, int r_begin, const std::vector<int32_t>& nb, const std::vector<int32_t>& cov, int reso) {
+    const int64_t nr = (int64_t)nb.size();
+    std::vector<int64_t> first((size_t)nr + 1, 0);
+    for (int64_t k = 0; k < nr; k++) first[(size_t)k + 1] = first[(size_t)k] + nb[(size_t)k];
+    const int64_t chunk = 256, window = (int64_t)host_threads() * 8;
+    const int64_t n_chunks = (nr + chunk - 1) / chunk;
+    std::vector<std::vector<char>> buf((size_t)std::min(window, std::max<int64_t>(n_chunks, 1)));
+    for (int64_t w0 = 0; w0 < n_chunks; w0 += window) {
+        const int64_t w1 = std::min(n_chunks, w0 + window);
+        parallel_dynamic(w1 - w0, 1, [&](int64_t c0, int64_t c1) {
+            for (int64_t c = c0; c < c1; c++) {
+                const int64_t k0 = (w0 + c) * chunk, k1 = std::min(nr, k0 + chunk);
+                std::vector<char>& b = buf[(size_t)c];
+                b.resize((size_t)((k1 - k0) * 32 + (first[(size_t)k1] - first[(size_t)k0]) * 24));   // upper bound
+                char* p = b.data();
+                for (int64_t k = k0; k < k1; k++) {
+                    memcpy(p, "read ", 5); p += 5;
+                    p = put_int(p, r_begin + k);
+                    *p++ = ' ';
+                    const int32_t* c32 = cov.data() + first[(size_t)k];
+                    for (int j = 0; j < nb[(size_t)k]; j++) {
+                        p = put_int(p, (long long)reso * j);
+                        *p++ = ',';
+                        p = put_int(p, c32[j]);
+                        *p++ = ' ';
+                    }
+                    *p++ = '\n';
+                }
+                b.resize((size_t)(p - b.data()));
+            }
+        });
+        for (int64_t c = 0; c < w1 - w0; c++) fwrite(buf[(size_t)c].data(), 1, buf[(size_t)c].size(), f);
+    }
+}
+
+// HIP runtime initialisation (80-250 ms) and the first .las part's ingest (CPU only) run side by side: the context is
+// created on a helper thread as soon as the arguments are parsed and joined right before its first use.
+struct CtxInit {
+    hinge_ctx* ctx = nullptr;
+    int rc = HINGE_OK;
+    std::thread t;
+    void start() { t = std::thread([this] { rc = hinge_ctx_create(0, &ctx); }); }
+    int join() { if (t.joinable()) t.join(); return rc; }
+    ~CtxInit() { if (t.joinable()) t.join(); }
+};
+// the first part is loaded before the context is joined; later parts when their turn comes
+struct PartLoader {
+    std::unique_ptr<LasPart> first;
+    int first_rc = 0;
+    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first_rc = first->load(path, rlen); }
+    // returns the part (ownership passes to the caller) and its load() code
+    LasPart* take(size_t part, const std::string& path, const std::vector<int32_t>& rlen, int& rc) {
+        if (part == 0 && first) { rc = first_rc; return first.release(); }
+        LasPart* p = new LasPart();
+        rc = p->load(path, rlen);
+        return p;
     }
 };
 

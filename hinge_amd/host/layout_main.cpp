@@ -108,6 +108,9 @@ int main(int argc, char* argv[]) {
 
     Log console;
     console.open(cmdp.get("log"));
+    PhaseTimer tm("layout");
+    CtxInit gpu;
+    gpu.start();
     console.info("Hinging layout");
     const std::string name_db = cmdp.get("db"), name_las_base = cmdp.get("las"), name_paf = cmdp.get("paf"), name_fasta = cmdp.get("fasta");
     const std::string name_config = cmdp.get("config"), out = cmdp.get("prefix"), out_name = cmdp.get("out");
@@ -164,10 +167,17 @@ int main(int argc, char* argv[]) {
         if (eff[(size_t)i * 2 + 1] - eff[(size_t)i * 2] < LENGTH_THRESHOLD) { active[(size_t)i] = 0; fprintf(garbage_out, "%d\n", i); }
     fclose(garbage_out);
 
-    hinge_ctx* ctx = nullptr;
-    if (hinge_ctx_create(0, &ctx) != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    const std::string name_las = las_name(name_las_base, mlas);
+    std::vector<std::string> las_list;
+    if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
+    PartLoader loader;
+    if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
+    tm.mark("setup + las ingest (part 1) || HIP init");
+    if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    hinge_ctx* ctx = gpu.ctx;
     HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), nullptr));
     HH_CHECK(ctx, hinge_set_eff_reads(ctx, eff.data()));
+    tm.mark("setup + ctx_create + set_reads");
 
     // ---- GetAlignment, hinging.cpp:347-610 ---------------------------------------------------------------
     {
@@ -178,36 +188,42 @@ int main(int argc, char* argv[]) {
         for (int i = 0; i < n_read; i++) active[(size_t)i] = active[(size_t)i] && maximal[(size_t)i];
     }
     std::vector<std::vector<Match>> matches_forward((size_t)n_read), matches_backward((size_t)n_read);
-    const std::string name_las = las_name(name_las_base, mlas);
-    std::vector<std::string> las_list;
-    if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
     std::vector<LasPart*> parts;   // kept mapped: GetMatchingPosition needs the traces again
     for (size_t part = 0; part < las_list.size(); part++) {
-        LasPart* lp = new LasPart();
+        int lrc = 0;
+        LasPart* lp = loader.take(part, las_list[part], db.rlen, lrc);
         parts.push_back(lp);
         LasPart& las = *lp;
-        const int lrc = las.load(las_list[part], db.rlen);
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
         if (lrc != 0) { fprintf(stderr, "hinging: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        tm.mark("las ingest");
         if (las.novl == 0) { console.error("No alignments!"); return 2; }
         const int r_begin = las.r_begin, r_end = las.r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
         HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
         HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
+        tm.mark("set_pileups + set_traces (H2D)");
         // pairs between reads that are active now (the map only ever receives active x active records, hinging.cpp:478-490)
         std::vector<std::vector<PairPick>> picks(nr);
         std::vector<int64_t> sel;
         std::vector<int32_t> a_of;
+        parallel_dynamic((int64_t)nr, 64, [&](int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; k++) {
+                const int i = r_begin + (int)k;
+                if (!active[(size_t)i]) continue;
+                pick_pairs(las, i, USE_TWO_MATCHES, 1, [&](int b) { return active[(size_t)b] && KEEP_ONLY_MAX; }, picks[(size_t)k]);
+            }
+        });
         for (int i = r_begin; i <= r_end; i++) {
             if (!active[(size_t)i]) continue;
-            std::vector<PairPick>& pp = picks[(size_t)(i - r_begin)];
-            pick_pairs(las, i, USE_TWO_MATCHES, 1, [&](int b) { return active[(size_t)b] && KEEP_ONLY_MAX; }, pp);
-            for (auto& p : pp)
+            for (auto& p : picks[(size_t)(i - r_begin)])
                 for (int w = 0; w < 2; w++)
                     if (p.pick[w] >= 0) { sel.push_back(p.pick[w]); a_of.push_back(i); }
         }
+        tm.mark("pick_pairs");
         std::vector<Classified> cls(std::max<size_t>(sel.size(), 1));
         HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
+        tm.mark("trim_classify (GPU)");
         size_t c = 0;
         for (int i = r_begin; i <= r_end; i++) {
             // NOTE: `active` is the state BEFORE this loop for the pair filter above (the reference fills idx_ab for the
@@ -235,6 +251,7 @@ int main(int argc, char* argv[]) {
         }
     }
 
+    tm.mark("matches");
     auto by_weight = [](const Match& x, const Match& y) { return x.c.weight > y.c.weight; };   // compare_overlap_weight
     for (int i = 0; i < n_read; i++)
         if (active[(size_t)i]) {
@@ -263,6 +280,7 @@ int main(int argc, char* argv[]) {
         fclose(ob);
     }
 
+    tm.mark("sort + debug dumps");
     FILE* out_g1 = fopen((out_name + ".edges.1").c_str(), "w");
     FILE* out_g2 = fopen((out_name + ".edges.2").c_str(), "w");
     FILE* out_hg = fopen((out_name + ".edges.hinges").c_str(), "w");
@@ -333,6 +351,7 @@ int main(int argc, char* argv[]) {
     std::vector<int> node_base((size_t)n_read + 1, 0);
     for (int i = 0; i < n_read; i++) { node_base[(size_t)i] = num_hinges; num_hinges += (int)hinges_vec[(size_t)i].size(); }
     std::vector<std::pair<int, int>> graph_edges;
+    tm.mark("hinges + matching positions");
     FILE* out_hgraph = fopen((out_name + ".hgraph").c_str(), "w");
     FILE* out_debug = fopen((out_name + ".debug").c_str(), "w");
     fclose(fopen("overlap_debug.txt", "w"));

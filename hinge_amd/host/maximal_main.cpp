@@ -22,6 +22,9 @@ int main(int argc, char* argv[]) {
     cmdp.add_flag("debug", '\0', "debug mode");
     cmdp.parse_check(argc, argv);
 
+    PhaseTimer tm("maximal");
+    CtxInit gpu;
+    gpu.start();
     Log console;
     console.open(cmdp.get("log"));
     console.info("Getting maximal reads");
@@ -68,23 +71,31 @@ int main(int argc, char* argv[]) {
     for (int i = 0; i < n_read; i++)
         if (eff[(size_t)i * 2 + 1] - eff[(size_t)i * 2] < LENGTH_THRESHOLD) active[(size_t)i] = 0;
 
-    hinge_ctx* ctx = nullptr;
-    if (hinge_ctx_create(0, &ctx) != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    tm.mark("db + ini + mas");
+    PartLoader loader;
+    if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
+    tm.mark("las ingest (part 1) || HIP init");
+    if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    hinge_ctx* ctx = gpu.ctx;
     HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), nullptr));
     HH_CHECK(ctx, hinge_set_eff_reads(ctx, eff.data()));
+    tm.mark("ctx_create + set_reads");
 
     for (size_t part = 0; part < las_list.size(); part++) {
         console.info("name of las: %s", las_list[part].c_str());
-        LasPart las;
-        const int lrc = las.load(las_list[part], db.rlen);
+        int lrc = 0;
+        std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
+        LasPart& las = *las_owner;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
         if (lrc != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        tm.mark("las ingest");
         if (las.novl == 0) { console.error("No alignments!"); return 1; }
         const int r_begin = las.r_begin, r_end = las.r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
         HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
         HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
 
+        tm.mark("set_pileups + set_traces (H2D)");
         // .coverage.txt is truncated and rewritten with the same content (maximal.cpp:517,659-685)
         {
             std::vector<int32_t> nb(nr);
@@ -93,30 +104,33 @@ int main(int argc, char* argv[]) {
             for (size_t k = 0; k < nr; k++) tot += nb[k];
             std::vector<int32_t> cov((size_t)std::max<int64_t>(tot, 1));
             HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, reso, 0, nb.data(), cov.data(), tot));
-            int64_t o = 0;
-            for (size_t k = 0; k < nr; k++) {
-                fprintf(f_cov, "read %d ", r_begin + (int)k);
-                for (int j = 0; j < nb[k]; j++) fprintf(f_cov, "%d,%d ", reso * j, cov[(size_t)(o + j)]);
-                fprintf(f_cov, "\n");
-                o += nb[k];
-            }
+            write_coverage_txt(f_cov, r_begin, nb, cov, reso);
         }
 
+        tm.mark("coverage.txt");
         // pairs of every read that is active when its turn comes (activity only changes at a read's own turn)
         std::vector<std::vector<PairPick>> picks(nr);
         std::vector<int64_t> sel;
         std::vector<int32_t> a_of;
+        // every read's grouping is independent (activity does not change before the containment pass below)
+        parallel_dynamic((int64_t)nr, 64, [&](int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; k++) {
+                const int i = r_begin + (int)k;
+                if (!active[(size_t)i]) continue;
+                pick_pairs(las, i, USE_TWO_MATCHES, 2, [](int) { return true; }, picks[(size_t)k]);
+            }
+        });
         for (int i = r_begin; i <= r_end; i++) {
             if (!active[(size_t)i]) continue;
-            std::vector<PairPick>& pp = picks[(size_t)(i - r_begin)];
-            pick_pairs(las, i, USE_TWO_MATCHES, 2, [](int) { return true; }, pp);
-            for (auto& p : pp)
+            for (auto& p : picks[(size_t)(i - r_begin)])
                 for (int w = 0; w < 2; w++)
                     if (p.pick[w] >= 0) { sel.push_back(p.pick[w]); a_of.push_back(i); }
         }
+        tm.mark("pick_pairs");
         std::vector<Classified> cls(std::max<size_t>(sel.size(), 1));
         HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
 
+        tm.mark("trim_classify (GPU)");
         // sequential containment resolution, maximal.cpp:780-858
         size_t c = 0;
         int64_t n_classified = 0;
@@ -140,6 +154,7 @@ int main(int argc, char* argv[]) {
         int n_active = 0;
         for (int i = r_begin; i <= r_end; i++)
             if (active[(size_t)i]) { n_active++; fprintf(f_max, "%d\n", i); }
+        tm.mark("containment + max txt");
         console.info("classified %lld overlaps; removed contained reads, active reads: %d / %zu", (long long)n_classified, n_active, nr);
     }
     fclose(f_cov); fclose(f_contained); fclose(f_max);

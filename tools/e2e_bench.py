@@ -57,9 +57,10 @@ def main():
         for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
             t0 = time.perf_counter()
             r = subprocess.run([hinge, sub, "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini"] + extra, cwd=dirs["hip"],
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, HINGE_HOST_TIMING="1"))
             g[sub] = time.perf_counter() - t0
             assert r.returncode == 0, r.stderr.decode()[-1000:]
+            sys.stderr.write("".join(l + "\n" for l in r.stderr.decode().splitlines() if l.startswith("[timing]")))
         out["gpu_cli_s"] = g
         same = all(filecmp.cmp(os.path.join(dirs["oracle"], "G" + s), os.path.join(dirs["hip"], "G" + s), shallow=False)
                    for s in (".mas", ".repeat.txt", ".hinges.txt", ".max", ".edges.hinges", ".hinge.list", ".deadends.txt", ".coverage.txt"))
