@@ -480,6 +480,93 @@ struct LasPart {
         return ok ? 0 : -1;
     }
 
+    // A record that could start at byte p: every field in range for this DB.  Only used to GUESS where a thread may
+    // start walking; guesses are verified against the true chain below, so a wrong guess costs time, never correctness.
+    bool plausible(size_t p, const std::vector<int32_t>& rlen) const {
+        if (p + 40 > file.n) return false;
+        const uint8_t* r = file.p + p;
+        const int tl = rd<int32_t>(r), abpos = rd<int32_t>(r + 8), bbpos = rd<int32_t>(r + 12), aepos = rd<int32_t>(r + 16),
+                  bepos = rd<int32_t>(r + 20), a = rd<int32_t>(r + 28), b = rd<int32_t>(r + 32);
+        const uint32_t flags = rd<uint32_t>(r + 24);
+        const int n_reads = (int)rlen.size();
+        if (tl < 0 || (tl & 1) || p + 40 + (size_t)tl * tbytes > file.n) return false;
+        if (a < 0 || a >= n_reads || b < 0 || b >= n_reads || flags >= 64u) return false;
+        if (abpos < 0 || abpos >= aepos || aepos > rlen[(size_t)a] || bbpos < 0 || bbpos >= bepos || bepos > rlen[(size_t)b]) return false;
+        if (tl / 2 != (aepos + tspace - 1) / tspace - abpos / tspace) return false;   // one (diffs, b-advance) pair per tspace panel of A
+        return true;
+    }
+
+    // off[j] = byte offset of record j.  Every record's position depends on the previous tlen, so one thread walking a
+    // 5 GB file is ~0.5 s.  Instead the file is cut into byte ranges; each thread guesses the first record start in its
+    // range (first position from which 16 consecutive records look plausible), walks to the end of its range, and the
+    // pieces are accepted only if every walk ends exactly where the next one started.  Anything else (an unusual
+    // writer, corrupt data, a false guess) falls back to the sequential walk, which also produces the error codes.
+    mutable bool indexed_in_pieces = false;   // diagnostics: the verified multi-thread walk was used
+    bool index_records(UVec<int64_t>& off, const std::vector<int32_t>& rlen) const {
+        const size_t fn = file.n;
+        const int T = host_threads();
+        const size_t body = fn - 12;
+        if (T > 1 && novl >= (int64_t)T * 64 && body / (size_t)T > (64u << 10)) {
+            const int S = T;
+            std::vector<size_t> start((size_t)S + 1, 0), stop((size_t)S, 0);
+            std::vector<std::vector<int64_t>> pieces((size_t)S);
+            std::vector<char> ok((size_t)S, 0);
+            start[0] = 12;
+            start[(size_t)S] = fn;
+            parallel_chunks(S, S, [&](int c, int64_t, int64_t) {
+                size_t p = 12 + body * (size_t)c / (size_t)S;
+                if (c > 0) {   // guess: first byte position from which 16 records in a row are plausible
+                    const size_t limit = std::min(fn, p + (1u << 20));
+                    bool found = false;
+                    for (; p < limit; p++) {
+                        size_t q = p;
+                        int good = 0;
+                        while (good < 16 && q < fn && plausible(q, rlen)) { q += 40 + (size_t)rd<int32_t>(file.p + q) * tbytes; good++; }
+                        if (good == 16 || (good > 0 && q == fn)) { found = true; break; }
+                    }
+                    if (!found) return;
+                    start[(size_t)c] = p;
+                }
+                const size_t end = c + 1 < S ? 12 + body * (size_t)(c + 1) / (size_t)S : fn;
+                std::vector<int64_t>& v = pieces[(size_t)c];
+                v.reserve((size_t)(novl / S + novl / (8 * S) + 1024));
+                while (p < end) {
+                    if (p + 40 > fn) return;
+                    const int tl = rd<int32_t>(file.p + p);
+                    if (tl < 0) return;
+                    v.push_back((int64_t)p);
+                    p += 40 + (size_t)tl * tbytes;
+                }
+                stop[(size_t)c] = p;
+                ok[(size_t)c] = 1;
+            });
+            bool all = true;
+            int64_t total = 0;
+            for (int c = 0; c < S && all; c++) {
+                all = ok[(size_t)c] && stop[(size_t)c] == start[(size_t)c + 1];
+                total += (int64_t)pieces[(size_t)c].size();
+            }
+            if (all && total == novl) {
+                std::vector<int64_t> base((size_t)S + 1, 0);
+                for (int c = 0; c < S; c++) base[(size_t)c + 1] = base[(size_t)c] + (int64_t)pieces[(size_t)c].size();
+                parallel_chunks(S, S, [&](int c, int64_t, int64_t) {
+                    if (!pieces[(size_t)c].empty()) memcpy(off.data() + base[(size_t)c], pieces[(size_t)c].data(), pieces[(size_t)c].size() * sizeof(int64_t));
+                });
+                indexed_in_pieces = true;
+                return true;
+            }
+        }
+        size_t pos = 12;
+        for (int64_t j = 0; j < novl; j++) {
+            if (pos + 40 > fn) return false;
+            off[(size_t)j] = (int64_t)pos;
+            const int tl = rd<int32_t>(file.p + pos);
+            if (tl < 0) return false;
+            pos += 40 + (size_t)tl * tbytes;
+        }
+        return pos <= fn;
+    }
+
     // 0 ok; -1 cannot open / truncated (reference: exit(1)); -2 records not grouped by ascending A read
     // The record chain (every record's position depends on the previous tlen) is walked once; everything else -
     // validation, the strand flip of LAInterface.cpp:1619-1626, the SoA fill, both CSR row tables - runs on
@@ -497,19 +584,8 @@ struct LasPart {
         UVec<int64_t> off;
         off.resize((size_t)novl);
         if (novl > 0 && !off.data()) return -1;
-        {
-            size_t pos = 12;
-            const size_t fn = file.n;
-            for (int64_t j = 0; j < novl; j++) {
-                if (pos + 40 > fn) return -1;
-                off[(size_t)j] = (int64_t)pos;
-                const int tl = rd<int32_t>(file.p + pos);
-                if (tl < 0) return -1;
-                pos += 40 + (size_t)tl * tbytes;
-            }
-            if (pos > fn) return -1;
-        }
-        lt.mark("record chain");
+        if (!index_records(off, rlen)) return -1;
+        lt.mark(indexed_in_pieces ? "record chain (pieces)" : "record chain (1 thread)");
         row_ptr.assign((size_t)n_reads + 1, 0);
         rec_row_ptr.assign((size_t)n_reads + 1, 0);
         rec_b.resize((size_t)novl);

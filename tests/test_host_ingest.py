@@ -1,0 +1,112 @@
+"""CPU: the executables' threaded .las ingest (hinge_amd/host/host_common.h, LasPart::load) against the numpy reader,
+for 1 thread (sequential record walk) and many (guessed piece starts, verified against the chain)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from hinge_amd import formats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def ingest_dump(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("host") / "ingest_dump")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "host", "ingest_dump.cpp")], check=True)
+    return exe
+
+
+def _dump(exe, db, las, out, threads, how=None):
+    r = subprocess.run([exe, db, las, out], env=dict(os.environ, HINGE_THREADS=str(threads)), stdout=subprocess.PIPE)
+    if how is not None:
+        how.append(r.stdout.decode().strip())
+    return r.returncode
+
+
+def _read_dump(path):
+    raw = open(path, "rb").read()
+    hdr = np.frombuffer(raw, np.int64, 4)
+    pos = 32
+    cols = []
+    for dt in (np.int64, np.int32, np.int32, np.uint32, np.int64, np.int32, np.int64, np.int32, np.int64, np.int32, np.int32):
+        n = int(np.frombuffer(raw, np.int64, 1, pos)[0])
+        pos += 8
+        cols.append(np.frombuffer(raw, dt, n, pos).copy())
+        pos += n * np.dtype(dt).itemsize
+    assert pos == len(raw)
+    return hdr, cols
+
+
+@pytest.mark.parametrize("name,las", [("tiny", "G.las"), ("tiny_mlas", "G.2.las"), ("ties", "G.las"), ("long_reads", "G.las")])
+def test_ingest_matches_numpy_reader(datasets, ingest_dump, tmp_path, name, las):
+    wd, d = datasets(name)
+    db, lasp = os.path.join(wd, "G"), os.path.join(wd, las)
+    recs = formats.read_las(lasp)
+    pile = formats.pileups_from_las(recs, d.rlen)
+    ref = None
+    for threads in (1, 3, 32):
+        out = str(tmp_path / ("dump%d.bin" % threads))
+        how = []
+        assert _dump(ingest_dump, db, lasp, out, threads, how) == 0
+        assert how == ["sequential" if threads == 1 else "pieces"], how
+        hdr, c = _read_dump(out)
+        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span = c
+        assert hdr[0] == recs.novl and hdr[1] == recs.tspace
+        assert hdr[2] == recs.rec["aread"][0] and hdr[3] == recs.rec["aread"][-1]
+        np.testing.assert_array_equal(row_ptr, pile.row_ptr)
+        np.testing.assert_array_equal(a_span, pile.a_span.ravel())
+        np.testing.assert_array_equal(b_span, pile.b_span.ravel())
+        np.testing.assert_array_equal(b_flag, pile.b_flag)
+        np.testing.assert_array_equal(tlen, recs.rec["tlen"][pile.las_index])
+        np.testing.assert_array_equal(rec_b, recs.rec["bread"])
+        kept = np.full(recs.novl, -1, np.int64)
+        kept[pile.las_index] = np.arange(len(pile.las_index))
+        np.testing.assert_array_equal(rec_kept, kept)
+        np.testing.assert_array_equal(rec_row_ptr, np.concatenate([[0], np.cumsum(np.bincount(recs.rec["aread"], minlength=len(d.rlen)))]))
+        np.testing.assert_array_equal(self_a, pile.self_a)
+        np.testing.assert_array_equal(self_span, pile.self_span.ravel())
+        # trace offsets: 12-byte header, 40-byte records, tlen * tbytes trace bytes each
+        sizes = 40 + recs.rec["tlen"].astype(np.int64) * (1 if recs.tspace <= 125 else 2)
+        starts = 12 + np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        np.testing.assert_array_equal(trace_off, starts[pile.las_index] + 40)
+        if ref is None:
+            ref = open(out, "rb").read()
+        else:
+            assert open(out, "rb").read() == ref, "result depends on the number of threads"
+
+
+def test_ingest_rejects_damaged_files(datasets, ingest_dump, tmp_path):
+    wd, d = datasets("tiny")
+    db = os.path.join(wd, "G")
+    raw = open(os.path.join(wd, "G.las"), "rb").read()
+    out = str(tmp_path / "o.bin")
+    cases = {}
+    cases["truncated"] = raw[: len(raw) * 2 // 3]
+    cases["count_too_large"] = np.int64(np.frombuffer(raw, np.int64, 1)[0] + 5).tobytes() + raw[8:]
+    mid = 12 + (len(raw) - 12) // 2
+    cases["garbage_in_the_middle"] = raw[:mid] + bytes(4096) + raw[mid + 4096:]
+    for name, blob in cases.items():
+        p = str(tmp_path / (name + ".las"))
+        open(p, "wb").write(blob)
+        codes = {t: _dump(ingest_dump, db, p, out, t) for t in (1, 32)}
+        assert codes[1] == codes[32], (name, codes)
+        assert codes[1] != 0 or name == "garbage_in_the_middle", (name, codes)
+        if codes[1] == 0:   # whatever the sequential walk makes of the garbage, the threaded walk must make the same of it
+            a = str(tmp_path / "a.bin")
+            b = str(tmp_path / "b.bin")
+            assert _dump(ingest_dump, db, p, a, 1) == 0 and _dump(ingest_dump, db, p, b, 32) == 0
+            assert open(a, "rb").read() == open(b, "rb").read()
+    # records not sorted by A read: -2
+    recs = formats.read_las(os.path.join(wd, "G.las"))
+    import copy
+    r2 = copy.copy(recs)
+    r2.rec = recs.rec.copy()
+    n = recs.novl
+    r2.rec["aread"][n // 2] = recs.rec["aread"][-1]
+    p = str(tmp_path / "unsorted.las")
+    formats.write_las(p, r2)
+    for t in (1, 32):
+        assert _dump(ingest_dump, db, p, out, t) == 254
