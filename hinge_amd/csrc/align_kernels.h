@@ -59,7 +59,8 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
                                                          const unsigned* __restrict__ b_flag, const unsigned char* __restrict__ trace,
                                                          const int64_t* __restrict__ trace_off, const int* __restrict__ tlen,
                                                          const int2* __restrict__ eff /*[n_reads] effective_start/end*/, int aln_threshold,
-                                                         int theta, int theta2, ClassifyOut* __restrict__ out) {
+                                                         int theta, int theta2, ClassifyOut* __restrict__ out,
+                                                         unsigned char* __restrict__ type_out /*nullptr, or only the match type is wanted*/) {
     const int lane = lane_id();
     const int r = lane & 15;              // lane inside the row
     const int row = lane >> 4;            // 0..3
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
             o.length = av.y - av.x + bs.y - bs.x;
             o.start_idx = start_idx;
             o.end_idx = end_idx;
-            out[j] = o;
+            if (type_out) type_out[j] = (unsigned char)o.type; else out[j] = o;
         }
     }
 }

@@ -263,7 +263,7 @@ inline int host_threads() {
     static int n = [] {
         if (const char* e = getenv("HINGE_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 256); }
         const unsigned hw = std::thread::hardware_concurrency();
-        return (int)std::min<unsigned>(std::max<unsigned>(hw, 1u), 32u);
+        return (int)std::min<unsigned>(std::max<unsigned>(hw, 1u), 64u);
     }();
     return n;
 }

@@ -108,27 +108,50 @@ int main(int argc, char* argv[]) {
         }
 
         tm.mark("coverage.txt");
-        // pairs of every read that is active when its turn comes (activity only changes at a read's own turn)
-        std::vector<std::vector<PairPick>> picks(nr);
-        std::vector<int64_t> sel;
-        std::vector<int32_t> a_of;
-        // every read's grouping is independent (activity does not change before the containment pass below)
-        parallel_dynamic((int64_t)nr, 64, [&](int64_t k0, int64_t k1) {
-            for (int64_t k = k0; k < k1; k++) {
-                const int i = r_begin + (int)k;
-                if (!active[(size_t)i]) continue;
-                pick_pairs(las, i, USE_TWO_MATCHES, 2, [](int) { return true; }, picks[(size_t)k]);
+        // pairs of every read that is active when its turn comes (activity only changes at a read's own turn).
+        // Every read's grouping is independent: chunks of 64 reads go to host threads, each chunk emits its selected
+        // overlaps (best one or two per (A,B) pair, in the map's iteration order) into its own buffer; the buffers
+        // are stitched in read order.  B of a selected overlap is in b_flag, so nothing else has to be kept.
+        const int64_t CH = 64, n_chunks = ((int64_t)nr + CH - 1) / CH;
+        std::vector<std::vector<int64_t>> chunk_sel((size_t)n_chunks);
+        std::vector<int32_t> n_sel_of(nr, 0);
+        parallel_dynamic(n_chunks, 1, [&](int64_t c0, int64_t c1) {
+            std::vector<PairPick> pp;
+            for (int64_t c = c0; c < c1; c++) {
+                const int64_t k0 = c * CH, k1 = std::min<int64_t>((int64_t)nr, k0 + CH);
+                std::vector<int64_t>& out = chunk_sel[(size_t)c];
+                out.reserve((size_t)(las.rec_row_ptr[(size_t)(r_begin + k1)] - las.rec_row_ptr[(size_t)(r_begin + k0)]));
+                for (int64_t k = k0; k < k1; k++) {
+                    const int i = r_begin + (int)k;
+                    if (!active[(size_t)i]) continue;
+                    pick_pairs(las, i, USE_TWO_MATCHES, 2, [](int) { return true; }, pp);
+                    int cnt = 0;
+                    for (auto& p : pp)
+                        for (int w = 0; w < 2; w++)
+                            if (p.pick[w] >= 0) { out.push_back(p.pick[w]); cnt++; }
+                    n_sel_of[(size_t)k] = cnt;
+                }
             }
         });
-        for (int i = r_begin; i <= r_end; i++) {
-            if (!active[(size_t)i]) continue;
-            for (auto& p : picks[(size_t)(i - r_begin)])
-                for (int w = 0; w < 2; w++)
-                    if (p.pick[w] >= 0) { sel.push_back(p.pick[w]); a_of.push_back(i); }
-        }
+        std::vector<int64_t> chunk_base((size_t)n_chunks + 1, 0);
+        for (int64_t c = 0; c < n_chunks; c++) chunk_base[(size_t)c + 1] = chunk_base[(size_t)c] + (int64_t)chunk_sel[(size_t)c].size();
+        const int64_t n_sel = chunk_base[(size_t)n_chunks];
+        UVec<int64_t> sel;
+        UVec<int32_t> a_of;
+        UVec<uint8_t> mtype;
+        sel.resize((size_t)std::max<int64_t>(n_sel, 1)); a_of.resize((size_t)std::max<int64_t>(n_sel, 1)); mtype.resize((size_t)std::max<int64_t>(n_sel, 1));
+        parallel_dynamic(n_chunks, 16, [&](int64_t c0, int64_t c1) {
+            for (int64_t c = c0; c < c1; c++) {
+                int64_t o = chunk_base[(size_t)c];
+                if (!chunk_sel[(size_t)c].empty()) memcpy(sel.data() + o, chunk_sel[(size_t)c].data(), chunk_sel[(size_t)c].size() * sizeof(int64_t));
+                const int64_t k0 = c * CH, k1 = std::min<int64_t>((int64_t)nr, k0 + CH);
+                for (int64_t k = k0; k < k1; k++)
+                    for (int t = 0; t < n_sel_of[(size_t)k]; t++) a_of[(size_t)o++] = r_begin + (int)k;
+                std::vector<int64_t>().swap(chunk_sel[(size_t)c]);
+            }
+        });
         tm.mark("pick_pairs");
-        std::vector<Classified> cls(std::max<size_t>(sel.size(), 1));
-        HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
+        HH_CHECK(ctx, hinge_trim_classify_types(ctx, n_sel, sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, mtype.data()));
 
         tm.mark("trim_classify (GPU)");
         // sequential containment resolution, maximal.cpp:780-858
@@ -138,14 +161,13 @@ int main(int argc, char* argv[]) {
             if (!active[(size_t)i]) continue;
             bool contained = false;
             int containing_read = 0;
-            for (auto& p : picks[(size_t)(i - r_begin)])
-                for (int w = 0; w < 2; w++) {
-                    if (p.pick[w] < 0) continue;
-                    const bool ca = cls[c++].type == MT_BCOVERA;
-                    n_classified++;
-                    if (ca) containing_read = p.b;
-                    if (active[(size_t)p.b]) contained = contained || ca;
-                }
+            for (int t = 0; t < n_sel_of[(size_t)(i - r_begin)]; t++, c++) {
+                const int b = (int)(las.b_flag[(size_t)sel[c]] & 0x7fffffffu);
+                const bool ca = mtype[c] == MT_BCOVERA;
+                n_classified++;
+                if (ca) containing_read = b;
+                if (active[(size_t)b]) contained = contained || ca;
+            }
             if (contained) {
                 active[(size_t)i] = 0;
                 fprintf(f_contained, "%d\t%d\n", i, containing_read);

@@ -9,6 +9,7 @@
 // of the same libstdc++ here.  Only the selected overlaps (at most two per pair) go to the GPU.
 #pragma once
 #include <algorithm>
+#include <memory_resource>
 #include <unordered_map>
 #include <vector>
 #include "host_common.h"
@@ -28,11 +29,18 @@ inline void pick_pairs(const LasPart& las, int a, bool two_matches, int n_sorts,
     out.clear();
     const int64_t r0 = las.rec_row_ptr[(size_t)a], r1 = las.rec_row_ptr[(size_t)a + 1];
     if (r0 == r1) return;
-    std::unordered_map<int, std::vector<int64_t>> groups;   // B -> record indices, in record order
+    // Same container, hash, rehash policy and insertion sequence as the reference (so the same iteration order); only the
+    // memory comes from a per-thread bump arena that is released once per read instead of ~4 malloc/free per record.
+    // (the buffer is owned by the thread: release() rewinds to it without touching the upstream allocator)
+    thread_local std::vector<char> arena_buf(1 << 20);
+    thread_local std::pmr::monotonic_buffer_resource arena(arena_buf.data(), arena_buf.size());
+    struct Release { std::pmr::monotonic_buffer_resource& a; ~Release() { a.release(); } };
+    Release release_after_groups{arena};   // declared BEFORE `groups`: destroyed after it
+    std::pmr::unordered_map<int, std::pmr::vector<int64_t>> groups(&arena);   // B -> record indices, in record order
     for (int64_t j = r0; j < r1; j++) {
         const int b = las.rec_b[(size_t)j];
         if (!accept(b)) continue;
-        groups[b] = std::vector<int64_t>();                 // same insertion sequence as the reference's first loop
+        groups[b] = std::pmr::vector<int64_t>(&arena);      // same insertion sequence as the reference's first loop
     }
     for (int64_t j = r0; j < r1; j++) {
         const int b = las.rec_b[(size_t)j];
@@ -44,7 +52,7 @@ inline void pick_pairs(const LasPart& las, int a, bool two_matches, int n_sorts,
         return (long long)(las.a_span[(size_t)k * 2 + 1] - las.a_span[(size_t)k * 2]) + (las.b_span[(size_t)k * 2 + 1] - las.b_span[(size_t)k * 2]);
     };
     for (auto it = groups.begin(); it != groups.end(); ++it) {
-        std::vector<int64_t>& v = it->second;
+        std::pmr::vector<int64_t>& v = it->second;
         if (it->first == a) {   // the (A, A) pair: its overlaps are inactive, ProcessAlignment makes them NOT_ACTIVE and nothing
                                 // reads them again; the key itself had to be in the map for the iteration order of the others
             PairPick p{it->first, {-1, -1}};

@@ -139,6 +139,10 @@ int hinge_set_eff_reads(hinge_ctx* ctx, const int32_t* eff);
  * eff_bb, eff_be, match type (enum of LAInterface.h:30-33), active, weight, length, start idx, end idx.       */
 int hinge_trim_classify(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel, const int32_t* a_of, int32_t aln_threshold, int32_t theta,
                         int32_t theta2, int32_t* out);
+/* The same, returning only the match type (one byte per overlap): all `hinge maximal` reads of the result is
+ * `type == BCOVERA` (maximal.cpp:805-857), and 1 byte instead of 40 per overlap comes back over PCIe.            */
+int hinge_trim_classify_types(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel, const int32_t* a_of, int32_t aln_threshold, int32_t theta,
+                              int32_t theta2, uint8_t* type_out);
 /* LOverlap::GetMatchingPosition (LAInterface.cpp:4498-4546) for nq (overlap, position on A) queries.        */
 int hinge_matching_position(hinge_ctx* ctx, int64_t nq, const int64_t* q_ovl, const int32_t* q_pos, int32_t* out);
 
