@@ -62,6 +62,7 @@ int main(int argc, char* argv[]) {
 
     tm.mark("db + qual + ini");
     PartLoader loader;
+    loader.pairs = false;
     if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }

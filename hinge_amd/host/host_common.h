@@ -571,7 +571,8 @@ struct LasPart {
     // The record chain (every record's position depends on the previous tlen) is walked once; everything else -
     // validation, the strand flip of LAInterface.cpp:1619-1626, the SoA fill, both CSR row tables - runs on
     // host_threads() threads over contiguous record ranges.
-    int load(const std::string& path, const std::vector<int32_t>& rlen) {
+    // pairs = false: skip the columns only maximal / layout read (per-record B and kept index, trace offsets, tlen)
+    int load(const std::string& path, const std::vector<int32_t>& rlen, bool pairs = true) {
         PhaseTimer lt("  las.load");
         if (!file.open(path) || file.n < 12) return -1;
         file.prefault();
@@ -588,8 +589,7 @@ struct LasPart {
         lt.mark(indexed_in_pieces ? "record chain (pieces)" : "record chain (1 thread)");
         row_ptr.assign((size_t)n_reads + 1, 0);
         rec_row_ptr.assign((size_t)n_reads + 1, 0);
-        rec_b.resize((size_t)novl);
-        rec_kept.resize((size_t)novl);
+        if (pairs) { rec_b.resize((size_t)novl); rec_kept.resize((size_t)novl); }
         const int T = host_threads();
         std::vector<int64_t> self_cnt((size_t)T + 1, 0);
         std::vector<int> err((size_t)T, 0);
@@ -617,8 +617,7 @@ struct LasPart {
         a_span.resize((size_t)kept * 2);
         b_span.resize((size_t)kept * 2);
         b_flag.resize((size_t)kept);
-        trace_off.resize((size_t)kept);
-        tlen.resize((size_t)kept);
+        if (pairs) { trace_off.resize((size_t)kept); tlen.resize((size_t)kept); }
         self_a.resize((size_t)n_self);
         self_span.resize((size_t)n_self * 4);
         lt.mark("allocate");
@@ -640,20 +639,19 @@ struct LasPart {
                 const int comp = (int)(flags & 1u);                       // COMP()
                 int bb = bbpos, be = bepos;
                 if (comp) { bb = rlen[(size_t)b] - bepos; be = rlen[(size_t)b] - bbpos; }   // LAInterface.cpp:1619-1626
-                rec_b[(size_t)j] = b;
+                if (pairs) rec_b[(size_t)j] = b;
                 if (a == b) {
-                    rec_kept[(size_t)j] = -1;
+                    if (pairs) rec_kept[(size_t)j] = -1;
                     self_a[(size_t)si] = a;
                     self_span[(size_t)si * 4] = abpos; self_span[(size_t)si * 4 + 1] = aepos; self_span[(size_t)si * 4 + 2] = bb; self_span[(size_t)si * 4 + 3] = be;
                     si++;
                     continue;
                 }
-                rec_kept[(size_t)j] = k;
+                if (pairs) rec_kept[(size_t)j] = k;
                 a_span[(size_t)k * 2] = abpos; a_span[(size_t)k * 2 + 1] = aepos;
                 b_span[(size_t)k * 2] = bb; b_span[(size_t)k * 2 + 1] = be;
                 b_flag[(size_t)k] = (uint32_t)b | ((uint32_t)comp << 31);
-                trace_off[(size_t)k] = off[(size_t)j] + 40;
-                tlen[(size_t)k] = tl;
+                if (pairs) { trace_off[(size_t)k] = off[(size_t)j] + 40; tlen[(size_t)k] = tl; }
                 k++;
             }
         });
@@ -732,12 +730,13 @@ struct CtxInit {
 struct PartLoader {
     std::unique_ptr<LasPart> first;
     int first_rc = 0;
-    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first_rc = first->load(path, rlen); }
+    bool pairs = true;   // false in `hinge filter`: see LasPart::load
+    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first_rc = first->load(path, rlen, pairs); }
     // returns the part (ownership passes to the caller) and its load() code
     LasPart* take(size_t part, const std::string& path, const std::vector<int32_t>& rlen, int& rc) {
         if (part == 0 && first) { rc = first_rc; return first.release(); }
         LasPart* p = new LasPart();
-        rc = p->load(path, rlen);
+        rc = p->load(path, rlen, pairs);
         return p;
     }
 };

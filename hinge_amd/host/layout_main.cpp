@@ -92,6 +92,45 @@ std::vector<int> components(int n, const std::vector<std::pair<int, int>>& edges
 
 }  // namespace
 
+// The overlaps of one .las part that layout sends to the GPU, packed: SoA rows in selection order (= A read order)
+// and their trace bytes back to back.
+struct PackedPart {
+    int r_begin = 0, r_end = -1, tbytes = 1;
+    std::vector<int64_t> row_ptr;
+    std::vector<int32_t> a_span, b_span, tlen;
+    std::vector<uint32_t> b_flag;
+    std::vector<int64_t> trace_off;
+    std::vector<uint8_t> trace;
+    void build(const LasPart& las, const std::vector<int64_t>& sel, const std::vector<int32_t>& a_of, int n_read) {
+        r_begin = las.r_begin; r_end = las.r_end; tbytes = las.tbytes;
+        const size_t n = sel.size();
+        row_ptr.assign((size_t)n_read + 1, 0);
+        for (size_t t = 0; t < n; t++) row_ptr[(size_t)a_of[t] + 1]++;
+        for (int i = 0; i < n_read; i++) row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
+        a_span.resize(2 * n); b_span.resize(2 * n); tlen.resize(n); b_flag.resize(n); trace_off.resize(n);
+        int64_t bytes = 0;
+        for (size_t t = 0; t < n; t++) {
+            const size_t k = (size_t)sel[t];
+            a_span[2 * t] = las.a_span[2 * k]; a_span[2 * t + 1] = las.a_span[2 * k + 1];
+            b_span[2 * t] = las.b_span[2 * k]; b_span[2 * t + 1] = las.b_span[2 * k + 1];
+            b_flag[t] = las.b_flag[k];
+            tlen[t] = las.tlen[k];
+            trace_off[t] = bytes;
+            bytes += (int64_t)las.tlen[k] * las.tbytes;
+        }
+        trace.resize((size_t)std::max<int64_t>(bytes, 1));
+        for (size_t t = 0; t < n; t++) {
+            const size_t k = (size_t)sel[t];
+            memcpy(trace.data() + trace_off[t], las.file.p + las.trace_off[k], (size_t)las.tlen[k] * (size_t)las.tbytes);
+        }
+    }
+    int upload(hinge_ctx* ctx) const {
+        int rc = hinge_set_pileups(ctx, r_begin, r_end, (int64_t)b_flag.size(), row_ptr.data(), a_span.data(), b_span.data(), b_flag.data(), 0);
+        if (rc != HINGE_OK) return rc;
+        return hinge_set_traces(ctx, trace.data(), (int64_t)trace.size(), trace_off.data(), tlen.data(), tbytes, 0);
+    }
+};
+
 int main(int argc, char* argv[]) {
     CmdLine cmdp;
     cmdp.add_string("db", 'b', "db file name", false, "");
@@ -188,7 +227,9 @@ int main(int argc, char* argv[]) {
         for (int i = 0; i < n_read; i++) active[(size_t)i] = active[(size_t)i] && maximal[(size_t)i];
     }
     std::vector<std::vector<Match>> matches_forward((size_t)n_read), matches_backward((size_t)n_read);
-    std::vector<LasPart*> parts;   // kept mapped: GetMatchingPosition needs the traces again
+    std::vector<LasPart*> parts;
+    std::vector<PackedPart*> packed;   // the selected overlaps of every part (GetMatchingPosition needs their traces again)
+    int resident_part = -1;            // which packed part the GPU context currently holds
     for (size_t part = 0; part < las_list.size(); part++) {
         int lrc = 0;
         LasPart* lp = loader.take(part, las_list[part], db.rlen, lrc);
@@ -200,9 +241,6 @@ int main(int argc, char* argv[]) {
         if (las.novl == 0) { console.error("No alignments!"); return 2; }
         const int r_begin = las.r_begin, r_end = las.r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
-        HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
-        HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
-        tm.mark("set_pileups + set_traces (H2D)");
         // pairs between reads that are active now (the map only ever receives active x active records, hinging.cpp:478-490)
         std::vector<std::vector<PairPick>> picks(nr);
         std::vector<int64_t> sel;
@@ -221,8 +259,17 @@ int main(int argc, char* argv[]) {
                     if (p.pick[w] >= 0) { sel.push_back(p.pick[w]); a_of.push_back(i); }
         }
         tm.mark("pick_pairs");
+        // Only the selected overlaps (active x active pairs, best one or two each: thousands out of tens of millions) go to
+        // the GPU: their SoA rows and trace bytes are packed here; Match.k is the index into this packed part.
+        PackedPart* pk = new PackedPart();
+        packed.push_back(pk);
+        pk->build(las, sel, a_of, n_read);
+        if (!sel.empty()) { HH_CHECK(ctx, pk->upload(ctx)); resident_part = (int)part; }
+        tm.mark("pack + upload selected overlaps");
+        std::vector<int64_t> sel_packed(sel.size());
+        for (size_t t = 0; t < sel.size(); t++) sel_packed[t] = (int64_t)t;
         std::vector<Classified> cls(std::max<size_t>(sel.size(), 1));
-        HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
+        if (!sel.empty()) HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel_packed.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
         tm.mark("trim_classify (GPU)");
         size_t c = 0;
         for (int i = r_begin; i <= r_end; i++) {
@@ -242,7 +289,7 @@ int main(int argc, char* argv[]) {
                     m.bb = las.b_span[(size_t)k * 2]; m.be = las.b_span[(size_t)k * 2 + 1];
                     m.a_rs = eff[(size_t)i * 2]; m.a_re = eff[(size_t)i * 2 + 1];
                     m.b_rs = eff[(size_t)p.b * 2]; m.b_re = eff[(size_t)p.b * 2 + 1];
-                    m.k = k; m.part = (int)part; m.c = r;
+                    m.k = (int64_t)(c - 1); m.part = (int)part; m.c = r;   // c - 1: this overlap's index in the packed part
                     if (active[(size_t)p.b]) contained = contained || (r.type == MT_BCOVERA);
                     if (r.type == MT_FORWARD || r.type == MT_FORWARD_INTERNAL) matches_forward[(size_t)i].push_back(m);
                     else if (r.type == MT_BACKWARD || r.type == MT_BACKWARD_INTERNAL) matches_backward[(size_t)i].push_back(m);
@@ -339,11 +386,7 @@ int main(int argc, char* argv[]) {
         for (size_t p = 0; p < parts.size(); p++) {
             pos_of_query[p].assign(std::max<size_t>(q_ovl[p].size(), 1), 0);
             if (q_ovl[p].empty()) continue;
-            LasPart& las = *parts[p];
-            if (parts.size() > 1 || p != parts.size() - 1) {   // the last loaded part is still resident
-                HH_CHECK(ctx, hinge_set_pileups(ctx, las.r_begin, las.r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
-                HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
-            }
+            if ((int)p != resident_part) { HH_CHECK(ctx, packed[p]->upload(ctx)); resident_part = (int)p; }
             HH_CHECK(ctx, hinge_matching_position(ctx, (int64_t)q_ovl[p].size(), q_ovl[p].data(), q_pos[p].data(), pos_of_query[p].data()));
         }
     }
