@@ -175,6 +175,5 @@ int main(int argc, char* argv[]) {
     }
     if (f_rep) fclose(f_rep);
     fclose(f_cov); fclose(f_hg); fclose(f_mask); fclose(f_cmask); fclose(f_covflag); fclose(f_selfflag);
-    hinge_ctx_destroy(ctx);
-    return 0;
+    return finish(ctx, tm);
 }

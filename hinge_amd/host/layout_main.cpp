@@ -530,8 +530,7 @@ int main(int argc, char* argv[]) {
         }
     }
     fclose(out_g1); fclose(out_g2); fclose(out_hg); fclose(out_hg2); fclose(out_greedy); fclose(out_skipped); fclose(deadend_out);
-    for (auto* p : parts) delete p;
-    hinge_ctx_destroy(ctx);
     console.info("sort and output finished");
-    return 0;
+    if (getenv("HINGE_SLOW_EXIT")) { for (auto* p : parts) delete p; for (auto* p : packed) delete p; }
+    return finish(ctx, tm);
 }

@@ -180,6 +180,5 @@ int main(int argc, char* argv[]) {
         console.info("classified %lld overlaps; removed contained reads, active reads: %d / %zu", (long long)n_classified, n_active, nr);
     }
     fclose(f_cov); fclose(f_contained); fclose(f_max);
-    hinge_ctx_destroy(ctx);
-    return 0;
+    return finish(ctx, tm);
 }
