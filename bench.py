@@ -294,7 +294,7 @@ def main():
                 "reads_per_gpu": int(hi - lo),
                 "overlaps_per_gpu": int(n_ovl),
                 "total_overlaps": int(total_ovl),
-                "parallelism": "shard-by-block x%d, merged-las semantics, 2 all-gathers per step" % world,
+                "parallelism": "shard-by-block x%d, merged-las semantics; per step one 16 KiB all-reduce (coverage histogram) + one all-gather (masks, 8 B per read)" % world,
                 "hinges_found": n_hinges,
                 "reads_in_hinge_pass": int(counters[0]),
                 "annotations_on_exact_path": int(counters[1]),

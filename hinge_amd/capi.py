@@ -52,6 +52,8 @@ SYMBOLS = [
     ("hinge_clear_masks", C.c_int, [_VP]),
     ("hinge_filter_stats", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_median", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, C.POINTER(CovEstimate)]),
+    ("hinge_filter_median_hist", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, _VP]),
+    ("hinge_filter_median_from_hist", C.c_int, [_VP, C.POINTER(FilterParams), _VP]),
     ("hinge_filter_set_min_cov", C.c_int, [_VP, C.c_int32]),
     ("hinge_filter_get_min_cov", C.c_int, [_VP, C.POINTER(C.c_int32)]),
     ("hinge_filter_mask_annotate", C.c_int, [_VP, C.POINTER(FilterParams)]),
@@ -207,6 +209,13 @@ class Context:
         est = CovEstimate()
         self._ck(self.lib.hinge_filter_median(self.h, C.byref(p), lo, hi, C.byref(est) if fetch else None))
         return est if fetch else None
+
+    def filter_median_hist(self, p: FilterParams, lo: int, hi: int, hist_dev):
+        """Local histogram of the mean coverages of reads lo..hi into hist_dev (device int32[4096 + 2])."""
+        self._ck(self.lib.hinge_filter_median_hist(self.h, C.byref(p), lo, hi, _VP(_ptr(hist_dev))))
+
+    def filter_median_from_hist(self, p: FilterParams, hist_dev):
+        self._ck(self.lib.hinge_filter_median_from_hist(self.h, C.byref(p), _VP(_ptr(hist_dev))))
 
     def set_min_cov(self, v: int):
         self._ck(self.lib.hinge_filter_set_min_cov(self.h, int(v)))

@@ -33,6 +33,7 @@ constexpr int ST_ANNO_CAP = 2;     // annotation buffer full
 constexpr int ST_QUEUE_CAP = 4;    // exact queue full
 constexpr int ST_ARENA_CAP = 8;    // exact-path scratch arena full
 constexpr int ST_NO_LONG_READ = 16;
+constexpr int ST_MEDIAN_RANGE = 32;   // sharded median: a mean coverage outside [0, MED_BINS), the histogram exchange cannot be used
 
 #ifdef HINGE_ABLATE
 #define HINGE_ABLATE_POINT(k) if (P.ablate == (k)) continue;
@@ -252,7 +253,8 @@ constexpr int MED_MAX_BLOCKS = 64;
 __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
                                                      unsigned* __restrict__ med, int* __restrict__ est, int* __restrict__ min_cov,
                                                      int* __restrict__ status, const unsigned long long* __restrict__ wave_totals,
-                                                     int n_wave_totals, unsigned long long* __restrict__ totals) {
+                                                     int n_wave_totals, unsigned long long* __restrict__ totals,
+                                                     unsigned* __restrict__ hist_out /*nullptr, or [MED_BINS + 2]: histogram, valid, out of range*/) {
     __shared__ unsigned hist[MED_BINS];
     __shared__ unsigned s_valid, s_oor, s_last, s_lo, s_hi, s_general;
     __shared__ unsigned long long s_tc, s_ts, s_ticket;
@@ -354,6 +356,15 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
         for (int k = 0; k < 16; k++) hist[tid * 16 + k] = (unsigned)acc[k];
     }
     if (tid == 0) { med[MED_HDR] = 0; med[MED_HDR + 1] = 0; }
+    if (hist_out) {   // sharded runs: the block's histogram goes out to be summed over ranks (k_median_from_hist finishes)
+        __syncthreads();
+        for (int b = tid; b < MED_BINS; b += blockDim.x) hist_out[b] = hist[b];
+        if (tid == 0) {
+            hist_out[MED_BINS] = (unsigned)(s_ticket & ((1ull << 40) - 1ull));   // < 2^32 values per rank
+            hist_out[MED_BINS + 1] = (unsigned)(s_ticket >> 52);
+        }
+        return;
+    }
     const unsigned glo = 0, ghi = MED_BINS - 1;
     if (tid == 0) {
         const unsigned nvalid = (unsigned)(s_ticket & ((1ull << 40) - 1ull));
@@ -392,6 +403,42 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
 #endif
     __syncthreads();
     if (s_general == 1) median_radix_select(mean_cov, lo, hi, est_cov_override, est, min_cov, status);
+}
+
+// Median from a histogram that was summed over ranks (hist[MED_BINS + 2]: bins, valid values, ranks that saw a value
+// outside [0, MED_BINS)).  One workgroup; same walk and MIN_COV update as the tail of k_median_hist.
+__global__ __launch_bounds__(256) void k_median_from_hist(const unsigned* __restrict__ hist_in, int est_cov_override, int* __restrict__ est,
+                                                          int* __restrict__ min_cov, int* __restrict__ status) {
+    __shared__ unsigned hist[MED_BINS];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < MED_BINS; b += blockDim.x) hist[b] = hist_in[b];
+    const unsigned nvalid = hist_in[MED_BINS], bad = hist_in[MED_BINS + 1];
+    __syncthreads();
+    if (nvalid == 0) {
+        if (tid == 0) { est[0] = 0; est[1] = 0; atomicOr(status, ST_NO_LONG_READ); }
+        return;
+    }
+    if (bad) {   // needs the values themselves: the caller has to all-gather the means and use k_median_hist
+        if (tid == 0) atomicOr(status, ST_MEDIAN_RANGE);
+        return;
+    }
+    if (tid < WAVE) {
+        const int r = (int)(nvalid / 2);
+        int carry = 0, found = -1;
+        for (int base = 0; base < MED_BINS && found < 0; base += WAVE) {
+            const int incl = wave_incl_scan((int)hist[base + tid]) + carry;
+            const unsigned long long hit = __ballot(incl > r);
+            if (hit) found = base + __ffsll((long long)hit) - 1;
+            carry = wave_last(incl);
+        }
+        if (tid == 0) {
+            int cov_est = found;
+            est[0] = cov_est;
+            est[1] = (int)nvalid;
+            if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
+            atomicMax(min_cov, cov_est / 3);                          // filter.cpp:677-678
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

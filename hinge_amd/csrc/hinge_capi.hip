@@ -482,7 +482,7 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
         const int grid = std::max(1, std::min((n + 1023) / 1024, MED_MAX_BLOCKS));
         hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
                            (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status,
-                           (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals);
+                           (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals, (unsigned*)nullptr);
     }
     CK(hipGetLastError());
     if (out) {
@@ -495,6 +495,35 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
         out->num_slot = (int64_t)h.totals[1];
         if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part: the reference is undefined here (filter.cpp:660-666)");
     }
+    return HINGE_OK;
+}
+
+// ---- sharded median: local histogram -> (all-reduce by the caller) -> median -------------------------------------
+int hinge_filter_median_hist(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, uint32_t* hist_dev) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (lo < 0 || hi >= ctx->n_reads || hi < lo || !hist_dev) return fail(ctx, HINGE_E_ARG, "median_hist: bad arguments");
+    CK(hipSetDevice(ctx->device));
+    ProfScope _ps(ctx, KID_MEDIAN);
+    const int n = hi - lo + 1;
+    const int grid = std::max(1, std::min((n + 1023) / 1024, MED_MAX_BLOCKS));
+    hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
+                       (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status,
+                       (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals, (unsigned*)hist_dev);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
+int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, const uint32_t* hist_dev) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (!hist_dev) return fail(ctx, HINGE_E_ARG, "median_from_hist: bad arguments");
+    CK(hipSetDevice(ctx->device));
+    if ((rc = flush_min_cov(ctx))) return rc;
+    ProfScope _ps(ctx, KID_MEDIAN);
+    hipLaunchKernelGGL(k_median_from_hist, dim3(1), dim3(256), 0, ctx->stream, (const unsigned*)hist_dev, p->est_cov, sc(ctx)->est,
+                       &sc(ctx)->min_cov, &sc(ctx)->status);
+    CK(hipGetLastError());
     return HINGE_OK;
 }
 
@@ -690,6 +719,7 @@ static int check_status(hinge_ctx* ctx) {
     CK(hipStreamSynchronize(ctx->stream));
     if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part");
     if (h.status & ST_RANGE) return fail(ctx, HINGE_E_RANGE, "overlap coordinate beyond read length + cut_off");
+    if (h.status & ST_MEDIAN_RANGE) return fail(ctx, HINGE_E_RANGE, "a mean coverage lies outside [0, 4096): all-gather the means and call hinge_filter_median instead of the histogram exchange");
     if (h.status & (ST_ANNO_CAP | ST_QUEUE_CAP | ST_ARENA_CAP))
         return fail(ctx, HINGE_E_CAPACITY, "device buffer overflow in hinge_filter_run: use the staged calls (they regrow)");
     return HINGE_OK;

@@ -66,6 +66,7 @@ class Exchange:
         self.S = blocks.max_size
         # HINGE_FORCE_COLLECTIVES=1 runs the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
         self.force = dist.is_initialized() and os.environ.get("HINGE_FORCE_COLLECTIVES", "0") == "1"
+        self._buffers = {}
 
     @property
     def my_range(self) -> Tuple[int, int]:
@@ -73,19 +74,34 @@ class Exchange:
 
     def all_gather_rows(self, table: torch.Tensor) -> None:
         """table[n_reads, ...]: every rank has filled the rows of its own block; on return every rank
-        holds all rows.  One all_gather_into_tensor of world x S padded rows."""
+        holds all rows.  Equal blocks: ONE in-place all_gather_into_tensor on the table itself.  Unequal blocks:
+        copy-in to a cached padded shard, all-gather, one indexed copy-out (buffers and index maps are built once)."""
         if self.world == 1 and not self.force:
             return
         lo, hi = self.my_range
-        tail = table.shape[1:]
-        send = torch.zeros((self.S,) + tuple(tail), dtype=table.dtype, device=table.device)
-        send[: hi - lo] = table[lo:hi]
-        recv = torch.empty((self.world * self.S,) + tuple(tail), dtype=table.dtype, device=table.device)
+        if all(self.blocks.size(k) == self.S for k in range(self.world)):
+            dist.all_gather_into_tensor(table, table[lo:hi], group=self.group)   # in place: rank r's rows sit at r * S
+            return
+        key = (table.dtype, tuple(table.shape[1:]), table.device)
+        buf = self._buffers.get(key)
+        if buf is None:
+            tail = tuple(table.shape[1:])
+            send = torch.zeros((self.S,) + tail, dtype=table.dtype, device=table.device)
+            recv = torch.empty((self.world * self.S,) + tail, dtype=table.dtype, device=table.device)
+            src = np.concatenate([k * self.S + np.arange(self.blocks.size(k)) for k in range(self.world) if k != self.rank] or [np.zeros(0, np.int64)])
+            dst = np.concatenate([np.arange(self.blocks.first[k], self.blocks.first[k + 1]) for k in range(self.world) if k != self.rank] or [np.zeros(0, np.int64)])
+            buf = (send, recv, torch.from_numpy(src.astype(np.int64)).to(table.device), torch.from_numpy(dst.astype(np.int64)).to(table.device))
+            self._buffers[key] = buf
+        send, recv, src, dst = buf
+        send[: hi - lo].copy_(table[lo:hi])
         dist.all_gather_into_tensor(recv, send, group=self.group)
-        for k in range(self.world):
-            a, b = self.blocks.first[k], self.blocks.first[k + 1]
-            if k != self.rank:
-                table[a:b] = recv[k * self.S: k * self.S + (b - a)]
+        if src.numel():
+            table.index_copy_(0, dst, recv.index_select(0, src))
+
+    def all_reduce_sum(self, t: torch.Tensor) -> None:
+        if self.world == 1 and not self.force:
+            return
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_gather_scalar(self, v: int) -> List[int]:
         if self.world == 1 and not self.force:
@@ -134,11 +150,15 @@ class ShardedFilter:
     logic on CPU with gloo.
     """
 
-    def __init__(self, backend, exchange: Exchange, mode: str = "merged"):
+    def __init__(self, backend, exchange: Exchange, mode: str = "merged", median: str = "hist"):
         assert mode in ("merged", "mlas")
+        assert median in ("hist", "gather")
         self.b = backend
         self.x = exchange
         self.mode = mode
+        # "hist": exchange 1 is a 16 KiB all-reduce of a 4096-bin histogram of the mean coverages (exact while every
+        # mean is in [0, 4096); otherwise the backend reports it and "gather" - all-gather of 4 bytes per read - is the way)
+        self.median = median
         n = exchange.blocks.n_reads
         dev = exchange.device
         self.mean_cov = torch.full((n,), MEAN_SENTINEL, dtype=torch.int32, device=dev)
@@ -150,9 +170,13 @@ class ShardedFilter:
         lo, hi = x.my_range
         b.begin()
         b.stats()                                   # fills mean_cov[lo:hi]
-        if self.mode == "merged":
-            x.all_gather_rows(self.mean_cov)        # exchange 1
-            b.median(0, x.blocks.n_reads - 1)       # same global median on every rank (device side)
+        if self.mode == "merged" and self.median == "hist":
+            h = b.median_hist(lo, hi - 1)           # this block's histogram of mean coverages (device)
+            x.all_reduce_sum(h)                     # exchange 1: 16 KiB
+            b.median_from_hist(h)                   # same global median on every rank (device side)
+        elif self.mode == "merged":
+            x.all_gather_rows(self.mean_cov)        # exchange 1, general form
+            b.median(0, x.blocks.n_reads - 1)
         else:
             est = b.median_fetch(lo, hi - 1)        # per-part median (host scalar)
             ests = x.all_gather_scalar(est)         # exchange 1 (8 bytes per rank)
@@ -177,6 +201,7 @@ class HipBackend:
         self.ini_min_cov = int(params.min_cov)
         self.est_cov = int(params.est_cov)
         self.r_begin, self.r_end = r_begin, r_end
+        self._hist = None
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_reads(rlen, qv_mask)
         self._tensors = (row_ptr, a_span, b_span, b_flag)
@@ -199,6 +224,15 @@ class HipBackend:
 
     def median_fetch(self, lo: int, hi: int) -> int:
         return int(self.ctx.filter_median(self.p, lo, hi, fetch=True).cov_est)
+
+    def median_hist(self, lo: int, hi: int) -> torch.Tensor:
+        if self._hist is None:
+            self._hist = torch.zeros(4096 + 2, dtype=torch.int32, device=self.mean_cov.device)
+        self.ctx.filter_median_hist(self.p, lo, hi, self._hist)
+        return self._hist
+
+    def median_from_hist(self, hist: torch.Tensor):
+        self.ctx.filter_median_from_hist(self.p, hist)
 
     def set_min_cov(self, v: int):
         self.ctx.set_min_cov(v)

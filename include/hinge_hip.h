@@ -97,6 +97,14 @@ int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p);
  * filter.cpp:671-678 done on the device scalar. If `out` is non-NULL the estimate is copied back
  * (synchronises).                                                                                 */
 int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out);
+/* Sharded runs (one context per GPU, reads split by block): the global median without gathering 4 bytes per read.
+ * median_hist() histograms the mean coverages of this rank's reads lo..hi into hist_dev[4096 + 2] (device memory:
+ * bins, number of values, 1 if a value fell outside [0, 4096)); the caller sums hist_dev over ranks (one 16 KiB
+ * all-reduce); median_from_hist() takes the element of rank n/2 and applies the MIN_COV update (filter.cpp:660-678).
+ * An out-of-range value makes the next status check fail with HINGE_E_RANGE: gather the means and use
+ * hinge_filter_median.                                                                                          */
+int hinge_filter_median_hist(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, uint32_t* hist_dev);
+int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, const uint32_t* hist_dev);
 /* Get / set the running MIN_COV (it carries across parts, filter.cpp:677-678).                     */
 int hinge_filter_set_min_cov(hinge_ctx* ctx, int32_t min_cov);
 int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* min_cov);

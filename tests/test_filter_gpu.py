@@ -198,6 +198,25 @@ def test_median_kernel_matches_nth_element(kind):
         assert est.n_long == len(valid)
         assert est.cov_est == int(valid[len(valid) // 2])
     assert ctx.get_min_cov() == max(5, int(valid[len(valid) // 2]) // 3)
+    # the sharded form: two half-range histograms, summed (what the all-reduce does), then the same median
+    if kind in ("clustered", "wide", "sentinels", "single"):
+        h1 = torch.zeros(4096 + 2, dtype=torch.int32, device="cuda")
+        h2 = torch.zeros(4096 + 2, dtype=torch.int32, device="cuda")
+        ctx.set_min_cov(5)
+        ctx.filter_median_hist(P, 0, n // 2 - 1, h1)
+        ctx.filter_median_hist(P, n // 2, n - 1, h2)
+        h = h1 + h2
+        assert int(h[4096].item()) == len(valid) and int(h[4097].item()) == 0
+        assert np.array_equal(h[:4096].cpu().numpy(), np.bincount(valid, minlength=4096))
+        ctx.filter_median_from_hist(P, h)
+        assert ctx.get_min_cov() == max(5, int(valid[len(valid) // 2]) // 3)
+    elif kind == "out_of_range":
+        h1 = torch.zeros(4096 + 2, dtype=torch.int32, device="cuda")
+        ctx.filter_median_hist(P, 0, n - 1, h1)
+        assert int(h1[4097].item()) != 0
+        ctx.filter_median_from_hist(P, h1)
+        with pytest.raises(capi.HingeError):
+            ctx.check()
 
 
 def test_filter_long_reads_all_lds_classes(datasets, oracle_lib, tmp_path):
