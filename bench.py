@@ -151,11 +151,13 @@ def main():
         out = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(out, t)
         sizes = [int(v) for v in out.cpu().tolist()]
-    first = [0]
-    for s in sizes:
-        first.append(first[-1] + s)
+    # Every block gets the same number of read ids (the largest block's; the extra ids are reads of length 0 without
+    # overlaps): the per-read tables are then exchanged by ONE in-place all-gather.  Only the id space is padded.
+    S = max(sizes) + int(os.environ.get("HINGE_BENCH_PAD", "0"))   # HINGE_BENCH_PAD: exercise the padding with one rank
+    first = [k * S for k in range(world + 1)]
     blocks = BlockTable(first)
-    lo, hi = first[rank], first[rank + 1]
+    lo = first[rank]
+    hi = lo + d.n_reads          # real reads of this rank: [lo, hi); ids [hi, lo + S) are padding
     n_total = first[-1]
 
     # global-id views of this rank's block: rlen table of ALL reads, row_ptr with empty rows elsewhere
@@ -166,7 +168,7 @@ def main():
         dist.all_reduce(t)
         rlen_all = t.cpu().numpy()
     else:
-        rlen_all[:] = d.rlen
+        rlen_all[lo:hi] = d.rlen
     row_ptr = np.zeros(n_total + 1, np.int64)
     row_ptr[lo:hi + 1] = pile.row_ptr
     row_ptr[hi + 1:] = pile.row_ptr[-1]
@@ -181,7 +183,7 @@ def main():
 
     P = default_filter_params()
     ctx = capi.Context(local_rank)
-    backend = HipBackend(ctx, P, rlen_all, None, lo, hi - 1, t_row, t_a, t_b, t_f)
+    backend = HipBackend(ctx, P, rlen_all, None, lo, lo + S - 1, t_row, t_a, t_b, t_f)
     xch = Exchange(blocks, dev)
     job = ShardedFilter(backend, xch, mode="merged")
 
