@@ -18,15 +18,15 @@ all: $(LIB) $(PROGS) oracle
 
 $(BIN)/Reads_filter: $(HOST)/filter_main.cpp $(HOSTDEPS)
 	mkdir -p $(BIN)
-	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -Wl,-rpath,'$$ORIGIN/../lib'
+	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
 
 $(BIN)/get_maximal_reads: $(HOST)/maximal_main.cpp $(HOSTDEPS)
 	mkdir -p $(BIN)
-	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -Wl,-rpath,'$$ORIGIN/../lib'
+	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
 
 $(BIN)/hinging: $(HOST)/layout_main.cpp $(HOSTDEPS)
 	mkdir -p $(BIN)
-	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -Wl,-rpath,'$$ORIGIN/../lib'
+	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
 
 $(BIN)/hinge: $(HOST)/hinge
 	mkdir -p $(BIN)

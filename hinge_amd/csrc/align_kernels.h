@@ -60,7 +60,8 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
                                                          const int64_t* __restrict__ trace_off, const int* __restrict__ tlen,
                                                          const int2* __restrict__ eff /*[n_reads] effective_start/end*/, int aln_threshold,
                                                          int theta, int theta2, ClassifyOut* __restrict__ out,
-                                                         unsigned char* __restrict__ type_out /*nullptr, or only the match type is wanted*/) {
+                                                         unsigned char* __restrict__ type_out /*nullptr, or only the match type is wanted*/,
+                                                         int trim /*0: PAF input, ProcessAlignment(trim = false): the match is taken as it is*/) {
     const int lane = lane_id();
     const int r = lane & 15;              // lane inside the row
     const int row = lane >> 4;            // 0..3
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
             toff = trace_off[k];
         }
         const int ninner = max(tl / 2 - 1, 0);
-        const int np = live ? ninner + 2 : 0;          // trace points incl. the two end points
+        const int np = (live && trim) ? ninner + 2 : 0;   // trace points incl. the two end points
         const int sign = 1 - 2 * comp;
         const int b_first = comp ? bs.y : bs.x;        // tp[0].second
         const int b_last = comp ? bs.x : bs.y;         // tp[np-1].second
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
                 if (s_found) { o.eff_ab = s_a; o.eff_be = s_b; }
                 if (e_found) { o.eff_ae = e_a; o.eff_bb = e_b; }
             }
-            bool active = !(start_idx >= end_idx);
+            bool active = trim ? !(start_idx >= end_idx) : true;   // without trimming match->active keeps its value (maximal.cpp:97-104)
+            if (!trim) { start_idx = 0; end_idx = 0; }
             int type;
             if (((o.eff_be - o.eff_bb) < aln_threshold) || ((o.eff_ae - o.eff_ab) < aln_threshold) || !active) {
                 active = false;

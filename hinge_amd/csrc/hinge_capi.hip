@@ -52,6 +52,7 @@ struct hinge_ctx {
     int n_wave_totals = 0;
     size_t lds_attr_set = 0;
     int force_exact = 0;
+    int trim = 1;                 // ProcessAlignment's trim flag: 0 for PAF input (no trace points)
     int force_general_mask = 0;
     bool debug_paths = false;     // HINGE_DEBUG_PATHS: path counters (same-line global atomics, ~12 ns each: off by default)
     bool min_cov_pending = false;   // hinge_filter_set_min_cov is applied by the next launch that needs it

@@ -314,3 +314,37 @@ def pileups_from_las(recs: LasRecords, rlen: np.ndarray) -> Pileups:
         self_a=r["aread"][is_self].astype(np.int32),
         self_span=self_span,
     )
+
+
+# ---- FASTA + PAF (the reference's second input mode: filter.cpp:289-291,499-503) -----------------------------
+def read_name(i: int, length: int) -> str:
+    """PacBio-style name whose middle field is the 1-based read id (get_id_from_string, LAInterface.cpp:4808-4819)."""
+    return "synth/%d/0_%d" % (i + 1, length)
+
+
+def write_fasta(path: str, rlen: np.ndarray, seed: int = 0, line: int = 80, gz: bool = False) -> None:
+    """Reads of the given lengths (random bases: only the length reaches the path), `line` bases per line."""
+    import gzip
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ACGT", np.uint8)
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for i, n in enumerate(np.asarray(rlen).tolist()):
+            f.write((">%s\n" % read_name(i, n)).encode())
+            seq = alphabet[rng.integers(0, 4, size=n)].tobytes()
+            for k in range(0, n, line):
+                f.write(seq[k:k + line] + b"\n")
+
+
+def write_paf(path: str, rlen: np.ndarray, aread, bread, comp, ab, ae, bb, be, gz: bool = False) -> None:
+    """One 12-column PAF line per overlap; target coordinates on the forward strand of B (minimap convention)."""
+    import gzip
+    rlen = np.asarray(rlen)
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for a, b, c, s0, e0, s1, e1 in zip(np.asarray(aread).tolist(), np.asarray(bread).tolist(), np.asarray(comp).tolist(),
+                                           np.asarray(ab).tolist(), np.asarray(ae).tolist(), np.asarray(bb).tolist(), np.asarray(be).tolist()):
+            ml = min(e0 - s0, e1 - s1)
+            f.write(("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t255\n" % (
+                read_name(a, int(rlen[a])), int(rlen[a]), s0, e0, "-" if c else "+", read_name(b, int(rlen[b])), int(rlen[b]), s1, e1,
+                ml, max(e0 - s0, e1 - s1))).encode())

@@ -34,23 +34,27 @@ int main(int argc, char* argv[]) {
     if (!fa_and_paf && !db_and_las) { console.error("Pass in at least one of the following two combinations: a db and a las or a fasta and a paf"); return 1; }
     const bool mlas = cmdp.exist("mlas");
     if (mlas && !db_and_las) { console.error("--mlas works only with db and las"); return 1; }
-    if (fa_and_paf) { console.error("fasta + paf input is not supported by this build (SURVEY 8f-3): use a db and a las"); return 1; }
     if (!cmdp.get("restrictreads").empty()) { console.error("--restrictreads (debug path of filter.cpp:680-694,767-773) is not supported by this build"); return 1; }
 
     ReadDB db;
-    if (db.open(name_db) != 0) { fprintf(stderr, "Reads_filter: Could not open database %s\n", name_db.c_str()); exit(1); }
+    std::vector<std::vector<uint8_t>> qv;
+    bool has_qv = false;
+    std::vector<std::string> las_list;
+    int64_t novl0 = 0;
+    int tspace0 = 100;
+    if (fa_and_paf) {   // reads from the FASTA, one "part" = the PAF, no QV track (filter.cpp:289-291,467-468)
+        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", name_fasta.c_str()); exit(1); }
+        las_list.push_back(name_paf);
+    } else {
+        if (db.open(name_db) != 0) { fprintf(stderr, "Reads_filter: Could not open database %s\n", name_db.c_str()); exit(1); }
+        has_qv = db.load_qual(qv);
+        const std::string name_las = las_name(name_las_base, mlas);
+        if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
+        if (las_list.empty()) { console.error("No alignments!"); return 1; }
+        if (LasPart::header(las_list[0], novl0, tspace0) != 0) { fprintf(stderr, "Reads_filter: cannot open %s\n", las_list[0].c_str()); exit(1); }
+    }
     const int n_read = (int)db.rlen.size();
     console.info("# Reads: %d", n_read);
-    std::vector<std::vector<uint8_t>> qv;
-    bool has_qv = db.load_qual(qv);
-
-    const std::string name_las = las_name(name_las_base, mlas);
-    std::vector<std::string> las_list;
-    if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
-    if (las_list.empty()) { console.error("No alignments!"); return 1; }
-    int64_t novl0;
-    int tspace0;
-    if (LasPart::header(las_list[0], novl0, tspace0) != 0) { fprintf(stderr, "Reads_filter: cannot open %s\n", las_list[0].c_str()); exit(1); }
     std::vector<int32_t> qvm;
     if (has_qv) qv_masks(qv, tspace0, qvm);
 
@@ -63,6 +67,7 @@ int main(int argc, char* argv[]) {
     tm.mark("db + qual + ini");
     PartLoader loader;
     loader.pairs = false;
+    loader.paf = fa_and_paf;
     if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
@@ -88,6 +93,7 @@ int main(int argc, char* argv[]) {
         std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
         LasPart& las = *las_owner;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
+        if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
         if (lrc != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", las_list[part].c_str()); exit(1); }
         tm.mark("las ingest");
         console.info("# Alignments: %lld", (long long)las.novl);

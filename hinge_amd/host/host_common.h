@@ -27,6 +27,7 @@
 #include <thread>
 #include <unistd.h>
 #include <vector>
+#include <zlib.h>
 
 #include "../../include/hinge_hip.h"
 
@@ -450,13 +451,81 @@ inline void qv_masks(const std::vector<std::vector<uint8_t>>& qv, int tspace, st
 }
 
 // ---------------------------------------------------------------------------------------------------
-// .las ingest: one header-hop pass over the mapped file, then a fill pass into the SoA arrays
+// --fasta / --paf input (filter.cpp:289-291,499-503): reads = the records of a FASTA/FASTQ file in file order
+// (only their lengths matter here), alignments = PAF lines whose read names carry the 1-based id between the
+// first two '/' (LAInterface.cpp:4808-4845).  Both files go through zlib like the reference's kseq / paf.c.
+// ---------------------------------------------------------------------------------------------------
+inline bool slurp_gz(const std::string& path, std::string& out) {
+    gzFile f = gzopen(path.c_str(), "r");
+    if (!f) return false;
+    gzbuffer(f, 1 << 20);
+    std::vector<char> buf(1 << 22);
+    int n;
+    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), (size_t)n);
+    gzclose(f);
+    return n >= 0;
+}
+
+// kseq_read (include/kseq.h:193-232 of the reference): a record starts at the next '>' or '@'; the sequence is every
+// following non-empty line, whole, until a line that starts with '>', '+' or '@'; after '+' whole quality lines are read
+// until they hold as many characters (a different count ends the file's parsing).
+inline int read_fasta_lengths(const std::string& path, std::vector<int32_t>& rlen) {
+    typedef int32_t RLEN_T;
+    std::string t;
+    if (!slurp_gz(path, t)) return -1;
+    size_t i = 0;
+    const size_t n = t.size();
+    int last_char = 0;
+    for (;;) {
+        if (last_char == 0) {                                      // jump to the next header character, wherever it is
+            while (i < n && t[i] != '>' && t[i] != '@') i++;
+            if (i >= n) break;
+            last_char = t[i++];
+        }
+        if (i >= n) break;                                         // ks_getuntil(name) at end of stream: -1
+        while (i < n && !isspace((unsigned char)t[i])) i++;        // name
+        const int dc = i < n ? t[i] : 0;
+        if (i < n) i++;
+        if (dc != '\n') { while (i < n && t[i] != '\n') i++; if (i < n) i++; }   // comment
+        size_t len = 0;
+        int c = -1;
+        bool last_cr = false;                                      // is the last accumulated sequence character a '\r'?
+        while (i < n) {
+            c = (unsigned char)t[i++];
+            if (c == '>' || c == '+' || c == '@') break;
+            if (c == '\n') { c = -1; continue; }
+            len++; last_cr = (c == '\r');
+            while (i < n && t[i] != '\n') { len++; last_cr = (t[i] == '\r'); i++; }
+            if (i < n) i++;
+            if (len > 1 && last_cr) { len--; last_cr = false; }    // KS_SEP_LINE drops one trailing CR of the accumulated string
+            c = -1;
+        }
+        if (c == '>' || c == '@') last_char = c;
+        if (c != '+') { rlen.push_back((RLEN_T)len); if (c == -1) { if (i >= n) break; } continue; }
+        while (i < n && t[i] != '\n') i++;                         // rest of the '+' line
+        if (i >= n) break;                                         // no quality string: kseq_read returns -2, the record is dropped
+        i++;
+        size_t ql = 0;
+        bool q_cr = false;
+        while (i < n && ql < len) {                                // whole lines until at least len quality characters
+            while (i < n && t[i] != '\n') { ql++; q_cr = (t[i] == '\r'); i++; }
+            if (i < n) i++;
+            if (ql > 1 && q_cr) { ql--; q_cr = false; }
+        }
+        last_char = 0;
+        if (ql != len) break;                                      // -2: loadFASTA's loop ends, the record is dropped
+        rlen.push_back((RLEN_T)len);
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct LasPart {
     Mapped file;
     int64_t novl = 0;
     int tspace = 0, tbytes = 1;
     int r_begin = 0, r_end = -1;               // A read of the first / last record (filter.cpp:516-517)
+    bool is_paf = false;                       // loaded by load_paf(): no traces, ProcessAlignment(trim = false)
     // kept (non-self) overlaps in .las order
     std::vector<int64_t> row_ptr;              // n_reads + 1
     UVec<int32_t> a_span, b_span;              // 2 per overlap
@@ -565,6 +634,92 @@ struct LasPart {
             pos += 40 + (size_t)tl * tbytes;
         }
         return pos <= fn;
+    }
+
+    // PAF input: same columns as load(), no traces (tlen 0).  Records may come in any order: the reference files every
+    // alignment under its A read in file order (filter.cpp:529-548), which is a stable sort by A; r_begin / r_end are
+    // the A reads of the first / last LINE (filter.cpp:515-516).
+    // 0 ok; -1 cannot open; -3 a read name without "/id/" or an id outside the FASTA (the reference crashes)
+    int load_paf(const std::string& path, const std::vector<int32_t>& rlen) {
+        PhaseTimer lt("  paf.load");
+        std::string t;
+        if (!slurp_gz(path, t)) return -1;
+        tspace = 100; tbytes = 1;
+        const int n_reads = (int)rlen.size();
+        struct Rec { int a, b, ab, ae, bb, be, comp; };
+        std::vector<Rec> recs;
+        auto id_of = [](const char* q, const char* qe, bool& ok) {   // get_id_from_string - 1
+            const char* s0 = (const char*)memchr(q, '/', (size_t)(qe - q));
+            if (!s0) { ok = false; return 0; }
+            const char* s1 = s0 + 1;
+            const char* s2 = (const char*)memchr(s1, '/', (size_t)(qe - s1));
+            if (!s2 || s2 - s1 >= 15) { ok = false; return 0; }
+            char sub[16];
+            memcpy(sub, s1, (size_t)(s2 - s1)); sub[s2 - s1] = 0;
+            return atoi(sub) - 1;
+        };
+        size_t i = 0;
+        const size_t n = t.size();
+        while (i < n) {
+            size_t e = t.find('\n', i);
+            if (e == std::string::npos) e = n;
+            size_t le = e;
+            if (le > i && t[le - 1] == '\r') le--;
+            const char* f[12];
+            const char* fe[12];
+            int nf = 0;
+            size_t p0 = i;
+            for (size_t k = i; k <= le && nf < 12; k++)
+                if (k == le || t[k] == '\t') { f[nf] = t.data() + p0; fe[nf] = t.data() + k; nf++; p0 = k + 1; }
+            // (fields beyond the 12th are never looked at; a line needs at least 10)
+            int total = nf;
+            if (nf == 12) for (size_t k = (size_t)(fe[11] - t.data()); k < le; k++) if (t[k] == '\t') total++;
+            i = e + 1;
+            if (total < 10) continue;
+            auto num = [&](int k) { char tmp[24]; size_t l = std::min<size_t>((size_t)(fe[k] - f[k]), 23); memcpy(tmp, f[k], l); tmp[l] = 0; return (int)(uint32_t)strtol(tmp, nullptr, 10); };
+            bool ok = true;
+            Rec r;
+            r.ab = num(2); r.ae = num(3); r.bb = num(7); r.be = num(8);
+            r.comp = (fe[4] > f[4] && *f[4] == '-') ? 1 : 0;
+            r.a = id_of(f[0], fe[0], ok);
+            r.b = id_of(f[5], fe[5], ok);
+            if (!ok || r.a < 0 || r.a >= n_reads || r.b < 0 || r.b >= n_reads) return -3;
+            recs.push_back(r);
+        }
+        lt.mark("parse");
+        novl = (int64_t)recs.size();
+        if (novl > 0) { r_begin = recs.front().a; r_end = recs.back().a; }
+        // stable counting sort by A
+        rec_row_ptr.assign((size_t)n_reads + 1, 0);
+        row_ptr.assign((size_t)n_reads + 1, 0);
+        for (auto& r : recs) { rec_row_ptr[(size_t)r.a + 1]++; if (r.a != r.b) row_ptr[(size_t)r.a + 1]++; }
+        for (int q = 0; q < n_reads; q++) { rec_row_ptr[(size_t)q + 1] += rec_row_ptr[(size_t)q]; row_ptr[(size_t)q + 1] += row_ptr[(size_t)q]; }
+        const int64_t kept = row_ptr[(size_t)n_reads];
+        a_span.resize((size_t)kept * 2); b_span.resize((size_t)kept * 2); b_flag.resize((size_t)kept);
+        trace_off.resize((size_t)kept); tlen.resize((size_t)kept);
+        rec_b.resize((size_t)novl); rec_kept.resize((size_t)novl);
+        std::vector<int64_t> next_rec(rec_row_ptr.begin(), rec_row_ptr.end() - 1), next_kept(row_ptr.begin(), row_ptr.end() - 1);
+        std::vector<std::pair<int64_t, Rec>> selfs;   // (position among the sorted records, record): self_a order = pile-up order
+        for (auto& r : recs) {
+            const int64_t j = next_rec[(size_t)r.a]++;
+            rec_b[(size_t)j] = r.b;
+            if (r.a == r.b) { rec_kept[(size_t)j] = -1; selfs.emplace_back(j, r); continue; }
+            const int64_t k = next_kept[(size_t)r.a]++;
+            rec_kept[(size_t)j] = k;
+            a_span[(size_t)k * 2] = r.ab; a_span[(size_t)k * 2 + 1] = r.ae;
+            b_span[(size_t)k * 2] = r.bb; b_span[(size_t)k * 2 + 1] = r.be;   // no strand flip: PAF target coordinates are forward-strand
+            b_flag[(size_t)k] = (uint32_t)r.b | ((uint32_t)r.comp << 31);
+            trace_off[(size_t)k] = 0; tlen[(size_t)k] = 0;
+        }
+        // self overlaps in FILE order (filter.cpp:537-544 walks aln[] in file order)
+        self_a.resize(selfs.size()); self_span.resize(selfs.size() * 4);
+        {
+            size_t si = 0;
+            for (auto& r : recs)
+                if (r.a == r.b) { self_a[si] = r.a; self_span[si * 4] = r.ab; self_span[si * 4 + 1] = r.ae; self_span[si * 4 + 2] = r.bb; self_span[si * 4 + 3] = r.be; si++; }
+        }
+        is_paf = true;
+        return 0;
     }
 
     // 0 ok; -1 cannot open / truncated (reference: exit(1)); -2 records not grouped by ascending A read
@@ -731,12 +886,13 @@ struct PartLoader {
     std::unique_ptr<LasPart> first;
     int first_rc = 0;
     bool pairs = true;   // false in `hinge filter`: see LasPart::load
-    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first_rc = first->load(path, rlen, pairs); }
+    bool paf = false;    // the (single) part is a PAF file
+    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first_rc = paf ? first->load_paf(path, rlen) : first->load(path, rlen, pairs); }
     // returns the part (ownership passes to the caller) and its load() code
     LasPart* take(size_t part, const std::string& path, const std::vector<int32_t>& rlen, int& rc) {
         if (part == 0 && first) { rc = first_rc; return first.release(); }
         LasPart* p = new LasPart();
-        rc = p->load(path, rlen, pairs);
+        rc = paf ? p->load_paf(path, rlen) : p->load(path, rlen, pairs);
         return p;
     }
 };

@@ -96,13 +96,14 @@ std::vector<int> components(int n, const std::vector<std::pair<int, int>>& edges
 // and their trace bytes back to back.
 struct PackedPart {
     int r_begin = 0, r_end = -1, tbytes = 1;
+    bool is_paf = false;
     std::vector<int64_t> row_ptr;
     std::vector<int32_t> a_span, b_span, tlen;
     std::vector<uint32_t> b_flag;
     std::vector<int64_t> trace_off;
     std::vector<uint8_t> trace;
     void build(const LasPart& las, const std::vector<int64_t>& sel, const std::vector<int32_t>& a_of, int n_read) {
-        r_begin = las.r_begin; r_end = las.r_end; tbytes = las.tbytes;
+        r_begin = las.r_begin; r_end = las.r_end; tbytes = las.tbytes; is_paf = las.is_paf;
         const size_t n = sel.size();
         row_ptr.assign((size_t)n_read + 1, 0);
         for (size_t t = 0; t < n; t++) row_ptr[(size_t)a_of[t] + 1]++;
@@ -121,12 +122,13 @@ struct PackedPart {
         trace.resize((size_t)std::max<int64_t>(bytes, 1));
         for (size_t t = 0; t < n; t++) {
             const size_t k = (size_t)sel[t];
-            memcpy(trace.data() + trace_off[t], las.file.p + las.trace_off[k], (size_t)las.tlen[k] * (size_t)las.tbytes);
+            if (las.tlen[k] > 0) memcpy(trace.data() + trace_off[t], las.file.p + las.trace_off[k], (size_t)las.tlen[k] * (size_t)las.tbytes);
         }
     }
     int upload(hinge_ctx* ctx) const {
         int rc = hinge_set_pileups(ctx, r_begin, r_end, (int64_t)b_flag.size(), row_ptr.data(), a_span.data(), b_span.data(), b_flag.data(), 0);
         if (rc != HINGE_OK) return rc;
+        if ((rc = hinge_set_trim(ctx, is_paf ? 0 : 1)) != HINGE_OK) return rc;   // ProcessAlignment(trim = false) without trace points
         return hinge_set_traces(ctx, trace.data(), (int64_t)trace.size(), trace_off.data(), tlen.data(), tbytes, 0);
     }
 };
@@ -161,11 +163,12 @@ int main(int argc, char* argv[]) {
     if (db_or_las && fa_or_paf) { console.error("Pass in either a db and a las or a fasta and a paf"); return 1; }
     if (!fa_and_paf && !db_and_las) { console.error("Pass in at least one of the following two combinations: a db and a las or a fasta and a paf"); return 1; }
     if (mlas && !db_and_las) { console.error("--mlas works only with db and las"); return 1; }
-    if (fa_and_paf) { console.error("fasta + paf input is not supported by this build (SURVEY 8f-3): use a db and a las"); return 1; }
     if (!deadend_out || !garbage_out) { console.error("cannot open output files"); return 2; }
 
     ReadDB db;
-    if (db.open(name_db) != 0) { fprintf(stderr, "hinging: Could not open database %s\n", name_db.c_str()); exit(1); }
+    if (fa_and_paf) {
+        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "hinging: cannot read %s\n", name_fasta.c_str()); exit(1); }
+    } else if (db.open(name_db) != 0) { fprintf(stderr, "hinging: Could not open database %s\n", name_db.c_str()); exit(1); }
     const int n_read = (int)db.rlen.size();
     console.info("# Reads: %d", n_read);
 
@@ -208,8 +211,10 @@ int main(int argc, char* argv[]) {
 
     const std::string name_las = las_name(name_las_base, mlas);
     std::vector<std::string> las_list;
-    if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
+    if (fa_and_paf) las_list.push_back(name_paf);
+    else if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
     PartLoader loader;
+    loader.paf = fa_and_paf;
     if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
     tm.mark("setup + las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
@@ -236,6 +241,7 @@ int main(int argc, char* argv[]) {
         parts.push_back(lp);
         LasPart& las = *lp;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
+        if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
         if (lrc != 0) { fprintf(stderr, "hinging: cannot read %s\n", las_list[part].c_str()); exit(1); }
         tm.mark("las ingest");
         if (las.novl == 0) { console.error("No alignments!"); return 2; }

@@ -36,15 +36,19 @@ int main(int argc, char* argv[]) {
     if (!fa_and_paf && !db_and_las) { console.error("Pass in at least one of the following two combinations: a db and a las or a fasta and a paf"); return 1; }
     const bool mlas = cmdp.exist("mlas");
     if (mlas && !db_and_las) { console.error("--mlas works only with db and las"); return 1; }
-    if (fa_and_paf) { console.error("fasta + paf input is not supported by this build (SURVEY 8f-3): use a db and a las"); return 1; }
 
     ReadDB db;
-    if (db.open(name_db) != 0) { fprintf(stderr, "get_maximal_reads: Could not open database %s\n", name_db.c_str()); exit(1); }
+    std::vector<std::string> las_list;
+    if (fa_and_paf) {
+        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", name_fasta.c_str()); exit(1); }
+        las_list.push_back(name_paf);
+    } else {
+        if (db.open(name_db) != 0) { fprintf(stderr, "get_maximal_reads: Could not open database %s\n", name_db.c_str()); exit(1); }
+        const std::string name_las = las_name(name_las_base, mlas);
+        if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
+    }
     const int n_read = (int)db.rlen.size();
     console.info("# Reads: %d", n_read);
-    const std::string name_las = las_name(name_las_base, mlas);
-    std::vector<std::string> las_list;
-    if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
 
     Config ini(name_config);
     if (ini.error < 0) { console.warn("Can't load %s", name_config.c_str()); return 1; }
@@ -73,6 +77,7 @@ int main(int argc, char* argv[]) {
 
     tm.mark("db + ini + mas");
     PartLoader loader;
+    loader.paf = fa_and_paf;
     if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
@@ -87,13 +92,18 @@ int main(int argc, char* argv[]) {
         std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
         LasPart& las = *las_owner;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
+        if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
         if (lrc != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", las_list[part].c_str()); exit(1); }
         tm.mark("las ingest");
         if (las.novl == 0) { console.error("No alignments!"); return 1; }
         const int r_begin = las.r_begin, r_end = las.r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
         HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
-        HH_CHECK(ctx, hinge_set_traces(ctx, las.file.p, (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
+        {
+            static const uint8_t no_trace[1] = {0};   // PAF: no trace points, ProcessAlignment(trim = false)
+            HH_CHECK(ctx, hinge_set_trim(ctx, las.is_paf ? 0 : 1));
+            HH_CHECK(ctx, hinge_set_traces(ctx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
+        }
 
         tm.mark("set_pileups + set_traces (H2D)");
         // .coverage.txt is truncated and rewritten with the same content (maximal.cpp:517,659-685)

@@ -359,6 +359,15 @@ def write_dataset(d: SynthData, directory: str, name: str = "G", write_bases: bo
     return db
 
 
+def write_paf_dataset(d: SynthData, directory: str, name: str = "G", gz: bool = False) -> None:
+    """NAME.fasta + NAME.paf of the same reads and overlaps (the reference's --fasta / --paf input mode)."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    ext = ".gz" if gz else ""
+    formats.write_fasta(os.path.join(directory, name + ".fasta" + ext), d.rlen, seed=d.spec.seed, gz=gz)
+    formats.write_paf(os.path.join(directory, name + ".paf" + ext), d.rlen, d.aread, d.bread, d.comp, d.ab, d.ae, d.bb, d.be, gz=gz)
+
+
 def to_pileups(d: SynthData) -> formats.Pileups:
     """SoA pile-ups straight from the generator (no file round trip) for bench.py."""
     keep = d.aread != d.bread

@@ -141,6 +141,9 @@ int hinge_set_traces(hinge_ctx* ctx, const uint8_t* trace, int64_t trace_bytes, 
                      int on_device);
 /* effective_start / effective_end of every read (the .mas file: maximal.cpp:524-531, hinging.cpp:867-874) */
 int hinge_set_eff_reads(hinge_ctx* ctx, const int32_t* eff);
+/* ProcessAlignment's `trim` argument (maximal.cpp:799-804, hinging.cpp:542-549): 1 (default) with a DAZZ_DB / .las,
+ * 0 for FASTA + PAF input, where overlaps have no trace points and the match is classified as it stands.           */
+int hinge_set_trim(hinge_ctx* ctx, int trim);
 /* ProcessAlignment(match, A, B, ALN_THRESHOLD, THETA, THETA2, trim=true) (maximal.cpp:65-134 ==
  * hinging.cpp:78-147 -> LOverlap::trim_overlap LAInterface.cpp:4552-4683, AddTypesAsymmetric :4721-4806) for
  * n_sel overlaps: sel[j] indexes the pile-up arrays, a_of[j] is its A read.  out[j][10] = eff_ab, eff_ae,

@@ -220,7 +220,7 @@ int oracle_filter(const char* name_db, const char* las_base, int mlas, const cha
 
     for (int part = 0; part < (int)name_las_list.size(); part++) {
         LasHeader h;
-        if (load_overlaps(name_las_list[part], db, aln, h) != 0) { rc = -1; break; }
+        { int lrc = load_overlaps(name_las_list[part], db, aln, h); if (lrc != 0) { rc = lrc; break; } }
         if (h.novl == 0) { rc = 1; break; }
         int r_begin = aln.front()->a;
         int r_end = aln.back()->a;
@@ -476,7 +476,7 @@ int oracle_maximal(const char* name_db, const char* las_base, int mlas, const ch
     int rc = 0;
     for (int part = 0; part < (int)name_las_list.size(); part++) {
         LasHeader h;
-        if (load_overlaps(name_las_list[part], db, aln, h) != 0) { rc = -1; break; }
+        { int lrc = load_overlaps(name_las_list[part], db, aln, h); if (lrc != 0) { rc = lrc; break; } }
         if (h.novl == 0) { rc = 1; break; }
         int r_begin = aln.front()->a;
         int r_end = aln.back()->a;
@@ -513,7 +513,7 @@ int oracle_maximal(const char* name_db, const char* las_base, int mlas, const ch
                 for (int w = 0; w < 2; w++) {
                     if (w == 0 ? (it->second.size() > 0) : ((it->second.size() > 1) && P.USE_TWO_MATCHES)) {
                         Ovl* ovl = it->second[w];
-                        bool ca = process_alignment(ovl, reads[ovl->a], reads[ovl->b], P.ALN_THRESHOLD, P.THETA, P.THETA2, true);
+                        bool ca = process_alignment(ovl, reads[ovl->a], reads[ovl->b], P.ALN_THRESHOLD, P.THETA, P.THETA2, !db.fasta);   // trim only with a DB, maximal.cpp:799-804
                         if (ca == true) containing_read = ovl->b;
                         if (reads[ovl->b]->active == true) contained = contained || ca;
                     }
@@ -698,7 +698,7 @@ extern "C" int oracle_layout(const char* name_db, const char* las_base, int mlas
         for (int part = 0; part < (int)name_las_list.size(); part++) {
             std::vector<Ovl*> aln;
             LasHeader h;
-            if (load_overlaps(name_las_list[part], db, aln, h) != 0) return -1;
+            { int lrc = load_overlaps(name_las_list[part], db, aln, h); if (lrc != 0) return lrc; }
             if (aln.empty()) return -3;
             int r_begin = aln.front()->a;
             int r_end = aln.back()->a;
@@ -722,7 +722,7 @@ extern "C" int oracle_layout(const char* name_db, const char* las_base, int mlas
                     for (int w = 0; w < 2; w++) {
                         if (w == 0 ? (it->second.size() > 0) : ((it->second.size() > 1) && USE_TWO_MATCHES)) {
                             Ovl* ovl = it->second[w];
-                            bool ca = process_alignment(ovl, reads[ovl->a], reads[ovl->b], ALN_THRESHOLD, THETA, THETA2, true);
+                            bool ca = process_alignment(ovl, reads[ovl->a], reads[ovl->b], ALN_THRESHOLD, THETA, THETA2, !db.fasta);   // hinging.cpp:542-549
                             if (reads[ovl->b]->active == true) contained = contained || ca;
                             if ((ovl->type == FORWARD) || (ovl->type == FORWARD_INTERNAL)) matches_forward[i].push_back(ovl);
                             else if ((ovl->type == BACKWARD) || (ovl->type == BACKWARD_INTERNAL)) matches_backward[i].push_back(ovl);
@@ -1072,6 +1072,23 @@ long oracle_load_las(const char* name_db, const char* las_path, int* out, long c
     }
     for (auto o : aln) delete o;
     return n;
+}
+
+// ---- FASTA + PAF input: the same three stages, reads from loadFASTA, alignments from loadPAF, no trace points ----
+int oracle_filter_paf(const char* fasta, const char* paf, const char* prefix, const char* name_config) {
+    return oracle_filter((std::string("fasta:") + fasta).c_str(), (std::string("paf:") + paf).c_str(), 0, prefix, name_config, "");
+}
+int oracle_maximal_paf(const char* fasta, const char* paf, const char* prefix, const char* name_config) {
+    return oracle_maximal((std::string("fasta:") + fasta).c_str(), (std::string("paf:") + paf).c_str(), 0, prefix, name_config);
+}
+int oracle_layout_paf(const char* fasta, const char* paf, const char* prefix, const char* out_name, const char* name_config) {
+    return oracle_layout((std::string("fasta:") + fasta).c_str(), (std::string("paf:") + paf).c_str(), 0, prefix, out_name, name_config);
+}
+int oracle_fasta_lengths(const char* fasta, int* out, int cap) {
+    std::vector<int> rlen;
+    if (load_fasta_lengths(fasta, rlen) != 0) return -1;
+    for (int i = 0; i < (int)rlen.size() && i < cap; i++) out[i] = rlen[i];
+    return (int)rlen.size();
 }
 
 }  // extern "C"

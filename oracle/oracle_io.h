@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cctype>
+#include <zlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -52,6 +53,7 @@ struct Ovl {  // the fields of LOverlap the path touches (LAInterface.h:76-110)
 };
 
 struct DB {
+    bool fasta = false;                             // reads came from --fasta (LAInterface::loadFASTA), no DAZZ_DB
     int ureads = 0, treads = 0, cutoff = 0, all = 1;
     std::vector<int> rlen;                          // trimmed
     std::vector<char> keep;                         // per untrimmed read
@@ -71,7 +73,100 @@ static inline std::string path_root(const std::string& p, const char* suffix) {
 }
 
 // Open_DB + Trim_DB (DB.c:395-683): returns 0 ok, -1 on failure (reference exits 1).
+// ---- FASTA / PAF input (filter.cpp:289-291,499-503; LAInterface.cpp:4808-4870; lib/paf.c:59-92) -----------
+// A name prefixed "fasta:" / "paf:" selects this input in open_db() / load_overlaps(), so the three stage
+// restatements below are shared between the two input modes exactly like the reference's mains are.
+static inline bool has_prefix(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
+
+// whole file through zlib (gzopen reads plain files too), like kseq / kstream over gzread
+static inline int slurp_gz(const std::string& path, std::string& out) {
+    gzFile f = gzopen(path.c_str(), "r");
+    if (!f) return -1;
+    char buf[1 << 16];
+    int n;
+    while ((n = gzread(f, buf, sizeof(buf))) > 0) out.append(buf, (size_t)n);
+    gzclose(f);
+    return n < 0 ? -1 : 0;
+}
+
+// loadFASTA (LAInterface.cpp:4849-4870) over this tree's kseq_read (include/kseq.h:193-232): a record starts at the
+// next '>' or '@'; name = up to the first whitespace, rest of the line = comment; the sequence is every following
+// non-empty line, WHOLE (blanks included), until a line that starts with '>', '+' or '@'; for '+' the rest of that
+// line is skipped and whole quality lines are read until they hold at least as many characters, which must then be
+// exactly as many (otherwise kseq_read fails and loadFASTA stops).  Only the length reaches the path; read k is the
+// k-th record.
+static inline int load_fasta_lengths(const std::string& path, std::vector<int>& rlen) {
+    typedef int RLEN_T;
+    std::string t;
+    if (slurp_gz(path, t) != 0) return -1;
+    size_t i = 0;
+    const size_t n = t.size();
+    int last_char = 0;
+    for (;;) {
+        if (last_char == 0) {                                      // jump to the next header character, wherever it is
+            while (i < n && t[i] != '>' && t[i] != '@') i++;
+            if (i >= n) break;
+            last_char = t[i++];
+        }
+        if (i >= n) break;                                         // ks_getuntil(name) at end of stream: -1
+        while (i < n && !isspace((unsigned char)t[i])) i++;        // name
+        const int dc = i < n ? t[i] : 0;
+        if (i < n) i++;
+        if (dc != '\n') { while (i < n && t[i] != '\n') i++; if (i < n) i++; }   // comment
+        size_t len = 0;
+        int c = -1;
+        bool last_cr = false;                                      // is the last accumulated sequence character a '\r'?
+        while (i < n) {
+            c = (unsigned char)t[i++];
+            if (c == '>' || c == '+' || c == '@') break;
+            if (c == '\n') { c = -1; continue; }
+            len++; last_cr = (c == '\r');
+            while (i < n && t[i] != '\n') { len++; last_cr = (t[i] == '\r'); i++; }
+            if (i < n) i++;
+            if (len > 1 && last_cr) { len--; last_cr = false; }    // KS_SEP_LINE drops one trailing CR of the accumulated string
+            c = -1;
+        }
+        if (c == '>' || c == '@') last_char = c;
+        if (c != '+') { rlen.push_back((RLEN_T)len); if (c == -1) { if (i >= n) break; } continue; }
+        while (i < n && t[i] != '\n') i++;                         // rest of the '+' line
+        if (i >= n) break;                                         // no quality string: kseq_read returns -2, the record is dropped
+        i++;
+        size_t ql = 0;
+        bool q_cr = false;
+        while (i < n && ql < len) {                                // whole lines until at least len quality characters
+            while (i < n && t[i] != '\n') { ql++; q_cr = (t[i] == '\r'); i++; }
+            if (i < n) i++;
+            if (ql > 1 && q_cr) { ql--; q_cr = false; }
+        }
+        last_char = 0;
+        if (ql != len) break;                                      // -2: loadFASTA's loop ends, the record is dropped
+        rlen.push_back((RLEN_T)len);
+    }
+    return 0;
+}
+
+// get_id_from_string (LAInterface.cpp:4808-4819): the number between the first and the second '/'.
+// The reference dereferences NULL when a name has fewer than two '/': reported as -1 here (undefined).
+static inline int id_from_name(const char* name, bool& ok) {
+    const char* s0 = strchr(name, '/');
+    if (!s0) { ok = false; return 0; }
+    const char* s1 = s0 + 1;
+    const char* s2 = strchr(s1, '/');
+    if (!s2) { ok = false; return 0; }
+    char sub[32];
+    size_t l = (size_t)(s2 - s1);
+    if (l >= 15) { ok = false; return 0; }                       // the reference's char substr[15] would overflow
+    memcpy(sub, s1, l); sub[l] = 0;
+    return atoi(sub);
+}
+
 static inline int open_db(const std::string& name, DB& db) {
+    if (has_prefix(name, "fasta:")) {
+        db.fasta = true;
+        if (load_fasta_lengths(name.substr(6), db.rlen) != 0) return -1;
+        db.treads = db.ureads = (int)db.rlen.size();
+        return 0;
+    }
     db.dir = path_dir(name);
     db.root = path_root(name, ".db");
     std::string stub = db.dir + "/" + db.root + ".db";
@@ -116,6 +211,7 @@ static inline int open_db(const std::string& name, DB& db) {
 
 // getQV (LAInterface.cpp:4369-4494): 0 ok, 1 = no (usable) qual track.
 static inline int load_qv(const DB& db, std::vector<std::vector<int>>& QV) {
+    if (db.fasta) return -1;   // has_qv = false, filter.cpp:291
     std::string pre = db.dir + "/." + db.root + ".qual";
     FILE* a = fopen((pre + ".anno").c_str(), "rb");
     if (!a) return 1;
@@ -146,6 +242,7 @@ static inline int load_qv(const DB& db, std::vector<std::vector<int>>& QV) {
 struct LasHeader { int64_t novl = 0; int tspace = 0; int tbytes = 1; };
 
 static inline int las_header(const std::string& path, LasHeader& h) {
+    if (has_prefix(path, "paf:")) { h.novl = 0; h.tspace = 100; h.tbytes = 1; return 0; }
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return -1;
     int ok = fread(&h.novl, 8, 1, f) == 1 && fread(&h.tspace, 4, 1, f) == 1;
@@ -156,7 +253,55 @@ static inline int las_header(const std::string& path, LasHeader& h) {
 }
 
 // getOverlap(vec, 0, n_read) (LAInterface.cpp:1519-1634)
+// loadPAF (LAInterface.cpp:4822-4845) over paf_read / paf_parse (lib/paf.c:59-92): tab-separated lines, lines with
+// fewer than 10 fields are skipped, numbers by strtol base 10 into uint32, strand = (first char == '-').
+// B coordinates are NOT flipped for reverse matches here (minimap's target coordinates are forward-strand already),
+// there are no trace points (tlen 0).  Returns -3 when a read name has no "/id/" part (the reference crashes).
+static inline int load_paf(const std::string& path, std::vector<Ovl*>& out, int64_t& n_rec) {
+    std::string t;
+    if (slurp_gz(path, t) != 0) return -1;
+    n_rec = 0;
+    size_t i = 0, n = t.size();
+    while (i < n) {
+        size_t e = t.find('\n', i);
+        if (e == std::string::npos) e = n;
+        std::string line = t.substr(i, e - i);
+        i = e + 1;
+        if (!line.empty() && line[line.size() - 1] == '\r') { /* ks_getuntil(KS_SEP_LINE) strips a trailing CR */ line.erase(line.size() - 1); }
+        std::vector<std::string> f;
+        size_t p0 = 0;
+        for (size_t k = 0; k <= line.size(); k++)
+            if (k == line.size() || line[k] == '\t') { f.push_back(line.substr(p0, k - p0)); p0 = k + 1; }
+        if (f.size() < 10) continue;
+        bool ok = true;
+        Ovl* o = new Ovl();
+        o->ab = (int)(uint32_t)strtol(f[2].c_str(), NULL, 10);
+        o->ae = (int)(uint32_t)strtol(f[3].c_str(), NULL, 10);
+        o->bb = (int)(uint32_t)strtol(f[7].c_str(), NULL, 10);
+        o->be = (int)(uint32_t)strtol(f[8].c_str(), NULL, 10);
+        o->alen = (int)(uint32_t)strtol(f[1].c_str(), NULL, 10);
+        o->blen = (int)(uint32_t)strtol(f[6].c_str(), NULL, 10);
+        o->comp = (!f[4].empty() && f[4][0] == '-') ? 1 : 0;
+        o->a = id_from_name(f[0].c_str(), ok) - 1;
+        o->b = id_from_name(f[5].c_str(), ok) - 1;
+        o->tlen = 0;
+        if (!ok) { delete o; return -3; }
+        out.push_back(o);
+        n_rec++;
+    }
+    return 0;
+}
+
 static inline int load_overlaps(const std::string& path, const DB& db, std::vector<Ovl*>& out, LasHeader& h) {
+    if (has_prefix(path, "paf:")) {
+        h.tspace = 100; h.tbytes = 1;
+        int rc = load_paf(path.substr(4), out, h.novl);
+        if (rc != 0) return rc;
+        int n_read = (int)db.rlen.size();
+        for (size_t k = 0; k < out.size(); k++)   // the reference indexes reads[] / idx_pileup[] with these ids unchecked
+            if (out[k]->a < 0 || out[k]->a >= n_read || out[k]->b < 0 || out[k]->b >= n_read) return -3;
+        return 0;
+    }
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return -1;
     if (fread(&h.novl, 8, 1, f) != 1 || fread(&h.tspace, 4, 1, f) != 1) { fclose(f); return -1; }
@@ -299,6 +444,7 @@ static inline std::vector<std::string> las_parts(const std::string& base) {
 }
 
 static inline std::string las_name(const std::string& base, bool mlas) {
+    if (has_prefix(base, "paf:")) return base;
     if (mlas) return base;
     if (base.size() >= 4 && base.substr(base.size() - 4) == ".las") return base;
     return base + ".las";

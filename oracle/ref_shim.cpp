@@ -153,6 +153,31 @@ void ref_sort_perm(int n, const int* key, int mode, int* perm) {
     for (int i = 0; i < n; i++) { perm[i] = v[i]->tps; delete v[i]; }
 }
 
+// LAInterface::loadPAF over the reference's own lib/paf.c: n x 8 ints (a, b, ab, ae, bb, be, comp, 0)
+long ref_load_paf(const char* paf_path, int* out, long cap) {
+    LAInterface la;
+    std::vector<LOverlap*> aln;
+    long n = la.loadPAF(std::string(paf_path), aln);
+    for (long i = 0; i < n && i < cap; i++) {
+        LOverlap* o = aln[i];
+        int* p = out + i * 8;
+        p[0] = o->read_A_id_; p[1] = o->read_B_id_; p[2] = o->read_A_match_start_; p[3] = o->read_A_match_end_;
+        p[4] = o->read_B_match_start_; p[5] = o->read_B_match_end_; p[6] = o->reverse_complement_match_; p[7] = 0;
+    }
+    for (auto o : aln) { o->trace_pts = NULL; delete o; }   // loadPAF leaves trace_pts uninitialised and ~LOverlap frees it
+    return n;
+}
+
+// LAInterface::loadFASTA: read lengths in file order
+int ref_fasta_lengths(const char* fasta_path, int* out, int cap) {
+    LAInterface la;
+    std::vector<Read*> reads;
+    int n = la.loadFASTA(std::string(fasta_path), reads);
+    for (int i = 0; i < n && i < cap; i++) out[i] = reads[i]->len;
+    for (auto r : reads) delete r;
+    return n;
+}
+
 long ref_ini_int(const char* file, const char* section, const char* name, long def) { INIReader r(file); return r.GetInteger(section, name, def); }
 int ref_ini_bool(const char* file, const char* section, const char* name, int def) { INIReader r(file); return (int)r.GetBoolean(section, name, def != 0); }
 double ref_ini_real(const char* file, const char* section, const char* name, double def) { INIReader r(file); return r.GetReal(section, name, def); }

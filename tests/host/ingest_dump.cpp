@@ -10,12 +10,25 @@ template <typename V> static void put(FILE* f, const V& v) {
     if (n) fwrite(v.data(), sizeof(*v.data()), (size_t)n, f);
 }
 
+// usage: ingest_dump DB LAS OUT | ingest_dump --paf FASTA PAF OUT | ingest_dump --fasta FASTA OUT (read lengths as int32)
 int main(int argc, char** argv) {
+    if (argc == 4 && std::string(argv[1]) == "--fasta") {
+        std::vector<int32_t> rlen;
+        if (read_fasta_lengths(argv[2], rlen) != 0) return 3;
+        FILE* f = fopen(argv[3], "wb");
+        if (!f) return 4;
+        if (!rlen.empty()) fwrite(rlen.data(), 4, rlen.size(), f);
+        fclose(f);
+        return 0;
+    }
+    const bool paf = argc == 5 && std::string(argv[1]) == "--paf";
+    if (paf) { argv++; argc--; }
     if (argc != 4) return 2;
     ReadDB db;
-    if (db.open(argv[1]) != 0) return 3;
+    if (paf) { if (read_fasta_lengths(argv[1], db.rlen) != 0) return 3; }
+    else if (db.open(argv[1]) != 0) return 3;
     LasPart las;
-    const int rc = las.load(argv[2], db.rlen);
+    const int rc = paf ? las.load_paf(argv[2], db.rlen) : las.load(argv[2], db.rlen);
     if (rc != 0) return rc & 255;
     printf("%s\n", las.indexed_in_pieces ? "pieces" : "sequential");
     FILE* f = fopen(argv[3], "wb");

@@ -67,3 +67,56 @@ def test_cli_error_behaviour(datasets, tmp_path):
     assert run("layout", "--db", "G", "--las", "G.las", "--config", "nominal.ini") == 1          # -x / -o are required
     assert run("filter", "--db", "G", "--las", "G.las", "--bogus", "-x", "G", "--config", "nominal.ini") == 1
     assert run("nosuchcommand") == 1
+
+
+# ---- FASTA + PAF input (the reference's second input mode, filter.cpp:289-291,499-503) --------------------------------
+def _write_paf_inputs(d, wd, shuffle, gz):
+    import numpy as np
+    from hinge_amd import formats
+    os.makedirs(wd, exist_ok=True)
+    ext = ".gz" if gz else ""
+    formats.write_fasta(os.path.join(wd, "G.fasta" + ext), d.rlen, seed=3, gz=gz)
+    order = np.arange(d.novl)
+    if shuffle:   # PAF lines need not be grouped by query: the reference files each line under its A read in file order
+        order = np.random.default_rng(5).permutation(d.novl)
+        # the reference takes r_begin / r_end from the first / last LINE (filter.cpp:515-516): keep the whole id range defined
+        first = int(np.nonzero(d.aread[order] == d.aread.min())[0][0])
+        order[[0, first]] = order[[first, 0]]
+        last = int(np.nonzero(d.aread[order] == d.aread.max())[0][-1])
+        order[[-1, last]] = order[[last, -1]]
+    formats.write_paf(os.path.join(wd, "G.paf" + ext), d.rlen, d.aread[order], d.bread[order], d.comp[order], d.ab[order], d.ae[order],
+                      d.bb[order], d.be[order], gz=gz)
+    return "G.fasta" + ext, "G.paf" + ext
+
+
+@pytest.mark.parametrize("name,shuffle,gz", [("tiny", False, False), ("long_repeat", False, True), ("chimera", True, False), ("long_repeat", True, False)])
+def test_cli_paf_pipeline_matches_oracle(datasets, oracle_lib, tmp_path, name, shuffle, gz):
+    _, d = datasets(name)
+    wd_o, wd_h = str(tmp_path / "oracle"), str(tmp_path / "hip")
+    for wd in (wd_o, wd_h):
+        fa, paf = _write_paf_inputs(d, wd, shuffle, gz)
+        write_ini(os.path.join(wd, "v.ini"))
+    rcs = [run_in(wd_o, oracle_lib.oracle_filter_paf, fa.encode(), paf.encode(), b"G", b"v.ini"),
+           run_in(wd_o, oracle_lib.oracle_maximal_paf, fa.encode(), paf.encode(), b"G", b"v.ini"),
+           run_in(wd_o, oracle_lib.oracle_layout_paf, fa.encode(), paf.encode(), b"G", b"G", b"v.ini")]
+    assert rcs == [0, 0, 0]
+    for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+        r = subprocess.run([HINGE, sub, "--fasta", fa, "--paf", paf, "-x", "G", "--config", "v.ini"] + extra, cwd=wd_h, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+    bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
+    assert os.path.getsize(os.path.join(wd_h, "G.edges.hinges")) > 0 and os.path.getsize(os.path.join(wd_h, "G.max")) > 0
+    if name == "long_repeat" and not shuffle:
+        assert sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_h, "G.hinges.txt"))) > 0
+
+
+def test_cli_paf_bad_read_names(datasets, tmp_path):
+    _, d = datasets("tiny")
+    wd = str(tmp_path / "w")
+    fa, paf = _write_paf_inputs(d, wd, False, False)
+    write_ini(os.path.join(wd, "v.ini"))
+    txt = open(os.path.join(wd, paf)).read().replace("synth/1/", "synth_1_", 1)   # a name without "/id/": the reference dereferences NULL
+    open(os.path.join(wd, paf), "w").write(txt)
+    r = subprocess.run([HINGE, "filter", "--fasta", fa, "--paf", paf, "-x", "G", "--config", "v.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 1

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="session")
 def ingest_dump(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("host") / "ingest_dump")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "host", "ingest_dump.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "host", "ingest_dump.cpp"), "-lz"], check=True)
     return exe
 
 
@@ -110,3 +110,44 @@ def test_ingest_rejects_damaged_files(datasets, ingest_dump, tmp_path):
     formats.write_las(p, r2)
     for t in (1, 32):
         assert _dump(ingest_dump, db, p, out, t) == 254
+
+
+def test_fasta_and_paf_ingest_matches_the_oracle(datasets, ingest_dump, oracle_lib, tmp_path):
+    """The executables' FASTA / PAF readers against the oracle's (which is pinned to the reference's kseq.h / paf.c)."""
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_pinned import FASTA_CORNERS, FASTA_CORNERS_GOLDEN, _awkward_fasta_and_paf
+    ip = ctypes.POINTER(ctypes.c_int)
+    for name, blob in FASTA_CORNERS.items():
+        p = str(tmp_path / (name + ".fa"))
+        open(p, "wb").write(blob)
+        out = str(tmp_path / "len.bin")
+        assert subprocess.run([ingest_dump, "--fasta", p, out]).returncode == 0
+        assert np.fromfile(out, np.int32).tolist() == FASTA_CORNERS_GOLDEN[name], name
+    from hinge_amd import synth
+    _, d = datasets("chimera")
+    wd = str(tmp_path / "paf")
+    synth.write_paf_dataset(d, wd, "G", gz=True)
+    fa_c, paf_c = _awkward_fasta_and_paf(tmp_path)
+    oracle_lib.oracle_load_las.restype = ctypes.c_long
+    for fa, paf, n_rec in ((os.path.join(wd, "G.fasta.gz"), os.path.join(wd, "G.paf.gz"), d.novl), (fa_c, paf_c, 5)):
+        x = np.zeros((n_rec + 2, 8), np.int32)
+        assert oracle_lib.oracle_load_las(b"fasta:" + fa.encode(), b"paf:" + paf.encode(), x.ctypes.data_as(ip), ctypes.c_long(len(x))) == n_rec
+        x = x[:n_rec]
+        out = str(tmp_path / "paf.bin")
+        assert subprocess.run([ingest_dump, "--paf", fa, paf, out], stdout=subprocess.DEVNULL).returncode == 0
+        hdr, c = _read_dump(out)
+        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span = c
+        assert hdr[0] == n_rec and hdr[2] == x[0, 0] and hdr[3] == x[-1, 0]
+        order = np.argsort(x[:, 0], kind="stable")           # the reference files every line under its A read, in file order
+        xs = x[order]
+        keep = xs[:, 0] != xs[:, 1]
+        np.testing.assert_array_equal(a_span.reshape(-1, 2), xs[keep][:, 2:4])
+        np.testing.assert_array_equal(b_span.reshape(-1, 2), xs[keep][:, 4:6])
+        np.testing.assert_array_equal(b_flag, xs[keep][:, 1].astype(np.uint32) | (xs[keep][:, 6].astype(np.uint32) << np.uint32(31)))
+        np.testing.assert_array_equal(rec_b, xs[:, 1])
+        assert (tlen == 0).all()
+        sf = x[x[:, 0] == x[:, 1]]                            # self overlaps stay in file order
+        np.testing.assert_array_equal(self_a, sf[:, 0])
+        np.testing.assert_array_equal(self_span.reshape(-1, 4), sf[:, 2:6])

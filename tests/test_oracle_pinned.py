@@ -152,3 +152,108 @@ def test_live_reference_db_and_qv(oracle_lib, ref_lib, datasets):
     py = formats.read_qual_track(os.path.join(wd, "G"))
     for i in range(d.n_reads):
         assert np.array_equal(vals[offs[i]:offs[i + 1]], py[i].astype(np.int32))
+
+
+def _awkward_fasta_and_paf(tmp_path):
+    """Inputs that exercise the parsers' corners: multi-line and single-line FASTA records, a FASTQ record, blank lines,
+    lower case; PAF lines with 12, 10, 9 (skipped) and 14 columns, '-' strand, CRLF, an empty line."""
+    fa = str(tmp_path / "r.fasta")
+    with open(fa, "w") as f:
+        f.write(">x/1/0_10 some comment\nACGTACGTAC\n")
+        f.write(">x/2/0_25\nACGTACGTAC\nacgtacgtac\nACGTA\n\n")
+        f.write("@x/3/0_7\nACGTACG\n+\nIIIIIII\n")
+        f.write(">x/4/0_0\n")
+        f.write(">x/5/0_12\nAC GT\tAC\nGTACGT\n")
+    paf = str(tmp_path / "r.paf")
+    with open(paf, "w") as f:
+        f.write("x/1/0_10\t10\t1\t9\t+\tx/2/0_25\t25\t3\t11\t8\t8\t255\n")
+        f.write("x/2/0_25\t25\t0\t20\t-\tx/5/0_12\t12\t2\t12\t10\t20\n")                       # 11 columns
+        f.write("x/3/0_7\t7\t0\t7\t+\tx/1/0_10\t10\t0\t7\t7\n")                              # 10 columns: kept
+        f.write("x/3/0_7\t7\t0\t7\t+\tx/1/0_10\t10\t0\t7\n")                                 # 9 columns: skipped
+        f.write("\n")
+        f.write("x/5/0_12\t12\t4\t12\t-\tx/5/0_12\t12\t0\t8\t8\t8\t60\ttp:A:S\tcm:i:3\r\n")   # self overlap, tags, CRLF
+        f.write("x/4/0_0\t0\t0\t0\t+\tx/2/0_25\t25\t5\t5\t0\t0\t0")                          # no trailing newline
+    return fa, paf
+
+
+FASTA_CORNERS = {
+    "crlf": b">x/1/0\r\nACGT\r\nAC\r\n>x/2/0\r\n\r\nA\r\n",
+    "no_final_newline": b">x/1/0\nACGTAC\n>x/2/0\nAC",
+    "fastq_two": b"@x/1/0\nACGTAC\n+x/1/0\nIIIIII\n@x/2/0\nAC\nGT\n+\nII\nII\n",
+    "fastq_quality_starts_with_at": b"@x/1/0\nACGT\n+\n@III\n@x/2/0\nAC\n+\nII\n",
+    "fastq_short_quality": b"@x/1/0\nACGT\n+\nII\n@x/2/0\nAC\n+\nII\n",
+    "fastq_long_quality": b">x/0/0\nA\n@x/1/0\nACGT\n+\nIIIIII\n@x/2/0\nAC\n+\nII\n",
+    "junk_before_first_header": b"junk line\nmore junk > x/1/0\nACG\n>x/2/0\nA\n",
+    "header_only_at_eof": b">x/1/0\nACG\n>x/2/0",
+    "plus_line_in_fasta": b">x/1/0\nACG\n+\nIII\n>x/2/0\nAC\n",
+    "empty": b"",
+}
+# values returned by the reference's own library (LAInterface::loadFASTA) for the inputs above
+FASTA_CORNERS_GOLDEN = {"crlf": [6, 2], "no_final_newline": [6, 2], "fastq_two": [6, 4], "fastq_quality_starts_with_at": [4, 2],
+                        "fastq_short_quality": [], "fastq_long_quality": [1], "junk_before_first_header": [3, 1], "header_only_at_eof": [3, 0],
+                        "plus_line_in_fasta": [3, 2], "empty": []}
+
+
+def test_live_reference_fasta_corner_cases(oracle_lib, ref_lib, tmp_path):
+    got = {}
+    for name, blob in FASTA_CORNERS.items():
+        p = str(tmp_path / (name + ".fa"))
+        open(p, "wb").write(blob)
+        a = np.full(8, -7, np.int32)
+        b = np.full(8, -7, np.int32)
+        na = oracle_lib.oracle_fasta_lengths(p.encode(), P(a), 8)
+        nb = ref_lib.ref_fasta_lengths(p.encode(), P(b), 8)
+        assert na == nb and np.array_equal(a, b), (name, na, nb, a, b)
+        got[name] = a[:na].tolist()
+    assert got == FASTA_CORNERS_GOLDEN, got
+
+
+def test_fasta_corner_cases_golden(oracle_lib, tmp_path):
+    for name, blob in FASTA_CORNERS.items():
+        p = str(tmp_path / (name + ".fa"))
+        open(p, "wb").write(blob)
+        a = np.full(8, -7, np.int32)
+        na = oracle_lib.oracle_fasta_lengths(p.encode(), P(a), 8)
+        assert a[:na].tolist() == FASTA_CORNERS_GOLDEN[name], (name, a[:na].tolist())
+
+
+def test_live_reference_fasta_and_paf(oracle_lib, ref_lib, datasets, tmp_path):
+    """loadFASTA / loadPAF (over the reference's own kseq.h and lib/paf.c) against the oracle's restatement."""
+    from hinge_amd import synth
+    _, d = datasets("tiny")
+    ref_lib.ref_load_paf.restype = ctypes.c_long
+    ref_lib.ref_load_paf.argtypes = [ctypes.c_char_p, ip, ctypes.c_long]
+    oracle_lib.oracle_load_las.restype = ctypes.c_long
+    cases = []
+    for gz in (False, True):
+        wd = str(tmp_path / ("gz" if gz else "plain"))
+        synth.write_paf_dataset(d, wd, "G", gz=gz)
+        ext = ".gz" if gz else ""
+        cases.append((os.path.join(wd, "G.fasta" + ext), os.path.join(wd, "G.paf" + ext), d.n_reads, d.novl))
+    fa, paf = _awkward_fasta_and_paf(tmp_path)
+    cases.append((fa, paf, 5, 5))
+    for fa, paf, n_reads, n_rec in cases:
+        a = np.zeros(n_reads + 4, np.int32)
+        b = np.zeros(n_reads + 4, np.int32)
+        assert oracle_lib.oracle_fasta_lengths(fa.encode(), P(a), len(a)) == n_reads
+        assert ref_lib.ref_fasta_lengths(fa.encode(), P(b), len(b)) == n_reads
+        assert np.array_equal(a, b), (a, b)
+        x = np.zeros((n_rec + 4, 8), np.int32)
+        y = np.zeros((n_rec + 4, 8), np.int32)
+        assert oracle_lib.oracle_load_las(b"fasta:" + fa.encode(), b"paf:" + paf.encode(), P(x), ctypes.c_long(len(x))) == n_rec
+        assert ref_lib.ref_load_paf(paf.encode(), P(y), len(y)) == n_rec
+        assert np.array_equal(x, y), (x[:n_rec], y[:n_rec])
+
+
+def test_fasta_and_paf_parsers_golden(oracle_lib, tmp_path):
+    """The same corner cases with the values the reference's library returned for them (captured by the live test's
+    inputs; runs where the reference tree is absent)."""
+    fa, paf = _awkward_fasta_and_paf(tmp_path)
+    a = np.zeros(8, np.int32)
+    assert oracle_lib.oracle_fasta_lengths(fa.encode(), P(a), 8) == 5
+    assert a[:5].tolist() == [10, 25, 7, 0, 14]   # blanks inside a sequence line count (this kseq.h keeps whole lines)
+    oracle_lib.oracle_load_las.restype = ctypes.c_long
+    x = np.zeros((8, 8), np.int32)
+    assert oracle_lib.oracle_load_las(b"fasta:" + fa.encode(), b"paf:" + paf.encode(), P(x), ctypes.c_long(8)) == 5
+    assert x[:5].tolist() == [[0, 1, 1, 9, 3, 11, 0, 0], [1, 4, 0, 20, 2, 12, 1, 0], [2, 0, 0, 7, 0, 7, 0, 0], [4, 4, 4, 12, 0, 8, 1, 0],
+                              [3, 1, 0, 0, 5, 5, 0, 0]]
