@@ -54,6 +54,7 @@ SYMBOLS = [
     ("hinge_filter_median", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, C.POINTER(CovEstimate)]),
     ("hinge_filter_median_hist", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, _VP]),
     ("hinge_filter_median_from_hist", C.c_int, [_VP, C.POINTER(FilterParams), _VP]),
+    ("hinge_set_read_restriction", C.c_int, [_VP, _VP]),
     ("hinge_filter_set_min_cov", C.c_int, [_VP, C.c_int32]),
     ("hinge_filter_get_min_cov", C.c_int, [_VP, C.POINTER(C.c_int32)]),
     ("hinge_filter_mask_annotate", C.c_int, [_VP, C.POINTER(FilterParams)]),

@@ -475,6 +475,7 @@ __global__ __launch_bounds__(BLOCK) void k_pileup_facts(int r_begin, int r_end, 
 // ------------------------------------------------------------------------------------------------
 struct AnnoOut {   // per-part outputs of K2
     const int2* qv_mask;
+    const unsigned char* keep;   // --restrictreads (filter.cpp:680-694,767-773): nullptr, or 0 for reads whose masks are emptied
     int2* mask;
     int2* cmask;
     unsigned char* rflags;
@@ -539,7 +540,8 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
     }
     int2 mk;
     {
-        const int2 q = o.qv_mask ? o.qv_mask[i] : make_int2(0, 0);
+        int2 q = o.qv_mask ? o.qv_mask[i] : make_int2(0, 0);
+        if (o.keep && !o.keep[i]) { maxend = maxstart; q.y = q.x; }   // filter.cpp:767-773
         if (P.use_qv && P.use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
         else if (P.use_cov && !P.use_qv) mk = make_int2(maxstart, maxend);
         else mk = q;

@@ -39,7 +39,8 @@ struct hinge_ctx {
     int2* mask = nullptr;     // active table (own or attached)
     DevBuf mean_own;
     int* mean_cov = nullptr;
-    DevBuf cmask, rflags, nbins0;
+    DevBuf cmask, rflags, nbins0, keep;
+    bool has_keep = false;
     DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list;
     unsigned anno_cap = 0;
     DevBuf exact_queue;
@@ -212,7 +213,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
+                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -528,6 +529,18 @@ int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, 
     return HINGE_OK;
 }
 
+int hinge_set_read_restriction(hinge_ctx* ctx, const uint8_t* keep) {
+    if (!ctx || ctx->n_reads <= 0) return fail(ctx, HINGE_E_ARG, "hinge_set_read_restriction: call hinge_set_reads first");
+    CK(hipSetDevice(ctx->device));
+    ctx->has_keep = keep != nullptr;
+    if (!keep) return HINGE_OK;
+    int rc = ensure(ctx, ctx->keep, (size_t)ctx->n_reads);
+    if (rc) return rc;
+    CK(hipMemcpyAsync(ctx->keep.p, keep, (size_t)ctx->n_reads, hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
 int hinge_filter_set_min_cov(hinge_ctx* ctx, int32_t v) {
     if (!ctx) return HINGE_E_ARG;
     ctx->min_cov_pending = true;   // applied, in stream order, by the next launch that reads or updates MIN_COV
@@ -546,6 +559,7 @@ int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* v) {
 static AnnoOut anno_out(hinge_ctx* ctx) {
     AnnoOut o;
     o.qv_mask = ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr;
+    o.keep = ctx->has_keep ? (const unsigned char*)ctx->keep.p : (const unsigned char*)nullptr;
     o.mask = ctx->mask;
     o.cmask = (int2*)ctx->cmask.p;
     o.rflags = (unsigned char*)ctx->rflags.p;

@@ -34,7 +34,6 @@ int main(int argc, char* argv[]) {
     if (!fa_and_paf && !db_and_las) { console.error("Pass in at least one of the following two combinations: a db and a las or a fasta and a paf"); return 1; }
     const bool mlas = cmdp.exist("mlas");
     if (mlas && !db_and_las) { console.error("--mlas works only with db and las"); return 1; }
-    if (!cmdp.get("restrictreads").empty()) { console.error("--restrictreads (debug path of filter.cpp:680-694,767-773) is not supported by this build"); return 1; }
 
     ReadDB db;
     std::vector<std::vector<uint8_t>> qv;
@@ -65,8 +64,18 @@ int main(int argc, char* argv[]) {
     console.info("MIN_COV = %d CUT_OFF = %d THETA = %d EST_COV = %d", P.min_cov, P.cut_off, P.theta, P.est_cov);
 
     tm.mark("db + qual + ini");
+    // --restrictreads FILE: one read id per line (filter.cpp:300-316)
+    std::set<int> reads_to_keep;
+    const std::string name_restrict = cmdp.get("restrictreads");
+    if (!name_restrict.empty()) {
+        FILE* rf = fopen(name_restrict.c_str(), "r");
+        char line[256];
+        while (rf && fgets(line, sizeof(line), rf)) reads_to_keep.insert(atoi(line));   // `ss >> num` of an unparsable line gives 0
+        if (rf) fclose(rf);
+        console.info("Restricting to %zu reads", reads_to_keep.size());
+    }
     PartLoader loader;
-    loader.pairs = false;
+    loader.pairs = !reads_to_keep.empty();   // the neighbours of the listed reads need the per-record B column
     loader.paf = fa_and_paf;
     if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
@@ -119,6 +128,17 @@ int main(int argc, char* argv[]) {
         }
 
         tm.mark("self matches");
+        if (!reads_to_keep.empty()) {   // + every B the listed reads have an alignment with (idx_ab, filter.cpp:680-694); cumulative over parts
+            const std::set<int> initial = reads_to_keep;
+            for (int i : initial) {
+                if (i < 0 || i >= n_read) continue;
+                for (int64_t j = las.rec_row_ptr[(size_t)i]; j < las.rec_row_ptr[(size_t)i + 1]; j++) reads_to_keep.insert(las.rec_b[(size_t)j]);
+            }
+            console.info("After accounting for neighbours of reads selected, have %zu reads", reads_to_keep.size());
+            std::vector<uint8_t> keep((size_t)n_read, 0);
+            for (int i : reads_to_keep) if (i >= 0 && i < n_read) keep[(size_t)i] = 1;
+            HH_CHECK(ctx, hinge_set_read_restriction(ctx, keep.data()));
+        }
         hinge_cov_estimate est;
         HH_CHECK(ctx, hinge_filter_stats(ctx, &P));
         HH_CHECK(ctx, hinge_filter_median(ctx, &P, r_begin, r_end, &est));

@@ -105,6 +105,10 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
  * hinge_filter_median.                                                                                          */
 int hinge_filter_median_hist(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, uint32_t* hist_dev);
 int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, const uint32_t* hist_dev);
+/* --restrictreads (filter.cpp:680-694,767-773): keep[n_reads], 0 = the read's coverage and QV masks are emptied
+ * (maxend = maxstart, QV.second = QV.first) before the mask is formed; NULL = no restriction.  The caller builds the
+ * set (the listed reads plus every B read they overlap).                                                             */
+int hinge_set_read_restriction(hinge_ctx* ctx, const uint8_t* keep);
 /* Get / set the running MIN_COV (it carries across parts, filter.cpp:677-678).                     */
 int hinge_filter_set_min_cov(hinge_ctx* ctx, int32_t min_cov);
 int hinge_filter_get_min_cov(hinge_ctx* ctx, int32_t* min_cov);

@@ -66,7 +66,7 @@ int main() {
     int* fb; (void)hipMalloc(&fb, nr * 4);
     int* ids; (void)hipMalloc(&ids, nr * 4);
     (void)hipMemcpy(ids, lst.data(), nr * 4, hipMemcpyHostToDevice);
-    AnnoOut o{nullptr, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * (unsigned)nr, wl, st};
+    AnnoOut o{nullptr, nullptr, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * (unsigned)nr, wl, st};
     const int grid = (nr + 3) / 4;
     const int grid20 = (n1 + 3) / 4 + (n2 + 1) / 2 + n4;
     for (int mode = 1; mode <= 5; mode++) {

@@ -120,3 +120,26 @@ def test_cli_paf_bad_read_names(datasets, tmp_path):
     open(os.path.join(wd, paf), "w").write(txt)
     r = subprocess.run([HINGE, "filter", "--fasta", fa, "--paf", paf, "-x", "G", "--config", "v.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 1
+
+
+@pytest.mark.parametrize("name,mlas", [("long_repeat", False), ("tiny_mlas", True)])
+def test_cli_filter_restrictreads(datasets, oracle_lib, tmp_path, name, mlas):
+    """--restrictreads FILE (filter.cpp:300-316,680-694,767-773): the listed reads and their neighbours keep their masks."""
+    src, d = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    keep = [5, 17, 40, d.n_reads - 3]
+    for wd in (wd_o, wd_h):
+        write_ini(os.path.join(wd, "v.ini"))
+        open(os.path.join(wd, "keep.txt"), "w").write("".join("%d\n" % k for k in keep))
+    las = b"G" if mlas else b"G.las"
+    assert run_in(wd_o, oracle_lib.oracle_filter, b"G", las, int(mlas), b"G", b"v.ini", b"keep.txt") == 0
+    args = ["--las", "G", "--mlas"] if mlas else ["--las", "G.las"]
+    r = subprocess.run([HINGE, "filter", "--db", "G"] + args + ["-x", "G", "--config", "v.ini", "--restrictreads", "keep.txt"], cwd=wd_h,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    files = ["G.mas", "G.cmas", "G.repeat.txt", "G.hinges.txt", "G.coverage.txt", "G.cov.flag", "G.self.flag"]
+    bad = [f for f in files if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
+    emptied = sum(1 for l in open(os.path.join(wd_h, "G.mas")) if l.split()[1] == l.split()[2])
+    assert 0 < emptied < d.n_reads
