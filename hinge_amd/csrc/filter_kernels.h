@@ -37,7 +37,7 @@ constexpr int ST_MEDIAN_RANGE = 32;   // sharded median: a mean coverage outside
 
 #ifdef HINGE_ABLATE
 #define HINGE_ABLATE_POINT(k) if (P.ablate == (k)) continue;
-#define HINGE_ABLATE_RETURN(k) if (P.ablate == (k)) return;
+#define HINGE_ABLATE_RETURN(k) if (P.ablate == (k) || ((k) == 2 && P.ablate >= 6)) return;
 #else
 #define HINGE_ABLATE_POINT(k)
 #define HINGE_ABLATE_RETURN(k)
@@ -803,12 +803,16 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
     if ((int)blockIdx.x < g1) { width = 1; item = (int)blockIdx.x * 4 + wib; if (item >= n1) return; }
     else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g1) * 2 + (wib >> 1); if (item >= n2) return; item += n1; }
     else { width = 4; if (wib != 0) return; item = n1 + n2 + ((int)blockIdx.x - g1 - g2); }
-    const int qcap = width * slot_ints - HOT * WAVE;
-    int* Pq = lds + (size_t)wib * slot_ints;
-    int* hot = Pq + qcap;
-    const int MIN_COV = *d_min_cov;
     constexpr int reso = 40;
     const int SH = P.cut_off / 20;
+    // Zero words in front of the prefix array and copies of the totals behind it make PB[q < 0] = 0 and P[q > last] = P[last]
+    // plain loads: the profile accessors below need no clamps and issue their LDS reads back to back.
+    const int PADF = (SH + 2 + 3) & ~3, PADT = (2 * SH + 4 + 3) & ~3;
+    const int qcap = width * slot_ints - HOT * WAVE - PADF - PADT;
+    int* Pq = lds + (size_t)wib * slot_ints + PADF;
+    int* hot = Pq + qcap + PADT;
+    const int MIN_COV = *d_min_cov;
+    for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
 #pragma unroll
     for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
     int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
@@ -891,6 +895,9 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
 
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
         int carry = 0;
+#ifdef HINGE_ABLATE
+        if (P.ablate != 6 && P.ablate != 8)
+#endif
         for (int base = 0; base < Qn; base += 4 * WAVE) {
             const int t = base + 4 * lane;
             int4 v = t < Qn ? *reinterpret_cast<const int4*>(Pq + t) : make_int4(0, 0, 0, 0);
@@ -901,14 +908,18 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
             if (t < Qn) *reinterpret_cast<int4*>(Pq + t) = v;
             carry += wave_last(incl);
         }
-        const int qlast = Qn - 1;
-        auto PB = [&](int q) { return q < 0 ? 0 : (Pq[min(q, qlast)] & 0xffff); };
-        auto PE = [&](int q) { return q < 0 ? 0 : (int)((unsigned)Pq[min(q, qlast)] >> 16); };
-        auto cov0 = [&](int k) { const int q = 2 * k - 1; if (q < 0) return 0; const int p = Pq[min(q, qlast)]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
-        auto covc = [&](int k) { return PB(2 * k - 1 - SH) - PE(2 * k - 1 + SH); };
+        {   // copies of the totals behind the scanned bins (the scan ran over [0, round-up-to-4 of Qn))
+            const int Qs = (Qn + 3) & ~3;
+            for (int t = lane; t < PADT; t += WAVE) Pq[Qs + t] = carry;
+        }
+        auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
+        auto covc = [&](int k) { return (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16); };
 
         // ---- coverage mask on the cutoff profile ------------------------------------------------------
         RunState run{0, 0ull, 0, 0};
+#ifdef HINGE_ABLATE
+        if (P.ablate != 7 && P.ablate != 8)
+#endif
         for (int base = 0; base < KC; base += WAVE) {
             const int left = KC - base;
             const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);

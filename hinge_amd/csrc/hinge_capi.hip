@@ -597,10 +597,12 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     // grid-stride loop does (measured 137 -> 119 us at 87 k reads)
     const int grid = std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
     // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
-    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && ctx->force_general_mask == 0;
+    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0;
     if (q20) {
-        const int slot = k2_slot_ints(ctx);
-        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // <= 20 KiB: eight workgroups per CU
+        // bins + hot words (the read classes of hinge_set_pileups are cut for this much) + the zero / total pads of this cut_off
+        const int SH = p->cut_off / 20;
+        const int slot = k2_slot_ints(ctx) + ((SH + 2 + 3) & ~3) + ((2 * SH + 4 + 3) & ~3);
+        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // ~20.5 KiB: seven workgroups per CU
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
         const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
         const int g = std::max(1, (n1 + 3) / 4 + (n2 + 1) / 2 + n4);

@@ -55,9 +55,10 @@ int main() {
     const int kcap = ((maxrl + 300) / 40 + 4 + 3) & ~3;
     const size_t lds = 4 * 2 * kcap * 4;
     (void)hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int slot = ((((std::min(maxrl, 18000)) / 20 + 1 + 3) & ~3) + 4) + 5 * 64;
+    const int slot0 = ((((std::min(maxrl, 18000)) / 20 + 1 + 3) & ~3) + 4) + 5 * 64;
+    const int slot = slot0 + 20 + 36;   // + zero / total pads for cut_off 300
     const size_t lds20 = 4 * (size_t)slot * 4;
-    const int len1 = (slot - 5 * 64 - 1) * 20 + 19, len2 = (2 * slot - 5 * 64 - 1) * 20 + 19;
+    const int len1 = (slot0 - 5 * 64 - 1) * 20 + 19, len2 = (2 * slot0 - 5 * 64 - 1) * 20 + 19;
     std::vector<int> l1, l2, l4;
     for (int i = 0; i < nr; i++) (hl[i] <= len1 ? l1 : hl[i] <= len2 ? l2 : l4).push_back(i);
     std::vector<int> lst(l1); lst.insert(lst.end(), l2.begin(), l2.end()); lst.insert(lst.end(), l4.begin(), l4.end());
@@ -69,13 +70,13 @@ int main() {
     AnnoOut o{nullptr, nullptr, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * (unsigned)nr, wl, st};
     const int grid = (nr + 3) / 4;
     const int grid20 = (n1 + 3) / 4 + (n2 + 1) / 2 + n4;
-    for (int mode = 1; mode <= 5; mode++) {
+    for (int mode = 1; mode <= 8; mode++) {
         P.ablate = mode;
         float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
             hipLaunchKernelGGL(k_mask_annotate<40>, dim3(grid), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, mc, kcap, o, (const int*)nullptr, (const unsigned*)nullptr); });
         float t2 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
             hipLaunchKernelGGL(k_mask_annotate_q20, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, mc, slot, o, fb, cnt + 2); });
-        printf("stop after phase %d: general %7.1f us   q20 %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all)\n", mode, t * 1e3, t2 * 1e3);
+        printf("stop after phase %d: general %7.1f us   q20 %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all; to end of phase 2: 6 no scan, 7 no mask pass, 8 neither)\n", mode, t * 1e3, t2 * 1e3);
     }
     unsigned hc[4]; (void)hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost);
     printf("counters: anno %u work %u fallback %u\n", hc[0], hc[1], hc[2]);
