@@ -170,12 +170,12 @@ class ShardedFilter:
         lo, hi = x.my_range
         b.begin()
         b.stats()                                   # fills mean_cov[lo:hi]
-        if self.mode == "merged" and self.median == "hist":
+        if self.mode == "merged" and self.median == "hist" and (x.world > 1 or x.force):
             h = b.median_hist(lo, hi - 1)           # this block's histogram of mean coverages (device)
             x.all_reduce_sum(h)                     # exchange 1: 16 KiB
             b.median_from_hist(h)                   # same global median on every rank (device side)
-        elif self.mode == "merged":
-            x.all_gather_rows(self.mean_cov)        # exchange 1, general form
+        elif self.mode == "merged":                 # one rank, or the general form of exchange 1
+            x.all_gather_rows(self.mean_cov)
             b.median(0, x.blocks.n_reads - 1)
         else:
             est = b.median_fetch(lo, hi - 1)        # per-part median (host scalar)
