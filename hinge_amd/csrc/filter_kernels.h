@@ -25,10 +25,6 @@ constexpr int BLOCK = WAVE * WAVES_PER_BLOCK;
 constexpr int MEAN_SENTINEL = INT_MIN;  // mean_cov of reads that do not enter the median
 
 constexpr int MED_BINS = 4096;  // one-pass median histogram range
-#ifndef HINGE_K2_R
-#define HINGE_K2_R 2
-#endif
-constexpr int K2_READS_PER_WAVE = HINGE_K2_R;   // reads a wavefront of k_mask_annotate_q20 runs back to back (software pipeline)
 constexpr int LOADS_IN_FLIGHT = 8;   // 8-byte pile-up loads a lane issues back to back (4 KiB per wave)
 
 // status word bits (device -> host)
@@ -124,25 +120,9 @@ __device__ __forceinline__ int nbins_of(int n_ovl, int max_ev, int reso) {
 // K1: per-read cutoff-0 coverage sum and bin count without materialising the bins:
 //     sum_k cov[k] = sum_o (bin_of(aepos) - bin_of(abpos)),  K = bin_of(max event) + 1.
 // ------------------------------------------------------------------------------------------------
-// PACKED: the spans come from the 16|16-bit copy (abpos | aepos << 16, see k_pileup_facts): half the bytes of the
-// int32 pairs, available when every read of the part is shorter than 65536 bp and every coordinate lies in its read.
-template <bool PACKED> struct SpanLoad;
-template <> struct SpanLoad<false> {
-    typedef int2 raw;
-    static constexpr int IN_FLIGHT = LOADS_IN_FLIGHT;
-    static __device__ __forceinline__ raw zero() { return make_int2(0, 0); }
-    static __device__ __forceinline__ int2 get(raw v) { return v; }
-};
-template <> struct SpanLoad<true> {
-    typedef unsigned raw;
-    static constexpr int IN_FLIGHT = LOADS_IN_FLIGHT;       // 512 overlaps per batch: most pile-ups in one
-    static __device__ __forceinline__ raw zero() { return 0u; }
-    static __device__ __forceinline__ int2 get(raw v) { return make_int2((int)(v & 0xffffu), (int)(v >> 16)); }
-};
-
-template <int RESO, bool PACKED>
+template <int RESO>
 __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
-                                                     const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen, int reso,
+                                                     const int2* __restrict__ a_span, const int* __restrict__ rlen, int reso,
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
                                                      unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/,
                                                      int* __restrict__ pass_scalars, int n_pass_scalars, int* __restrict__ d_min_cov,
@@ -163,20 +143,18 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
         const int rl = rlen[i];
         int sum = 0;
         int mx = INT_MIN;
-        typedef SpanLoad<PACKED> SL;
-        for (int64_t base = s; base < e; base += SL::IN_FLIGHT * WAVE) {   // all loads of a batch are issued before the first use
-            typename SL::raw v[SL::IN_FLIGHT];
+        for (int64_t base = s; base < e; base += LOADS_IN_FLIGHT * WAVE) {   // all loads of a batch are issued before the first use
+            int2 v[LOADS_IN_FLIGHT];
 #pragma unroll
-            for (int u = 0; u < SL::IN_FLIGHT; u++) {
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                 const int64_t k = base + u * WAVE + lane;
-                v[u] = k < e ? a_span[k] : SL::zero();
+                v[u] = k < e ? a_span[k] : make_int2(0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < SL::IN_FLIGHT; u++) {
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                 if (base + u * WAVE + lane < e) {
-                    const int2 w = SL::get(v[u]);
-                    sum += bin_of<RESO>(w.y, reso) - bin_of<RESO>(w.x, reso);
-                    mx = max(mx, max(w.x, w.y));
+                    sum += bin_of<RESO>(v[u].y, reso) - bin_of<RESO>(v[u].x, reso);
+                    mx = max(mx, max(v[u].x, v[u].y));
                 }
             }
         }
@@ -466,12 +444,11 @@ __global__ __launch_bounds__(256) void k_median_from_hist(const unsigned* __rest
 // ------------------------------------------------------------------------------------------------
 // Facts about a part's pile-ups that stay true for every pass over it (run once by hinge_set_pileups):
 // facts[0] = largest pile-up, facts[1] = 1 if some coordinate lies outside [0, rlen].  With them the host
-// knows when the hand-back launch of K2 and the serial exact-path kernel of K3 cannot have work.  The same sweep
-// writes the 16|16-bit copy of the spans that the two streaming kernels read when every read is < 65536 bp.
+// knows when the hand-back launch of K2 and the serial exact-path kernel of K3 cannot have work.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_pileup_facts(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                         const int2* __restrict__ a_span, const int* __restrict__ rlen,
-                                                        unsigned* __restrict__ facts, unsigned* __restrict__ span16 /*nullptr or [n_ovl]*/) {
+                                                        unsigned* __restrict__ facts) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
     const int nwaves = (gridDim.x * BLOCK) >> 6;
@@ -483,7 +460,6 @@ __global__ __launch_bounds__(BLOCK) void k_pileup_facts(int r_begin, int r_end, 
         for (int64_t k = s + lane; k < e; k += WAVE) {
             const int2 v = a_span[k];
             bad |= ((unsigned)v.x > rl) || ((unsigned)v.y > rl);   // unsigned: negative coordinates are "too large"
-            if (span16) span16[k] = ((unsigned)v.x & 0xffffu) | ((unsigned)v.y << 16);   // used only if the facts allow it
         }
     }
     if (__ballot(bad != 0) && lane == 0) atomicOr(&facts[1], 1u);
@@ -809,13 +785,9 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
 // words (hot[5][64]) so they never collide; they are summed once per read.
 // A read goes to the fallback list (run by k_mask_annotate afterwards) when its pile-up has 65536+ overlaps
 // or any coordinate lies outside [0, rlen], or the read is too long even for a whole workgroup's LDS.
-#ifndef HINGE_K2_WAVES
-#define HINGE_K2_WAVES 7
-#endif
-template <bool PACKED>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HINGE_K2_WAVES, 8))) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
+__global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
                                                              const int64_t* __restrict__ row_ptr,
-                                                             const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
+                                                             const int2* __restrict__ a_span, const int* __restrict__ rlen,
                                                              const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count) {
     extern __shared__ int lds[];
@@ -826,14 +798,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HINGE_K2_
     // n4 reads that need all four]; the first ceil(n1/4) workgroups run four reads, the next ceil(n2/2) two (wavefronts 0
     // and 2, each over two slots), the last n4 one.  One launch, LDS sized for the common short read, and the few long
     // reads of a part overlap with everything else instead of costing every read its occupancy.
-    // every active wavefront runs K2_READS_PER_WAVE consecutive reads of its class, one after the other (see below)
-    constexpr int R = K2_READS_PER_WAVE;
-    const int g1 = (n1 + 4 * R - 1) / (4 * R), g2 = (n2 + 2 * R - 1) / (2 * R);
-    int width, item, item_end;
-    if ((int)blockIdx.x < g1) { width = 1; item = ((int)blockIdx.x * 4 + wib) * R; item_end = min(item + R, n1); }
-    else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = (((int)blockIdx.x - g1) * 2 + (wib >> 1)) * R; item_end = min(item + R, n2); item += n1; item_end += n1; }
-    else { width = 4; if (wib != 0) return; item = ((int)blockIdx.x - g1 - g2) * R; item_end = min(item + R, n4); item += n1 + n2; item_end += n1 + n2; }
-    if (item >= item_end) return;
+    const int g1 = (n1 + 3) / 4, g2 = (n2 + 1) / 2;
+    int width, item;
+    if ((int)blockIdx.x < g1) { width = 1; item = (int)blockIdx.x * 4 + wib; if (item >= n1) return; }
+    else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g1) * 2 + (wib >> 1); if (item >= n2) return; item += n1; }
+    else { width = 4; if (wib != 0) return; item = n1 + n2 + ((int)blockIdx.x - g1 - g2); }
     constexpr int reso = 40;
     const int SH = P.cut_off / 20;
     // Zero words in front of the prefix array and copies of the totals behind it make PB[q < 0] = 0 and P[q > last] = P[last]
@@ -849,52 +818,39 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HINGE_K2_
     int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
     int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1, 2}
 
-    // Software pipeline over the wavefront's reads: one read costs a full memory round trip (~3 us under load) before its
-    // first LDS add and ~5 us of LDS / scalar work after its last one; the first batch of the NEXT read is requested as
-    // soon as the current read's spans have been consumed, so that round trip runs under phases 2-5 of the current read.
-    typedef SpanLoad<PACKED> SL;
-    typename SL::raw v[SL::IN_FLIGHT];
-    int i = read_list[item];
-    int64_t s = row_ptr[i], e = row_ptr[i + 1];
-    int rl = rlen[i];
-    if (e - s < 65536) {
-#pragma unroll
-        for (int u = 0; u < SL::IN_FLIGHT; u++) {
-            const int64_t k = s + u * WAVE + lane;
-            v[u] = k < e ? a_span[k] : SL::zero();
-        }
-    }
-    for (; item < item_end; item++) {
-        const bool has_next = item + 1 < item_end;
-        int i_next = 0, rl_next = 0;
-        int64_t s_next = 0, e_next = 0;
-        if (has_next) { i_next = read_list[item + 1]; s_next = row_ptr[i_next]; e_next = row_ptr[i_next + 1]; rl_next = rlen[i_next]; }
-        do {   // `continue` inside leaves this read (ablation points, hand-backs)
+    for (int once = 0; once < 1; once++) {         // one read per wavefront; `continue` leaves
+        const int i = read_list[item];
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int rl = rlen[i];
         const int64_t n64 = e - s;
-        const bool too_big = n64 >= 65536 || rl < 0;   // 16-bit counts would overflow: general kernel
-        const int n = too_big ? 0 : (int)n64;
-        const typename SL::raw* __restrict__ row = a_span + s;
-        const int qe = max(rl, 0) / 20;               // last bin a well-formed event can fall in
+        if (n64 >= 65536 || rl < 0) {   // 16-bit counts would overflow: general kernel
+            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
+            continue;
+        }
+        const int n = (int)n64;
+        const int2* __restrict__ row = a_span + s;
+        const int qe = rl / 20;                       // last bin a well-formed event can fall in
         const int Qn = min(qe + 1, qcap);             // bins in use; qcap >= max_rlen / 20 + 1 by construction
         const unsigned qclamp = (unsigned)(Qn - 1);
         unsigned mxb = 0, mxe = 0;                    // maxima as unsigned: a negative coordinate shows up as > rl
-        {   // (the first batch of this read is already on its way or here)
-            int4* z4 = reinterpret_cast<int4*>(Pq);
-            for (int t = lane; t < (Qn + 3) / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
-        }
-        for (int base = 0; base < n; base += SL::IN_FLIGHT * WAVE) {
-            if (base > 0) {
+        bool cleared = false;
+        for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
+            int2 v[LOADS_IN_FLIGHT];
 #pragma unroll
-                for (int u = 0; u < SL::IN_FLIGHT; u++) {
-                    const int k = base + u * WAVE + lane;
-                    v[u] = k < n ? row[k] : SL::zero();
-                }
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                const int k = base + u * WAVE + lane;
+                v[u] = k < n ? row[k] : make_int2(0, 0);
+            }
+            if (!cleared) {   // cleared while the first batch is in flight
+                int4* z4 = reinterpret_cast<int4*>(Pq);
+                for (int t = lane; t < (Qn + 3) / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
+                cleared = true;
             }
 #pragma unroll
-            for (int u = 0; u < SL::IN_FLIGHT; u++) {
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                 if (base + u * WAVE >= n) break;   // wave-uniform
                 if (base + u * WAVE + lane < n) {
-                    const int2 w = SL::get(v[u]);
+                    const int2 w = v[u];
                     const unsigned qb = min((unsigned)w.x / 20u, qclamp), qd = min((unsigned)w.y / 20u, qclamp);
                     const unsigned de = (unsigned)qe - qd;
                     int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;
@@ -905,17 +861,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HINGE_K2_
                     mxe = max(mxe, (unsigned)w.y);
                 }
             }
-        }
-        if (has_next && e_next - s_next < 65536) {   // v[] is free: request the next read's first batch now
-#pragma unroll
-            for (int u = 0; u < SL::IN_FLIGHT; u++) {
-                const int64_t k = s_next + u * WAVE + lane;
-                v[u] = k < e_next ? a_span[k] : SL::zero();
-            }
-        }
-        if (too_big) {
-            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
-            continue;
         }
         {   // fold the lane-private hot words into their bins (and zero them for the next read)
             int hv[HOT];
@@ -981,8 +926,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HINGE_K2_
             run_feed(run, base, __ballot(covc(base + lane) > MIN_COV) & V, V, reso);
         }
         mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o);
-        } while (false);
-        i = i_next; s = s_next; e = e_next; rl = rl_next;
     }
 }
 

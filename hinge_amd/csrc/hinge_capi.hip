@@ -40,10 +40,6 @@ struct hinge_ctx {
     DevBuf mean_own;
     int* mean_cov = nullptr;
     DevBuf cmask, rflags, nbins0, keep;
-    DevBuf span16;             // 16|16-bit copy of a_span (abpos | aepos << 16) for the two streaming kernels
-    bool use_span16 = false;   // every read < 65536 bp and every coordinate inside its read (k_pileup_facts)
-    int want_span16 = 0;       // HINGE_SPAN16=1: the streaming kernels read the 16|16-bit copy (half the HBM bytes; measured: same
-                               // time, both kernels are instruction-issue bound, so it is off by default)
     bool has_keep = false;
     DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list;
     unsigned anno_cap = 0;
@@ -202,7 +198,6 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->scalars.bytes = sizeof(Scalars);
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
-    if (const char* g = getenv("HINGE_SPAN16")) ctx->want_span16 = atoi(g);
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
     ctx->med.bytes = sizeof(unsigned) * MED_WORDS;
@@ -218,7 +213,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
+                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -340,18 +335,14 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         // one sweep over the spans, once per part: largest pile-up, any coordinate outside [0, rlen]
         unsigned* facts = sc(ctx)->facts;
         CK(hipMemsetAsync(facts, 0, 2 * sizeof(unsigned), ctx->stream));
-        const bool pack = ctx->max_rlen < 65536 && n_ovl > 0 && ctx->want_span16;
-        if (pack && (rc = ensure(ctx, ctx->span16, sizeof(unsigned) * (size_t)n_ovl))) return rc;
         hipLaunchKernelGGL(k_pileup_facts, dim3(std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->n_cu * 8))), dim3(BLOCK), 0, ctx->stream, r_begin, r_end,
-                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts,
-                           pack ? (unsigned*)ctx->span16.p : (unsigned*)nullptr);
+                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts);
         CK(hipGetLastError());
         unsigned h[2] = {0, 0};
         CK(hipMemcpyAsync(h, facts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         ctx->max_pile = h[0];
         ctx->spans_in_range = h[1] == 0;
-        ctx->use_span16 = pack && ctx->spans_in_range;
     }
     if (!on_device) CK(hipStreamSynchronize(ctx->stream));
     return HINGE_OK;
@@ -461,14 +452,14 @@ static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int set_mc = ctx->min_cov_pending ? 1 : 0, mc = ctx->min_cov_value;
     ctx->min_cov_pending = false;
     ProfScope _ps(ctx, KID_STATS);
-#define LAUNCH_COV_STATS(RESO, PACKED, SPANS)                                                                                          \
-    hipLaunchKernelGGL((k_cov_stats<RESO, PACKED>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end,                   \
-                       (const int64_t*)ctx->row_ptr.p, SPANS, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p,      \
-                       (unsigned long long*)ctx->wave_totals.p, (int*)ctx->scalars.p, n_reset, &sc(ctx)->min_cov, set_mc, mc)
-    if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(40, true, (const unsigned*)ctx->span16.p);
-    else if (p->reso == 40) LAUNCH_COV_STATS(40, false, (const int2*)ctx->a_span.p);
-    else if (ctx->use_span16) LAUNCH_COV_STATS(0, true, (const unsigned*)ctx->span16.p);
-    else LAUNCH_COV_STATS(0, false, (const int2*)ctx->a_span.p);
+    if (p->reso == 40)
+        hipLaunchKernelGGL(k_cov_stats<40>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p,
+                           (int*)ctx->scalars.p, n_reset, &sc(ctx)->min_cov, set_mc, mc);
+    else
+        hipLaunchKernelGGL(k_cov_stats<0>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
+                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p,
+                           (int*)ctx->scalars.p, n_reset, &sc(ctx)->min_cov, set_mc, mc);
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -614,16 +605,10 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // ~20.5 KiB: seven workgroups per CU
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
         const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
-        const int R = K2_READS_PER_WAVE;
-        const int g = std::max(1, (n1 + 4 * R - 1) / (4 * R) + (n2 + 2 * R - 1) / (2 * R) + (n4 + R - 1) / R);
-        if (ctx->use_span16)
-            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
-                               (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
-        else
-            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
-                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
+        const int g = std::max(1, (n1 + 3) / 4 + (n2 + 1) / 2 + n4);
+        hipLaunchKernelGGL(k_mask_annotate_q20, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
+                           (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is
