@@ -781,8 +781,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
 //     cov0[k] = PB[2k-1] - PE[2k-1]               (bin_of(v) <= k  <=>  v/20 <= 2k-1)
 //     covc[k] = PB[2k-1-SH] - PE[2k-1+SH]         ((v +- cut_off)/20 = v/20 +- SH exactly)
 // with PB[<0] = 0 and P[> last] = P[last]: 2 bin computations and 2 LDS adds per overlap instead of 4 + 4.
-// Events in the five hot bins (begins in bins 0-1, ends in the read's last three) go to lane-private LDS
-// words (hot[5][64]) so they never collide; they are summed once per read.
+// Events in the four hot bins (begins in bins 0-1, ends in the read's last two) go to lane-private LDS
+// words (hot[4][64]) so they never collide; they are summed once per read.
 // A read goes to the fallback list (run by k_mask_annotate afterwards) when its pile-up has 65536+ overlaps
 // or any coordinate lies outside [0, rlen], or the read is too long even for a whole workgroup's LDS.
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
                                                              const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count) {
     extern __shared__ int lds[];
-    constexpr int HOT = 5;
+    constexpr int HOT = 4;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // A workgroup has four LDS slots of slot_ints words.  read_list = [n1 reads that fit one slot | n2 reads that need two |
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
 #pragma unroll
     for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
     int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
-    int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1, 2}
+    int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1}
 
     for (int once = 0; once < 1; once++) {         // one read per wavefront; `continue` leaves
         const int i = read_list[item];
@@ -832,14 +832,14 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
         const int qe = rl / 20;                       // last bin a well-formed event can fall in
         const int Qn = min(qe + 1, qcap);             // bins in use; qcap >= max_rlen / 20 + 1 by construction
         const unsigned qclamp = (unsigned)(Qn - 1);
-        unsigned mxb = 0, mxe = 0;                    // maxima as unsigned: a negative coordinate shows up as > rl
+        unsigned mx = 0;                              // max coordinate as unsigned: a negative one shows up as > rl
         bool cleared = false;
+        const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
         for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
             int2 v[LOADS_IN_FLIGHT];
+            if (n > 0) {   // unconditional loads from a clamped index (no exec-mask branch per load); unused slots are skipped below
 #pragma unroll
-            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
-                const int k = base + u * WAVE + lane;
-                v[u] = k < n ? row[k] : make_int2(0, 0);
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
             }
             if (!cleared) {   // cleared while the first batch is in flight
                 int4* z4 = reinterpret_cast<int4*>(Pq);
@@ -854,11 +854,10 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
                     const unsigned qb = min((unsigned)w.x / 20u, qclamp), qd = min((unsigned)w.y / 20u, qclamp);
                     const unsigned de = (unsigned)qe - qd;
                     int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;
-                    int* pe = de < 3u ? hot_e + de * WAVE : Pq + qd;
+                    int* pe = de < 2u ? hot_e + de * WAVE : Pq + qd;
                     atomicAdd(pb, 1);
                     atomicAdd(pe, 0x10000);
-                    mxb = max(mxb, (unsigned)w.x);
-                    mxe = max(mxe, (unsigned)w.y);
+                    mx = max(mx, max((unsigned)w.x, (unsigned)w.y));
                 }
             }
         }
@@ -866,32 +865,27 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
             int hv[HOT];
 #pragma unroll
             for (int h = 0; h < HOT; h++) { hv[h] = hot[h * WAVE + lane]; hot[h * WAVE + lane] = 0; }
-            // per-lane counts are < 65536, wave totals too (n < 65536): pack two per scan
+            // per-lane counts are < 65536, wave totals too (n < 65536): two per scan
             const int sb = wave_sum(hv[0] | (hv[1] << 16));                                  // B0 | B1 << 16
             const int se = wave_sum((int)((unsigned)hv[2] >> 16) | (hv[3] & (int)0xffff0000));   // E0 | E1 << 16
-            const int s2 = wave_sum((int)((unsigned)hv[4] >> 16));                             // E2
-            int idx = -1, val = 0;
-            switch (lane) {
-                case 0: idx = 0; val = sb & 0xffff; break;
-                case 1: idx = 1; val = (int)((unsigned)sb >> 16); break;
-                case 2: idx = qe; val = (se & 0xffff) << 16; break;
-                case 3: idx = qe - 1; val = se & (int)0xffff0000; break;
-                case 4: idx = qe - 2; val = s2 << 16; break;
-                default: break;
-            }
-            if (val != 0) atomicAdd(&Pq[min((unsigned)idx, qclamp)], val);   // non-zero only if some event had that bin
+            // lanes 0-3 add B0 -> bin 0, B1 -> bin 1, E0 -> bin qe, E1 -> bin qe - 1
+            const int pick = (lane & 2) ? se : sb;
+            const int cnt = (lane & 1) ? (int)((unsigned)pick >> 16) : (pick & 0xffff);
+            const int idx = (lane & 2) ? qe - (lane & 1) : (lane & 1);
+            const int val = (lane & 2) ? cnt << 16 : cnt;
+            if (lane < 4 && val != 0) atomicAdd(&Pq[min((unsigned)idx, qclamp)], val);   // non-zero only if some event had that bin
         }
         HINGE_ABLATE_POINT(1)
-        mxb = (unsigned)wave_max((int)min(mxb, 0x7fffffffu));
-        mxe = (unsigned)wave_max((int)min(mxe, 0x7fffffffu));
-        if (mxb > (unsigned)rl || mxe > (unsigned)rl || qe >= qcap) {   // malformed or out of range: the general kernel decides
+        mx = (unsigned)wave_max((int)min(mx, 0x7fffffffu));
+        if (mx > (unsigned)rl || qe >= qcap) {   // malformed or out of range: the general kernel decides
             if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
             continue;
         }
-        const int mx0 = (int)max(mxb, mxe);
-        const int mxc = max((int)mxb + P.cut_off, (int)mxe - P.cut_off);
-        const int K0 = nbins_of<40>(n, mx0, reso);
-        const int KC = nbins_of<40>(n, mxc, reso);
+        const int K0 = nbins_of<40>(n, (int)mx, reso);
+        // The cutoff profile is zero from its last bin on (every event consumed: begins - ends = 0), and a zero bin that
+        // follows a zero bin changes nothing in the run search, so any bound >= the reference's K works: the largest a
+        // well-formed pile-up can have needs no second reduction.
+        const int KC = nbins_of<40>(n, rl + P.cut_off, reso);
 
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
         int carry = 0;

@@ -107,7 +107,7 @@ static const int K2_SHORT_RLEN = 18000;   // (18000 / 20 + 8 + 5 * 64) ints * 4 
 // words of LDS per wavefront slot of k_mask_annotate_q20: 20-bp bins of the longest "short" read + the hot words
 static int k2_slot_ints(const hinge_ctx* ctx) {
     const int len = std::min(ctx->max_rlen, K2_SHORT_RLEN);
-    return (((len / 20 + 1 + 3) & ~3) + 4) + 5 * WAVE;
+    return (((len / 20 + 1 + 3) & ~3) + 4) + 4 * WAVE;
 }
 
 // device scalars, one allocation
@@ -319,7 +319,7 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
     {   // K2 length classes: reads that fit one, two or four LDS slots of a workgroup (see k_mask_annotate_q20)
         const int nr = r_end - r_begin + 1;
         const int slot = k2_slot_ints(ctx);
-        const int len1 = (slot - 5 * WAVE - 1) * 20 + 19, len2 = (2 * slot - 5 * WAVE - 1) * 20 + 19;   // longest read per class
+        const int len1 = (slot - 4 * WAVE - 1) * 20 + 19, len2 = (2 * slot - 4 * WAVE - 1) * 20 + 19;   // longest read per class
         std::vector<int> lst((size_t)nr);
         int n1 = 0, n2 = 0, n4 = 0;
         for (int i = r_begin; i <= r_end; i++) { const int l = ctx->h_rlen[(size_t)i]; n1 += l <= len1; n2 += l > len1 && l <= len2; }
@@ -613,7 +613,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is
         // skipped when the part's facts rule all three out
-        const bool no_handback = ctx->max_pile < 65536u && ctx->spans_in_range && ctx->max_rlen / 20 < WAVES_PER_BLOCK * slot - 5 * WAVE;
+        const bool no_handback = ctx->max_pile < 65536u && ctx->spans_in_range && ctx->max_rlen / 20 < WAVES_PER_BLOCK * k2_slot_ints(ctx) - 4 * WAVE;   // (bins-only slots: conservative)
         if (no_handback) return HINGE_OK;
         ProfScope _ps2(ctx, KID_MASK_FALLBACK);
         LAUNCH_MASK_ANNOTATE(40, std::min(grid, 64), (const int*)ctx->fallback_list.p, (const unsigned*)&sc(ctx)->fallback_count);
