@@ -141,26 +141,58 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
     for (int i = r_begin + wave; i <= r_end; i += nwaves) {
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];
-        int sum = 0;
+        long long tot;
         int mx = INT_MIN;
-        for (int64_t base = s; base < e; base += LOADS_IN_FLIGHT * WAVE) {   // all loads of a batch are issued before the first use
-            int2 v[LOADS_IN_FLIGHT];
+        if (e - s < 65536) {
+            // common case: 32-bit lane offsets from the scalar row base, unconditional loads from a clamped index (no
+            // exec-mask branch and no 64-bit address arithmetic per load), one 32-bit sum (n * K < 2^32 for n < 65536)
+            const int n = (int)(e - s);
+            const int2* __restrict__ row = a_span + s;
+            const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
+            unsigned sum = 0;
+            for (int base = 0; base < n; base += LOADS_IN_FLIGHT * WAVE) {
+                int2 v[LOADS_IN_FLIGHT];
 #pragma unroll
-            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
-                const int64_t k = base + u * WAVE + lane;
-                v[u] = k < e ? a_span[k] : make_int2(0, 0);
-            }
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
 #pragma unroll
-            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
-                if (base + u * WAVE + lane < e) {
-                    sum += bin_of<RESO>(v[u].y, reso) - bin_of<RESO>(v[u].x, reso);
-                    mx = max(mx, max(v[u].x, v[u].y));
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                    if (base + u * WAVE >= n) break;   // wave-uniform
+                    if (base + u * WAVE + lane < n) {
+                        sum += (unsigned)(bin_of<RESO>(v[u].y, reso) - bin_of<RESO>(v[u].x, reso));
+                        mx = max(mx, max(v[u].x, v[u].y));
+                    }
                 }
             }
+            // |bin difference| <= bin_of(largest coordinate): the 32-bit (modular) sum is exact while n times that stays below
+            // 2^31; otherwise (absurd coordinates) the row is summed again in 64 bits
+            mx = wave_max(mx);
+            tot = (long long)(int)wave_sum((int)sum);
+            if ((long long)n * (long long)(bin_of<RESO>(mx, reso) + 1) >= (1LL << 31)) {
+                long long s64 = 0;
+                for (int k = lane; k < n; k += WAVE) s64 += bin_of<RESO>(row[k].y, reso) - bin_of<RESO>(row[k].x, reso);
+                tot = wave_sum64(s64);
+            }
+        } else {
+            int sum = 0;
+            for (int64_t base = s; base < e; base += LOADS_IN_FLIGHT * WAVE) {   // all loads of a batch are issued before the first use
+                int2 v[LOADS_IN_FLIGHT];
+#pragma unroll
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                    const int64_t k = base + u * WAVE + lane;
+                    v[u] = k < e ? a_span[k] : make_int2(0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                    if (base + u * WAVE + lane < e) {
+                        sum += bin_of<RESO>(v[u].y, reso) - bin_of<RESO>(v[u].x, reso);
+                        mx = max(mx, max(v[u].x, v[u].y));
+                    }
+                }
+            }
+            // per-lane partial sums fit 32 bits (<= 2^31 / 64 bins*overlaps per lane); widen for the total
+            tot = wave_sum64((long long)sum);
+            mx = wave_max(mx);
         }
-        // per-lane partial sums fit 32 bits (<= 2^31 / 64 bins*overlaps per lane); widen for the total
-        const long long tot = wave_sum64((long long)sum);
-        mx = wave_max(mx);
         if (lane == 0) {
             const int K = nbins_of<RESO>((int)(e - s), mx, reso);
             nbins0[i] = K;
