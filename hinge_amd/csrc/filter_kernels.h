@@ -120,9 +120,23 @@ __device__ __forceinline__ int nbins_of(int n_ovl, int max_ev, int reso) {
 // K1: per-read cutoff-0 coverage sum and bin count without materialising the bins:
 //     sum_k cov[k] = sum_o (bin_of(aepos) - bin_of(abpos)),  K = bin_of(max event) + 1.
 // ------------------------------------------------------------------------------------------------
-template <int RESO>
+// PACKED: the spans come from the 16|16-bit copy (abpos | aepos << 16, written by k_pileup_facts): half the bytes of
+// the int32 pairs, usable when every read of the part is shorter than 65536 bp and every coordinate lies in its read.
+// K1 and the histogram phase of K2 sit at the HBM floor with int32 spans, so the bytes are what is left to cut.
+template <bool PACKED> struct SpanLoad;
+template <> struct SpanLoad<false> {
+    typedef int2 raw;
+    static __device__ __forceinline__ int2 get(raw v) { return v; }
+};
+template <> struct SpanLoad<true> {
+    typedef unsigned raw;
+    static __device__ __forceinline__ int2 get(raw v) { return make_int2((int)(v & 0xffffu), (int)(v >> 16)); }
+};
+
+template <int RESO, bool PACKED>
 __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
-                                                     const int2* __restrict__ a_span, const int* __restrict__ rlen, int reso,
+                                                     const int2* __restrict__ a_span, const unsigned* __restrict__ span16,
+                                                     const int* __restrict__ rlen, int reso,
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
                                                      unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/,
                                                      int* __restrict__ pass_scalars, int n_pass_scalars, int* __restrict__ d_min_cov,
@@ -147,19 +161,21 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
             // common case: 32-bit lane offsets from the scalar row base, unconditional loads from a clamped index (no
             // exec-mask branch and no 64-bit address arithmetic per load), one 32-bit sum (n * K < 2^32 for n < 65536)
             const int n = (int)(e - s);
-            const int2* __restrict__ row = a_span + s;
+            typedef SpanLoad<PACKED> SL;
+            const typename SL::raw* __restrict__ row = (PACKED ? (const typename SL::raw*)(const void*)span16 : (const typename SL::raw*)(const void*)a_span) + s;
             const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
             unsigned sum = 0;
             for (int base = 0; base < n; base += LOADS_IN_FLIGHT * WAVE) {
-                int2 v[LOADS_IN_FLIGHT];
+                typename SL::raw v[LOADS_IN_FLIGHT];
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                     if (base + u * WAVE >= n) break;   // wave-uniform
                     if (base + u * WAVE + lane < n) {
-                        sum += (unsigned)(bin_of<RESO>(v[u].y, reso) - bin_of<RESO>(v[u].x, reso));
-                        mx = max(mx, max(v[u].x, v[u].y));
+                        const int2 w = SL::get(v[u]);
+                        sum += (unsigned)(bin_of<RESO>(w.y, reso) - bin_of<RESO>(w.x, reso));
+                        mx = max(mx, max(w.x, w.y));
                     }
                 }
             }
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
             tot = (long long)(int)wave_sum((int)sum);
             if ((long long)n * (long long)(bin_of<RESO>(mx, reso) + 1) >= (1LL << 31)) {
                 long long s64 = 0;
-                for (int k = lane; k < n; k += WAVE) s64 += bin_of<RESO>(row[k].y, reso) - bin_of<RESO>(row[k].x, reso);
+                for (int k = lane; k < n; k += WAVE) { const int2 w = SL::get(row[k]); s64 += bin_of<RESO>(w.y, reso) - bin_of<RESO>(w.x, reso); }
                 tot = wave_sum64(s64);
             }
         } else {
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(256) void k_median_from_hist(const unsigned* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_pileup_facts(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                         const int2* __restrict__ a_span, const int* __restrict__ rlen,
-                                                        unsigned* __restrict__ facts) {
+                                                        unsigned* __restrict__ facts, unsigned* __restrict__ span16 /*nullptr or [n_ovl]*/) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
     const int nwaves = (gridDim.x * BLOCK) >> 6;
@@ -492,6 +508,7 @@ __global__ __launch_bounds__(BLOCK) void k_pileup_facts(int r_begin, int r_end, 
         for (int64_t k = s + lane; k < e; k += WAVE) {
             const int2 v = a_span[k];
             bad |= ((unsigned)v.x > rl) || ((unsigned)v.y > rl);   // unsigned: negative coordinates are "too large"
+            if (span16) span16[k] = ((unsigned)v.x & 0xffffu) | ((unsigned)v.y << 16);   // only used if the facts allow it
         }
     }
     if (__ballot(bad != 0) && lane == 0) atomicOr(&facts[1], 1u);
@@ -817,9 +834,10 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
 // words (hot[4][64]) so they never collide; they are summed once per read.
 // A read goes to the fallback list (run by k_mask_annotate afterwards) when its pile-up has 65536+ overlaps
 // or any coordinate lies outside [0, rlen], or the read is too long even for a whole workgroup's LDS.
+template <bool PACKED>
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
                                                              const int64_t* __restrict__ row_ptr,
-                                                             const int2* __restrict__ a_span, const int* __restrict__ rlen,
+                                                             const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
                                                              const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count) {
     extern __shared__ int lds[];
@@ -860,7 +878,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
             continue;
         }
         const int n = (int)n64;
-        const int2* __restrict__ row = a_span + s;
+        typedef SpanLoad<PACKED> SL;
+        const typename SL::raw* __restrict__ row = a_span + s;
         const int qe = rl / 20;                       // last bin a well-formed event can fall in
         const int Qn = min(qe + 1, qcap);             // bins in use; qcap >= max_rlen / 20 + 1 by construction
         const unsigned qclamp = (unsigned)(Qn - 1);
@@ -868,7 +887,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
         bool cleared = false;
         const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
         for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
-            int2 v[LOADS_IN_FLIGHT];
+            typename SL::raw v[LOADS_IN_FLIGHT];
             if (n > 0) {   // unconditional loads from a clamped index (no exec-mask branch per load); unused slots are skipped below
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
@@ -882,7 +901,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
             for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                 if (base + u * WAVE >= n) break;   // wave-uniform
                 if (base + u * WAVE + lane < n) {
-                    const int2 w = v[u];
+                    const int2 w = SL::get(v[u]);
                     const unsigned qb = min((unsigned)w.x / 20u, qclamp), qd = min((unsigned)w.y / 20u, qclamp);
                     const unsigned de = (unsigned)qe - qd;
                     int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;

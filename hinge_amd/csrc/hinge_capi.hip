@@ -40,6 +40,9 @@ struct hinge_ctx {
     DevBuf mean_own;
     int* mean_cov = nullptr;
     DevBuf cmask, rflags, nbins0, keep;
+    DevBuf span16;             // 16|16-bit copy of a_span (abpos | aepos << 16) for the two streaming kernels
+    bool use_span16 = false;   // every read < 65536 bp and every coordinate inside its read (k_pileup_facts)
+    int no_span16 = 0;         // HINGE_NO_SPAN16=1: keep the streaming kernels on the int32 spans
     bool has_keep = false;
     DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list;
     unsigned anno_cap = 0;
@@ -198,6 +201,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->scalars.bytes = sizeof(Scalars);
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
+    if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
     ctx->med.bytes = sizeof(unsigned) * MED_WORDS;
@@ -213,7 +217,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
+                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -335,14 +339,18 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         // one sweep over the spans, once per part: largest pile-up, any coordinate outside [0, rlen]
         unsigned* facts = sc(ctx)->facts;
         CK(hipMemsetAsync(facts, 0, 2 * sizeof(unsigned), ctx->stream));
+        const bool pack = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
+        if (pack && (rc = ensure(ctx, ctx->span16, sizeof(unsigned) * (size_t)n_ovl))) return rc;
         hipLaunchKernelGGL(k_pileup_facts, dim3(std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->n_cu * 8))), dim3(BLOCK), 0, ctx->stream, r_begin, r_end,
-                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts);
+                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts,
+                           pack ? (unsigned*)ctx->span16.p : (unsigned*)nullptr);
         CK(hipGetLastError());
         unsigned h[2] = {0, 0};
         CK(hipMemcpyAsync(h, facts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         ctx->max_pile = h[0];
         ctx->spans_in_range = h[1] == 0;
+        ctx->use_span16 = pack && ctx->spans_in_range;
     }
     if (!on_device) CK(hipStreamSynchronize(ctx->stream));
     return HINGE_OK;
@@ -452,14 +460,15 @@ static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int set_mc = ctx->min_cov_pending ? 1 : 0, mc = ctx->min_cov_value;
     ctx->min_cov_pending = false;
     ProfScope _ps(ctx, KID_STATS);
-    if (p->reso == 40)
-        hipLaunchKernelGGL(k_cov_stats<40>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
-                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p,
-                           (int*)ctx->scalars.p, n_reset, &sc(ctx)->min_cov, set_mc, mc);
-    else
-        hipLaunchKernelGGL(k_cov_stats<0>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end, (const int64_t*)ctx->row_ptr.p,
-                           (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p,
-                           (int*)ctx->scalars.p, n_reset, &sc(ctx)->min_cov, set_mc, mc);
+#define LAUNCH_COV_STATS(RESO, PACKED)                                                                                                 \
+    hipLaunchKernelGGL((k_cov_stats<RESO, PACKED>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end,                   \
+                       (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, \
+                       p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p, (int*)ctx->scalars.p, n_reset, \
+                       &sc(ctx)->min_cov, set_mc, mc)
+    if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(40, true);
+    else if (p->reso == 40) LAUNCH_COV_STATS(40, false);
+    else if (ctx->use_span16) LAUNCH_COV_STATS(0, true);
+    else LAUNCH_COV_STATS(0, false);
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -606,9 +615,14 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
         const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
         const int g = std::max(1, (n1 + 3) / 4 + (n2 + 1) / 2 + n4);
-        hipLaunchKernelGGL(k_mask_annotate_q20, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
-                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
-                           (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
+        if (ctx->use_span16)
+            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+                               (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p,
+                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
+        else
+            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
+                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is

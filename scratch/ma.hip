@@ -75,7 +75,7 @@ int main() {
         float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
             hipLaunchKernelGGL(k_mask_annotate<40>, dim3(grid), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, mc, kcap, o, (const int*)nullptr, (const unsigned*)nullptr); });
         float t2 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
-            hipLaunchKernelGGL(k_mask_annotate_q20, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, mc, slot, o, fb, cnt + 2); });
+            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, mc, slot, o, fb, cnt + 2); });
         printf("stop after phase %d: general %7.1f us   q20 %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all; to end of phase 2: 6 no scan, 7 no mask pass, 8 neither)\n", mode, t * 1e3, t2 * 1e3);
     }
     unsigned hc[4]; (void)hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost);

@@ -234,3 +234,16 @@ def test_filter_long_reads_all_lds_classes(datasets, oracle_lib, tmp_path):
     assert run_in(wd_h, stages.run_filter, "G", "G.las", "G", "nominal.ini", False, 0, True, False, ctx) == 0
     assert ctx.fallback_reads() == n_too_long
     _compare(wd_o, wd_h)
+
+
+def test_filter_int32_spans(datasets, oracle_lib, tmp_path, monkeypatch):
+    """HINGE_NO_SPAN16=1: the streaming kernels read the int32 spans (what they do by themselves when a read is 65536+ bp,
+    as in the long_reads data set) instead of the 16|16-bit copy."""
+    monkeypatch.setenv("HINGE_NO_SPAN16", "1")
+    for name in ("tiny_qv", "long_repeat"):
+        src, _ = datasets(name)
+        wd_o = clone_dataset(src, str(tmp_path / (name + "_oracle")))
+        wd_h = clone_dataset(src, str(tmp_path / (name + "_hip")))
+        assert _oracle_filter(oracle_lib, wd_o, False) == 0
+        assert _hip_filter(wd_h, False) == 0
+        _compare(wd_o, wd_h)
