@@ -629,11 +629,14 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
             const int j = base + lane;
             int code = -1;
-            if (j >= jlo && j <= jhi) {
-                const int cv = z(j);
-                const int g = z(j + 1) - cv;
+            const bool in = j >= jlo && j <= jhi;
+            int cv = 0, g = 0;
+            if (in) { cv = z(j); g = z(j + 1) - cv; }
+            const int G = g < 0 ? -g : g;
+            // an annotation needs |g| > min(lo, hi) on the division-free path: most 64-bin words have none at all
+            if (mulpath && !__ballot(in && G > min(P.min_ra, P.max_ra))) continue;
+            if (in) {
                 const int x = cv + MIN_COV;
-                const int G = g < 0 ? -g : g;
                 if (mulpath && x >= 0 && (unsigned)G < 131072u) {   // thr >= 0 here: the sign of g picks the type, g == 0 never passes
                     if ((G > P.max_ra) || ((G > P.min_ra) && (G * P.cov_frac > x))) code = ((reso * j) << 1) | (g > 0 ? 1 : 0);
                 } else {
