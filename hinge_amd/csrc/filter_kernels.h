@@ -522,6 +522,17 @@ __global__ __launch_bounds__(BLOCK) void k_pileup_facts(int r_begin, int r_end, 
 //   k_mask_annotate      any reso / cut_off / pile-up size: two 40-bp difference histograms; also runs
 //                        the reads the fast kernel hands back (fallback list)
 // ------------------------------------------------------------------------------------------------
+// A read that goes on to hinge calling, with everything k_hinge_count needs to start streaming its pile-up after ONE
+// dependent load (instead of work list -> row_ptr / mask / anno_off / anno_cnt -> anno_buf -> spans).
+struct alignas(16) WorkItem {
+    int read, n;          // read id, pile-up size
+    long long row;        // row_ptr[read]
+    int mask_lo, mask_hi; // its own mask
+    unsigned off;         // anno_off[read]
+    int cnt;              // anno_cnt[read]
+    int2 anno[4];         // the first four annotations (pos, type); further ones are read from anno_buf
+};
+
 struct AnnoOut {   // per-part outputs of K2
     const int2* qv_mask;
     const unsigned char* keep;   // --restrictreads (filter.cpp:680-694,767-773): nullptr, or 0 for reads whose masks are emptied
@@ -534,7 +545,7 @@ struct AnnoOut {   // per-part outputs of K2
     int* anno_cnt;
     unsigned* counters;   // [0] = annotation allocator, [1] = work-list length
     unsigned anno_cap;
-    int* work_list;
+    WorkItem* work_list;
     int* status;
 };
 
@@ -566,7 +577,8 @@ __device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long lo
 // packed candidates (pos << 1 | (type == +1)): slot t is written only after z(j) was read for every j <= t.
 template <typename ZF, typename CF>
 __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
-                                                   const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o) {
+                                                   const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o,
+                                                   const long long row, const int n_pile) {
     int maxstart = 0, maxend = 0, msc = 0, mec = 0;
     if (run.best_len > 0) {
         mec = run.best_j - 1;
@@ -687,7 +699,11 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         o.anno_cnt[i] = m;
         if (m > 0 && !gate_skip) {
             const unsigned w = atomicAdd(&o.counters[1], 1u);
-            o.work_list[w] = i;
+            WorkItem it;
+            it.read = i; it.n = n_pile; it.row = row; it.mask_lo = mk.x; it.mask_hi = mk.y; it.off = off; it.cnt = m;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int cd = t < m ? cand[t] : 0; it.anno[t] = make_int2(cd >> 1, (cd & 1) ? 1 : -1); }
+            o.work_list[w] = it;
         }
     }
     m = __builtin_amdgcn_readfirstlane(m);
@@ -824,7 +840,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
             run_feed(run, base, __ballot(c > MIN_COV) & V, V, reso);   // c[j] > 0 after subtracting MIN_COV
         }
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, [&](int j) { return h0[j]; }, [&](int j) { return hc[j]; }, hc, o);
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, [&](int j) { return h0[j]; }, [&](int j) { return hc[j]; }, hc, o, (long long)s, n);
     }
 }
 
@@ -973,7 +989,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const 
             const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
             run_feed(run, base, __ballot(covc(base + lane) > MIN_COV) & V, V, reso);
         }
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o);
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n);
     }
 }
 

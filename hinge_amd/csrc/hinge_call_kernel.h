@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
                                                        const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
                                                        const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
                                                        const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
-                                                       const int* __restrict__ work_list, const unsigned* __restrict__ counters,
+                                                       const WorkItem* __restrict__ work_list, const unsigned* __restrict__ counters,
                                                        unsigned char* __restrict__ hinge_flag, HeavyItem* __restrict__ heavy,
                                                        unsigned* __restrict__ heavy_count, int force_exact, unsigned* __restrict__ dbg) {
     __shared__ int s_sup[PRE_MAXA][WAVES_PER_BLOCK], s_near[PRE_MAXA][WAVES_PER_BLOCK];
@@ -81,11 +81,12 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
 #ifdef HINGE_TIMING
         const unsigned long long tc0 = wall_clock64();
 #endif
-        const int i = work_list[w];
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        const int2 mk = mask[i];
-        const unsigned off = anno_off[i];
-        const int cnt = anno_cnt[i];
+        const WorkItem wi = work_list[w];
+        const int i = wi.read;
+        const int64_t s = wi.row, e = wi.row + wi.n;
+        const int2 mk = make_int2(wi.mask_lo, wi.mask_hi);
+        const unsigned off = wi.off;
+        const int cnt = wi.cnt;
         const int q = slice_len((int)(e - s));
         const int64_t k_lo = s + (int64_t)wib * q, k_hi = min(e, k_lo + q);   // this wavefront's slice
         for (int a0 = 0; a0 < cnt; a0 += PRE_MAXA) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
             int apos[PRE_MAXA], atype[PRE_MAXA], csup[PRE_MAXA], cnear[PRE_MAXA];
 #pragma unroll
             for (int a = 0; a < PRE_MAXA; a++) {
-                const int2 an = a < na ? anno_buf[off + a0 + a] : make_int2(0, 0);
+                const int2 an = a < na ? (a0 == 0 ? wi.anno[a] : anno_buf[off + a0 + a]) : make_int2(0, 0);
                 apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0;
             }
             for (int64_t k0 = k_lo; k0 < k_hi; k0 += GATHER_LOADS * WAVE) {

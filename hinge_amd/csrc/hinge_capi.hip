@@ -262,7 +262,7 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->nbins0, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_off, sizeof(unsigned) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
-    if ((rc = ensure(ctx, ctx->work_list, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->work_list, sizeof(WorkItem) * n))) return rc;
     if ((rc = ensure(ctx, ctx->fallback_list, sizeof(int) * n))) return rc;
     if (!ctx->mask) ctx->mask = (int2*)ctx->mask_own.p;
     if (!ctx->mean_cov) ctx->mean_cov = (int*)ctx->mean_own.p;
@@ -578,7 +578,7 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
     o.anno_cnt = (int*)ctx->anno_cnt.p;
     o.counters = sc(ctx)->counters;
     o.anno_cap = ctx->anno_cap;
-    o.work_list = (int*)ctx->work_list.p;
+    o.work_list = (WorkItem*)ctx->work_list.p;
     o.status = &sc(ctx)->status;
     return o;
 }
@@ -670,7 +670,7 @@ static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     hipLaunchKernelGGL(k_hinge_count, dim3(ctx->n_cu * 8), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
-                       (const int*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
+                       (const WorkItem*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
                        (HeavyItem*)ctx->heavy_list.p, &sc(ctx)->heavy_count, ctx->force_exact, ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr); }
     CK(hipGetLastError());
     { ProfScope _ps(ctx, KID_HINGE_CALL);

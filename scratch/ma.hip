@@ -43,10 +43,10 @@ int main() {
         }
     }
     printf("overlaps %ld, max rlen %d\n", n, maxrl);
-    int2* a; int64_t* rp; int* rl; int2 *mask, *cmask, *anno; unsigned char *rf, *hf; unsigned *aoff, *cnt; int *acnt, *wl, *st, *mc;
+    int2* a; int64_t* rp; int* rl; int2 *mask, *cmask, *anno; unsigned char *rf, *hf; unsigned *aoff, *cnt; int *acnt, *st, *mc; WorkItem* wl;
     (void)hipMalloc(&a, n * 8); (void)hipMalloc(&rp, (nr + 1) * 8); (void)hipMalloc(&rl, nr * 4); (void)hipMalloc(&mask, nr * 8); (void)hipMalloc(&cmask, nr * 8);
     (void)hipMalloc(&anno, 4 * nr * 8); (void)hipMalloc(&rf, nr); (void)hipMalloc(&hf, 4 * nr); (void)hipMalloc(&aoff, nr * 4); (void)hipMalloc(&acnt, nr * 4);
-    (void)hipMalloc(&wl, nr * 4); (void)hipMalloc(&cnt, 16); (void)hipMalloc(&st, 4); (void)hipMalloc(&mc, 4);
+    (void)hipMalloc(&wl, (size_t)nr * sizeof(WorkItem)); (void)hipMalloc(&cnt, 16); (void)hipMalloc(&st, 4); (void)hipMalloc(&mc, 4);
     (void)hipMemcpy(rp, h.data(), (nr + 1) * 8, hipMemcpyHostToDevice); (void)hipMemcpy(rl, hl.data(), nr * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(a, ha.data(), n * 8, hipMemcpyHostToDevice);
     int minc = 50; (void)hipMemcpy(mc, &minc, 4, hipMemcpyHostToDevice);
