@@ -854,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
 // A read goes to the fallback list (run by k_mask_annotate afterwards) when its pile-up has 65536+ overlaps
 // or any coordinate lies outside [0, rlen], or the read is too long even for a whole workgroup's LDS.
 template <bool PACKED>
-__global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(64))) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
                                                              const int64_t* __restrict__ row_ptr,
                                                              const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
                                                              const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,

@@ -105,7 +105,7 @@ struct ProfScope {
     ~ProfScope() { stop(); }
 };
 
-static const int K2_SHORT_RLEN = 18000;   // (18000 / 20 + 8 + 5 * 64) ints * 4 waves = 19.6 KiB per workgroup: 8 workgroups per CU
+static const int K2_SHORT_RLEN = 16000;   // 20-bp bins of a 16 kb read + hot words + pads = 1120 ints per wavefront, 17.5 KiB per workgroup: 8 workgroups per CU
 
 // words of LDS per wavefront slot of k_mask_annotate_q20: 20-bp bins of the longest "short" read + the hot words
 static int k2_slot_ints(const hinge_ctx* ctx) {

@@ -55,7 +55,7 @@ int main() {
     const int kcap = ((maxrl + 300) / 40 + 4 + 3) & ~3;
     const size_t lds = 4 * 2 * kcap * 4;
     (void)hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int slot0 = ((((std::min(maxrl, 18000)) / 20 + 1 + 3) & ~3) + 4) + 4 * 64;
+    const int slot0 = ((((std::min(maxrl, 16000)) / 20 + 1 + 3) & ~3) + 4) + 4 * 64;
     const int slot = slot0 + 20 + 36;   // + zero / total pads for cut_off 300
     const size_t lds20 = 4 * (size_t)slot * 4;
     const int len1 = (slot0 - 4 * 64 - 1) * 20 + 19, len2 = (2 * slot0 - 4 * 64 - 1) * 20 + 19;
