@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2_ecoli160")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-genome", type=int, default=1_000_000, help="genome length of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample-genome", type=int, default=3_000_000, help="genome length of the CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -275,7 +275,7 @@ def main():
             "path_achieved_GBs": PATH_BYTES_PER_OVERLAP * n_ovl / (ms_per_step * 1e-3) / 1e9,
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             cpu = cpu_baseline(args.workload, args.cpu_sample_genome)
         out = {
             "metric": "overlaps/sec through filter+hinge-detect, E. coli 160x",
