@@ -247,3 +247,22 @@ def test_filter_int32_spans(datasets, oracle_lib, tmp_path, monkeypatch):
         assert _oracle_filter(oracle_lib, wd_o, False) == 0
         assert _hip_filter(wd_h, False) == 0
         _compare(wd_o, wd_h)
+
+
+@pytest.mark.parametrize("name,genome,mlas", [("cfg3_nctc", 400_000, False), ("cfg4_yeast", 600_000, True), ("cfg2_ecoli160", 250_000, False)])
+def test_baseline_configs_scaled_down(oracle_lib, tmp_path, name, genome, mlas):
+    """BASELINE.json's other configurations (repeat-rich NCTC-like with chimeras; 8-block yeast-like with --mlas; the bench
+    workload itself) at a genome size the oracle finishes in seconds: every output file of `hinge filter`."""
+    import dataclasses
+    from hinge_amd import synth
+    spec = dataclasses.replace(synth.CONFIGS[name], genome_len=genome)
+    d = synth.generate(spec)
+    src = str(tmp_path / "src")
+    synth.write_dataset(d, src, "G", write_bases=False)
+    write_ini(os.path.join(src, "nominal.ini"))
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, mlas) == 0
+    assert _hip_filter(wd_h, mlas) == 0
+    _compare(wd_o, wd_h)
+    assert sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.repeat.txt"))) > 0
