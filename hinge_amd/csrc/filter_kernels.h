@@ -621,13 +621,24 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         auto jfirst = [&](int lo) { return lo <= 0 ? 0 : (lo + reso - 1) / reso; };
         auto jlast = [&](int hi) { return hi < 0 ? -1 : min(hi / reso, K0 - 1); };
         const int s0 = jfirst(mk.x), s1 = jlast(mk.x + P.nhr);
-        for (int j = s0 + lane; j <= s1; j += WAVE) S += z(j);
         const int e0 = jfirst(mk.y - P.nhr), e1 = jlast(mk.y);
-        for (int j = e0 + lane; j <= e1; j += WAVE) E += z(j);
         nS = max(s1 - s0 + 1, 0);
         nE = max(e1 - e0 + 1, 0);
+        if (nS <= 32 && nE <= 32) {
+            // both windows are a dozen bins: lanes 0-31 take the start window, lanes 32-63 the end window, ONE scan gives both
+            // sums (integer adds: the order of summation is immaterial)
+            const int half = lane & 31;
+            const int j = lane < 32 ? s0 + half : e0 + half;
+            const bool in = lane < 32 ? half < nS : half < nE;
+            const int incl = wave_incl_scan(in ? z(j) : 0);
+            S = __builtin_amdgcn_readlane(incl, 31);
+            E = wave_last(incl) - S;
+        } else {
+            for (int j = s0 + lane; j <= s1; j += WAVE) S += z(j);
+            for (int j = e0 + lane; j <= e1; j += WAVE) E += z(j);
+            S = wave_sum(S); E = wave_sum(E);
+        }
     }
-    S = wave_sum(S); E = wave_sum(E);
     HINGE_ABLATE_RETURN(3)
     // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
     {
