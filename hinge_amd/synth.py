@@ -317,11 +317,16 @@ def make_traces(d: SynthData, sel: Optional[np.ndarray] = None):
         if rem.any():
             m = rem > 0
             adv[off[1:][m] - 1] += (sgn[m] * rem[m]).astype(np.int16)
-        assert adv.min() >= 0 and adv.max() <= 255, (adv.min(), adv.max())
-    tr = np.empty(2 * tot, dtype=np.uint8)
-    tr[0::2] = dif
-    tr[1::2] = adv.astype(np.uint8)
-    return tr, (2 * off).astype(np.int64)
+        assert adv.min() >= 0 and adv.max() <= (255 if ts <= formats.TRACE_XOVR else 65535), (adv.min(), adv.max())
+    if ts <= formats.TRACE_XOVR:       # one byte per trace value (LAInterface.cpp:607-614)
+        tr = np.empty(2 * tot, dtype=np.uint8)
+        tr[0::2] = dif
+        tr[1::2] = adv.astype(np.uint8)
+        return tr, (2 * off).astype(np.int64)
+    tr16 = np.empty(2 * tot, dtype="<u2")   # two bytes per trace value
+    tr16[0::2] = dif
+    tr16[1::2] = adv.astype(np.uint16)
+    return tr16.view(np.uint8), (4 * off).astype(np.int64)
 
 
 def to_las_records(d: SynthData, sel: Optional[np.ndarray] = None) -> formats.LasRecords:
@@ -330,7 +335,7 @@ def to_las_records(d: SynthData, sel: Optional[np.ndarray] = None) -> formats.La
     rec = np.zeros(len(idx), dtype=formats.LAS_REC_DTYPE)
     comp = d.comp[idx].astype(np.int32)
     blen = d.rlen[d.bread[idx]]
-    rec["tlen"] = (toff[1:] - toff[:-1]).astype(np.int32)
+    rec["tlen"] = ((toff[1:] - toff[:-1]) // (1 if d.spec.tspace <= formats.TRACE_XOVR else 2)).astype(np.int32)
     rec["diffs"] = ((d.ae[idx] - d.ab[idx]) // 8).astype(np.int32)
     rec["abpos"] = d.ab[idx]
     rec["aepos"] = d.ae[idx]
@@ -400,6 +405,9 @@ CONFIGS = {
     # reads from 4 kb to 120 kb: every LDS-slot class of the mask/annotate kernel (1, 2, 4 slots, and > 91 kb: general kernel)
     "long_reads": SynthSpec(genome_len=400_000, coverage=40, len_dist="lognormal", len_mean=25000, len_sigma=0.7, len_min=4000,
                             len_max=120000, repeat_len=(9000, 9000), repeat_copies=(3, 3), seed=31),
+    # trace spacing 200: two bytes per trace value on disk (tspace > 125), a QV track at that spacing
+    "tspace200": SynthSpec(genome_len=150_000, coverage=45, seed=41, tspace=200, with_qv=True, n_repeat_families=2,
+                           repeat_len=(6000, 6000), repeat_copies=(2, 2)),
     "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
                                  repeat_len=(1000, 5000), repeat_copies=(2, 3)),
     "cfg2_ecoli160": SynthSpec(genome_len=4_600_000, coverage=160, len_dist="lognormal", len_mean=8500,
