@@ -41,6 +41,9 @@ class SynthSpec:
     n_blocks: int = 1
     with_qv: bool = False
     tie_quantum: int = 0               # >0: snap alignment end points to this grid (heavy ties)
+    short_reads: int = 0               # reads of 500..999 bp (below the default length_threshold)
+    orphan_reads: int = 0              # interior reads left without a single overlap
+    self_overlap_reads: int = 0        # reads given A == B records (filter.cpp:538-561, .self.flag)
 
 
 @dataclass
@@ -124,6 +127,8 @@ def generate(spec: SynthSpec) -> SynthData:
         mu = np.log(spec.len_mean) - 0.5 * spec.len_sigma ** 2
         lens = np.clip(rng.lognormal(mu, spec.len_sigma, size=n_reads), spec.len_min, spec.len_max).astype(np.int64)
     lens = np.minimum(lens, G // 2)
+    if spec.short_reads > 0:
+        lens[:spec.short_reads] = rng.integers(500, 1000, size=spec.short_reads)
     starts = rng.integers(0, G - lens + 1)
     # reads are stored in DB order = order of genome start only loosely (shuffle like a real run)
     perm = rng.permutation(n_reads)
@@ -248,7 +253,32 @@ def generate(spec: SynthSpec) -> SynthData:
     comp = np.concatenate(rec_comp).astype(np.uint8)
     rl = lens.astype(np.int32)
     ok = (ab >= 0) & (ae <= rl[aread]) & (bb >= 0) & (be <= rl[bread]) & (ae - ab >= 100) & (be - bb >= 100)
+    if spec.orphan_reads > 0:
+        orphan = np.zeros(n_reads, bool)
+        orphan[rng.choice(np.arange(1, n_reads - 1), size=spec.orphan_reads, replace=False)] = True
+        ok &= ~orphan[aread] & ~orphan[bread]
     aread, bread, ab, ae, bb, be, comp = (v[ok] for v in (aread, bread, ab, ae, bb, be, comp))
+    if spec.self_overlap_reads > 0:
+        # tandem-like self matches; every other chosen read is long and gets enough of them to cross
+        # the 4.5x self-coverage flag (filter.cpp:552-561), the rest stay below it
+        long_ids = np.nonzero(rl > 10000)[0]
+        pick = rng.choice(long_ids if len(long_ids) >= spec.self_overlap_reads else np.arange(n_reads),
+                          size=spec.self_overlap_reads, replace=False)
+        sa, sab, sae, sbb, sbe = [], [], [], [], []
+        for k, r in enumerate(pick):
+            L = int(rl[r])
+            nrec = 7 if k % 2 == 0 else 2
+            for _ in range(nrec):
+                span = int(L * rng.uniform(0.35, 0.45))
+                a0 = int(rng.integers(0, L - 2 * span - 1))
+                b0 = int(rng.integers(a0 + span // 2, L - span))
+                sa.append(r); sab.append(a0); sae.append(a0 + span)
+                sbb.append(b0); sbe.append(b0 + span - int(rng.integers(0, 5)))
+        sa = np.asarray(sa, np.int32)
+        aread = np.concatenate([aread, sa]); bread = np.concatenate([bread, sa])
+        ab = np.concatenate([ab, np.asarray(sab, np.int32)]); ae = np.concatenate([ae, np.asarray(sae, np.int32)])
+        bb = np.concatenate([bb, np.asarray(sbb, np.int32)]); be = np.concatenate([be, np.asarray(sbe, np.int32)])
+        comp = np.concatenate([comp, np.zeros(len(sa), np.uint8)])
 
     # LAsort order: (aread, bread, comp, abpos)
     if d_bits_ok(len(rl), int(rl.max())):
@@ -408,6 +438,10 @@ CONFIGS = {
     # trace spacing 200: two bytes per trace value on disk (tspace > 125), a QV track at that spacing
     "tspace200": SynthSpec(genome_len=150_000, coverage=45, seed=41, tspace=200, with_qv=True, n_repeat_families=2,
                            repeat_len=(6000, 6000), repeat_copies=(2, 2)),
+    # reads below length_threshold, reads without any overlap, A == B records on both sides of the
+    # self-coverage flag (filter.cpp:538-561)
+    "edges": SynthSpec(genome_len=130_000, coverage=42, seed=43, len_max=14000, min_ovl=500, short_reads=24,
+                       orphan_reads=6, self_overlap_reads=6, with_qv=True),
     "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
                                  repeat_len=(1000, 5000), repeat_copies=(2, 3)),
     "cfg2_ecoli160": SynthSpec(genome_len=4_600_000, coverage=160, len_dist="lognormal", len_mean=8500,

@@ -47,10 +47,27 @@ def ref_lib():
 
 
 def write_ini(path, extra_filter="", extra_layout=""):
-    txt = NOMINAL_INI.replace("use_qv = true;\n", "use_qv = true;\n" + extra_filter)
-    txt = txt + extra_layout
+    """nominal.ini with overrides.  A key that nominal.ini already has is REPLACED in place: the
+    reference's INIReader joins duplicate keys with a newline and strtol then reads the first value
+    (src/lib/INIReader.cpp:76-79), so an appended duplicate would change nothing."""
+    lines = NOMINAL_INI.split("\n")
+
+    def apply(section, extra):
+        lo = lines.index("[%s]" % section)
+        hi = next((i for i in range(lo + 1, len(lines)) if lines[i].startswith("[")), len(lines))
+        for ov in [x for x in extra.split("\n") if x.strip()]:
+            key = ov.split("=")[0].strip()
+            hit = [i for i in range(lo + 1, hi) if lines[i].split("=")[0].strip() == key]
+            if hit:
+                lines[hit[0]] = ov
+            else:
+                lines.insert(hi, ov)
+                hi += 1
+
+    apply("filter", extra_filter)
+    apply("layout", extra_layout)
     with open(path, "w") as f:
-        f.write(txt)
+        f.write("\n".join(lines))
     return path
 
 

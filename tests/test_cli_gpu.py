@@ -35,7 +35,8 @@ def _cli(wd, mlas, ini):
 
 
 CASES = [("tiny", False, "", ""), ("tiny_qv", False, "", ""), ("tiny_mlas", True, "", ""), ("tiny_mlas", False, "", ""), ("ties", False, "", ""),
-         ("chimera", False, "", ""), ("long_repeat", False, "", ""), ("tspace200", False, "", ""),
+         ("chimera", False, "", ""), ("long_repeat", False, "", ""), ("tspace200", False, "", ""), ("edges", False, "", ""),
+         ("edges", False, "length_threshold = 400\n", "del_telomere = 1\ndel_telomeres = 1\n"),
          ("tiny", False, "", "min_connected_component_size = 2\n"),
          ("tiny_qv", False, "ec = 60\nhinge_min_support = 3\nhinge_unbridged = 2\nhinge_min_pileup = 3\n", "del_telomere = 1\ndel_telomeres = 1\nuse_two_matches = 0\n"),
          ("long_repeat", False, "theta2 = 100\naln_threshold = 2500\n", "hinge_tolerance = 400\nmatching_hinge_slack = 500\nmin_connected_component_size = 1\nhinge_slack = 10\n")]

@@ -28,7 +28,7 @@ def _compare(wd_o, wd_h):
 
 
 @pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("tiny_mlas", True), ("tiny_mlas", False),
-                                       ("ties", False), ("chimera", False), ("long_repeat", False), ("tspace200", False)])
+                                       ("ties", False), ("chimera", False), ("long_repeat", False), ("tspace200", False), ("edges", False)])
 @pytest.mark.parametrize("exact", [0, 1, 2])
 def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas, exact):
     src, _ = datasets(name)

@@ -40,7 +40,7 @@ def _read_dump(path):
     return hdr, cols
 
 
-@pytest.mark.parametrize("name,las", [("tiny", "G.las"), ("tiny_mlas", "G.2.las"), ("ties", "G.las"), ("long_reads", "G.las"), ("tspace200", "G.las")])
+@pytest.mark.parametrize("name,las", [("tiny", "G.las"), ("tiny_mlas", "G.2.las"), ("ties", "G.las"), ("long_reads", "G.las"), ("tspace200", "G.las"), ("edges", "G.las")])
 def test_ingest_matches_numpy_reader(datasets, ingest_dump, tmp_path, name, las):
     wd, d = datasets(name)
     db, lasp = os.path.join(wd, "G"), os.path.join(wd, las)
