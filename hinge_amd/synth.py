@@ -44,6 +44,8 @@ class SynthSpec:
     short_reads: int = 0               # reads of 500..999 bp (below the default length_threshold)
     orphan_reads: int = 0              # interior reads left without a single overlap
     self_overlap_reads: int = 0        # reads given A == B records (filter.cpp:538-561, .self.flag)
+    orphan_ends: int = 0               # this many reads at EACH end of the id range without overlaps: they fall
+                                       # outside [first A, last A] and get no .mas line (filter.cpp:515-517)
 
 
 @dataclass
@@ -257,6 +259,9 @@ def generate(spec: SynthSpec) -> SynthData:
         orphan = np.zeros(n_reads, bool)
         orphan[rng.choice(np.arange(1, n_reads - 1), size=spec.orphan_reads, replace=False)] = True
         ok &= ~orphan[aread] & ~orphan[bread]
+    if spec.orphan_ends > 0:
+        k = spec.orphan_ends
+        ok &= (aread >= k) & (aread < n_reads - k) & (bread >= k) & (bread < n_reads - k)
     aread, bread, ab, ae, bb, be, comp = (v[ok] for v in (aread, bread, ab, ae, bb, be, comp))
     if spec.self_overlap_reads > 0:
         # tandem-like self matches; every other chosen read is long and gets enough of them to cross
@@ -442,6 +447,7 @@ CONFIGS = {
     # self-coverage flag (filter.cpp:538-561)
     "edges": SynthSpec(genome_len=130_000, coverage=42, seed=43, len_max=14000, min_ovl=500, short_reads=24,
                        orphan_reads=6, self_overlap_reads=6, with_qv=True),
+    "orphan_ends": SynthSpec(genome_len=100_000, coverage=40, seed=47, orphan_ends=3),
     "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
                                  repeat_len=(1000, 5000), repeat_copies=(2, 3)),
     "cfg2_ecoli160": SynthSpec(genome_len=4_600_000, coverage=160, len_dist="lognormal", len_mean=8500,

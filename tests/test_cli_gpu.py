@@ -56,6 +56,25 @@ def test_cli_pipeline_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas,
     assert os.path.getsize(os.path.join(wd_h, "G.edges.hinges")) > 0 and os.path.getsize(os.path.join(wd_h, "G.max")) > 0
 
 
+def test_cli_reads_outside_the_overlap_id_range(datasets, oracle_lib, tmp_path):
+    """Reads before the first / after the last A id get no .mas line (filter.cpp:515-517,696); filter still
+    has defined output, maximal and layout would read uninitialised masks in the reference: refused here."""
+    src, d = datasets("orphan_ends")
+    assert d.aread.min() == 3 and d.aread.max() == d.n_reads - 4
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert run_in(wd_o, oracle_lib.oracle_filter, b"G", b"G.las", 0, b"G", b"nominal.ini", b"") == 0
+    run = lambda *a: subprocess.run([HINGE] + list(a), cwd=wd_h, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode  # noqa: E731
+    assert run("filter", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini") == 0
+    filt = ["G.mas", "G.cmas", "G.repeat.txt", "G.hinges.txt", "G.coverage.txt", "G.cov.flag", "G.self.flag", "G.homologous.txt", "G.filtered.fasta"]
+    bad = [f for f in filt if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
+    assert sum(1 for _ in open(os.path.join(wd_h, "G.mas"))) == d.n_reads - 6
+    assert _oracle(oracle_lib, wd_o, False, "nominal.ini")[1:] == [-3, -3]          # (maximal truncates .coverage.txt first)
+    assert run("maximal", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini") == 2
+    assert run("layout", "--db", "G", "--las", "G.las", "-x", "G", "-o", "G", "--config", "nominal.ini") == 2
+
+
 def test_cli_error_behaviour(datasets, tmp_path):
     """Exit codes of the reference's argument / config error paths (filter.cpp:218-226,372-375, hinging.cpp required flags)."""
     src, _ = datasets("tiny")
