@@ -85,6 +85,31 @@ SYMBOLS = [
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """A PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one process do not
+    share the GPU: whichever comes second reports "No HIP GPUs are available".  If torch is installed but not imported
+    yet, load ITS runtime first (same SONAME), so that libhinge_hip.so binds to it and a later `import torch` finds the
+    GPU whatever the import order.  HINGE_SYSTEM_HIP=1 keeps the ROCm installation's runtime instead."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("HINGE_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library() -> C.CDLL:
     """Load libhinge_hip.so and bind every declared symbol (fails loudly if one is missing)."""
     global _lib
@@ -92,6 +117,7 @@ def load_library() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libhinge_hip.so not built (%s): run `make` / __graft_entry__.build()" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS + EXTRA_SYMBOLS:
         f = getattr(lib, name)

@@ -53,6 +53,8 @@ struct FilterDev {   // device copy of hinge_filter_params + derived values
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+// ballot of a predicate as the compiler holds it (a lane mask in SGPRs): __ballot(int) materialises 0/1 per lane and compares again
+__device__ __forceinline__ unsigned long long ballot_of(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 template <int RESO>
 __device__ __forceinline__ int bin_of(int v, int reso) {
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
         const int rl = rlen[i];
         long long tot;
         int mx = INT_MIN;
+        bool q20_ok = false;     // every coordinate in [0, rl] and fewer than 65536 overlaps: k_mask_annotate_q20 may take the read
         if (e - s < 65536) {
             // common case: 32-bit lane offsets from the scalar row base, unconditional loads from a clamped index (no
             // exec-mask branch and no 64-bit address arithmetic per load), one 32-bit sum (n * K < 2^32 for n < 65536)
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
             typedef SpanLoad<PACKED> SL;
             const typename SL::raw* __restrict__ row = (PACKED ? (const typename SL::raw*)(const void*)span16 : (const typename SL::raw*)(const void*)a_span) + s;
             const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
-            unsigned sum = 0;
+            unsigned sum = 0, umx = 0;   // max as unsigned: a negative coordinate shows up as a huge one
             for (int base = 0; base < n; base += LOADS_IN_FLIGHT * WAVE) {
                 typename SL::raw v[LOADS_IN_FLIGHT];
 #pragma unroll
@@ -175,15 +178,26 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
                     if (base + u * WAVE + lane < n) {
                         const int2 w = SL::get(v[u]);
                         sum += (unsigned)(bin_of<RESO>(w.y, reso) - bin_of<RESO>(w.x, reso));
-                        mx = max(mx, max(w.x, w.y));
+                        umx = max(umx, max((unsigned)w.x, (unsigned)w.y));
                     }
                 }
             }
-            // |bin difference| <= bin_of(largest coordinate): the 32-bit (modular) sum is exact while n times that stays below
-            // 2^31; otherwise (absurd coordinates) the row is summed again in 64 bits
-            mx = wave_max(mx);
+            const int cmx = wave_max((int)min(umx, 0x7fffffffu));
+            if (n > 0) {
+                mx = cmx;
+                q20_ok = rl >= 0 && cmx <= rl;
+                if (cmx == 0x7fffffff) {   // a negative (or absurd) coordinate: the signed maximum needs its own sweep
+                    int m2 = INT_MIN;
+                    for (int k = lane; k < n; k += WAVE) { const int2 w = SL::get(row[k]); m2 = max(m2, max(w.x, w.y)); }
+                    mx = wave_max(m2);
+                }
+            } else {
+                q20_ok = rl >= 0;
+            }
+            // |bin difference| <= bin_of(largest coordinate) when none is negative: the 32-bit (modular) sum is exact while n
+            // times that stays below 2^31; otherwise (absurd coordinates) the row is summed again in 64 bits
             tot = (long long)(int)wave_sum((int)sum);
-            if ((long long)n * (long long)(bin_of<RESO>(mx, reso) + 1) >= (1LL << 31)) {
+            if (cmx == 0x7fffffff || (long long)n * (long long)(bin_of<RESO>(mx, reso) + 1) >= (1LL << 31)) {
                 long long s64 = 0;
                 for (int k = lane; k < n; k += WAVE) { const int2 w = SL::get(row[k]); s64 += bin_of<RESO>(w.y, reso) - bin_of<RESO>(w.x, reso); }
                 tot = wave_sum64(s64);
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
         }
         if (lane == 0) {
             const int K = nbins_of<RESO>((int)(e - s), mx, reso);
-            nbins0[i] = K;
+            nbins0[i] = q20_ok ? K : -1;   // bins of the plain profile for k_mask_annotate_q20, -1 = not a read for that kernel
             if (rl >= 5000) {
                 const long long m = tot / (long long)max(1, K);   // C division, filter.cpp:654
                 mean_cov[i] = (int)m;
@@ -657,7 +671,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
             if (in) { cv = z(j); g = z(j + 1) - cv; }
             const int G = g < 0 ? -g : g;
             // an annotation needs |g| > min(lo, hi) on the division-free path: most 64-bin words have none at all
-            if (mulpath && !__ballot(in && G > min(P.min_ra, P.max_ra))) continue;
+            if (mulpath && !ballot_of(in && G > min(P.min_ra, P.max_ra))) continue;
             if (in) {
                 const int x = cv + MIN_COV;
                 if (mulpath && x >= 0 && (unsigned)G < 131072u) {   // thr >= 0 here: the sign of g picks the type, g == 0 never passes
@@ -668,7 +682,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
                     else if (g < -thr) code = ((reso * j) << 1) | 0;
                 }
             }
-            const unsigned long long bal = __ballot(code != -1);
+            const unsigned long long bal = ballot_of(code != -1);
             if (code != -1) cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = code;
             ncand += __popcll(bal);
         }
@@ -868,7 +882,7 @@ template <bool PACKED>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(64))) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
                                                              const int64_t* __restrict__ row_ptr,
                                                              const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
-                                                             const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
+                                                             const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count) {
     extern __shared__ int lds[];
     constexpr int HOT = 4;
@@ -890,35 +904,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
     const int PADF = (SH + 2 + 3) & ~3, PADT = (2 * SH + 4 + 3) & ~3;
     const int qcap = width * slot_ints - HOT * WAVE - PADF - PADT;
     int* Pq = lds + (size_t)wib * slot_ints + PADF;
-    int* hot = Pq + qcap + PADT;
-    const int MIN_COV = *d_min_cov;
-    for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
+    int* hot = Pq + qcap + PADT;                   // lane-private words for the four hot bins (see below)
 #pragma unroll
     for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
     int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
     int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1}
+    const int MIN_COV = *d_min_cov;
+    for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
 
     for (int once = 0; once < 1; once++) {         // one read per wavefront; `continue` leaves
         const int i = read_list[item];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];
+        const int K0 = nbins0[i];                     // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
         const int64_t n64 = e - s;
-        if (n64 >= 65536 || rl < 0) {   // 16-bit counts would overflow: general kernel
+        const int qe = rl / 20;                       // last bin an event can fall in
+        if (n64 >= 65536 || K0 < 0 || qe >= qcap) {   // 16-bit counts would overflow / malformed / too long: general kernel
             if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
             continue;
         }
         const int n = (int)n64;
         typedef SpanLoad<PACKED> SL;
         const typename SL::raw* __restrict__ row = a_span + s;
-        const int qe = rl / 20;                       // last bin a well-formed event can fall in
-        const int Qn = min(qe + 1, qcap);             // bins in use; qcap >= max_rlen / 20 + 1 by construction
-        const unsigned qclamp = (unsigned)(Qn - 1);
-        unsigned mx = 0;                              // max coordinate as unsigned: a negative one shows up as > rl
+        const int Qn = qe + 1;                        // bins in use
         bool cleared = false;
         const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
         for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
             typename SL::raw v[LOADS_IN_FLIGHT];
-            if (n > 0) {   // unconditional loads from a clamped index (no exec-mask branch per load); unused slots are skipped below
+            if constexpr (PACKED) {
+                // the 16|16 copy is padded by half a batch, so the loads need neither a clamp nor a branch each: scalar row base
+                // + one lane offset + immediates, the whole batch or its first half
+                const typename SL::raw* __restrict__ p = row + (unsigned)(base + lane);
+                if (n - base > (LOADS_IN_FLIGHT / 2) * WAVE) {
+#pragma unroll
+                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = p[u * WAVE];
+                } else if (n > 0) {
+#pragma unroll
+                    for (int u = 0; u < LOADS_IN_FLIGHT / 2; u++) v[u] = p[u * WAVE];
+                }
+            } else if (n > 0) {   // (the int32 spans may be the caller's buffer: clamped index)
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
             }
@@ -931,14 +955,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
             for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                 if (base + u * WAVE >= n) break;   // wave-uniform
                 if (base + u * WAVE + lane < n) {
+                    // k_cov_stats vouches for 0 <= abpos, aepos <= rl: the bins need no clamp
                     const int2 w = SL::get(v[u]);
-                    const unsigned qb = min((unsigned)w.x / 20u, qclamp), qd = min((unsigned)w.y / 20u, qclamp);
+                    const unsigned qb = (unsigned)w.x / 20u, qd = (unsigned)w.y / 20u;
                     const unsigned de = (unsigned)qe - qd;
                     int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;
                     int* pe = de < 2u ? hot_e + de * WAVE : Pq + qd;
                     atomicAdd(pb, 1);
                     atomicAdd(pe, 0x10000);
-                    mx = max(mx, max((unsigned)w.x, (unsigned)w.y));
                 }
             }
         }
@@ -954,18 +978,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
             const int cnt = (lane & 1) ? (int)((unsigned)pick >> 16) : (pick & 0xffff);
             const int idx = (lane & 2) ? qe - (lane & 1) : (lane & 1);
             const int val = (lane & 2) ? cnt << 16 : cnt;
-            if (lane < 4 && val != 0) atomicAdd(&Pq[min((unsigned)idx, qclamp)], val);   // non-zero only if some event had that bin
+            if (lane < 4 && val != 0) atomicAdd(&Pq[idx], val);   // non-zero only if some event had that bin
         }
         HINGE_ABLATE_POINT(1)
-        mx = (unsigned)wave_max((int)min(mx, 0x7fffffffu));
-        if (mx > (unsigned)rl || qe >= qcap) {   // malformed or out of range: the general kernel decides
-            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
-            continue;
-        }
-        const int K0 = nbins_of<40>(n, (int)mx, reso);
         // The cutoff profile is zero from its last bin on (every event consumed: begins - ends = 0), and a zero bin that
         // follows a zero bin changes nothing in the run search, so any bound >= the reference's K works: the largest a
-        // well-formed pile-up can have needs no second reduction.
+        // well-formed pile-up can have needs no reduction.
         const int KC = nbins_of<40>(n, rl + P.cut_off, reso);
 
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
@@ -996,9 +1014,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         if (P.ablate != 7 && P.ablate != 8)
 #endif
         for (int base = 0; base < KC; base += WAVE) {
+            const unsigned long long M = ballot_of(covc(base + lane) > MIN_COV);
             const int left = KC - base;
-            const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-            run_feed(run, base, __ballot(covc(base + lane) > MIN_COV) & V, V, reso);
+            if (left >= 64) {
+                // 64 bins above MIN_COV (the interior of nearly every read) open or continue a run and close none
+                if (M == ~0ull) { run.prev_pos = 1ull; continue; }
+                run_feed(run, base, M, ~0ull, reso);
+            } else {
+                const unsigned long long V = (1ull << left) - 1ull;
+                run_feed(run, base, M & V, V, reso);
+            }
         }
         mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n);
     }

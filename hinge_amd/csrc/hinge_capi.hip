@@ -40,6 +40,7 @@ struct hinge_ctx {
     DevBuf mean_own;
     int* mean_cov = nullptr;
     DevBuf cmask, rflags, nbins0, keep;
+    int nbins0_reso = -1;               // reso k_cov_stats last filled nbins0[] at for the current pile-ups (-1: not yet)
     DevBuf span16;             // 16|16-bit copy of a_span (abpos | aepos << 16) for the two streaming kernels
     bool use_span16 = false;   // every read < 65536 bp and every coordinate inside its read (k_pileup_facts)
     int no_span16 = 0;         // HINGE_NO_SPAN16=1: keep the streaming kernels on the int32 spans
@@ -300,6 +301,7 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
     if (r_begin < 0 || r_end >= ctx->n_reads || r_end < r_begin || n_ovl < 0 || !row_ptr) return fail(ctx, HINGE_E_ARG, "hinge_set_pileups: bad range");
     CK(hipSetDevice(ctx->device));
     ctx->r_begin = r_begin; ctx->r_end = r_end; ctx->n_ovl = n_ovl;
+    ctx->nbins0_reso = -1;
     int rc;
     if ((rc = adopt(ctx, ctx->row_ptr, row_ptr, sizeof(int64_t) * ((size_t)ctx->n_reads + 1), on_device))) return rc;
     if ((rc = adopt(ctx, ctx->a_span, a_span, sizeof(int2) * (size_t)n_ovl, on_device))) return rc;
@@ -340,7 +342,8 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         unsigned* facts = sc(ctx)->facts;
         CK(hipMemsetAsync(facts, 0, 2 * sizeof(unsigned), ctx->stream));
         const bool pack = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
-        if (pack && (rc = ensure(ctx, ctx->span16, sizeof(unsigned) * (size_t)n_ovl))) return rc;
+        // (+ half a batch of elements: k_mask_annotate_q20 reads its last batch without clamping the index)
+        if (pack && (rc = ensure(ctx, ctx->span16, sizeof(unsigned) * ((size_t)n_ovl + (LOADS_IN_FLIGHT / 2) * WAVE)))) return rc;
         hipLaunchKernelGGL(k_pileup_facts, dim3(std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->n_cu * 8))), dim3(BLOCK), 0, ctx->stream, r_begin, r_end,
                            (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts,
                            pack ? (unsigned*)ctx->span16.p : (unsigned*)nullptr);
@@ -470,6 +473,7 @@ static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     else if (ctx->use_span16) LAUNCH_COV_STATS(0, true);
     else LAUNCH_COV_STATS(0, false);
     CK(hipGetLastError());
+    ctx->nbins0_reso = p->reso;   // nbins0[] now describes these pile-ups at this reso
     return HINGE_OK;
 }
 
@@ -606,22 +610,23 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     // grid-stride loop does (measured 137 -> 119 us at 87 k reads)
     const int grid = std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
     // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
-    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0;
+    // (it takes the bin count and the well-formedness of each pile-up from k_cov_stats<40> of this pass)
+    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0 && ctx->nbins0_reso == 40;
     if (q20) {
         // bins + hot words (the read classes of hinge_set_pileups are cut for this much) + the zero / total pads of this cut_off
         const int SH = p->cut_off / 20;
         const int slot = k2_slot_ints(ctx) + ((SH + 2 + 3) & ~3) + ((2 * SH + 4 + 3) & ~3);
-        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // ~20.5 KiB: seven workgroups per CU
+        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // ~17.5 KiB for 16 kb reads: eight workgroups (32 waves) per CU
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
         const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
         const int g = std::max(1, (n1 + 3) / 4 + (n2 + 1) / 2 + n4);
         if (ctx->use_span16)
             hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
-                               (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p,
+                               (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
                                (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
         else
             hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
-                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,
+                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
                                (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
         CK(hipGetLastError());
         _ps.stop();

@@ -67,6 +67,14 @@ int main() {
     int* fb; (void)hipMalloc(&fb, nr * 4);
     int* ids; (void)hipMalloc(&ids, nr * 4);
     (void)hipMemcpy(ids, lst.data(), nr * 4, hipMemcpyHostToDevice);
+    // 16|16 copy (+ one wavefront of padding), bin counts from k_cov_stats
+    std::vector<unsigned> h16(n + 256, 0u);
+    for (long i = 0; i < n; i++) h16[i] = (unsigned)ha[i].x | ((unsigned)ha[i].y << 16);
+    unsigned* a16; (void)hipMalloc(&a16, (n + 256) * 4); (void)hipMemcpy(a16, h16.data(), (n + 256) * 4, hipMemcpyHostToDevice);
+    int *meanc, *nb0, *psc; unsigned long long* wt;
+    (void)hipMalloc(&meanc, nr * 4); (void)hipMalloc(&nb0, nr * 4); (void)hipMalloc(&psc, 64 * 4); (void)hipMalloc(&wt, 2048 * 4 * 2 * 8);
+    float tk1 = timeit([&] { hipLaunchKernelGGL((k_cov_stats<40, true>), dim3(2048), dim3(256), 0, 0, 0, nr - 1, rp, a, a16, rl, 40, meanc, nb0, wt, psc, 16, mc, 0, 0); });
+    printf("k_cov_stats<40, packed>: %7.1f us\n", tk1 * 1e3);
     AnnoOut o{nullptr, nullptr, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * (unsigned)nr, wl, st};
     const int grid = (nr + 3) / 4;
     const int grid20 = (n1 + 3) / 4 + (n2 + 1) / 2 + n4;
@@ -75,8 +83,10 @@ int main() {
         float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
             hipLaunchKernelGGL(k_mask_annotate<40>, dim3(grid), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, mc, kcap, o, (const int*)nullptr, (const unsigned*)nullptr); });
         float t2 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
-            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, mc, slot, o, fb, cnt + 2); });
-        printf("stop after phase %d: general %7.1f us   q20 %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all; to end of phase 2: 6 no scan, 7 no mask pass, 8 neither)\n", mode, t * 1e3, t2 * 1e3);
+            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, nb0, mc, slot, o, fb, cnt + 2); });
+        float t3 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
+            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a16, rl, nb0, mc, slot, o, fb, cnt + 2); });
+        printf("stop after phase %d: general %7.1f us   q20 %7.1f us   q20 packed %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all; to end of phase 2: 6 no scan, 7 no mask pass, 8 neither)\n", mode, t * 1e3, t2 * 1e3, t3 * 1e3);
     }
     unsigned hc[4]; (void)hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost);
     printf("counters: anno %u work %u fallback %u\n", hc[0], hc[1], hc[2]);

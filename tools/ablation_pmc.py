@@ -13,10 +13,11 @@ for r in rows:
         continue
     d.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(d)
-per = 11
+per = int(sys.argv[2]) if len(sys.argv) > 2 else 11      # q20 launches per stop point
+pick = int(sys.argv[3]) if len(sys.argv) > 3 else 5     # which of them to read
 prev = None
 for m in range(len(ids) // per):
-    x = d[ids[m * per + 5]]
+    x = d[ids[m * per + pick]]
     w = x["SQ_WAVES"]
     cur = (x["SQ_INSTS_VALU"] / w, x["SQ_INSTS_SALU"] / w, x["SQ_INSTS_LDS"] / w, 4 * x["SQ_WAVE_CYCLES"] / w)
     delta = "" if prev is None or m >= 5 else "   (+%.0f VALU +%.0f scalar +%.0f LDS)" % tuple(c - p for c, p in zip(cur[:3], prev[:3]))
