@@ -77,6 +77,7 @@ SYMBOLS = [
     ("hinge_profile_select", C.c_int, [_VP, C.c_uint32]),
     ("hinge_profile_kernels", C.c_int, []),
     ("hinge_profile_kernel_name", C.c_char_p, [C.c_int]),
+    ("hinge_resolve_containment", C.c_int, [C.c_int32, _VP, C.c_int64, _VP, _VP]),
     ("hinge_profile_report", C.c_int, [_VP, _VP, _VP]),
     ("hinge_timer_start", C.c_int, [_VP]),
     ("hinge_timer_stop_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -314,6 +315,16 @@ class Context:
         self._ck(self.lib.hinge_trim_classify(self.h, len(sel), _ptr(sel), _ptr(a_of), aln_threshold, theta, theta2, _ptr(out)))
         return out[:len(sel)]
 
+    def trim_classify_types(self, sel: np.ndarray, a_of: np.ndarray, aln_threshold: int, theta: int, theta2: int) -> np.ndarray:
+        sel = np.ascontiguousarray(sel, dtype=np.int64)
+        a_of = np.ascontiguousarray(a_of, dtype=np.int32)
+        out = np.zeros(max(len(sel), 1), np.uint8)
+        self._ck(self.lib.hinge_trim_classify_types(self.h, len(sel), _ptr(sel), _ptr(a_of), aln_threshold, theta, theta2, _ptr(out)))
+        return out[:len(sel)]
+
+    def set_trim(self, trim: bool):
+        self._ck(self.lib.hinge_set_trim(self.h, 1 if trim else 0))
+
     def matching_position(self, q_ovl: np.ndarray, q_pos: np.ndarray) -> np.ndarray:
         q_ovl = np.ascontiguousarray(q_ovl, dtype=np.int64)
         q_pos = np.ascontiguousarray(q_pos, dtype=np.int32)
@@ -356,3 +367,19 @@ class Context:
         ms = C.c_float()
         self._ck(self.lib.hinge_timer_stop_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+
+MT_BCOVERA = 3   # match type "B covers A" (LAInterface.h:30-33)
+
+
+def resolve_containment(active: np.ndarray, pairs: np.ndarray):
+    """hinge_resolve_containment: active (uint8 [n_reads], modified in place) -> maximal-read mask; returns the
+    container printed for every removed read (-1 elsewhere)."""
+    lib = load_library()
+    assert active.dtype == np.uint8 and active.flags.c_contiguous
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    containing = np.empty(len(active), np.int32)
+    rc = lib.hinge_resolve_containment(len(active), _ptr(active), len(pairs), _ptr(pairs), _ptr(containing))
+    if rc != 0:
+        raise HingeError(rc, "hinge_resolve_containment: malformed candidate list")
+    return containing

@@ -1,11 +1,12 @@
-"""Multi-GPU `hinge filter`: one process per GPU, reads sharded by DAZZ_DB block (contiguous read-id
-ranges, the unit HPC.daligner/LAmerge already emit one sorted .las for: filter.cpp:35-63,474), with
-the path's three real exchange steps as RCCL all-gathers over xGMI (torch.distributed backend "nccl";
+"""Multi-GPU `hinge filter` and `hinge maximal`: one process per GPU, reads sharded by DAZZ_DB block (contiguous
+read-id ranges, the unit HPC.daligner/LAmerge already emit one sorted .las for: filter.cpp:35-63,474), with
+the path's real exchange steps as RCCL collectives over xGMI (torch.distributed backend "nccl";
 "gloo" on CPU in the tests):
 
   1. per-read mean coverage  -> median / MIN_COV            (filter.cpp:642-678, a global reduction)
   2. per-read masks          -> maskvec[B] of every B read  (filter.cpp:778-787 feeding :883-890)
   3. hinge lists             -> global hinge list on rank 0 (the input of `hinge layout`)
+  4. containment candidates  -> maximal-read mask on every rank (maximal.cpp:780-858, ShardedMaximal below)
 
 All three are small (4-12 bytes per read); they are latency-bound, never xGMI-bandwidth-bound, so a
 plain all-gather of equal-sized padded shards is used rather than anything bucketed.
@@ -249,4 +250,90 @@ class HipBackend:
         sel = ish.astype(bool)
         rows = np.stack([reads[sel], pos[sel], typ[sel]], axis=1).astype(np.int32) if sel.any() else np.zeros((0, 3), np.int32)
         t = torch.from_numpy(np.ascontiguousarray(rows)).to(self.mask.device)
+        return t, int(t.shape[0])
+
+
+# ---- hinge maximal ---------------------------------------------------------------------------------------------
+def pick_best_pairs(row_ptr: np.ndarray, a_span: np.ndarray, b_span: np.ndarray, b_flag: np.ndarray, lo: int, hi: int,
+                    active: np.ndarray, use_two_matches: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """The overlaps `hinge maximal` classifies for the reads [lo, hi) of a block: for every (A, B) pair of an active A
+    read the longest overlap, and the second longest with use_two_matches (maximal.cpp:790-805; longest = std::sort by
+    compare_overlap, i.e. descending aepos - abpos + bepos - bbpos).  Returns (sel, a_of): indices into the pile-up
+    arrays, grouped by ascending A.  A pair with more than 16 overlaps is refused: libstdc++'s std::sort is an
+    insertion sort (stable) only up to 16 elements, and the tie order beyond that is not restated here (the
+    `get_maximal_reads` executable replays it)."""
+    s, e = int(row_ptr[lo]), int(row_ptr[hi])
+    idx = np.arange(s, e, dtype=np.int64)
+    a_of = (np.searchsorted(row_ptr, idx, side="right") - 1).astype(np.int32)
+    keep = active[a_of].astype(bool)
+    idx, a_of = idx[keep], a_of[keep]
+    b = (b_flag[idx] & np.uint32(0x7FFFFFFF)).astype(np.int64)
+    length = (a_span[idx, 1].astype(np.int64) - a_span[idx, 0] + b_span[idx, 1] - b_span[idx, 0])
+    order = np.lexsort((-length, b, a_of))            # stable: equal lengths keep file order
+    idx, a_of, b = idx[order], a_of[order], b[order]
+    key = a_of.astype(np.int64) * (int(b.max()) + 1 if len(b) else 1) + b
+    first = np.ones(len(key), bool)
+    first[1:] = key[1:] != key[:-1]
+    start = np.nonzero(first)[0]
+    sizes = np.diff(np.append(start, len(key)))
+    if len(sizes) and sizes.max() > 16:
+        raise NotImplementedError("more than 16 overlaps between one pair of reads")
+    rank_in_group = np.arange(len(key)) - np.repeat(start, sizes)
+    take = rank_in_group < (2 if use_two_matches else 1)
+    return idx[take], a_of[take]
+
+
+class ShardedMaximal:
+    """One rank's share of a sharded `hinge maximal`: classification of the block's best overlaps on this rank's GPU,
+    ONE exchange (exchange 4: the (a, b) rows of overlaps in which B covers A, 8 bytes each, all-gathered in rank =
+    read-id order), then every rank resolves containment over the gathered rows - a sequential pass in read-id order
+    (a container of lower id counts with its final state, one of higher id with its initial state), the same for
+    one merged .las and for the reference's --mlas loop because a read's pile-up lies in its own block.
+    Returns the maximal-read mask (uint8 [n_reads]).  (.contained.txt also names ONE container per removed read, the last
+    in the reference's hash-map order: that column stays with the `get_maximal_reads` executable.)"""
+
+    def __init__(self, backend, exchange: Exchange):
+        self.b, self.x = backend, exchange
+
+    def step(self) -> np.ndarray:
+        from . import capi
+        rows, count = self.b.candidates()           # int32 [m, 2] on the exchange device, ascending a
+        allrows = self.x.gather_lists(rows, count)   # exchange 4
+        active = np.ascontiguousarray(self.b.initial_active(), dtype=np.uint8).copy()
+        capi.resolve_containment(active, allrows.cpu().numpy())
+        return active
+
+
+class HipMaximalBackend:
+    """Per-block compute of `hinge maximal` through libhinge_hip: trim + classify (k_trim_classify) of the block's
+    selected overlaps.  eff = the global mask table (.mas / exchange 2), [n_reads, 2]."""
+
+    def __init__(self, ctx, rlen: np.ndarray, eff: np.ndarray, r_begin: int, r_end: int, row_ptr: np.ndarray, a_span: np.ndarray,
+                 b_span: np.ndarray, b_flag: np.ndarray, trace: np.ndarray, trace_off: np.ndarray, tlen: np.ndarray, tbytes: int,
+                 length_threshold: int, aln_threshold: int, theta: int, theta2: int, use_two_matches: bool, device: torch.device):
+        self.ctx = ctx
+        self.lo, self.hi = r_begin, r_end + 1
+        self.arr = (row_ptr, a_span, b_span, b_flag)
+        self.thr = (int(aln_threshold), int(theta), int(theta2))
+        self.use_two = bool(use_two_matches)
+        self.device = device
+        eff = np.ascontiguousarray(eff, dtype=np.int32).reshape(-1, 2)
+        self.active0 = ((eff[:, 1] - eff[:, 0]) >= length_threshold).astype(np.uint8)   # maximal.cpp:560-563
+        ctx.set_reads(rlen, None)
+        ctx.set_pileups(r_begin, r_end, row_ptr, a_span, b_span, b_flag)
+        ctx.set_trim(True)
+        ctx.set_traces(trace, trace_off, tlen, tbytes)
+        ctx.set_eff_reads(eff)
+
+    def initial_active(self) -> np.ndarray:
+        return self.active0
+
+    def candidates(self):
+        from . import capi
+        row_ptr, a_span, b_span, b_flag = self.arr
+        sel, a_of = pick_best_pairs(row_ptr, a_span, b_span, b_flag, self.lo, self.hi, self.active0, self.use_two)
+        types = self.ctx.trim_classify_types(sel, a_of, *self.thr)
+        hit = types == capi.MT_BCOVERA
+        rows = np.stack([a_of[hit], (b_flag[sel[hit]] & np.uint32(0x7FFFFFFF)).astype(np.int32)], axis=1).astype(np.int32)
+        t = torch.from_numpy(np.ascontiguousarray(rows.reshape(-1, 2))).to(self.device)
         return t, int(t.shape[0])

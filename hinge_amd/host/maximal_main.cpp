@@ -164,25 +164,21 @@ int main(int argc, char* argv[]) {
         HH_CHECK(ctx, hinge_trim_classify_types(ctx, n_sel, sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, mtype.data()));
 
         tm.mark("trim_classify (GPU)");
-        // sequential containment resolution, maximal.cpp:780-858
-        size_t c = 0;
-        int64_t n_classified = 0;
-        for (int i = r_begin; i <= r_end; i++) {
-            if (!active[(size_t)i]) continue;
-            bool contained = false;
-            int containing_read = 0;
-            for (int t = 0; t < n_sel_of[(size_t)(i - r_begin)]; t++, c++) {
-                const int b = (int)(las.b_flag[(size_t)sel[c]] & 0x7fffffffu);
-                const bool ca = mtype[c] == MT_BCOVERA;
-                n_classified++;
-                if (ca) containing_read = b;
-                if (active[(size_t)b]) contained = contained || ca;
+        // sequential containment resolution, maximal.cpp:780-858: one (a, b) row per overlap that classified as BCOVERA
+        const int64_t n_classified = n_sel;
+        std::vector<int32_t> pairs;
+        for (int64_t c = 0; c < n_sel; c++)
+            if (mtype[(size_t)c] == MT_BCOVERA) {
+                pairs.push_back(a_of[(size_t)c]);
+                pairs.push_back((int32_t)(las.b_flag[(size_t)sel[(size_t)c]] & 0x7fffffffu));
             }
-            if (contained) {
-                active[(size_t)i] = 0;
-                fprintf(f_contained, "%d\t%d\n", i, containing_read);
-            }
+        std::vector<int32_t> containing((size_t)n_read);
+        if (hinge_resolve_containment(n_read, active.data(), (int64_t)(pairs.size() / 2), pairs.data(), containing.data()) != HINGE_OK) {
+            console.error("containment resolution: malformed candidate list");
+            return 2;
         }
+        for (int i = r_begin; i <= r_end; i++)
+            if (containing[(size_t)i] >= 0) fprintf(f_contained, "%d\t%d\n", i, containing[(size_t)i]);
         int n_active = 0;
         for (int i = r_begin; i <= r_end; i++)
             if (active[(size_t)i]) { n_active++; fprintf(f_max, "%d\n", i); }

@@ -158,6 +158,14 @@ int hinge_trim_classify(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel, const
  * `type == BCOVERA` (maximal.cpp:805-857), and 1 byte instead of 40 per overlap comes back over PCIe.            */
 int hinge_trim_classify_types(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel, const int32_t* a_of, int32_t aln_threshold, int32_t theta,
                               int32_t theta2, uint8_t* type_out);
+/* Sequential containment resolution of `hinge maximal` (maximal.cpp:780-858), host side, no device work: reads in
+ * ascending id; a read that is still active is removed if one of its containers is active at that moment (containers
+ * of lower id have their final state by then, those of higher id their initial one).  pairs = n_pairs (a, b) int32 rows,
+ * one per selected overlap that classified as BCOVERA, grouped by ascending a; inside a group in the reference's iteration
+ * order (only the LAST b of a group is order dependent: it is what .contained.txt prints).  active[n_reads]: in = reads
+ * whose mask is at least length_threshold long, out = the maximal-read mask.  containing[n_reads] (may be NULL): the
+ * container printed for a removed read, -1 for the others.  With shards, every rank resolves the all-gathered pairs.  */
+int hinge_resolve_containment(int32_t n_reads, uint8_t* active, int64_t n_pairs, const int32_t* pairs, int32_t* containing);
 /* LOverlap::GetMatchingPosition (LAInterface.cpp:4498-4546) for nq (overlap, position on A) queries.        */
 int hinge_matching_position(hinge_ctx* ctx, int64_t nq, const int64_t* q_ovl, const int32_t* q_pos, int32_t* out);
 

@@ -175,3 +175,93 @@ def test_mlas_min_cov_is_a_running_max():
     assert mlas_min_cov(5, [3, 6]) == [5, 5]
     assert mlas_min_cov(-1, [2, 0]) == [0, 0]
     assert mlas_min_cov(5, [30, 90], est_cov_override=45) == [15, 15]
+
+
+# ---- sharded `hinge maximal`: exchange 4 (containment candidates) + the sequential resolution on every rank ---------------
+class OracleMaximalBackend:
+    """Stands in for HipMaximalBackend: the block's best overlaps are picked by the product's host code
+    (dist.pick_best_pairs), classified one by one by the CPU oracle's ProcessAlignment."""
+
+    def __init__(self, oracle_lib, pile, recs, eff, lo, hi, length_threshold, thr, use_two):
+        import ctypes
+        from hinge_amd.dist import pick_best_pairs
+        self.active0 = ((eff[:, 1] - eff[:, 0]) >= length_threshold).astype(np.uint8)
+        sel, a_of = pick_best_pairs(pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag, lo, hi, self.active0, use_two)
+        ip, u16p = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint16)
+        toff = recs.trace_off[:-1][pile.las_index]
+        tlen = recs.rec["tlen"][pile.las_index]
+        rows = []
+        want = np.zeros(10, np.int32)
+        for k, a in zip(sel, a_of):
+            b = int(pile.b_flag[k] & 0x7FFFFFFF)
+            hdr = np.array([pile.a_span[k, 0], pile.a_span[k, 1], pile.b_span[k, 0], pile.b_span[k, 1], int(pile.b_flag[k] >> 31),
+                            eff[a, 0], eff[a, 1], eff[b, 0], eff[b, 1]], np.int32)
+            tr = recs.trace[toff[k]:toff[k] + tlen[k]].astype(np.uint16)
+            oracle_lib.oracle_process_alignment(hdr.ctypes.data_as(ip), tr.ctypes.data_as(u16p), len(tr), thr[0], thr[1], thr[2], want.ctypes.data_as(ip))
+            if want[4] == 3:    # BCOVERA
+                rows.append((int(a), b))
+        self.rows = np.array(rows, np.int32).reshape(-1, 2)
+
+    def initial_active(self):
+        return self.active0
+
+    def candidates(self):
+        t = torch.from_numpy(np.ascontiguousarray(self.rows))
+        return t, int(t.shape[0])
+
+
+def _maximal_worker(rank, world, port, wd, first, rlen, want_active, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from hinge_amd import formats
+        from hinge_amd.dist import BlockTable, Exchange, ShardedMaximal
+        lo, hi = first[rank], first[rank + 1]
+        recs = formats.read_las(os.path.join(wd, "G.%d.las" % (rank + 1)))          # this rank's block only
+        pile = formats.pileups_from_las(recs, rlen)
+        eff = np.loadtxt(os.path.join(wd, "G.mas"), dtype=np.int64)[:, 1:].astype(np.int32)
+        be = OracleMaximalBackend(oracle.oracle_lib(), pile, recs, eff, lo, hi, 1000, (1000, 300, 0), True)
+        assert len(be.rows) > 0 and be.rows[:, 0].min() >= lo and be.rows[:, 0].max() < hi
+        job = ShardedMaximal(be, Exchange(BlockTable(first), torch.device("cpu")))
+        active = job.step()
+        assert np.array_equal(active, want_active), "maximal-read mask"
+        ret[rank] = int(active.sum())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_maximal_mask(oracle_lib, tmp_path):
+    """world 2: each rank classifies its own block, the candidate rows are all-gathered, both ranks end with the
+    maximal-read mask of the reference's sequential --mlas loop (= .max of the oracle)."""
+    import dataclasses
+    from hinge_amd import synth
+    from conftest import write_ini
+    d = synth.generate(dataclasses.replace(synth.CONFIGS["tiny_mlas"], n_blocks=2))
+    wd = str(tmp_path / "data")
+    synth.write_dataset(d, wd, "G")
+    write_ini(os.path.join(wd, "nominal.ini"))
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G", 1, b"G", b"nominal.ini", b"") == 0
+    assert run_in(wd, oracle_lib.oracle_maximal, b"G", b"G", 1, b"G", b"nominal.ini") == 0
+    want = np.zeros(d.n_reads, np.uint8)
+    want[np.loadtxt(os.path.join(wd, "G.max"), dtype=np.int64)] = 1
+    assert 0 < want.sum() < d.n_reads
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_maximal_worker, args=(2, port, wd, list(d.block_first), d.rlen, want, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: int(want.sum()), 1: int(want.sum())}
+
+
+def test_resolve_containment_order_semantics():
+    """A container of lower id counts with its final state, one of higher id with its initial state; the last row of a
+    removed read's group is the container .contained.txt names (maximal.cpp:780-858)."""
+    from hinge_amd import capi
+    a = np.array([1, 1, 1, 1, 0], np.uint8)
+    c = capi.resolve_containment(a, np.array([[0, 1], [1, 2], [1, 4], [2, 3], [3, 0]], np.int32))
+    assert a.tolist() == [0, 0, 0, 1, 0] and c.tolist() == [1, 4, 3, -1, -1]
+    with pytest.raises(capi.HingeError):
+        capi.resolve_containment(np.ones(3, np.uint8), np.array([[1, 0], [0, 1]], np.int32))     # not grouped by ascending a
+    with pytest.raises(capi.HingeError):
+        capi.resolve_containment(np.ones(3, np.uint8), np.array([[0, 3]], np.int32))             # id out of range
