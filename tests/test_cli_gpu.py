@@ -75,6 +75,28 @@ def test_cli_reads_outside_the_overlap_id_range(datasets, oracle_lib, tmp_path):
     assert run("layout", "--db", "G", "--las", "G.las", "-x", "G", "-o", "G", "--config", "nominal.ini") == 2
 
 
+def test_cli_inputs_the_reference_cannot_process(oracle_lib, tmp_path):
+    """An empty .las ("No alignments!", exit 1 as filter.cpp:511-514) and a data set without a read of 5000 bp (the
+    reference indexes an empty vector, filter.cpp:660-666: the oracle says -3, the executable refuses with an error)."""
+    import numpy as np
+    from hinge_amd import formats, synth
+    d = synth.generate(synth.SynthSpec(genome_len=30_000, coverage=25, len_min=1500, len_max=4000, seed=3))
+    wd = str(tmp_path / "short")
+    synth.write_dataset(d, wd, "G")
+    write_ini(os.path.join(wd, "nominal.ini"))
+    assert int(np.max(d.rlen)) < 5000
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G.las", 0, b"G", b"nominal.ini", b"") == -3
+    r = subprocess.run([HINGE, "filter", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode != 0 and b"the reference is undefined here" in r.stdout, r.stdout.decode()[-1000:]
+    # the same DB with an empty .las
+    recs = formats.read_las(os.path.join(wd, "G.las"))
+    empty = formats.LasRecords(tspace=recs.tspace, rec=recs.rec[:0], trace=recs.trace[:0], trace_off=recs.trace_off[:1])
+    formats.write_las(os.path.join(wd, "E.las"), empty)
+    for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+        r = subprocess.run([HINGE, sub, "--db", "G", "--las", "E.las", "-x", "G", "--config", "nominal.ini"] + extra, cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 1 or (sub != "filter" and r.returncode == 2), (sub, r.returncode, r.stdout.decode()[-500:])
+
+
 def test_cli_error_behaviour(datasets, tmp_path):
     """Exit codes of the reference's argument / config error paths (filter.cpp:218-226,372-375, hinging.cpp required flags)."""
     src, _ = datasets("tiny")
