@@ -154,7 +154,8 @@ int main(int argc, char* argv[]) {
             HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, P.reso, 0, nb.data(), nullptr, 0));
             int64_t tot = 0;
             for (size_t k = 0; k < nr; k++) tot += nb[k];
-            std::vector<int32_t> cov((size_t)std::max<int64_t>(tot, 1));
+            UVec<int32_t> cov;   // filled by the copy from the device: no zero fill, huge pages
+            cov.resize((size_t)std::max<int64_t>(tot, 1));
             HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, P.reso, 0, nb.data(), cov.data(), tot));
             write_coverage_txt(f_cov, r_begin, nb, cov, P.reso);
         }
