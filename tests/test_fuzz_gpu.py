@@ -1,0 +1,23 @@
+"""Randomised differential test (tools/fuzz_pipeline.py): random generator settings and nominal.ini values, the three
+executables against the oracle, every output file byte for byte.  A short batch here; `python tools/fuzz_pipeline.py
+--cases 100 --seed N` for more (340 cases over seeds 1-4 were run for round 1: no difference)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_cases_match_the_oracle(oracle_lib):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_pipeline
+    rng = np.random.default_rng(20260929)
+    results = []
+    for k in range(14):
+        spec, filt, lay = fuzz_pipeline.random_case(rng)
+        results.append(fuzz_pipeline.run_case(k, spec, filt, lay, oracle_lib, ""))
+    assert not [r for r in results if r.startswith("FAIL")], results
+    assert sum(r.startswith("ok") for r in results) >= 8, results

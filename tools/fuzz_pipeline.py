@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Randomised differential test: random generator settings and random nominal.ini values, the three executables against
+the oracle, every output file byte for byte.   tools/fuzz_pipeline.py [--cases 40] [--seed 1]   (needs a GPU)"""
+import argparse
+import filecmp
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FILES = ["G.mas", "G.cmas", "G.repeat.txt", "G.hinges.txt", "G.coverage.txt", "G.cov.flag", "G.self.flag", "G.max", "G.contained.txt",
+         "G.killed.hinges", "G.edges.hinges", "G.edges.hinges2", "G.hinge.list", "G.deadends.txt", "G.hgraph", "G.edges.greedy",
+         "G.edges.1", "G.edges.2", "G.edges.skipped", "edges.g_out.txt"]
+
+
+def random_case(rng):
+    from hinge_amd import synth
+    lmin = int(rng.integers(1500, 6000))
+    spec = synth.SynthSpec(
+        genome_len=int(rng.integers(60_000, 220_000)), coverage=float(rng.uniform(22, 70)), len_dist=str(rng.choice(["uniform", "lognormal"])),
+        len_min=lmin, len_max=int(lmin + rng.integers(4000, 16000)), len_mean=float(rng.uniform(6000, 11000)), len_sigma=float(rng.uniform(0.2, 0.6)),
+        n_repeat_families=int(rng.integers(0, 4)), repeat_len=(int(rng.integers(1500, 4000)), int(rng.integers(4000, 9000))),
+        repeat_copies=(2, int(rng.integers(2, 5))), inverted_copies=bool(rng.integers(0, 2)), chimera_frac=float(rng.choice([0.0, 0.0, 0.02, 0.05])),
+        min_ovl=int(rng.choice([500, 1000, 1500])), end_jitter=int(rng.choice([0, 10, 25, 60])), indel_max=int(rng.choice([0, 3, 6, 12])),
+        tspace=int(rng.choice([100, 100, 100, 50, 200])), seed=int(rng.integers(1, 1 << 30)), n_blocks=int(rng.choice([1, 1, 2, 3])),
+        with_qv=bool(rng.integers(0, 2)), tie_quantum=int(rng.choice([0, 0, 0, 40, 100])), short_reads=int(rng.choice([0, 0, 10])),
+        orphan_reads=int(rng.choice([0, 0, 4])), self_overlap_reads=int(rng.choice([0, 0, 4])))
+    filt, lay = [], []
+    if rng.random() < 0.5:
+        filt.append("cut_off = %d" % int(rng.choice([0, 100, 200, 300, 300, 400, 310])))
+    if rng.random() < 0.4:
+        filt.append("theta = %d" % int(rng.choice([100, 200, 300, 500])))
+    if rng.random() < 0.3:
+        filt.append("aln_threshold = %d" % int(rng.choice([500, 1000, 2500])))
+    if rng.random() < 0.3:
+        filt.append("min_cov = %d" % int(rng.choice([0, 3, 5, 12])))
+    if rng.random() < 0.3:
+        filt.append("ec = %d" % int(rng.choice([20, 45, 90])))
+    if rng.random() < 0.3:
+        filt.append("hinge_min_support = %d\nhinge_unbridged = %d\nhinge_min_pileup = %d" % (int(rng.integers(2, 9)), int(rng.integers(1, 8)), int(rng.integers(2, 9))))
+    if rng.random() < 0.2:
+        filt.append("no_hinge_region = %d\nrepeat_annotation_gap_threshold = %d" % (int(rng.choice([200, 500, 800])), int(rng.choice([100, 300, 600]))))
+    if rng.random() < 0.3:
+        lay.append("del_telomere = 1\ndel_telomeres = 1")
+    if rng.random() < 0.3:
+        lay.append("use_two_matches = 0")
+    if rng.random() < 0.4:
+        lay.append("min_connected_component_size = %d" % int(rng.choice([1, 2, 8])))
+    if rng.random() < 0.3:
+        lay.append("hinge_slack = %d\nhinge_tolerance = %d\nmatching_hinge_slack = %d" % (int(rng.choice([10, 500, 1000])), int(rng.choice([50, 150, 400])), int(rng.choice([100, 200, 500]))))
+    return spec, "\n".join(filt) + ("\n" if filt else ""), "\n".join(lay) + ("\n" if lay else "")
+
+
+def run_case(k, spec, filt, lay, lib, keep_failures):
+    import conftest
+    from hinge_amd import synth
+    d = synth.generate(spec)
+    if d.novl == 0 or int(d.rlen.max()) < 5000:
+        return "skipped (no overlaps / no 5 kb read)"
+    tmp = tempfile.mkdtemp(prefix="hinge_fuzz_")
+    mlas = spec.n_blocks > 1
+    try:
+        src = os.path.join(tmp, "src")
+        try:
+            synth.write_dataset(d, src, "G", write_bases=False)
+        except AssertionError:
+            return "skipped (trace generator cannot express this indel / trace-spacing combination)"
+        conftest.write_ini(os.path.join(src, "v.ini"), extra_filter=filt, extra_layout=lay)
+        wd_o = conftest.clone_dataset(src, os.path.join(tmp, "oracle"))
+        wd_h = conftest.clone_dataset(src, os.path.join(tmp, "hip"))
+        las = b"G" if mlas else b"G.las"
+        rcs = [conftest.run_in(wd_o, lib.oracle_filter, b"G", las, int(mlas), b"G", b"v.ini", b""),
+               conftest.run_in(wd_o, lib.oracle_maximal, b"G", las, int(mlas), b"G", b"v.ini"),
+               conftest.run_in(wd_o, lib.oracle_layout, b"G", las, int(mlas), b"G", b"G", b"v.ini")]
+        hinge = os.path.join(ROOT, "hinge_amd", "bin", "hinge")
+        got = []
+        for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+            argv = [hinge, sub, "--db", "G", "--las", "G" if mlas else "G.las"] + (["--mlas"] if mlas else []) + ["-x", "G", "--config", "v.ini"] + extra
+            got.append(subprocess.run(argv, cwd=wd_h, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode)
+        if rcs[0] != 0:          # undefined in the reference (e.g. a part without a 5 kb read): both sides must refuse
+            ok = got[0] != 0
+            return "undefined input, both refuse" if ok else "FAIL: oracle rc %s, executables rc %s" % (rcs, got)
+        if rcs != [0, 0, 0] or got != [0, 0, 0]:
+            same_refusal = all((a == 0) == (b == 0) for a, b in zip(rcs, got))
+            return ("both refuse a later stage %s %s" % (rcs, got)) if same_refusal else "FAIL: oracle rc %s, executables rc %s" % (rcs, got)
+        bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+        if bad:
+            if keep_failures:
+                shutil.copytree(tmp, os.path.join(keep_failures, "case%03d" % k))
+            return "FAIL: differs in %s" % bad
+        return "ok (%d reads, %d overlaps, %d hinges)" % (d.n_reads, d.novl, sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_h, "G.hinges.txt"))))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--keep-failures", default="")
+    args = ap.parse_args()
+    import oracle
+    lib = oracle.oracle_lib()
+    rng = np.random.default_rng(args.seed)
+    fails = 0
+    for k in range(args.cases):
+        spec, filt, lay = random_case(rng)
+        res = run_case(k, spec, filt, lay, lib, args.keep_failures)
+        fails += res.startswith("FAIL")
+        print("case %3d: %s" % (k, res), flush=True)
+        if res.startswith("FAIL"):
+            print("   spec = %r\n   filter ini = %r\n   layout ini = %r" % (spec, filt, lay), flush=True)
+    print("%d cases, %d failures" % (args.cases, fails))
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
