@@ -203,6 +203,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
+    if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
     ctx->med.bytes = sizeof(unsigned) * MED_WORDS;

@@ -1,6 +1,6 @@
 """Randomised differential test (tools/fuzz_pipeline.py): random generator settings and nominal.ini values, the three
 executables against the oracle, every output file byte for byte.  A short batch here; `python tools/fuzz_pipeline.py
---cases 100 --seed N` for more (340 cases over seeds 1-4 were run for round 1: no difference)."""
+--cases 100 --seed N [--paths]` for more (540 cases were run for round 1: no difference)."""
 import os
 import sys
 
@@ -18,6 +18,7 @@ def test_random_cases_match_the_oracle(oracle_lib):
     results = []
     for k in range(14):
         spec, filt, lay = fuzz_pipeline.random_case(rng)
-        results.append(fuzz_pipeline.run_case(k, spec, filt, lay, oracle_lib, ""))
+        env, paf = fuzz_pipeline.random_paths(rng, spec)     # alternative kernel paths, thread counts, FASTA + PAF input
+        results.append(fuzz_pipeline.run_case(k, spec, filt, lay, oracle_lib, "", env, paf))
     assert not [r for r in results if r.startswith("FAIL")], results
     assert sum(r.startswith("ok") for r in results) >= 8, results

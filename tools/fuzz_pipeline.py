@@ -58,7 +58,26 @@ def random_case(rng):
     return spec, "\n".join(filt) + ("\n" if filt else ""), "\n".join(lay) + ("\n" if lay else "")
 
 
-def run_case(k, spec, filt, lay, lib, keep_failures):
+def random_paths(rng, spec):
+    """Which of the library's alternative code paths the executables are pushed onto, and whether the case runs on
+    FASTA + PAF input instead of DB + .las (one block only: --mlas needs a DB)."""
+    env = {}
+    if rng.random() < 0.25:
+        env["HINGE_NO_SPAN16"] = "1"                 # int32 spans instead of the 16|16 copy
+    if rng.random() < 0.25:
+        env["HINGE_DEBUG_GENERAL_MASK"] = "1"        # general two-histogram K2 instead of the 20-bp kernel
+    r = rng.random()
+    if r < 0.15:
+        env["HINGE_DEBUG_FORCE_EXACT"] = "1"         # serial exact hinge kernel
+    elif r < 0.35:
+        env["HINGE_DEBUG_FORCE_EXACT"] = "2"         # exact std::sort replay in LDS
+    if rng.random() < 0.3:
+        env["HINGE_THREADS"] = str(int(rng.choice([1, 3, 16])))
+    paf = spec.n_blocks == 1 and rng.random() < 0.2
+    return env, paf
+
+
+def run_case(k, spec, filt, lay, lib, keep_failures, env=None, paf=False):
     import conftest
     from hinge_amd import synth
     d = synth.generate(spec)
@@ -75,15 +94,28 @@ def run_case(k, spec, filt, lay, lib, keep_failures):
         conftest.write_ini(os.path.join(src, "v.ini"), extra_filter=filt, extra_layout=lay)
         wd_o = conftest.clone_dataset(src, os.path.join(tmp, "oracle"))
         wd_h = conftest.clone_dataset(src, os.path.join(tmp, "hip"))
-        las = b"G" if mlas else b"G.las"
-        rcs = [conftest.run_in(wd_o, lib.oracle_filter, b"G", las, int(mlas), b"G", b"v.ini", b""),
-               conftest.run_in(wd_o, lib.oracle_maximal, b"G", las, int(mlas), b"G", b"v.ini"),
-               conftest.run_in(wd_o, lib.oracle_layout, b"G", las, int(mlas), b"G", b"G", b"v.ini")]
         hinge = os.path.join(ROOT, "hinge_amd", "bin", "hinge")
+        penv = dict(os.environ, **(env or {}))
         got = []
-        for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
-            argv = [hinge, sub, "--db", "G", "--las", "G" if mlas else "G.las"] + (["--mlas"] if mlas else []) + ["-x", "G", "--config", "v.ini"] + extra
-            got.append(subprocess.run(argv, cwd=wd_h, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode)
+        if paf:
+            from hinge_amd import formats
+            for wd in (wd_o, wd_h):
+                formats.write_fasta(os.path.join(wd, "G.fasta"), d.rlen, seed=3)
+                formats.write_paf(os.path.join(wd, "G.paf"), d.rlen, d.aread, d.bread, d.comp, d.ab, d.ae, d.bb, d.be)
+            rcs = [conftest.run_in(wd_o, lib.oracle_filter_paf, b"G.fasta", b"G.paf", b"G", b"v.ini"),
+                   conftest.run_in(wd_o, lib.oracle_maximal_paf, b"G.fasta", b"G.paf", b"G", b"v.ini"),
+                   conftest.run_in(wd_o, lib.oracle_layout_paf, b"G.fasta", b"G.paf", b"G", b"G", b"v.ini")]
+            for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+                argv = [hinge, sub, "--fasta", "G.fasta", "--paf", "G.paf", "-x", "G", "--config", "v.ini"] + extra
+                got.append(subprocess.run(argv, cwd=wd_h, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=penv).returncode)
+        else:
+            las = b"G" if mlas else b"G.las"
+            rcs = [conftest.run_in(wd_o, lib.oracle_filter, b"G", las, int(mlas), b"G", b"v.ini", b""),
+                   conftest.run_in(wd_o, lib.oracle_maximal, b"G", las, int(mlas), b"G", b"v.ini"),
+                   conftest.run_in(wd_o, lib.oracle_layout, b"G", las, int(mlas), b"G", b"G", b"v.ini")]
+            for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+                argv = [hinge, sub, "--db", "G", "--las", "G" if mlas else "G.las"] + (["--mlas"] if mlas else []) + ["-x", "G", "--config", "v.ini"] + extra
+                got.append(subprocess.run(argv, cwd=wd_h, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=penv).returncode)
         if rcs[0] != 0:          # undefined in the reference (e.g. a part without a 5 kb read): both sides must refuse
             ok = got[0] != 0
             return "undefined input, both refuse" if ok else "FAIL: oracle rc %s, executables rc %s" % (rcs, got)
@@ -105,6 +137,7 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--keep-failures", default="")
+    ap.add_argument("--paths", action="store_true", help="also randomise the library's alternative kernel paths, the thread count and FASTA + PAF input")
     args = ap.parse_args()
     import oracle
     lib = oracle.oracle_lib()
@@ -112,11 +145,12 @@ def main():
     fails = 0
     for k in range(args.cases):
         spec, filt, lay = random_case(rng)
-        res = run_case(k, spec, filt, lay, lib, args.keep_failures)
+        env, paf = random_paths(rng, spec) if args.paths else ({}, False)
+        res = run_case(k, spec, filt, lay, lib, args.keep_failures, env, paf)
         fails += res.startswith("FAIL")
-        print("case %3d: %s" % (k, res), flush=True)
+        print("case %3d: %s%s%s" % (k, res, "  [PAF]" if paf else "", ("  " + " ".join("%s=%s" % kv for kv in sorted(env.items()))) if env else ""), flush=True)
         if res.startswith("FAIL"):
-            print("   spec = %r\n   filter ini = %r\n   layout ini = %r" % (spec, filt, lay), flush=True)
+            print("   spec = %r\n   filter ini = %r\n   layout ini = %r\n   env = %r paf = %r" % (spec, filt, lay, env, paf), flush=True)
     print("%d cases, %d failures" % (args.cases, fails))
     return 1 if fails else 0
 
