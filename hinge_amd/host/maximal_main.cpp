@@ -167,12 +167,24 @@ int main(int argc, char* argv[]) {
         tm.mark("trim_classify (GPU)");
         // sequential containment resolution, maximal.cpp:780-858: one (a, b) row per overlap that classified as BCOVERA
         const int64_t n_classified = n_sel;
-        std::vector<int32_t> pairs;
-        for (int64_t c = 0; c < n_sel; c++)
-            if (mtype[(size_t)c] == MT_BCOVERA) {
-                pairs.push_back(a_of[(size_t)c]);
-                pairs.push_back((int32_t)(las.b_flag[(size_t)sel[(size_t)c]] & 0x7fffffffu));
-            }
+        // (the rows keep the order of `sel`: counted and written in contiguous pieces by the host threads)
+        const int T = host_threads();
+        std::vector<int64_t> piece_rows((size_t)T + 1, 0);
+        parallel_chunks(n_sel, T, [&](int c, int64_t b, int64_t e) {
+            int64_t m = 0;
+            for (int64_t k = b; k < e; k++) m += mtype[(size_t)k] == MT_BCOVERA;
+            piece_rows[(size_t)c + 1] = m;
+        });
+        for (int c = 0; c < T; c++) piece_rows[(size_t)c + 1] += piece_rows[(size_t)c];
+        std::vector<int32_t> pairs((size_t)(2 * piece_rows[(size_t)T]));
+        parallel_chunks(n_sel, T, [&](int c, int64_t b, int64_t e) {
+            int32_t* out = pairs.data() + 2 * piece_rows[(size_t)c];
+            for (int64_t k = b; k < e; k++)
+                if (mtype[(size_t)k] == MT_BCOVERA) {
+                    *out++ = a_of[(size_t)k];
+                    *out++ = (int32_t)(las.b_flag[(size_t)sel[(size_t)k]] & 0x7fffffffu);
+                }
+        });
         std::vector<int32_t> containing((size_t)n_read);
         if (hinge_resolve_containment(n_read, active.data(), (int64_t)(pairs.size() / 2), pairs.data(), containing.data()) != HINGE_OK) {
             console.error("containment resolution: malformed candidate list");
