@@ -132,6 +132,7 @@ EXTRA_SYMBOLS = [
     ("hinge_debug_force_exact", C.c_int, [_VP, C.c_int]),
     ("hinge_debug_force_general_mask", C.c_int, [_VP, C.c_int]),
     ("hinge_debug_fallback_reads", C.c_int, [_VP, _VP]),
+    ("hinge_debug_heavy_items", C.c_int, [_VP, _VP]),
     ("hinge_debug_pileup_order", C.c_int, [_VP, C.c_int32, _VP, _VP]),
 ]
 
@@ -223,6 +224,12 @@ class Context:
         out = np.zeros(1, np.int64)
         self._ck(self.lib.hinge_debug_fallback_reads(self.h, _ptr(out)))
         return int(out[0])
+
+    def heavy_items(self):
+        """(half-size, full-size): undecided annotations of the last hinge pass by the k_hinge_call instance that took them."""
+        out = np.zeros(2, np.int64)
+        self._ck(self.lib.hinge_debug_heavy_items(self.h, _ptr(out)))
+        return int(out[0]), int(out[1])
 
     def debug_pileup_order(self, keys: np.ndarray) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.int32)

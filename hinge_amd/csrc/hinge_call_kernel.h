@@ -21,7 +21,7 @@ namespace hinge {
 
 constexpr int HC_SMALL = 64;    // lists up to this size try the tie-free shortcut
 constexpr int PRE_MAXA = 4;     // annotations covered by the count-only sweep
-constexpr int SF_BINS = 2 * PO_CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
+// (the sort-free scan evaluation bins f - f[0] at 1 bp into 2 * CAP bins of LDS scratch)
 constexpr int GATHER_LOADS = 8;       // pile-up loads a lane of k_hinge_call keeps in flight
 
 // One undecided annotation, produced by k_hinge_count for k_hinge_call.  Both kernels cut a pile-up into the
@@ -40,15 +40,16 @@ struct alignas(16) HeavyItem {   // everything k_hinge_call needs, so that it st
 };
 __device__ __forceinline__ int slice_len(int n) { return ((n + 4 * WAVE - 1) / (4 * WAVE)) * WAVE; }
 
-struct HingeCallLds {
-    WaveSortLds ws;
-    unsigned short ppos[PO_CAP];   // position of every overlap of the read in the sorted pile-up
-    alignas(16) int sF[PO_CAP];    // supporters in .las order: other end in scan-ascending form ...
-    alignas(16) int sS[PO_CAP];    // ... and the overhang on the far side; reused for the sorted lists
-    unsigned short sK[PO_CAP];     // ... and the local overlap index
+template <int CAP>
+struct HingeCallLdsT {
+    WaveSortLdsT<CAP> ws;
+    unsigned short ppos[CAP];      // position of every overlap of the read in the sorted pile-up
+    alignas(16) int sF[CAP];       // supporters in .las order: other end in scan-ascending form ...
+    alignas(16) int sS[CAP];       // ... and the overhang on the far side; reused for the sorted lists
+    unsigned short sK[CAP];        // ... and the local overlap index
     int sL[HC_SMALL];              // length sums of the first HC_SMALL supporters
-    int wF[PO_CAP];                // supporters in pile-up order
-    int wS[PO_CAP];
+    int wF[CAP];                   // supporters in pile-up order
+    int wS[CAP];
     int wcnt[2][WAVES_PER_BLOCK];
     int cnt;
     int need_order;
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
                                                        const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
                                                        const WorkItem* __restrict__ work_list, const unsigned* __restrict__ counters,
                                                        unsigned char* __restrict__ hinge_flag, HeavyItem* __restrict__ heavy,
-                                                       unsigned* __restrict__ heavy_count, int force_exact, unsigned* __restrict__ dbg) {
+                                                       unsigned* __restrict__ heavy_count, unsigned* __restrict__ heavy_count_big, unsigned heavy_cap,
+                                                       int force_exact, unsigned* __restrict__ dbg) {
     __shared__ int s_sup[PRE_MAXA][WAVES_PER_BLOCK], s_near[PRE_MAXA][WAVES_PER_BLOCK];
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -172,7 +174,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
                         it.pos = an.x; it.type = an.y;
                     }
                     it.slot = off + a0 + tid;
-                    heavy[atomicAdd(heavy_count, 1u)] = it;
+                    // pile-ups that fit the half-size instance of k_hinge_call from the front, the others from the back
+                    if (it.n <= PO_CAP_SMALL) heavy[atomicAdd(heavy_count, 1u)] = it;
+                    else heavy[heavy_cap - 1u - atomicAdd(heavy_count_big, 1u)] = it;
                 } else if (dbg) atomicAdd(&dbg[quick ? 3 : 0], 1u);
             }
             __syncthreads();
@@ -183,6 +187,10 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
     }
 }
 
+// CAP: capacity of the LDS lists (pile-up size, supporters) = half the number of 1-bp bins.  The host launches the
+// PO_CAP_SMALL instance (72 KiB of LDS: two workgroups per CU) over the items whose pile-up fits it - they are appended from
+// the front of `heavy` - and the PO_CAP instance (one workgroup per CU) over the rest, appended from the back (`from_back`).
+template <int CAP>
 __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
                                                       const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
                                                       const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
@@ -191,8 +199,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                                                       unsigned char* __restrict__ hinge_flag, int2* __restrict__ exact_queue,
                                                       unsigned* __restrict__ exact_count, unsigned exact_cap, int force_exact,
                                                       int* __restrict__ status, unsigned* __restrict__ work_next,
-                                                      unsigned* __restrict__ dbg) {
-    __shared__ HingeCallLds S;
+                                                      unsigned* __restrict__ dbg, int from_back, unsigned heavy_cap) {
+    constexpr int SF_BINS = 2 * CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
+    __shared__ HingeCallLdsT<CAP> S;
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
 #ifdef HINGE_TIMING
         const unsigned long long tm0 = wall_clock64();
 #endif
-        const HeavyItem item = heavy[w];
+        const HeavyItem item = heavy[from_back ? heavy_cap - 1u - w : w];
         const int i = item.read, a = item.anno;
         const int64_t s = item.row;
         const int n = item.n;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                             fmin_w = min(fmin_w, f);
                             fmax_w = max(fmax_w, f);
                             const int slot = slot0 + __popcll(bal & lmask);
-                            if (slot < PO_CAP) {
+                            if (slot < CAP) {
                                 S.sF[slot] = f;
                                 S.sS[slot] = sec;
                                 S.sK[slot] = (unsigned short)(k - s);
@@ -311,10 +320,10 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                 // is unbridged whatever the order inside that prefix is (filter.cpp:920-931 / 1019-1030).
                 action = 3;
             }
-            else if (sup > PO_CAP || force_exact == 1) action = 2;
+            else if (sup > CAP || force_exact == 1) action = 2;
             else action = 1;
             bool need_order = false;
-            if (action == 1 && force_exact == 0 && sup <= PO_CAP) {
+            if (action == 1 && force_exact == 0 && sup <= CAP) {
                 // ---- sort-free evaluation of the scan (filter.cpp:932-963 / 1031-1062) -----------------
                 // Past the first-branch prefix (c1 = near_end <= UNB elements) the scan walks the remaining
                 // supporters by ascending f.  With cat = 2 (sec < TH), 3 (sec > TH), 0 (sec == TH):
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                     // (stride-1 LDS accesses, DPP scan, carry in a register); the three cross-wave offsets are added at use
                     const int QW = nb / WAVES_PER_BLOCK;   // multiple of 64
                     {
-                        int run = 0;   // packed carry: low 16 bits prefix of g2 + g3, high 16 bits prefix of g (both <= sup <= PO_CAP)
+                        int run = 0;   // packed carry: low 16 bits prefix of g2 + g3, high 16 bits prefix of g (both <= sup <= CAP)
                         for (int b = wib * QW + lane; b < (wib + 1) * QW; b += WAVE) {
                             const int v = bin23[b];
                             const int c23 = (v & 0xffff) + (v >> 16);
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t
                     __syncthreads();
                     need_order = S.need_order != 0;
                 }
-                if (need_order && n > PO_CAP) action = 2;
+                if (need_order && n > CAP) action = 2;
             }
             if (action == 0 || action == 3) {
                 if (tid == 0) hinge_flag[item.slot] = action == 3 ? 1 : 0;

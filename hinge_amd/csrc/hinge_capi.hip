@@ -123,7 +123,9 @@ struct Scalars {
     unsigned fallback_count;            // reads k_mask_annotate_q20 handed back to the general kernel (directly after counters)
     unsigned exact_count;
     unsigned work_next;                 // k_hinge_call's work-list cursor
-    unsigned heavy_count;               // reads with annotations the count-only sweep could not decide
+    unsigned heavy_count;               // annotations the count-only sweep could not decide, pile-up <= PO_CAP_SMALL (front of heavy_list)
+    unsigned work_next_big;             // the same two for the pile-ups beyond PO_CAP_SMALL (back of heavy_list, PO_CAP instance)
+    unsigned heavy_count_big;
     int status;
     // ---- persistent across passes ----
     int est[2];                         // cov_est, n_long
@@ -420,6 +422,17 @@ int hinge_debug_fallback_reads(hinge_ctx* ctx, int64_t* out) {
     return HINGE_OK;
 }
 
+// tests: undecided annotations the last hinge pass sent through the half-size / the full-size instance of k_hinge_call
+int hinge_debug_heavy_items(hinge_ctx* ctx, int64_t* out) {
+    if (!ctx || !out) return HINGE_E_ARG;
+    unsigned v[3] = {0, 0, 0};   // heavy_count, work_next_big, heavy_count_big
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpy(v, &sc(ctx)->heavy_count, sizeof(v), hipMemcpyDeviceToHost));
+    out[0] = v[0];
+    out[1] = v[2];
+    return HINGE_OK;
+}
+
 // hidden knob for tests: 1 = route every scanned annotation through k_hinge_exact,
 // 2 = force the in-kernel exact pile-up order for every scanned annotation
 int hinge_debug_force_exact(hinge_ctx* ctx, int on) {
@@ -671,21 +684,28 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
 }
 
 static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
-    const int grid = ctx->n_cu;   // 145 KB of LDS: one workgroup per CU
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
     hipLaunchKernelGGL(k_hinge_count, dim3(ctx->n_cu * 8), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
                        (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
                        (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
                        (const WorkItem*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
-                       (HeavyItem*)ctx->heavy_list.p, &sc(ctx)->heavy_count, ctx->force_exact, ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr); }
+                       (HeavyItem*)ctx->heavy_list.p, &sc(ctx)->heavy_count, &sc(ctx)->heavy_count_big, ctx->anno_cap, ctx->force_exact,
+                       ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr); }
     CK(hipGetLastError());
+    // Undecided annotations: pile-ups of up to PO_CAP_SMALL overlaps go through the 72 KiB instance, two workgroups per CU (one
+    // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if the part has
+    // such a pile-up (k_pileup_facts).
+#define LAUNCH_HINGE_CALL(CAP, GRID, COUNT, NEXT, BACK)                                                                                 \
+    hipLaunchKernelGGL(k_hinge_call<CAP>, dim3(GRID), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,           \
+                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,    \
+                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const HeavyItem*)ctx->heavy_list.p,              \
+                       (const unsigned*)(COUNT), (unsigned char*)ctx->hinge_flag.p, (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count,     \
+                       ctx->exact_cap, ctx->force_exact, &sc(ctx)->status, (NEXT), ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr,  \
+                       (BACK), ctx->anno_cap)
     { ProfScope _ps(ctx, KID_HINGE_CALL);
-    hipLaunchKernelGGL(k_hinge_call, dim3(grid), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
-                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
-                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p,
-                       (const HeavyItem*)ctx->heavy_list.p, (const unsigned*)&sc(ctx)->heavy_count, (unsigned char*)ctx->hinge_flag.p,
-                       (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count, ctx->exact_cap, ctx->force_exact, &sc(ctx)->status,
-                       &sc(ctx)->work_next, ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr); }
+    LAUNCH_HINGE_CALL(PO_CAP_SMALL, 2 * ctx->n_cu, &sc(ctx)->heavy_count, &sc(ctx)->work_next, 0);
+    if (ctx->max_pile > (unsigned)PO_CAP_SMALL) LAUNCH_HINGE_CALL(PO_CAP, ctx->n_cu, &sc(ctx)->heavy_count_big, &sc(ctx)->work_next_big, 1); }
+#undef LAUNCH_HINGE_CALL
     CK(hipGetLastError());
     // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1)
     if (ctx->max_pile <= (unsigned)PO_CAP && ctx->force_exact != 1) return HINGE_OK;
@@ -725,7 +745,7 @@ int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 16; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 3 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count
+        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 5 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count, work_next_big, heavy_count_big
         CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
         if ((rc = launch_hinges(ctx, p))) return rc;
         int rerun = 0;
@@ -864,8 +884,8 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     for (unsigned char c : hf) nh += c;
     out[3] = nh;
     if (getenv("HINGE_DEBUG_PATHS"))
-        fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u\n",
-                h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7]);
+        fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u | last pass: %u items in the half-size instance, %u in the full-size one\n",
+                h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7], h.heavy_count, h.heavy_count_big);
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[15])
         fprintf(stderr, "[hinge] k_hinge_count per read (HINGE_TIMING builds): reads=%u mean %.1f us max %.1f us, largest pile-up %u\n", h.dbg[5], h.dbg[4] * 0.01 / std::max(1u, h.dbg[5]), h.dbg[15] * 0.01, h.dbg[7]);
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[10])

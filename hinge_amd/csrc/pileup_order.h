@@ -33,27 +33,32 @@
 namespace hinge {
 
 constexpr int PO_CAP = 4096;            // longest list sorted in LDS
-constexpr int SEG_CAP = PO_CAP / 8;     // segments alive on one level (each is > 16 long)
+constexpr int PO_CAP_SMALL = 2048;      // the half-size instance: two workgroups of k_hinge_call per CU
 
-struct WaveSortLds {
-    int key[PO_CAP];               // sort key by element index (never permuted)
-    int perm[PO_CAP];              // perm[p] = element at position p
-    unsigned short pl[PO_CAP];     // left stopper positions by rank (scratch); on return: position of every element
-    unsigned short pr[PO_CAP];     // right stopper positions by rank from the left (scratch)
-    unsigned short seglo[PO_CAP];  // leaf segment of every position
-    unsigned short seghi[PO_CAP];
+template <int CAP>
+struct WaveSortLdsT {
+    static constexpr int SEG_CAP = CAP / 8;   // segments alive on one level (each is > 16 long)
+    int key[CAP];                  // sort key by element index (never permuted)
+    int perm[CAP];                 // perm[p] = element at position p
+    unsigned short pl[CAP];        // left stopper positions by rank (scratch); on return: position of every element
+    unsigned short pr[CAP];        // right stopper positions by rank from the left (scratch)
+    unsigned short seglo[CAP];     // leaf segment of every position
+    unsigned short seghi[CAP];
     unsigned short seg_first[2][SEG_CAP], seg_last[2][SEG_CAP];
     unsigned char seg_depth[2][SEG_CAP];
     int seg_cnt[2];
 };
+typedef WaveSortLdsT<PO_CAP> WaveSortLds;
 
-__device__ __forceinline__ void mark_leaf(WaveSortLds& o, int first, int last, int lane) {
+template <typename WS>
+__device__ __forceinline__ void mark_leaf(WS& o, int first, int last, int lane) {
     for (int p = first + lane; p < last; p += 64) { o.seglo[p] = (unsigned short)first; o.seghi[p] = (unsigned short)last; }
 }
 
 // Call from ALL threads of a 256-thread workgroup (contains __syncthreads).  On return
 // o.pl[e] = position of element e in std::sort(order, comp) of the list 0..n-1.
-__device__ inline void block_std_sort_desc(WaveSortLds& o, int n, int tid) {
+template <typename WS>
+__device__ inline void block_std_sort_desc(WS& o, int n, int tid) {
     const int lane = tid & 63;
     const int wib = tid >> 6;
     const unsigned long long lmask = (1ull << lane) - 1ull;

@@ -447,6 +447,8 @@ CONFIGS = {
     # self-coverage flag (filter.cpp:538-561)
     "edges": SynthSpec(genome_len=130_000, coverage=42, seed=43, len_max=14000, min_ovl=500, short_reads=24,
                        orphan_reads=6, self_overlap_reads=6, with_qv=True),
+    # 450x over a 3-copy repeat: pile-ups of 2049-4096 overlaps with undecided annotations (the full-size instance of k_hinge_call)
+    "deep": SynthSpec(genome_len=50_000, coverage=450, seed=53, n_repeat_families=1, repeat_len=(5000, 5000), repeat_copies=(3, 3)),
     "orphan_ends": SynthSpec(genome_len=100_000, coverage=40, seed=47, orphan_ends=3),
     "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
                                  repeat_len=(1000, 5000), repeat_copies=(2, 3)),

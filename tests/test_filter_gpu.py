@@ -56,6 +56,25 @@ def test_filter_ini_variants(datasets, oracle_lib, tmp_path, extra):
     _compare(wd_o, wd_h)
 
 
+@pytest.mark.parametrize("exact", [0, 2])
+def test_filter_deep_pileups(datasets, oracle_lib, tmp_path, exact):
+    """Pile-ups of 2049-4096 overlaps: their undecided annotations go through the full-size instance of k_hinge_call (the
+    half-size one, two workgroups per CU, takes pile-ups up to 2048)."""
+    from hinge_amd import capi, stages
+    src, d = datasets("deep")
+    counts = np.bincount(d.aread[d.aread != d.bread], minlength=d.n_reads)
+    assert ((counts > 2048) & (counts <= 4096)).any()
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, False) == 0
+    ctx = capi.Context(0)
+    assert run_in(wd_h, stages.run_filter, "G", "G.las", "G", "nominal.ini", False, 0, True, exact, ctx) == 0
+    small, big = ctx.heavy_items()
+    assert big > 0, (small, big)      # (the half-size instance is what every other data set of this file runs)
+    _compare(wd_o, wd_h)
+    assert sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.hinges.txt"))) > 0
+
+
 def test_pileup_order_replays_std_sort(oracle_lib):
     """wave_pileup_order (parallel Hoare partitions in LDS) == std::sort(compare_overlap) of libstdc++."""
     import ctypes
