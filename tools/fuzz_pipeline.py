@@ -23,9 +23,16 @@ FILES = ["G.mas", "G.cmas", "G.repeat.txt", "G.hinges.txt", "G.coverage.txt", "G
 def random_case(rng):
     from hinge_amd import synth
     lmin = int(rng.integers(1500, 6000))
+    shape = rng.random()
+    if shape < 0.12:      # deep: pile-ups of thousands of overlaps (both k_hinge_call instances, the serial exact kernel beyond 4096)
+        genome, cov, lmax, lmean = int(rng.integers(25_000, 50_000)), float(rng.uniform(250, 600)), int(lmin + rng.integers(4000, 9000)), float(rng.uniform(5000, 8000))
+    elif shape < 0.24:    # long reads: two and four LDS slots per read in K2, reads beyond a workgroup's LDS
+        genome, cov, lmax, lmean = int(rng.integers(200_000, 400_000)), float(rng.uniform(25, 45)), int(rng.integers(40_000, 130_000)), float(rng.uniform(15_000, 30_000))
+    else:
+        genome, cov, lmax, lmean = int(rng.integers(60_000, 220_000)), float(rng.uniform(22, 70)), int(lmin + rng.integers(4000, 16000)), float(rng.uniform(6000, 11000))
     spec = synth.SynthSpec(
-        genome_len=int(rng.integers(60_000, 220_000)), coverage=float(rng.uniform(22, 70)), len_dist=str(rng.choice(["uniform", "lognormal"])),
-        len_min=lmin, len_max=int(lmin + rng.integers(4000, 16000)), len_mean=float(rng.uniform(6000, 11000)), len_sigma=float(rng.uniform(0.2, 0.6)),
+        genome_len=genome, coverage=cov, len_dist=("lognormal" if shape < 0.24 and shape >= 0.12 else str(rng.choice(["uniform", "lognormal"]))),
+        len_min=lmin, len_max=lmax, len_mean=lmean, len_sigma=float(rng.uniform(0.2, 0.7)),
         n_repeat_families=int(rng.integers(0, 4)), repeat_len=(int(rng.integers(1500, 4000)), int(rng.integers(4000, 9000))),
         repeat_copies=(2, int(rng.integers(2, 5))), inverted_copies=bool(rng.integers(0, 2)), chimera_frac=float(rng.choice([0.0, 0.0, 0.02, 0.05])),
         min_ovl=int(rng.choice([500, 1000, 1500])), end_jitter=int(rng.choice([0, 10, 25, 60])), indel_max=int(rng.choice([0, 3, 6, 12])),
