@@ -4,10 +4,8 @@
 //   LOverlap::AddTypesAsymmetric lib/LAInterface.cpp:4721-4806
 //   LOverlap::GetMatchingPosition lib/LAInterface.cpp:4498-4546
 //
-// One 16-lane DPP row owns one overlap (four overlaps per wavefront): the row streams the overlap's
-// trace, 16 trace points per step, turns the B advances into B coordinates with a row-local prefix sum,
-// evaluates "inside both masks" per point and finds the first / last such point with a ballot.
-// HBM-bound: 24 B of record + tlen bytes of trace per classified overlap, 40 B out.
+// One lane owns one overlap and walks its trace (see k_trim_classify).
+// HBM-bound: 24 B of record + tlen bytes of trace per classified overlap, 40 B (or 1 B: the type) out.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,14 +22,6 @@ struct ClassifyOut {   // 40 bytes
     int type, active, weight, length;
     int start_idx, end_idx;
 };
-
-__device__ __forceinline__ int row_incl_scan(int v) {   // inclusive + scan inside each 16-lane DPP row
-    v += dpp_or_old<0x111, 0xf>(0, v);
-    v += dpp_or_old<0x112, 0xf>(0, v);
-    v += dpp_or_old<0x114, 0xf>(0, v);
-    v += dpp_or_old<0x118, 0xf>(0, v);
-    return v;
-}
 
 __device__ __forceinline__ int add_types_asymmetric(int A_left, int A_right, int B_left, int B_right, int maxo, int mino) {
     // (B_left / B_right already swapped for complemented overlaps)
@@ -53,6 +43,10 @@ __device__ __forceinline__ int add_types_asymmetric(int A_left, int A_right, int
 
 // sel[j] = index (into the part's SoA arrays) of the j-th overlap to classify; a_of[j] = its A read.
 // TB = bytes per trace element (1 for tspace <= 125, else 2).
+// One LANE per overlap: the lane walks its trace front to back (B coordinate = running sum of the B advances), keeps the first
+// point inside both masks and the last one.  ~12 instructions per trace point and lane; the 16-lane-row form this replaces
+// (row-wide prefix sum, ballots and five cross-lane reads per 16 points) needed ~90 per point-row for 4 overlaps per wavefront
+// and was bound by instruction issue at 7 % of the HBM roofline (5.0 ms for 24.7 M overlaps, 120 B each).
 template <int TB>
 __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const int64_t* __restrict__ sel, const int* __restrict__ a_of,
                                                          const int2* __restrict__ a_span, const int2* __restrict__ b_span,
@@ -62,31 +56,17 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
                                                          int theta, int theta2, ClassifyOut* __restrict__ out,
                                                          unsigned char* __restrict__ type_out /*nullptr, or only the match type is wanted*/,
                                                          int trim /*0: PAF input, ProcessAlignment(trim = false): the match is taken as it is*/) {
-    const int lane = lane_id();
-    const int r = lane & 15;              // lane inside the row
-    const int row = lane >> 4;            // 0..3
-    const int64_t rows_total = (int64_t)gridDim.x * (BLOCK / 16);
-    const int64_t my_row = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
-    // all four rows of a wave iterate together; a row without work idles with j >= n_sel
-    for (int64_t j0 = (my_row - row); j0 < n_sel; j0 += rows_total) {   // j0 = first row's item of this wave
-        const int64_t j = j0 + row;
-        const bool live = j < n_sel;
-        int2 av = make_int2(0, 0), bs = make_int2(0, 0), ea = make_int2(0, 0), eb = make_int2(0, 0);
-        int comp = 0, tl = 0;
-        int64_t toff = 0;
-        if (live) {
-            const int64_t k = sel[j];
-            av = a_span[k];
-            bs = b_span[k];
-            const unsigned bf = b_flag[k];
-            comp = (int)(bf >> 31);
-            ea = eff[a_of[j]];
-            eb = eff[bf & 0x7fffffffu];
-            tl = tlen[k];
-            toff = trace_off[k];
-        }
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n_sel; j += stride) {
+        const int64_t k = sel[j];
+        const int2 av = a_span[k], bs = b_span[k];
+        const unsigned bf = b_flag[k];
+        const int comp = (int)(bf >> 31);
+        const int2 ea = eff[a_of[j]], eb = eff[bf & 0x7fffffffu];
+        const int tl = tlen[k];
+        const unsigned char* __restrict__ tp = trace + trace_off[k];
         const int ninner = max(tl / 2 - 1, 0);
-        const int np = (live && trim) ? ninner + 2 : 0;   // trace points incl. the two end points
+        const int np = trim ? ninner + 2 : 0;          // trace points incl. the two end points
         const int sign = 1 - 2 * comp;
         const int b_first = comp ? bs.y : bs.x;        // tp[0].second
         const int b_last = comp ? bs.x : bs.y;         // tp[np-1].second
@@ -94,79 +74,72 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
         int start_idx = np, end_idx = 0;
         int s_a = 0, s_b = 0, e_a = 0, e_b = 0;        // coordinates of the first / last point inside both masks
         bool s_found = false, e_found = false;
-        int carry = 0;                                 // sum of B advances consumed so far
-        int np_max = np;
-        np_max = max(np_max, __shfl_xor(np_max, 16));
-        np_max = max(np_max, __shfl_xor(np_max, 32));
-        for (int base = 0; base < np_max; base += 16) {
-            const int i = base + r;                    // trace point index
-            int adv = 0;
-            if (i >= 1 && i <= ninner) {
-                const int64_t p = toff + (int64_t)TB * (2 * (i - 1) + 1);
-                adv = TB == 1 ? (int)trace[p] : (int)(trace[p] | (trace[p + 1] << 8));
-            }
-            const int sc = row_incl_scan(adv);
-            int pa, pb;
-            if (i == 0) { pa = av.x; pb = b_first; }
-            else if (i == np - 1) { pa = av.y; pb = b_last; }
-            else { pa = a_base + 100 * i; pb = b_first + sign * (carry + sc); }
-            carry += __shfl(sc, (row << 4) | 15);
-            const bool valid = i < np;
+        auto visit = [&](int i, int pa, int pb) {
             bool cs, ce;
             if (comp == 0) {
-                cs = valid && (pa >= ea.x) && (pb >= eb.x);
-                ce = valid && (pa <= ea.y) && (pb <= eb.y);
+                cs = (pa >= ea.x) && (pb >= eb.x);
+                ce = (pa <= ea.y) && (pb <= eb.y);
             } else {
-                cs = valid && (pa >= ea.x) && (pb <= eb.y);
-                ce = valid && (pa <= ea.y) && (pb >= eb.x);
+                cs = (pa >= ea.x) && (pb <= eb.y);
+                ce = (pa <= ea.y) && (pb >= eb.x);
             }
-            const unsigned bs16 = (unsigned)((__ballot(cs) >> (row << 4)) & 0xffffull);
-            const unsigned be16 = (unsigned)((__ballot(ce) >> (row << 4)) & 0xffffull);
-            if (!s_found && bs16) {
-                const int f = __ffs(bs16) - 1;
-                s_a = __shfl(pa, (row << 4) | f);
-                s_b = __shfl(pb, (row << 4) | f);
-                start_idx = base + f;
-                s_found = true;
+            if (cs && !s_found) { s_a = pa; s_b = pb; start_idx = i; s_found = true; }
+            if (ce) { e_a = pa; e_b = pb; end_idx = i; e_found = true; }
+        };
+        if (np > 0) {
+            visit(0, av.x, b_first);
+            // the trace is read 8 bytes at a time (4 points of one byte pairs, 2 of two byte pairs; unaligned loads), two
+            // loads in flight; the bytes of the last, partial group are fetched one by one so that nothing is read past the trace
+            constexpr int PAIR = 2 * TB, CH = 8 / PAIR;
+            const int tbytes_total = tl * TB;
+            int pb_run = b_first;                      // B coordinate of the current inner point
+#pragma unroll 2
+            for (int base = 0; base < ninner; base += CH) {
+                unsigned long long w = 0;
+                if ((base + CH) * PAIR <= tbytes_total) {
+                    __builtin_memcpy(&w, tp + (size_t)base * PAIR, 8);
+                } else {
+                    for (int q = 0; base * PAIR + q < tbytes_total && q < 8; q++) w |= (unsigned long long)tp[(size_t)base * PAIR + q] << (8 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int i = base + q + 1;
+                    if (i > ninner) break;
+                    const int adv = TB == 1 ? (int)((w >> (16 * q + 8)) & 0xffull) : (int)((w >> (32 * q + 16)) & 0xffffull);
+                    pb_run += sign * adv;
+                    visit(i, a_base + 100 * i, pb_run);
+                }
             }
-            if (be16) {
-                const int l = 31 - __clz(be16);
-                e_a = __shfl(pa, (row << 4) | l);
-                e_b = __shfl(pb, (row << 4) | l);
-                end_idx = base + l;
-                e_found = true;
-            }
+            visit(np - 1, av.y, b_last);
         }
-        if (live && r == 0) {
-            ClassifyOut o;
-            o.eff_ab = av.x; o.eff_ae = av.y; o.eff_bb = bs.x; o.eff_be = bs.y;
-            if (comp == 0) {
-                if (s_found) { o.eff_ab = s_a; o.eff_bb = s_b; }
-                if (e_found) { o.eff_ae = e_a; o.eff_be = e_b; }
-            } else {
-                if (s_found) { o.eff_ab = s_a; o.eff_be = s_b; }
-                if (e_found) { o.eff_ae = e_a; o.eff_bb = e_b; }
-            }
-            bool active = trim ? !(start_idx >= end_idx) : true;   // without trimming match->active keeps its value (maximal.cpp:97-104)
-            if (!trim) { start_idx = 0; end_idx = 0; }
-            int type;
-            if (((o.eff_be - o.eff_bb) < aln_threshold) || ((o.eff_ae - o.eff_ab) < aln_threshold) || !active) {
-                active = false;
-                type = MT_NOT_ACTIVE;
-            } else {
-                const int A_left = o.eff_ab - ea.x, A_right = ea.y - o.eff_ae;
-                int B_left = o.eff_bb - eb.x, B_right = eb.y - o.eff_be;
-                if (comp) { const int t = B_left; B_left = B_right; B_right = t; }
-                type = add_types_asymmetric(A_left, A_right, B_left, B_right, theta, theta2);
-            }
-            o.type = type;
-            o.active = active ? 1 : 0;
-            o.weight = o.eff_ae - o.eff_ab + o.eff_be - o.eff_bb;
-            o.length = av.y - av.x + bs.y - bs.x;
-            o.start_idx = start_idx;
-            o.end_idx = end_idx;
-            if (type_out) type_out[j] = (unsigned char)o.type; else out[j] = o;
+        ClassifyOut o;
+        o.eff_ab = av.x; o.eff_ae = av.y; o.eff_bb = bs.x; o.eff_be = bs.y;
+        if (comp == 0) {
+            if (s_found) { o.eff_ab = s_a; o.eff_bb = s_b; }
+            if (e_found) { o.eff_ae = e_a; o.eff_be = e_b; }
+        } else {
+            if (s_found) { o.eff_ab = s_a; o.eff_be = s_b; }
+            if (e_found) { o.eff_ae = e_a; o.eff_bb = e_b; }
         }
+        bool active = trim ? !(start_idx >= end_idx) : true;   // without trimming match->active keeps its value (maximal.cpp:97-104)
+        if (!trim) { start_idx = 0; end_idx = 0; }
+        int type;
+        if (((o.eff_be - o.eff_bb) < aln_threshold) || ((o.eff_ae - o.eff_ab) < aln_threshold) || !active) {
+            active = false;
+            type = MT_NOT_ACTIVE;
+        } else {
+            const int A_left = o.eff_ab - ea.x, A_right = ea.y - o.eff_ae;
+            int B_left = o.eff_bb - eb.x, B_right = eb.y - o.eff_be;
+            if (comp) { const int t = B_left; B_left = B_right; B_right = t; }
+            type = add_types_asymmetric(A_left, A_right, B_left, B_right, theta, theta2);
+        }
+        o.type = type;
+        o.active = active ? 1 : 0;
+        o.weight = o.eff_ae - o.eff_ab + o.eff_be - o.eff_bb;
+        o.length = av.y - av.x + bs.y - bs.x;
+        o.start_idx = start_idx;
+        o.end_idx = end_idx;
+        if (type_out) type_out[j] = (unsigned char)o.type; else out[j] = o;
     }
 }
 
