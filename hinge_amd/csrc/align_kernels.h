@@ -43,11 +43,124 @@ __device__ __forceinline__ int add_types_asymmetric(int A_left, int A_right, int
 
 // sel[j] = index (into the part's SoA arrays) of the j-th overlap to classify; a_of[j] = its A read.
 // TB = bytes per trace element (1 for tspace <= 125, else 2).
-// One LANE per overlap: the lane walks its trace front to back (B coordinate = running sum of the B advances), keeps the first
-// point inside both masks and the last one.  ~12 instructions per trace point and lane; the 16-lane-row form this replaces
-// (row-wide prefix sum, ballots and five cross-lane reads per 16 points) needed ~90 per point-row for 4 overlaps per wavefront
-// and was bound by instruction issue at 7 % of the HBM roofline (5.0 ms for 24.7 M overlaps, 120 B each).
-template <int TB>
+// Eight lanes own one overlap (eight overlaps per wavefront).  Per step every lane loads 8 consecutive trace bytes - the group
+// reads one 64-byte line, coalesced - and owns the 4 (TB = 1) or 2 (TB = 2) trace points in them: B coordinates = b_first +
+// sign * (advances of earlier steps + exclusive prefix over the group's lanes + running sum inside the lane).  Every lane
+// keeps the first point inside both masks and the last one it has seen; the group's first / last are a min / max over 8 lanes.
+// History: 16 lanes per overlap with one point per lane and step (ballots and five cross-lane reads per 16 points) was bound by
+// instruction issue (5.0 ms for 24.7 M overlaps of ~120 B); one lane per overlap walking its own trace is lean in instructions
+// but every lane pulls its own 64-byte lines through L1 / L2 (4.0 ms).
+// The trim + classify of one overlap by the eight lanes of its group (call from all 64 lanes: cross-lane reads inside).
+// `o` is complete in the group's lane 0 when `live`.  PADDED: the trace buffer has 8 spare bytes behind it (the library's own copy).
+template <int TB, bool PADDED>
+__device__ __forceinline__ void classify_group(const bool live, const int2 av, const int2 bs, const int comp, const int2 ea, const int2 eb, const int tl,
+                                               const unsigned char* __restrict__ tp, const int aln_threshold, const int theta, const int theta2,
+                                               const int trim, const int lane, ClassifyOut& o) {
+    constexpr int GL = 8;                     // lanes per overlap
+    constexpr int PAIR = 2 * TB;              // bytes per trace point (diffs, B advance)
+    constexpr int PL = 8 / PAIR;              // trace points per lane and step
+    const int r = lane & (GL - 1);            // lane inside the group
+    const int glast = lane | (GL - 1);        // last lane of the group
+    {
+        const int ninner = max(tl / 2 - 1, 0);
+        const int np = (live && trim) ? ninner + 2 : 0;   // trace points incl. the two end points
+        const int sign = 1 - 2 * comp;
+        const int b_first = comp ? bs.y : bs.x;        // tp[0].second
+        const int b_last = comp ? bs.x : bs.y;         // tp[np-1].second
+        const int a_base = (av.x / 100) * 100;         // inner point i sits at a_base + 100*i (hard-coded 100, LAInterface.cpp:4581-4584)
+        const int tbytes_total = tl * TB;
+        // "inside both masks" on q = sign * (B coordinate), which ascends along the trace for both strands:
+        //   first point:  a >= ea.x  and  q >= qlo      last point:  a <= ea.y  and  q <= qhi
+        const int qlo = comp ? -eb.y : eb.x, qhi = comp ? -eb.x : eb.y;
+        const int q_first = sign * b_first;
+        // this lane's first point inside both masks / last one (index INT_MAX / -1: none); branch-free updates
+        int f_idx = INT_MAX, f_a = 0, f_q = 0, l_idx = -1, l_a = 0, l_q = 0;
+        auto visit = [&](bool valid, int i, int pa, int q) {   // called with ascending i inside a lane
+            const bool cs = valid && (pa >= ea.x) && (q >= qlo) && (f_idx == INT_MAX);
+            const bool ce = valid && (pa <= ea.y) && (q <= qhi);
+            f_idx = cs ? i : f_idx; f_a = cs ? pa : f_a; f_q = cs ? q : f_q;
+            l_idx = ce ? i : l_idx; l_a = ce ? pa : l_a; l_q = ce ? q : l_q;
+        };
+        visit(np > 0 && r == 0, 0, av.x, q_first);
+        int steps = np > 0 ? (ninner + GL * PL - 1) / (GL * PL) : 0;
+        int steps_max = steps;                         // wave-uniform trip count
+        steps_max = max(steps_max, __shfl_xor(steps_max, 8));
+        steps_max = max(steps_max, __shfl_xor(steps_max, 16));
+        steps_max = max(steps_max, __shfl_xor(steps_max, 32));
+        int carry = 0;                                 // B advances of all earlier steps of this overlap
+        for (int st = 0; st < steps_max; st++) {
+            const int p0 = (st * GL + r) * PL;         // 0-based index of this lane's first inner point of the step
+            unsigned long long w = 0;
+            if (PADDED) {   // 8 bytes behind the trace buffer are ours: the last group of an overlap reads on into the next record
+                if (p0 * PAIR < tbytes_total) __builtin_memcpy(&w, tp + (size_t)p0 * PAIR, 8);
+            } else if (p0 * PAIR < tbytes_total) {
+                if ((p0 + PL) * PAIR <= tbytes_total) {
+                    __builtin_memcpy(&w, tp + (size_t)p0 * PAIR, 8);
+                } else {   // the overlap's last, partial 8 bytes: byte by byte, nothing is read past the trace
+                    for (int q = 0; q < 8 && p0 * PAIR + q < tbytes_total; q++) w |= (unsigned long long)tp[(size_t)p0 * PAIR + q] << (8 * q);
+                }
+            }
+            int adv[PL], tot = 0;
+#pragma unroll
+            for (int q = 0; q < PL; q++) {
+                const int i = p0 + q + 1;
+                const int v = TB == 1 ? (int)((w >> (16 * q + 8)) & 0xffull) : (int)((w >> (32 * q + 16)) & 0xffffull);
+                adv[q] = i <= ninner ? v : 0;
+                tot += adv[q];
+            }
+            int incl = tot;                            // inclusive prefix of the lanes' totals inside the group
+#pragma unroll
+            for (int d = 1; d < GL; d <<= 1) { const int t = __shfl_up(incl, d); incl += r >= d ? t : 0; }
+            int run = carry + incl - tot;
+#pragma unroll
+            for (int q = 0; q < PL; q++) {
+                const int i = p0 + q + 1;
+                run += adv[q];
+                visit(np > 0 && i <= ninner, i, a_base + 100 * i, q_first + run);
+            }
+            carry += __shfl(incl, glast);
+        }
+        visit(np > 0 && r == 0, np - 1, av.y, sign * b_last);
+        // group minimum of (first index, lane) / maximum of (last index, lane), then the winners' coordinates
+        int fk = f_idx == INT_MAX ? INT_MAX : f_idx * GL + r, lk = l_idx < 0 ? -1 : l_idx * GL + r;
+#pragma unroll
+        for (int d = 1; d < GL; d <<= 1) { fk = min(fk, __shfl_xor(fk, d)); lk = max(lk, __shfl_xor(lk, d)); }
+        const bool s_found = fk != INT_MAX, e_found = lk >= 0;
+        const int fl = (lane & ~(GL - 1)) | (s_found ? (fk & (GL - 1)) : 0), ll = (lane & ~(GL - 1)) | (e_found ? (lk & (GL - 1)) : 0);
+        const int s_a = __shfl(f_a, fl), s_b = sign * __shfl(f_q, fl), e_a = __shfl(l_a, ll), e_b = sign * __shfl(l_q, ll);
+        int start_idx = s_found ? fk / GL : np, end_idx = e_found ? lk / GL : 0;
+        if (live && r == 0) {
+            o.eff_ab = av.x; o.eff_ae = av.y; o.eff_bb = bs.x; o.eff_be = bs.y;
+            if (comp == 0) {
+                if (s_found) { o.eff_ab = s_a; o.eff_bb = s_b; }
+                if (e_found) { o.eff_ae = e_a; o.eff_be = e_b; }
+            } else {
+                if (s_found) { o.eff_ab = s_a; o.eff_be = s_b; }
+                if (e_found) { o.eff_ae = e_a; o.eff_bb = e_b; }
+            }
+            bool active = trim ? !(start_idx >= end_idx) : true;   // without trimming match->active keeps its value (maximal.cpp:97-104)
+            if (!trim) { start_idx = 0; end_idx = 0; }
+            int type;
+            if (((o.eff_be - o.eff_bb) < aln_threshold) || ((o.eff_ae - o.eff_ab) < aln_threshold) || !active) {
+                active = false;
+                type = MT_NOT_ACTIVE;
+            } else {
+                const int A_left = o.eff_ab - ea.x, A_right = ea.y - o.eff_ae;
+                int B_left = o.eff_bb - eb.x, B_right = eb.y - o.eff_be;
+                if (comp) { const int t = B_left; B_left = B_right; B_right = t; }
+                type = add_types_asymmetric(A_left, A_right, B_left, B_right, theta, theta2);
+            }
+            o.type = type;
+            o.active = active ? 1 : 0;
+            o.weight = o.eff_ae - o.eff_ab + o.eff_be - o.eff_bb;
+            o.length = av.y - av.x + bs.y - bs.x;
+            o.start_idx = start_idx;
+            o.end_idx = end_idx;
+        }
+    }
+}
+
+template <int TB, bool PADDED>
 __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const int64_t* __restrict__ sel, const int* __restrict__ a_of,
                                                          const int2* __restrict__ a_span, const int2* __restrict__ b_span,
                                                          const unsigned* __restrict__ b_flag, const unsigned char* __restrict__ trace,
@@ -56,90 +169,75 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify(int64_t n_sel, const in
                                                          int theta, int theta2, ClassifyOut* __restrict__ out,
                                                          unsigned char* __restrict__ type_out /*nullptr, or only the match type is wanted*/,
                                                          int trim /*0: PAF input, ProcessAlignment(trim = false): the match is taken as it is*/) {
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n_sel; j += stride) {
-        const int64_t k = sel[j];
-        const int2 av = a_span[k], bs = b_span[k];
-        const unsigned bf = b_flag[k];
-        const int comp = (int)(bf >> 31);
-        const int2 ea = eff[a_of[j]], eb = eff[bf & 0x7fffffffu];
-        const int tl = tlen[k];
-        const unsigned char* __restrict__ tp = trace + trace_off[k];
-        const int ninner = max(tl / 2 - 1, 0);
-        const int np = trim ? ninner + 2 : 0;          // trace points incl. the two end points
-        const int sign = 1 - 2 * comp;
-        const int b_first = comp ? bs.y : bs.x;        // tp[0].second
-        const int b_last = comp ? bs.x : bs.y;         // tp[np-1].second
-        const int a_base = (av.x / 100) * 100;         // inner point i sits at a_base + 100*i (hard-coded 100, LAInterface.cpp:4581-4584)
-        int start_idx = np, end_idx = 0;
-        int s_a = 0, s_b = 0, e_a = 0, e_b = 0;        // coordinates of the first / last point inside both masks
-        bool s_found = false, e_found = false;
-        auto visit = [&](int i, int pa, int pb) {
-            bool cs, ce;
-            if (comp == 0) {
-                cs = (pa >= ea.x) && (pb >= eb.x);
-                ce = (pa <= ea.y) && (pb <= eb.y);
-            } else {
-                cs = (pa >= ea.x) && (pb <= eb.y);
-                ce = (pa <= ea.y) && (pb >= eb.x);
-            }
-            if (cs && !s_found) { s_a = pa; s_b = pb; start_idx = i; s_found = true; }
-            if (ce) { e_a = pa; e_b = pb; end_idx = i; e_found = true; }
-        };
-        if (np > 0) {
-            visit(0, av.x, b_first);
-            // the trace is read 8 bytes at a time (4 points of one byte pairs, 2 of two byte pairs; unaligned loads), two
-            // loads in flight; the bytes of the last, partial group are fetched one by one so that nothing is read past the trace
-            constexpr int PAIR = 2 * TB, CH = 8 / PAIR;
-            const int tbytes_total = tl * TB;
-            int pb_run = b_first;                      // B coordinate of the current inner point
-#pragma unroll 2
-            for (int base = 0; base < ninner; base += CH) {
-                unsigned long long w = 0;
-                if ((base + CH) * PAIR <= tbytes_total) {
-                    __builtin_memcpy(&w, tp + (size_t)base * PAIR, 8);
-                } else {
-                    for (int q = 0; base * PAIR + q < tbytes_total && q < 8; q++) w |= (unsigned long long)tp[(size_t)base * PAIR + q] << (8 * q);
-                }
-#pragma unroll
-                for (int q = 0; q < CH; q++) {
-                    const int i = base + q + 1;
-                    if (i > ninner) break;
-                    const int adv = TB == 1 ? (int)((w >> (16 * q + 8)) & 0xffull) : (int)((w >> (32 * q + 16)) & 0xffffull);
-                    pb_run += sign * adv;
-                    visit(i, a_base + 100 * i, pb_run);
-                }
-            }
-            visit(np - 1, av.y, b_last);
+    constexpr int GL = 8;
+    const int lane = lane_id();
+    const int64_t groups_total = (int64_t)gridDim.x * (BLOCK / GL);
+    const int64_t my_group = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / GL;
+    // the eight groups of a wave iterate together; a group without work idles with j >= n_sel
+    for (int64_t j0 = my_group - (lane >> 3); j0 < n_sel; j0 += groups_total) {
+        const int64_t j = j0 + (lane >> 3);
+        const bool live = j < n_sel;
+        int2 av = make_int2(0, 0), bs = make_int2(0, 0), ea = make_int2(0, 0), eb = make_int2(0, 0);
+        int comp = 0, tl = 0;
+        const unsigned char* tp = trace;
+        if (live) {
+            const int64_t k = sel[j];
+            av = a_span[k];
+            bs = b_span[k];
+            const unsigned bf = b_flag[k];
+            comp = (int)(bf >> 31);
+            ea = eff[a_of[j]];
+            eb = eff[bf & 0x7fffffffu];
+            tl = tlen[k];
+            tp = trace + trace_off[k];
         }
         ClassifyOut o;
-        o.eff_ab = av.x; o.eff_ae = av.y; o.eff_bb = bs.x; o.eff_be = bs.y;
-        if (comp == 0) {
-            if (s_found) { o.eff_ab = s_a; o.eff_bb = s_b; }
-            if (e_found) { o.eff_ae = e_a; o.eff_be = e_b; }
-        } else {
-            if (s_found) { o.eff_ab = s_a; o.eff_be = s_b; }
-            if (e_found) { o.eff_ae = e_a; o.eff_bb = e_b; }
+        classify_group<TB, PADDED>(live, av, bs, comp, ea, eb, tl, tp, aln_threshold, theta, theta2, trim, lane, o);
+        if (live && (lane & (GL - 1)) == 0) {
+            if (type_out) type_out[j] = (unsigned char)o.type; else out[j] = o;
         }
-        bool active = trim ? !(start_idx >= end_idx) : true;   // without trimming match->active keeps its value (maximal.cpp:97-104)
-        if (!trim) { start_idx = 0; end_idx = 0; }
-        int type;
-        if (((o.eff_be - o.eff_bb) < aln_threshold) || ((o.eff_ae - o.eff_ab) < aln_threshold) || !active) {
-            active = false;
-            type = MT_NOT_ACTIVE;
-        } else {
-            const int A_left = o.eff_ab - ea.x, A_right = ea.y - o.eff_ae;
-            int B_left = o.eff_bb - eb.x, B_right = eb.y - o.eff_be;
-            if (comp) { const int t = B_left; B_left = B_right; B_right = t; }
-            type = add_types_asymmetric(A_left, A_right, B_left, B_right, theta, theta2);
+    }
+}
+
+// The same for EVERY overlap of the part, in storage order: one wavefront per A read, eight overlaps per step.  All the
+// per-overlap arrays and the traces (consecutive in the .las) are read coalesced; only eff[B] is a gather (an 8-byte table
+// entry per read).  `hinge maximal` classifies nearly every overlap (the best one or two per (A, B) pair), and a list of
+// selected overlaps in hash-map order costs six scattered 64-byte lines per overlap: that, not the trace walk, is what held
+// the list form at 4-5 ms for 24.7 M overlaps whatever the lane layout.
+template <int TB, bool PADDED>
+__global__ __launch_bounds__(BLOCK) void k_trim_classify_rows(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+                                                              const int2* __restrict__ a_span, const int2* __restrict__ b_span,
+                                                              const unsigned* __restrict__ b_flag, const unsigned char* __restrict__ trace,
+                                                              const int64_t* __restrict__ trace_off, const int* __restrict__ tlen,
+                                                              const int2* __restrict__ eff, int aln_threshold, int theta, int theta2,
+                                                              unsigned char* __restrict__ type_out /*[n_ovl] of the part*/, int trim) {
+    constexpr int GL = 8;
+    const int lane = lane_id();
+    const int g = lane >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+    const int nwaves = (gridDim.x * BLOCK) >> 6;
+    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int2 ea = eff[i];
+        for (int64_t k0 = s; k0 < e; k0 += WAVE / GL) {
+            const int64_t k = k0 + g;
+            const bool live = k < e;
+            int2 av = make_int2(0, 0), bs = make_int2(0, 0), eb = make_int2(0, 0);
+            int comp = 0, tl = 0;
+            const unsigned char* tp = trace;
+            if (live) {
+                av = a_span[k];
+                bs = b_span[k];
+                const unsigned bf = b_flag[k];
+                comp = (int)(bf >> 31);
+                eb = eff[bf & 0x7fffffffu];
+                tl = tlen[k];
+                tp = trace + trace_off[k];
+            }
+            ClassifyOut o;
+            classify_group<TB, PADDED>(live, av, bs, comp, ea, eb, tl, tp, aln_threshold, theta, theta2, trim, lane, o);
+            if (live && (lane & (GL - 1)) == 0) type_out[k] = (unsigned char)o.type;
         }
-        o.type = type;
-        o.active = active ? 1 : 0;
-        o.weight = o.eff_ae - o.eff_ab + o.eff_be - o.eff_bb;
-        o.length = av.y - av.x + bs.y - bs.x;
-        o.start_idx = start_idx;
-        o.end_idx = end_idx;
-        if (type_out) type_out[j] = (unsigned char)o.type; else out[j] = o;
     }
 }
 

@@ -69,6 +69,7 @@ struct hinge_ctx {
 
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
+    bool trace_padded = false;   // the trace buffer is the library's own copy with 8 spare bytes behind it
     int64_t trace_bytes = 0;
     int tbytes = 1;
 

@@ -42,15 +42,15 @@ int main(int argc, char* argv[]) {
     int64_t novl0 = 0;
     int tspace0 = 100;
     if (fa_and_paf) {   // reads from the FASTA, one "part" = the PAF, no QV track (filter.cpp:289-291,467-468)
-        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", name_fasta.c_str()); exit(1); }
+        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", name_fasta.c_str()); quit(1); }
         las_list.push_back(name_paf);
     } else {
-        if (db.open(name_db) != 0) { fprintf(stderr, "Reads_filter: Could not open database %s\n", name_db.c_str()); exit(1); }
+        if (db.open(name_db) != 0) { fprintf(stderr, "Reads_filter: Could not open database %s\n", name_db.c_str()); quit(1); }
         has_qv = db.load_qual(qv);
         const std::string name_las = las_name(name_las_base, mlas);
         if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
         if (las_list.empty()) { console.error("No alignments!"); return 1; }
-        if (LasPart::header(las_list[0], novl0, tspace0) != 0) { fprintf(stderr, "Reads_filter: cannot open %s\n", las_list[0].c_str()); exit(1); }
+        if (LasPart::header(las_list[0], novl0, tspace0) != 0) { fprintf(stderr, "Reads_filter: cannot open %s\n", las_list[0].c_str()); quit(1); }
     }
     const int n_read = (int)db.rlen.size();
     console.info("# Reads: %d", n_read);
@@ -103,7 +103,7 @@ int main(int argc, char* argv[]) {
         LasPart& las = *las_owner;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
         if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
-        if (lrc != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        if (lrc != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", las_list[part].c_str()); quit(1); }
         tm.mark("las ingest");
         console.info("# Alignments: %lld", (long long)las.novl);
         if (las.novl == 0) { console.error("No alignments!"); return 1; }

@@ -31,6 +31,14 @@
 
 #include "../../include/hinge_hip.h"
 
+// Error exits while the HIP runtime may still be initialising on the helper thread (CtxInit): exit() would run the static
+// destructors under that thread's feet (an occasional SIGSEGV instead of the exit code); _exit() after a flush does not.
+[[noreturn]] inline void quit(int code) {
+    fflush(nullptr);
+    _exit(code);
+}
+
+
 namespace hh {
 
 // ---------------------------------------------------------------------------------------------------
@@ -118,12 +126,12 @@ public:
             }
             o->set = true;
         }
-        if (help) { usage(stdout); exit(0); }
+        if (help) { usage(stdout); quit(0); }
         for (auto& o : opts_) if (o.need && !o.set) errors.push_back("need option: --" + o.name);
         if (!errors.empty()) {
             for (auto& e : errors) fprintf(stderr, "%s\n", e.c_str());
             usage(stderr);
-            exit(1);
+            quit(1);
         }
     }
 
@@ -913,7 +921,7 @@ inline void write_coverage_txt(FILE* f, int r_begin, const std::vector<int32_t>&
                     }
                 }
             });
-            if (failed || fseeko(f, base + (off_t)at[(size_t)(w1 - w0)], SEEK_SET) != 0) { fprintf(stderr, "write error on the coverage file\n"); exit(1); }
+            if (failed || fseeko(f, base + (off_t)at[(size_t)(w1 - w0)], SEEK_SET) != 0) { fprintf(stderr, "write error on the coverage file\n"); quit(1); }
         } else {
             for (int64_t c = 0; c < w1 - w0; c++) fwrite(buf[(size_t)c].p, 1, buf[(size_t)c].len, f);
         }

@@ -167,8 +167,8 @@ int main(int argc, char* argv[]) {
 
     ReadDB db;
     if (fa_and_paf) {
-        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "hinging: cannot read %s\n", name_fasta.c_str()); exit(1); }
-    } else if (db.open(name_db) != 0) { fprintf(stderr, "hinging: Could not open database %s\n", name_db.c_str()); exit(1); }
+        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "hinging: cannot read %s\n", name_fasta.c_str()); quit(1); }
+    } else if (db.open(name_db) != 0) { fprintf(stderr, "hinging: Could not open database %s\n", name_db.c_str()); quit(1); }
     const int n_read = (int)db.rlen.size();
     console.info("# Reads: %d", n_read);
 
@@ -242,7 +242,7 @@ int main(int argc, char* argv[]) {
         LasPart& las = *lp;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
         if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
-        if (lrc != 0) { fprintf(stderr, "hinging: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        if (lrc != 0) { fprintf(stderr, "hinging: cannot read %s\n", las_list[part].c_str()); quit(1); }
         tm.mark("las ingest");
         if (las.novl == 0) { console.error("No alignments!"); return 2; }
         const int r_begin = las.r_begin, r_end = las.r_end;

@@ -40,10 +40,10 @@ int main(int argc, char* argv[]) {
     ReadDB db;
     std::vector<std::string> las_list;
     if (fa_and_paf) {
-        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", name_fasta.c_str()); exit(1); }
+        if (read_fasta_lengths(name_fasta, db.rlen) != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", name_fasta.c_str()); quit(1); }
         las_list.push_back(name_paf);
     } else {
-        if (db.open(name_db) != 0) { fprintf(stderr, "get_maximal_reads: Could not open database %s\n", name_db.c_str()); exit(1); }
+        if (db.open(name_db) != 0) { fprintf(stderr, "get_maximal_reads: Could not open database %s\n", name_db.c_str()); quit(1); }
         const std::string name_las = las_name(name_las_base, mlas);
         if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
     }
@@ -93,7 +93,7 @@ int main(int argc, char* argv[]) {
         LasPart& las = *las_owner;
         if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
         if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
-        if (lrc != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", las_list[part].c_str()); exit(1); }
+        if (lrc != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", las_list[part].c_str()); quit(1); }
         tm.mark("las ingest");
         if (las.novl == 0) { console.error("No alignments!"); return 1; }
         const int r_begin = las.r_begin, r_end = las.r_end;
@@ -162,7 +162,16 @@ int main(int argc, char* argv[]) {
             }
         });
         tm.mark("pick_pairs");
-        HH_CHECK(ctx, hinge_trim_classify_types(ctx, n_sel, sel.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, mtype.data()));
+        // Nearly every overlap is selected (one or two per (A, B) pair), so the whole part is classified in storage order -
+        // coalesced, nothing to upload - and the selected ones are picked out of the result.
+        {
+            UVec<uint8_t> all_types;
+            all_types.resize((size_t)std::max<int64_t>(las.n_kept(), 1));
+            HH_CHECK(ctx, hinge_trim_classify_part(ctx, ALN_THRESHOLD, THETA, THETA2, all_types.data()));
+            parallel_chunks(n_sel, host_threads(), [&](int, int64_t b, int64_t e) {
+                for (int64_t c = b; c < e; c++) mtype[(size_t)c] = all_types[(size_t)sel[(size_t)c]];
+            });
+        }
 
         tm.mark("trim_classify (GPU)");
         // sequential containment resolution, maximal.cpp:780-858: one (a, b) row per overlap that classified as BCOVERA

@@ -158,6 +158,10 @@ int hinge_trim_classify(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel, const
  * `type == BCOVERA` (maximal.cpp:805-857), and 1 byte instead of 40 per overlap comes back over PCIe.            */
 int hinge_trim_classify_types(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel, const int32_t* a_of, int32_t aln_threshold, int32_t theta,
                               int32_t theta2, uint8_t* type_out);
+/* The match type of EVERY overlap of the current part (type_out[n_ovl], storage order), for callers that classify most of
+ * them anyway (`hinge maximal`: the best one or two overlaps of every (A, B) pair): one wavefront per A read streams the part
+ * with coalesced loads instead of gathering a list (a list in hash-map order costs six scattered cache lines per overlap).   */
+int hinge_trim_classify_part(hinge_ctx* ctx, int32_t aln_threshold, int32_t theta, int32_t theta2, uint8_t* type_out);
 /* Sequential containment resolution of `hinge maximal` (maximal.cpp:780-858), host side, no device work: reads in
  * ascending id; a read that is still active is removed if one of its containers is active at that moment (containers
  * of lower id have their final state by then, those of higher id their initial one).  pairs = n_pairs (a, b) int32 rows,

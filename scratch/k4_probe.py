@@ -14,6 +14,14 @@ out = "/tmp/k4prof"
 env = dict(os.environ, TMPDIR="/tmp", HINGE_SLOW_EXIT="1")   # (the fast _exit() would skip the profiler's own exit handler)
 subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out, "-o", "k4", "--output-format", "csv", "--", B + "get_maximal_reads", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini"],
                cwd=wd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+out2 = "/tmp/k4pmc"
+subprocess.run(["rocprofv3", "--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "-d", out2, "-o", "k4", "--output-format", "csv", "--", B + "get_maximal_reads", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini"],
+               cwd=wd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+import csv
+for ff in glob.glob(out2 + "/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(ff)):
+        if "trim_classify" in row["Kernel_Name"]:
+            print(row["Counter_Name"], row["Counter_Value"])
 f = glob.glob(out + "/**/*kernel_stats.csv", recursive=True)[0]
 print("\n".join(l[:40] + " ... " + l[-90:] for l in open(f).read().splitlines()[:4]))
 tl = np.fromfile(os.path.join(wd, "G.las"), dtype=np.uint8, count=0)

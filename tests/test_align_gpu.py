@@ -26,7 +26,7 @@ def _setup(datasets, oracle_lib, tmp_path, name):
     ctx.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
     toff = recs.trace_off[:-1][pile.las_index]
     tlen = recs.rec["tlen"][pile.las_index]
-    ctx.set_traces(recs.trace, toff, tlen, 1)
+    ctx.set_traces(recs.trace, toff, tlen, 1 if recs.tspace <= 125 else 2)
     ctx.set_eff_reads(eff)
     a_of = np.repeat(np.arange(d.n_reads, dtype=np.int32), np.diff(pile.row_ptr).astype(np.int64))
     return ctx, recs, pile, eff, a_of, toff, tlen
@@ -54,6 +54,23 @@ def test_trim_classify_matches_oracle(datasets, oracle_lib, tmp_path, name, thr)
         assert np.array_equal(got[k], want), (k, got[k], want)
         types.add(int(want[4]))
     assert len(types) >= 5, types
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "chimera", "tspace200"])
+def test_trim_classify_part_equals_the_list_form(datasets, oracle_lib, tmp_path, name):
+    """hinge_trim_classify_part (every overlap of the part, one wavefront per A read, coalesced) == hinge_trim_classify /
+    hinge_trim_classify_types over the list of all overlaps (which the test above holds against the oracle)."""
+    ctx, recs, pile, eff, a_of, toff, tlen = _setup(datasets, oracle_lib, tmp_path, name)
+    n = pile.n_ovl
+    sel = np.arange(n, dtype=np.int64)
+    thr = (1000, 300, 0)
+    full = ctx.trim_classify(sel, a_of, *thr)
+    types = ctx.trim_classify_types(sel, a_of, *thr)
+    part = ctx.trim_classify_part(n, *thr)
+    assert np.array_equal(types, full[:, 4].astype(np.uint8))
+    assert np.array_equal(part, types)
+    assert len(set(part.tolist())) >= 4
     ctx.close()
 
 
