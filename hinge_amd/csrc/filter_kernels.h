@@ -883,7 +883,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
                                                              const int64_t* __restrict__ row_ptr,
                                                              const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
                                                              const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
-                                                             int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count) {
+                                                             int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int rpw) {
     extern __shared__ int lds[];
     constexpr int HOT = 4;
     const int lane = lane_id();
@@ -892,11 +892,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
     // n4 reads that need all four]; the first ceil(n1/4) workgroups run four reads, the next ceil(n2/2) two (wavefronts 0
     // and 2, each over two slots), the last n4 one.  One launch, LDS sized for the common short read, and the few long
     // reads of a part overlap with everything else instead of costing every read its occupancy.
-    const int g1 = (n1 + 3) / 4, g2 = (n2 + 1) / 2;
-    int width, item;
-    if ((int)blockIdx.x < g1) { width = 1; item = (int)blockIdx.x * 4 + wib; if (item >= n1) return; }
-    else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g1) * 2 + (wib >> 1); if (item >= n2) return; item += n1; }
-    else { width = 4; if (wib != 0) return; item = n1 + n2 + ((int)blockIdx.x - g1 - g2); }
+    // rpw: class-1 reads per wavefront (the per-wavefront set-up below is ~1/8 of a read's scalar instructions; a wavefront that
+    // runs `rpw` reads pays it once; the reads of a wavefront are g1 * 4 apart in the list)
+    const int g1 = ((n1 + 3) / 4 + rpw - 1) / rpw, g2 = (n2 + 1) / 2;
+    int width, item, item_end, item_step = 1;
+    if ((int)blockIdx.x < g1) { width = 1; item = (int)blockIdx.x * 4 + wib; if (item >= n1) return; item_end = n1; item_step = g1 * 4; }
+    else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g1) * 2 + (wib >> 1); if (item >= n2) return; item += n1; item_end = item + 1; }
+    else { width = 4; if (wib != 0) return; item = n1 + n2 + ((int)blockIdx.x - g1 - g2); item_end = item + 1; }
     constexpr int reso = 40;
     const int SH = P.cut_off / 20;
     // Zero words in front of the prefix array and copies of the totals behind it make PB[q < 0] = 0 and P[q > last] = P[last]
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
     const int MIN_COV = *d_min_cov;
     for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
 
-    for (int once = 0; once < 1; once++) {         // one read per wavefront; `continue` leaves
+    for (; item < item_end; item += item_step) {   // `continue` leaves a read
         const int i = read_list[item];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];

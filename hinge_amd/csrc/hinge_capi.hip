@@ -69,6 +69,7 @@ struct hinge_ctx {
 
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
+    int k2_rpw = 0;              // class-1 reads per wavefront of k_mask_annotate_q20 (0: chosen from the part's size)
     bool trace_padded = false;   // the trace buffer is the library's own copy with 8 spare bytes behind it
     int64_t trace_bytes = 0;
     int tbytes = 1;
@@ -206,6 +207,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
+    if (const char* g = getenv("HINGE_K2_RPW")) ctx->k2_rpw = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -634,15 +636,18 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // ~17.5 KiB for 16 kb reads: eight workgroups (32 waves) per CU
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
         const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
-        const int g = std::max(1, (n1 + 3) / 4 + (n2 + 1) / 2 + n4);
+        // class-1 reads per wavefront: 3 once the part has enough reads to fill the GPU several times over with a third of the
+        // wavefronts (84.1 us vs 88.8 us on 86 588 reads; 2: 87.4, 4: 84.5), 1 for small parts; HINGE_K2_RPW overrides
+        const int rpw = ctx->k2_rpw > 0 ? ctx->k2_rpw : std::min(3, std::max(1, n1 / 16384));
+        const int g = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4);
         if (ctx->use_span16)
             hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
                                (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
+                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
         else
             hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
                                (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count);
+                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is

@@ -77,15 +77,16 @@ int main() {
     printf("k_cov_stats<40, packed>: %7.1f us\n", tk1 * 1e3);
     AnnoOut o{nullptr, nullptr, mask, cmask, rf, anno, hf, aoff, acnt, cnt, 4u * (unsigned)nr, wl, st};
     const int grid = (nr + 3) / 4;
-    const int grid20 = (n1 + 3) / 4 + (n2 + 1) / 2 + n4;
+    const int rpw = getenv("MA_RPW") ? atoi(getenv("MA_RPW")) : 3;
+    const int grid20 = ((n1 + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4;
     for (int mode = 1; mode <= 8; mode++) {
         P.ablate = mode;
         float t = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
             hipLaunchKernelGGL(k_mask_annotate<40>, dim3(grid), dim3(256), lds, 0, P, 0, nr - 1, rp, a, rl, mc, kcap, o, (const int*)nullptr, (const unsigned*)nullptr); });
         float t2 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
-            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, nb0, mc, slot, o, fb, cnt + 2); });
+            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a, rl, nb0, mc, slot, o, fb, cnt + 2, rpw); });
         float t3 = timeit([&] { (void)hipMemsetAsync(cnt, 0, 16, 0);
-            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a16, rl, nb0, mc, slot, o, fb, cnt + 2); });
+            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(grid20), dim3(256), lds20, 0, P, ids, n1, n2, n4, rp, a16, rl, nb0, mc, slot, o, fb, cnt + 2, rpw); });
         printf("stop after phase %d: general %7.1f us   q20 %7.1f us   q20 packed %7.1f us   (1 histogram, 2 +mask, 3 +gate, 4 +candidates, 5 all; to end of phase 2: 6 no scan, 7 no mask pass, 8 neither)\n", mode, t * 1e3, t2 * 1e3, t3 * 1e3);
     }
     unsigned hc[4]; (void)hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost);
