@@ -14,7 +14,9 @@ HOST = hinge_amd/host
 HOSTDEPS = $(wildcard $(HOST)/*.h) include/hinge_hip.h $(LIB)
 PROGS = $(BIN)/Reads_filter $(BIN)/get_maximal_reads $(BIN)/hinging $(BIN)/hinge
 
-all: $(LIB) $(PROGS) oracle
+SYNTHIO = hinge_amd/lib/libhinge_synthio.so
+
+all: $(LIB) $(PROGS) $(SYNTHIO) oracle
 
 $(BIN)/Reads_filter: $(HOST)/filter_main.cpp $(HOSTDEPS)
 	mkdir -p $(BIN)
@@ -36,6 +38,11 @@ $(BIN)/hinge: $(HOST)/hinge
 $(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.inc) include/hinge_hip.h
 	mkdir -p hinge_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hinge_capi.hip
+
+# test / bench tooling: fast writer of synthetic .las files (no GPU code)
+$(SYNTHIO): hinge_amd/tools_c/synth_io.c
+	mkdir -p hinge_amd/lib
+	gcc -O2 -fPIC -shared -o $@ $<
 
 oracle:
 	$(MAKE) -C oracle

@@ -47,6 +47,9 @@ SYMBOLS = [
     ("hinge_synchronize", C.c_int, [_VP]),
     ("hinge_set_reads", C.c_int, [_VP, C.c_int32, _VP, _VP]),
     ("hinge_set_pileups", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_int]),
+    ("hinge_set_pileups_packed", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_uint32, C.c_int, C.c_int]),
+    ("hinge_span16_pad", C.c_int, []),
+    ("hinge_get_pileup_facts", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     ("hinge_attach_mask_table", C.c_int, [_VP, _VP]),
     ("hinge_attach_mean_cov", C.c_int, [_VP, _VP]),
     ("hinge_clear_masks", C.c_int, [_VP]),
@@ -63,6 +66,8 @@ SYMBOLS = [
     ("hinge_filter_get_masks", C.c_int, [_VP, _VP, _VP, _VP]),
     ("hinge_filter_get_annotations", C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     ("hinge_filter_coverage_bins", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
+    ("hinge_filter_coverage_out", C.c_int, [_VP, C.c_int]),
+    ("hinge_filter_get_coverage", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64]),
     ("hinge_filter_counters", C.c_int, [_VP, _VP]),
     ("hinge_set_traces", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int, C.c_int]),
     ("hinge_set_eff_reads", C.c_int, [_VP, _VP]),
@@ -129,6 +134,7 @@ def load_library() -> C.CDLL:
     return lib
 
 
+# test hooks (declared at the end of include/hinge_hip.h)
 EXTRA_SYMBOLS = [
     ("hinge_debug_force_exact", C.c_int, [_VP, C.c_int]),
     ("hinge_debug_force_general_mask", C.c_int, [_VP, C.c_int]),
@@ -202,6 +208,45 @@ class Context:
         self.r_begin, self.r_end = int(r_begin), int(r_end)
         self._ck(self.lib.hinge_set_pileups(self.h, r_begin, r_end, int(n_ovl), _ptr(row_ptr), _ptr(a_span), _ptr(b_span), _ptr(b_flag),
                                             1 if on_device else 0))
+
+    def set_pileups_packed(self, r_begin: int, r_end: int, row_ptr, a_span, b_span, b_flag, span16, max_pile: int, spans_in_range: bool,
+                           n_ovl: Optional[int] = None, on_device: bool = False):
+        """set_pileups with the ingest's facts: span16 (None, or abpos | aepos << 16 with span16_pad() spare elements behind it),
+        the largest pile-up and whether every span lies inside its read (see pack_spans)."""
+        if not on_device:
+            row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+            a_span = np.ascontiguousarray(a_span, dtype=np.int32)
+            b_span = np.ascontiguousarray(b_span, dtype=np.int32)
+            b_flag = np.ascontiguousarray(b_flag, dtype=np.uint32)
+            span16 = None if span16 is None else np.ascontiguousarray(span16, dtype=np.uint32)
+            n_ovl = int(b_flag.shape[0])
+        self._keep = [row_ptr, a_span, b_span, b_flag, span16]
+        self.r_begin, self.r_end = int(r_begin), int(r_end)
+        self._ck(self.lib.hinge_set_pileups_packed(self.h, r_begin, r_end, int(n_ovl), _ptr(row_ptr), _ptr(a_span), _ptr(b_span), _ptr(b_flag),
+                                                   _ptr(span16), int(max_pile), 1 if spans_in_range else 0, 1 if on_device else 0))
+
+    def pileup_facts(self):
+        """(largest pile-up, every span inside its read) of the current part."""
+        mp, ok = C.c_uint32(), C.c_int()
+        self._ck(self.lib.hinge_get_pileup_facts(self.h, C.byref(mp), C.byref(ok)))
+        return int(mp.value), bool(ok.value)
+
+    def coverage_out(self, on: bool):
+        """K2 also stores the cutoff-0 coverage bins (the .coverage.txt payload); read them with get_coverage()."""
+        self._ck(self.lib.hinge_filter_coverage_out(self.h, 1 if on else 0))
+
+    def get_coverage(self):
+        """(nbins[n], cov) with the bins of consecutive reads packed back to back (the layout coverage_bins() returns)."""
+        n = self.r_end - self.r_begin + 1
+        off = np.zeros(n + 1, np.int64)
+        self._ck(self.lib.hinge_filter_get_coverage(self.h, _ptr(off), None, None, 0))
+        nb = np.zeros(n, np.int32)
+        raw = np.zeros(max(int(off[-1]), 1), np.int32)
+        self._ck(self.lib.hinge_filter_get_coverage(self.h, _ptr(off), _ptr(nb), _ptr(raw), int(off[-1])))
+        if n == 0 or int(nb.sum()) == 0:
+            return nb, np.zeros(0, np.int32)
+        idx = np.repeat(off[:-1] - np.concatenate([[0], np.cumsum(nb.astype(np.int64))[:-1]]), nb.astype(np.int64)) + np.arange(int(nb.sum()), dtype=np.int64)
+        return nb, raw[idx]
 
     def attach_mask_table(self, dev_ptr):
         self._ck(self.lib.hinge_attach_mask_table(self.h, _VP(_ptr(dev_ptr)) if dev_ptr is not None else None))
@@ -381,6 +426,28 @@ class Context:
         ms = C.c_float()
         self._ck(self.lib.hinge_timer_stop_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+
+def span16_pad() -> int:
+    return int(load_library().hinge_span16_pad())
+
+
+def pack_spans(row_ptr: np.ndarray, a_span: np.ndarray, rlen: np.ndarray):
+    """What an ingest hands to set_pileups_packed besides the columns: (span16 or None, max_pile, spans_in_range).
+    numpy restatement of the per-record work of hinge_amd/host/host_common.h LasPart::load."""
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    a_span = np.asarray(a_span, dtype=np.int32).reshape(-1, 2)
+    n = int(a_span.shape[0])
+    counts = np.diff(row_ptr)
+    max_pile = int(counts.max()) if len(counts) else 0
+    a_of = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+    rl = np.asarray(rlen, dtype=np.int64)[a_of]
+    in_range = bool(np.all((a_span[:, 0] >= 0) & (a_span[:, 1] >= 0) & (a_span[:, 0] <= rl) & (a_span[:, 1] <= rl))) if n else True
+    span16 = None
+    if n and in_range and int(np.max(rlen)) < 65536:
+        span16 = np.zeros(n + span16_pad(), np.uint32)
+        span16[:n] = a_span[:, 0].astype(np.uint32) | (a_span[:, 1].astype(np.uint32) << np.uint32(16))
+    return span16, min(max_pile, 0x7FFFFFFF), in_range
 
 
 MT_BCOVERA = 3   # match type "B covers A" (LAInterface.h:30-33)

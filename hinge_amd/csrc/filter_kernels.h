@@ -561,6 +561,12 @@ struct AnnoOut {   // per-part outputs of K2
     unsigned anno_cap;
     WorkItem* work_list;
     int* status;
+    // optional: the cutoff-0 coverage bins themselves (the .coverage.txt payload, filter.cpp:599-602), written while they are
+    // in LDS anyway: bins of read i at cov_out[cov_off[i - cov_base] ..], their number at cov_nbins[i - cov_base]
+    int* cov_out;
+    const long long* cov_off;
+    int* cov_nbins;
+    int cov_base;
 };
 
 // Longest run of bins with coverage > MIN_COV (filter.cpp:696-728), fed 64 bins at a time as a ballot.
@@ -593,6 +599,11 @@ template <typename ZF, typename CF>
 __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
                                                    const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o,
                                                    const long long row, const int n_pile) {
+    if (o.cov_out) {   // before anything reuses the profile's LDS (cand)
+        int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
+        for (int j = lane; j < K0; j += WAVE) dst[j] = z(j);
+        if (lane == 0) o.cov_nbins[i - o.cov_base] = K0;
+    }
     int maxstart = 0, maxend = 0, msc = 0, mec = 0;
     if (run.best_len > 0) {
         mec = run.best_j - 1;

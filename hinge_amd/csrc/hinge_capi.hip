@@ -37,8 +37,10 @@ struct hinge_ctx {
 
     DevBuf mask_own;          // int2[n_reads]
     int2* mask = nullptr;     // active table (own or attached)
+    bool mask_attached = false;   // mask points at a caller-owned table (hinge_attach_mask_table)
     DevBuf mean_own;
     int* mean_cov = nullptr;
+    bool mean_attached = false;
     DevBuf cmask, rflags, nbins0, keep;
     int nbins0_reso = -1;               // reso k_cov_stats last filled nbins0[] at for the current pile-ups (-1: not yet)
     DevBuf span16;             // 16|16-bit copy of a_span (abpos | aepos << 16) for the two streaming kernels
@@ -74,6 +76,13 @@ struct hinge_ctx {
     int64_t trace_bytes = 0;
     int tbytes = 1;
 
+    // K2's optional coverage-bin output (hinge_filter_coverage_out)
+    bool cov_out_on = false;
+    DevBuf cov_buf, cov_off_d, cov_nb;
+    std::vector<int64_t> h_cov_off;          // [nr + 1] over the reads of the current part
+    int cov_key[4] = {-1, -1, -1, -1};       // r_begin, r_end, reso, cut_off the layout was made for
+    bool cov_valid = false;                  // the last K2 pass wrote the bins
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // per-kernel HIP-event timing (bench.py roofline): pairs recorded around every launch
@@ -84,9 +93,10 @@ struct hinge_ctx {
     std::vector<int> prof_kid;
 };
 
-enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY, KID_COUNT };
+enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY,
+                KID_PILEUP_FACTS, KID_MATCHING_POSITION, KID_SELECT_EDGES, KID_COUNT };
 static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_hist", "k_mask_annotate", "k_mask_annotate_fallback", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
-                                                     "k_coverage_bins", "k_trim_classify"};
+                                                     "k_coverage_bins", "k_trim_classify", "k_pileup_facts", "k_matching_position", "k_select_edges"};
 
 struct ProfScope {
     hinge_ctx* c;
@@ -108,6 +118,7 @@ struct ProfScope {
     ~ProfScope() { stop(); }
 };
 
+static_assert(HINGE_SPAN16_PAD == (LOADS_IN_FLIGHT / 2) * WAVE, "elements behind span16[n_ovl] a kernel may read (never uses)");
 static const int K2_SHORT_RLEN = 16000;   // 20-bp bins of a 16 kb read + hot words + pads = 1120 ints per wavefront, 17.5 KiB per workgroup: 8 workgroups per CU
 
 // words of LDS per wavefront slot of k_mask_annotate_q20: 20-bp bins of the longest "short" read + the hot words
@@ -134,6 +145,8 @@ struct Scalars {
     int min_cov;
     int pad;
     unsigned facts[2];                  // k_pileup_facts: largest pile-up, out-of-range flag
+    int bins_status;                    // hinge_filter_coverage_bins' own range flag
+    int pad2;
     unsigned dbg[16];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
@@ -225,7 +238,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
-                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out};
+                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -271,8 +284,9 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->work_list, sizeof(WorkItem) * n))) return rc;
     if ((rc = ensure(ctx, ctx->fallback_list, sizeof(int) * n))) return rc;
-    if (!ctx->mask) ctx->mask = (int2*)ctx->mask_own.p;
-    if (!ctx->mean_cov) ctx->mean_cov = (int*)ctx->mean_own.p;
+    // (the own tables may just have been reallocated: re-point unless a caller table is attached)
+    if (!ctx->mask_attached) ctx->mask = (int2*)ctx->mask_own.p;
+    if (!ctx->mean_attached) ctx->mean_cov = (int*)ctx->mean_own.p;
     CK(hipMemsetAsync(ctx->mask_own.p, 0, sizeof(int2) * n, ctx->stream));
     CK(hipMemsetAsync(ctx->anno_cnt.p, 0, sizeof(int) * n, ctx->stream));
     CK(hipMemsetAsync(ctx->anno_off.p, 0, sizeof(unsigned) * n, ctx->stream));
@@ -301,13 +315,15 @@ static int adopt(hinge_ctx* ctx, DevBuf& b, const void* src, size_t bytes, int o
     return HINGE_OK;
 }
 
-int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr, const int32_t* a_span,
-                      const int32_t* b_span, const uint32_t* b_flag, int on_device) {
+static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr, const int32_t* a_span,
+                            const int32_t* b_span, const uint32_t* b_flag, const uint32_t* span16, bool facts_given, uint32_t max_pile,
+                            int spans_in_range, int on_device) {
     if (!ctx || ctx->n_reads <= 0) return fail(ctx, HINGE_E_ARG, "hinge_set_pileups: call hinge_set_reads first");
     if (r_begin < 0 || r_end >= ctx->n_reads || r_end < r_begin || n_ovl < 0 || !row_ptr) return fail(ctx, HINGE_E_ARG, "hinge_set_pileups: bad range");
     CK(hipSetDevice(ctx->device));
     ctx->r_begin = r_begin; ctx->r_end = r_end; ctx->n_ovl = n_ovl;
     ctx->nbins0_reso = -1;
+    ctx->cov_valid = false;
     int rc;
     if ((rc = adopt(ctx, ctx->row_ptr, row_ptr, sizeof(int64_t) * ((size_t)ctx->n_reads + 1), on_device))) return rc;
     if ((rc = adopt(ctx, ctx->a_span, a_span, sizeof(int2) * (size_t)n_ovl, on_device))) return rc;
@@ -344,35 +360,77 @@ int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
         if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)nr))) return rc;
         CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
-        // one sweep over the spans, once per part: largest pile-up, any coordinate outside [0, rlen]
-        unsigned* facts = sc(ctx)->facts;
-        CK(hipMemsetAsync(facts, 0, 2 * sizeof(unsigned), ctx->stream));
-        const bool pack = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
-        // (+ half a batch of elements: k_mask_annotate_q20 reads its last batch without clamping the index)
-        if (pack && (rc = ensure(ctx, ctx->span16, sizeof(unsigned) * ((size_t)n_ovl + (LOADS_IN_FLIGHT / 2) * WAVE)))) return rc;
-        hipLaunchKernelGGL(k_pileup_facts, dim3(std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->n_cu * 8))), dim3(BLOCK), 0, ctx->stream, r_begin, r_end,
-                           (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts,
-                           pack ? (unsigned*)ctx->span16.p : (unsigned*)nullptr);
-        CK(hipGetLastError());
-        unsigned h[2] = {0, 0};
-        CK(hipMemcpyAsync(h, facts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-        ctx->max_pile = h[0];
-        ctx->spans_in_range = h[1] == 0;
-        ctx->use_span16 = pack && ctx->spans_in_range;
+        CK(hipStreamSynchronize(ctx->stream));   // lst is a local
+        const bool pack_ok = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
+        if (facts_given) {
+            // The ingest touched every record anyway: it hands over the facts and (when every coordinate fits 16 bits and
+            // lies inside its read) the 16|16 copy of the spans, so no device sweep is needed before the first pass.
+            ctx->max_pile = max_pile;
+            ctx->spans_in_range = spans_in_range != 0;
+            ctx->use_span16 = false;
+            if (pack_ok && span16 && ctx->spans_in_range) {
+                // (+ half a batch of elements: k_mask_annotate_q20 reads its last batch without clamping the index)
+                const size_t bytes = sizeof(unsigned) * ((size_t)n_ovl + HINGE_SPAN16_PAD);
+                if ((rc = adopt(ctx, ctx->span16, span16, bytes, on_device))) return rc;
+                ctx->use_span16 = true;
+            }
+        } else {
+            // one sweep over the spans, once per part: largest pile-up, any coordinate outside [0, rlen], the 16|16 copy
+            unsigned* facts = sc(ctx)->facts;
+            CK(hipMemsetAsync(facts, 0, 2 * sizeof(unsigned), ctx->stream));
+            if (pack_ok) {
+                if (!ctx->span16.owned) { ctx->span16.p = nullptr; ctx->span16.bytes = 0; ctx->span16.owned = true; }
+                if ((rc = ensure(ctx, ctx->span16, sizeof(unsigned) * ((size_t)n_ovl + HINGE_SPAN16_PAD)))) return rc;
+            }
+            {
+                ProfScope _ps(ctx, KID_PILEUP_FACTS);
+                hipLaunchKernelGGL(k_pileup_facts, dim3(std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->n_cu * 8))), dim3(BLOCK), 0, ctx->stream, r_begin, r_end,
+                                   (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, facts,
+                                   pack_ok ? (unsigned*)ctx->span16.p : (unsigned*)nullptr);
+            }
+            CK(hipGetLastError());
+            unsigned h[2] = {0, 0};
+            CK(hipMemcpyAsync(h, facts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));
+            ctx->max_pile = h[0];
+            ctx->spans_in_range = h[1] == 0;
+            ctx->use_span16 = pack_ok && ctx->spans_in_range;
+        }
     }
     if (!on_device) CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
+int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr, const int32_t* a_span,
+                      const int32_t* b_span, const uint32_t* b_flag, int on_device) {
+    return set_pileups_impl(ctx, r_begin, r_end, n_ovl, row_ptr, a_span, b_span, b_flag, nullptr, false, 0, 0, on_device);
+}
+
+int hinge_set_pileups_packed(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr, const int32_t* a_span,
+                             const int32_t* b_span, const uint32_t* b_flag, const uint32_t* span16, uint32_t max_pile, int spans_in_range,
+                             int on_device) {
+    return set_pileups_impl(ctx, r_begin, r_end, n_ovl, row_ptr, a_span, b_span, b_flag, span16, true, max_pile, spans_in_range, on_device);
+}
+
+int hinge_span16_pad(void) { return HINGE_SPAN16_PAD; }
+
+int hinge_get_pileup_facts(hinge_ctx* ctx, uint32_t* max_pile, int* spans_in_range) {
+    if (!ctx || ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "hinge_get_pileup_facts: no pile-ups set");
+    if (max_pile) *max_pile = ctx->max_pile;
+    if (spans_in_range) *spans_in_range = ctx->spans_in_range ? 1 : 0;
     return HINGE_OK;
 }
 
 int hinge_attach_mask_table(hinge_ctx* ctx, int32_t* d) {
     if (!ctx) return HINGE_E_ARG;
     ctx->mask = d ? (int2*)d : (int2*)ctx->mask_own.p;
+    ctx->mask_attached = d != nullptr;
     return HINGE_OK;
 }
 int hinge_attach_mean_cov(hinge_ctx* ctx, int32_t* d) {
     if (!ctx) return HINGE_E_ARG;
     ctx->mean_cov = d ? d : (int*)ctx->mean_own.p;
+    ctx->mean_attached = d != nullptr;
     return HINGE_OK;
 }
 int hinge_clear_masks(hinge_ctx* ctx) {
@@ -601,6 +659,10 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
     o.anno_cap = ctx->anno_cap;
     o.work_list = (WorkItem*)ctx->work_list.p;
     o.status = &sc(ctx)->status;
+    o.cov_out = ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr;
+    o.cov_off = (const long long*)ctx->cov_off_d.p;
+    o.cov_nbins = (int*)ctx->cov_nb.p;
+    o.cov_base = ctx->r_begin;
     return o;
 }
 
@@ -609,10 +671,33 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
                        (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,                     \
                        (const int*)&sc(ctx)->min_cov, kcap, anno_out(ctx), LIST, COUNT)
 
+// Layout of K2's coverage-bin output: read i of the part gets (rlen + cut_off) / reso + 3 slots, the most bins a profile the
+// kernels accept can have (more raises ST_RANGE).  Host-computable, so no device prefix sum and no second launch.
+static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
+    if (!ctx->cov_out_on) return HINGE_OK;
+    const int key[4] = {ctx->r_begin, ctx->r_end, p->reso, p->cut_off};
+    const int nr = ctx->r_end - ctx->r_begin + 1;
+    if (memcmp(key, ctx->cov_key, sizeof(key)) != 0 || ctx->h_cov_off.size() != (size_t)nr + 1) {
+        ctx->h_cov_off.assign((size_t)nr + 1, 0);
+        for (int k = 0; k < nr; k++)
+            ctx->h_cov_off[(size_t)k + 1] = ctx->h_cov_off[(size_t)k] + ((int64_t)std::max(ctx->h_rlen[(size_t)(ctx->r_begin + k)], 0) + std::max(p->cut_off, 0)) / p->reso + 3;
+        int rc;
+        if ((rc = ensure(ctx, ctx->cov_off_d, sizeof(int64_t) * ((size_t)nr + 1)))) return rc;
+        if ((rc = ensure(ctx, ctx->cov_nb, sizeof(int) * (size_t)nr))) return rc;
+        if ((rc = ensure(ctx, ctx->cov_buf, sizeof(int) * (size_t)std::max<int64_t>(ctx->h_cov_off[(size_t)nr], 1)))) return rc;
+        CK(hipMemcpyAsync(ctx->cov_off_d.p, ctx->h_cov_off.data(), sizeof(int64_t) * ((size_t)nr + 1), hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        memcpy(ctx->cov_key, key, sizeof(key));
+    }
+    ctx->cov_valid = true;
+    return HINGE_OK;
+}
+
 static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     {
         int rc = flush_min_cov(ctx);
         if (rc) return rc;
+        if ((rc = prepare_cov_out(ctx, p))) return rc;
     }
     const int kcap = kcap_for(ctx, p);
     const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
@@ -833,46 +918,75 @@ int hinge_filter_get_annotations(hinge_ctx* ctx, int64_t* off, int32_t* pos, int
     return HINGE_OK;
 }
 
+int hinge_filter_coverage_out(hinge_ctx* ctx, int enable) {
+    if (!ctx) return HINGE_E_ARG;
+    ctx->cov_out_on = enable != 0;
+    if (!enable) ctx->cov_valid = false;
+    return HINGE_OK;
+}
+
+int hinge_filter_get_coverage(hinge_ctx* ctx, int64_t* off, int32_t* nbins, int32_t* cov, int64_t cov_cap) {
+    if (!ctx || !off) return HINGE_E_ARG;
+    if (!ctx->cov_out_on || !ctx->cov_valid) return fail(ctx, HINGE_E_ARG, "hinge_filter_get_coverage: no K2 pass with hinge_filter_coverage_out(1) on these pile-ups");
+    const size_t nr = (size_t)(ctx->r_end - ctx->r_begin + 1);
+    memcpy(off, ctx->h_cov_off.data(), sizeof(int64_t) * (nr + 1));
+    if (!nbins && !cov) return HINGE_OK;
+    CK(hipSetDevice(ctx->device));
+    int rc = check_status(ctx);
+    if (rc) return rc;
+    if (cov && cov_cap < off[nr]) return fail(ctx, HINGE_E_ARG, "hinge_filter_get_coverage: cov_cap too small");
+    if (nbins) CK(hipMemcpyAsync(nbins, ctx->cov_nb.p, sizeof(int) * nr, hipMemcpyDeviceToHost, ctx->stream));
+    if (cov && off[nr] > 0) CK(hipMemcpyAsync(cov, ctx->cov_buf.p, sizeof(int) * (size_t)off[nr], hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
 int hinge_filter_coverage_bins(hinge_ctx* ctx, int32_t r0, int32_t r1, int32_t reso, int32_t cutoff, int32_t* nbins, int32_t* cov,
                                int64_t cov_cap) {
     if (!ctx || !nbins || r0 < 0 || r1 >= ctx->n_reads || r1 < r0 || reso <= 0) return fail(ctx, HINGE_E_ARG, "coverage_bins: bad arguments");
     CK(hipSetDevice(ctx->device));
     const size_t n = (size_t)(r1 - r0 + 1);
-    int* d_nb = nullptr;
-    int64_t* d_off = nullptr;
-    int* d_cov = nullptr;
-    CK(hipMalloc(&d_nb, sizeof(int) * n));
+    struct Tmp {   // freed on every return path
+        int* nb = nullptr; int64_t* off = nullptr; int* cov = nullptr;
+        ~Tmp() { if (nb) (void)hipFree(nb); if (off) (void)hipFree(off); if (cov) (void)hipFree(cov); }
+    } d;
+    CK(hipMalloc(&d.nb, sizeof(int) * n));
     const int kcap = ((ctx->max_rlen + std::max(cutoff, 0)) / reso + 4 + 3) & ~3;
     const size_t lds = (size_t)WAVES_PER_BLOCK * kcap * sizeof(int);
+    if (lds > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "coverage_bins: read too long for the LDS histogram");
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_coverage_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int grid = grid_for_reads(ctx, (int)n, WAVES_PER_BLOCK);
-    CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_coverage_bins, dim3(grid), dim3(BLOCK), lds, ctx->stream, r0, r1, (const int64_t*)ctx->row_ptr.p,
-                       (const int2*)ctx->a_span.p, reso, cutoff, kcap, d_nb, (const int64_t*)nullptr, (int*)nullptr, &sc(ctx)->status);
-    CK(hipMemcpyAsync(nbins, d_nb, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    int rc = HINGE_OK;
-    if (cov) {
-        std::vector<int64_t> off(n + 1, 0);
-        for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + nbins[i];
-        if (off[n] > cov_cap) rc = fail(ctx, HINGE_E_ARG, "coverage_bins: cov_cap too small");
-        else if (off[n] > 0) {
-            CK(hipMalloc(&d_off, sizeof(int64_t) * (n + 1)));
-            CK(hipMalloc(&d_cov, sizeof(int) * (size_t)off[n]));
-            CK(hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_coverage_bins, dim3(grid), dim3(BLOCK), lds, ctx->stream, r0, r1, (const int64_t*)ctx->row_ptr.p,
-                               (const int2*)ctx->a_span.p, reso, cutoff, kcap, d_nb, (const int64_t*)d_off, d_cov, &sc(ctx)->status);
-            CK(hipMemcpyAsync(cov, d_cov, sizeof(int) * (size_t)off[n], hipMemcpyDeviceToHost, ctx->stream));
-            CK(hipStreamSynchronize(ctx->stream));
-            int st = 0;
-            CK(hipMemcpy(&st, &sc(ctx)->status, sizeof(int), hipMemcpyDeviceToHost));
-            if (st & ST_RANGE) rc = fail(ctx, HINGE_E_RANGE, "coverage_bins: bins exceed LDS capacity");
-        }
+    // its own status word: the pass status (capacity / median flags of an asynchronous pass) is not this function's to clear
+    int* st = &sc(ctx)->bins_status;
+    CK(hipMemsetAsync(st, 0, sizeof(int), ctx->stream));
+    {
+        ProfScope _ps(ctx, KID_COVERAGE_BINS);
+        hipLaunchKernelGGL(k_coverage_bins, dim3(grid), dim3(BLOCK), lds, ctx->stream, r0, r1, (const int64_t*)ctx->row_ptr.p,
+                           (const int2*)ctx->a_span.p, reso, cutoff, kcap, d.nb, (const int64_t*)nullptr, (int*)nullptr, st);
     }
-    if (d_nb) (void)hipFree(d_nb);
-    if (d_off) (void)hipFree(d_off);
-    if (d_cov) (void)hipFree(d_cov);
-    return rc;
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(nbins, d.nb, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (!cov) return HINGE_OK;
+    std::vector<int64_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + nbins[i];
+    if (off[n] > cov_cap) return fail(ctx, HINGE_E_ARG, "coverage_bins: cov_cap too small");
+    if (off[n] == 0) return HINGE_OK;
+    CK(hipMalloc(&d.off, sizeof(int64_t) * (n + 1)));
+    CK(hipMalloc(&d.cov, sizeof(int) * (size_t)off[n]));
+    CK(hipMemcpyAsync(d.off, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    {
+        ProfScope _ps(ctx, KID_COVERAGE_BINS);
+        hipLaunchKernelGGL(k_coverage_bins, dim3(grid), dim3(BLOCK), lds, ctx->stream, r0, r1, (const int64_t*)ctx->row_ptr.p,
+                           (const int2*)ctx->a_span.p, reso, cutoff, kcap, d.nb, (const int64_t*)d.off, d.cov, st);
+    }
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(cov, d.cov, sizeof(int) * (size_t)off[n], hipMemcpyDeviceToHost, ctx->stream));
+    int stv = 0;
+    CK(hipMemcpyAsync(&stv, st, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (stv & ST_RANGE) return fail(ctx, HINGE_E_RANGE, "coverage_bins: bins exceed LDS capacity");
+    return HINGE_OK;
 }
 
 int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {

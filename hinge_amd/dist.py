@@ -105,12 +105,19 @@ class Exchange:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_gather_scalar(self, v: int) -> List[int]:
+        return [r[0] for r in self.all_gather_ints([v])]
+
+    def all_gather_ints(self, vals: Sequence[int]) -> List[List[int]]:
+        """A few host integers per rank -> the same list of per-rank rows on every rank (a host round trip: only used where the
+        host has to decide something, never inside the per-step kernel chain)."""
+        vals = [int(v) for v in vals]
         if self.world == 1 and not self.force:
-            return [int(v)]
-        t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
-        out = torch.empty(self.world, dtype=torch.int64, device=self.device)
+            return [vals]
+        t = torch.tensor(vals, dtype=torch.int64, device=self.device)
+        out = torch.empty(self.world * len(vals), dtype=torch.int64, device=self.device)
         dist.all_gather_into_tensor(out, t, group=self.group)
-        return [int(x) for x in out.cpu().tolist()]
+        flat = out.cpu().tolist()
+        return [[int(x) for x in flat[k * len(vals):(k + 1) * len(vals)]] for k in range(self.world)]
 
     def gather_lists(self, rows: torch.Tensor, count: int) -> Optional[torch.Tensor]:
         """Variable-length int32 row lists (e.g. (read, pos, type) hinges) -> concatenated in rank order
@@ -165,8 +172,16 @@ class ShardedFilter:
         self.mean_cov = torch.full((n,), MEAN_SENTINEL, dtype=torch.int32, device=dev)
         self.mask = torch.zeros((n, 2), dtype=torch.int32, device=dev)
         self.b.attach(self.mean_cov, self.mask)
+        # The histogram form of exchange 1 is exact while every mean coverage lies in [0, 4096).  A mean is an average of
+        # cutoff-0 coverage values, each between 0 and the pile-up's size, so the largest pile-up over all ranks decides it
+        # once, here, instead of a device flag the host would have to read back in every step.
+        if self.median == "hist" and self.mode == "merged" and max(self.x.all_gather_scalar(self.b.max_pileup())) >= 4096:
+            self.median = "gather"
 
-    def step(self, fetch_hinges: bool = True):
+    def step(self, fetch_hinges: bool = True, check: bool = True, _retried: bool = False):
+        """One pass.  check = True ends with the status exchange: every rank learns whether any rank overflowed a device
+        buffer (all regrow and the step is run again, together) or hit an input the reference is undefined on (all raise).
+        A caller that times a chain of steps passes check = False and calls ctx.check() after the chain."""
         x, b = self.x, self.b
         lo, hi = x.my_range
         b.begin()
@@ -179,17 +194,35 @@ class ShardedFilter:
             x.all_gather_rows(self.mean_cov)
             b.median(0, x.blocks.n_reads - 1)
         else:
-            est = b.median_fetch(lo, hi - 1)        # per-part median (host scalar)
-            ests = x.all_gather_scalar(est)         # exchange 1 (8 bytes per rank)
-            b.set_min_cov(mlas_min_cov(b.ini_min_cov, ests, b.est_cov)[x.rank])
+            try:                                    # per-part median (host scalar); a part the reference is undefined on
+                est, bad = b.median_fetch(lo, hi - 1), 0   # (no read >= 5000 bp) must stop every rank, not hang the others
+            except Exception as ex:                 # noqa: BLE001 - re-raised below on every rank
+                est, bad, first_error = 0, 1, ex
+            rows_ = x.all_gather_ints([est, bad])   # exchange 1 (16 bytes per rank)
+            if any(r[1] for r in rows_):
+                if bad:
+                    raise first_error
+                raise RuntimeError("sharded filter: rank(s) %s cannot estimate the coverage of their part" % [k for k, r in enumerate(rows_) if r[1]])
+            b.set_min_cov(mlas_min_cov(b.ini_min_cov, [r[0] for r in rows_], b.est_cov)[x.rank])
         b.mask_annotate()                           # fills mask[lo:hi]
         x.all_gather_rows(self.mask)                # exchange 2
         if self.mode == "mlas" and hi < x.blocks.n_reads:
             self.mask[hi:] = 0                      # later parts are not masked yet when part p runs
         b.hinges()
+        if check:
+            code = b.status_code()                  # 0, or the HINGE_E_* of this rank's pass
+            codes = x.all_gather_scalar(code)
+            if any(c == -3 for c in codes) and not _retried:     # HINGE_E_CAPACITY somewhere: everyone regrows, everyone reruns
+                b.regrow()
+                return self.step(fetch_hinges, check, True)
+            if any(c != 0 for c in codes):
+                b.raise_status(codes)
         if not fetch_hinges:
             return None
-        rows, count = b.hinge_rows()                # (read, pos, type) int32 rows on the device
+        # .hinges.txt stops before the part's last A read (`i < r_end`, filter.cpp:1091): one merged .las loses the hinges of
+        # the global last read only, the --mlas loop those of every part's last read
+        drop_last = self.mode == "mlas" or x.rank == x.world - 1
+        rows, count = b.hinge_rows(drop_last)       # (read, pos, type) int32 rows on the device
         return x.gather_lists(rows, count)          # exchange 3
 
 
@@ -197,17 +230,50 @@ class HipBackend:
     """Per-block compute through libhinge_hip (HIP kernels); tensors are torch CUDA tensors."""
 
     def __init__(self, ctx, params, rlen: np.ndarray, qv_mask: Optional[np.ndarray], r_begin: int, r_end: int,
-                 row_ptr: torch.Tensor, a_span: torch.Tensor, b_span: torch.Tensor, b_flag: torch.Tensor):
+                 row_ptr: torch.Tensor, a_span: torch.Tensor, b_span: torch.Tensor, b_flag: torch.Tensor,
+                 span16: Optional[torch.Tensor] = None, facts: Optional[Tuple[int, bool]] = None, last_a: Optional[int] = None,
+                 coverage_out: bool = False):
+        """row_ptr ... b_flag: device tensors (adopted).  facts = (max_pile, spans_in_range) and span16 (device uint32/int32
+        [n_ovl + capi.span16_pad()], or None) as the ingest produced them (capi.pack_spans): without facts the library sweeps the
+        spans itself (k_pileup_facts).  last_a: A read of the part's last .las record (default r_end)."""
         self.ctx, self.p = ctx, params
         self.ini_min_cov = int(params.min_cov)
         self.est_cov = int(params.est_cov)
         self.r_begin, self.r_end = r_begin, r_end
+        self.last_a = r_end if last_a is None else int(last_a)
         self._hist = None
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.set_reads(rlen, qv_mask)
-        self._tensors = (row_ptr, a_span, b_span, b_flag)
-        ctx.set_pileups(r_begin, r_end, row_ptr, a_span, b_span, b_flag, n_ovl=int(b_flag.shape[0]), on_device=True)
+        self._tensors = (row_ptr, a_span, b_span, b_flag, span16)
+        if facts is None:
+            ctx.set_pileups(r_begin, r_end, row_ptr, a_span, b_span, b_flag, n_ovl=int(b_flag.shape[0]), on_device=True)
+        else:
+            ctx.set_pileups_packed(r_begin, r_end, row_ptr, a_span, b_span, b_flag, span16, facts[0], facts[1], n_ovl=int(b_flag.shape[0]), on_device=True)
+        ctx.coverage_out(coverage_out)
         ctx.set_min_cov(self.ini_min_cov)
+
+    def max_pileup(self) -> int:
+        return self.ctx.pileup_facts()[0]
+
+    def status_code(self) -> int:
+        from .capi import HingeError
+        try:
+            self.ctx.check()
+            return 0
+        except HingeError as ex:
+            self._last_error = ex
+            return ex.code
+
+    def raise_status(self, codes):
+        if getattr(self, "_last_error", None) is not None and self.status_code() != 0:
+            raise self._last_error
+        raise RuntimeError("sharded filter: another rank failed (status codes per rank: %s)" % (codes,))
+
+    def regrow(self):
+        """After HINGE_E_CAPACITY: the synchronous entry points rerun their stage on this rank's data until the device
+        buffers are large enough (annotation buffer, exact-path queue and arena); the caller then repeats the step."""
+        self.ctx.filter_mask_annotate(self.p)
+        self.ctx.filter_hinges(self.p)
 
     def attach(self, mean_cov: torch.Tensor, mask: torch.Tensor):
         self.mean_cov, self.mask = mean_cov, mask
@@ -244,10 +310,12 @@ class HipBackend:
     def hinges(self):
         self.ctx.filter_hinges_async(self.p)
 
-    def hinge_rows(self):
+    def hinge_rows(self, drop_last: bool = True):
         off, pos, typ, ish = self.ctx.get_annotations()
         reads = np.repeat(np.arange(self.r_begin, self.r_end + 1, dtype=np.int32), np.diff(off).astype(np.int64))
         sel = ish.astype(bool)
+        if drop_last:
+            sel &= reads != self.last_a
         rows = np.stack([reads[sel], pos[sel], typ[sel]], axis=1).astype(np.int32) if sel.any() else np.zeros((0, 3), np.int32)
         t = torch.from_numpy(np.ascontiguousarray(rows)).to(self.mask.device)
         return t, int(t.shape[0])

@@ -77,6 +77,7 @@ int main(int argc, char* argv[]) {
     PartLoader loader;
     loader.pairs = !reads_to_keep.empty();   // the neighbours of the listed reads need the per-record B column
     loader.paf = fa_and_paf;
+    loader.span16 = true;
     if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
@@ -109,7 +110,9 @@ int main(int argc, char* argv[]) {
         if (las.novl == 0) { console.error("No alignments!"); return 1; }
         const int r_begin = las.r_begin, r_end = las.r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
-        HH_CHECK(ctx, hinge_set_pileups(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(), 0));
+        HH_CHECK(ctx, hinge_set_pileups_packed(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(),
+                                               las.span16_ptr(), las.max_pile, las.spans_in_range ? 1 : 0, 0));
+        HH_CHECK(ctx, hinge_filter_coverage_out(ctx, 1));   // K2 also stores the cutoff-0 bins: .coverage.txt needs no sweep of its own
 
         tm.mark("set_pileups (H2D)");
         // self_match_reads, filter.cpp:552-561 (float accumulation in record order)
@@ -148,16 +151,15 @@ int main(int argc, char* argv[]) {
         HH_CHECK(ctx, hinge_filter_hinges(ctx, &P));
 
         tm.mark("kernels (4 passes)");
-        // .coverage.txt, filter.cpp:599-602
+        // .coverage.txt, filter.cpp:599-602: the bins K2 stored
         {
+            std::vector<int64_t> coff(nr + 1);
+            HH_CHECK(ctx, hinge_filter_get_coverage(ctx, coff.data(), nullptr, nullptr, 0));
             std::vector<int32_t> nb(nr);
-            HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, P.reso, 0, nb.data(), nullptr, 0));
-            int64_t tot = 0;
-            for (size_t k = 0; k < nr; k++) tot += nb[k];
             UVec<int32_t> cov;   // filled by the copy from the device: no zero fill, huge pages
-            cov.resize((size_t)std::max<int64_t>(tot, 1));
-            HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, P.reso, 0, nb.data(), cov.data(), tot));
-            write_coverage_txt(f_cov, r_begin, nb, cov, P.reso);
+            cov.resize((size_t)std::max<int64_t>(coff[nr], 1));
+            HH_CHECK(ctx, hinge_filter_get_coverage(ctx, coff.data(), nb.data(), cov.data(), coff[nr]));
+            write_coverage_txt(f_cov, r_begin, nb, cov, P.reso, &coff);
         }
         tm.mark("coverage.txt");
         std::vector<int32_t> mask(2 * nr), cmask(2 * nr);

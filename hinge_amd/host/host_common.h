@@ -557,6 +557,17 @@ struct LasPart {
     std::vector<int64_t> row_ptr;              // n_reads + 1
     UVec<int32_t> a_span, b_span;              // 2 per overlap
     UVec<uint32_t> b_flag;
+    // what hinge_set_pileups_packed wants besides the columns (the fill pass touches every record anyway)
+    bool want_span16 = false;                  // `hinge filter` only: the 16|16 copy of a_span, the stream of the two coverage passes
+    UVec<uint32_t> span16;                     // abpos | aepos << 16, + HINGE_SPAN16_PAD spare elements; empty if unusable
+    uint32_t max_pile = 0;                     // largest pile-up of the part
+    bool spans_in_range = true;                // every (abpos, aepos) inside [0, rlen[A]]
+    const uint32_t* span16_ptr() const { return span16.size() ? span16.data() : nullptr; }
+    void finish_facts(int n_reads) {
+        int64_t mp = 0;
+        for (int q = 0; q < n_reads; q++) mp = std::max(mp, row_ptr[(size_t)q + 1] - row_ptr[(size_t)q]);
+        max_pile = (uint32_t)std::min<int64_t>(mp, 0x7fffffff);
+    }
     UVec<int64_t> trace_off;                   // byte offset of the trace inside the mapped file
     UVec<int32_t> tlen;
     // every record (self-overlaps included), for the (A, B) grouping of maximal / layout
@@ -737,6 +748,14 @@ struct LasPart {
             b_span[(size_t)k * 2] = r.bb; b_span[(size_t)k * 2 + 1] = r.be;   // no strand flip: PAF target coordinates are forward-strand
             b_flag[(size_t)k] = (uint32_t)r.b | ((uint32_t)r.comp << 31);
             trace_off[(size_t)k] = 0; tlen[(size_t)k] = 0;
+            const uint32_t rl = (uint32_t)std::max(rlen[(size_t)r.a], 0);
+            if ((uint32_t)r.ab > rl || (uint32_t)r.ae > rl) spans_in_range = false;
+        }
+        finish_facts(n_reads);
+        if (want_span16 && kept > 0 && spans_in_range && *std::max_element(rlen.begin(), rlen.end()) < 65536) {
+            span16.resize((size_t)kept + (size_t)HINGE_SPAN16_PAD);
+            for (int64_t k = 0; k < kept; k++) span16[(size_t)k] = (uint32_t)a_span[(size_t)k * 2] | ((uint32_t)a_span[(size_t)k * 2 + 1] << 16);
+            for (int t = 0; t < HINGE_SPAN16_PAD; t++) span16[(size_t)kept + (size_t)t] = 0;
         }
         // self overlaps in FILE order (filter.cpp:537-544 walks aln[] in file order)
         self_a.resize(selfs.size()); self_span.resize(selfs.size() * 4);
@@ -802,6 +821,9 @@ struct LasPart {
         if (pairs) { trace_off.resize((size_t)kept); tlen.resize((size_t)kept); }
         self_a.resize((size_t)n_self);
         self_span.resize((size_t)n_self * 4);
+        const bool fill16 = want_span16 && kept > 0 && !rlen.empty() && *std::max_element(rlen.begin(), rlen.end()) < 65536;
+        if (fill16) span16.resize((size_t)kept + (size_t)HINGE_SPAN16_PAD);
+        std::vector<char> out_of_range((size_t)chunks, 0);
         lt.mark("allocate");
         // phase B: fill.  Records are sorted by A, so row tables are written at the A boundaries:
         // row_ptr[r] = kept records with aread < r, rec_row_ptr[r] = records with aread < r
@@ -830,6 +852,11 @@ struct LasPart {
                     continue;
                 }
                 if (pairs) rec_kept[(size_t)j] = k;
+                {
+                    const uint32_t rl = (uint32_t)std::max(rlen[(size_t)a], 0);
+                    if ((uint32_t)abpos > rl || (uint32_t)aepos > rl) out_of_range[(size_t)c] = 1;   // unsigned: negative = too large
+                }
+                if (fill16) span16[(size_t)k] = ((uint32_t)abpos & 0xffffu) | ((uint32_t)aepos << 16);
                 a_span[(size_t)k * 2] = abpos; a_span[(size_t)k * 2 + 1] = aepos;
                 b_span[(size_t)k * 2] = bb; b_span[(size_t)k * 2 + 1] = be;
                 b_flag[(size_t)k] = (uint32_t)b | ((uint32_t)comp << 31);
@@ -845,6 +872,12 @@ struct LasPart {
         if (novl > 0) {
             r_begin = a_of(0);
             r_end = a_of(novl - 1);
+        }
+        for (int c = 0; c < chunks; c++) if (out_of_range[(size_t)c]) spans_in_range = false;
+        finish_facts(n_reads);
+        if (fill16) {
+            if (!spans_in_range) span16.resize(0);
+            else for (int t = 0; t < HINGE_SPAN16_PAD; t++) span16[(size_t)kept + (size_t)t] = 0;
         }
         return 0;
     }
@@ -863,10 +896,12 @@ inline char* put_int(char* p, long long v) {
 
 // `.coverage.txt`: "read i p,c p,c ...\n" per read (filter.cpp:599-602, maximal.cpp:659-685).  nb[k] bins of read
 // r_begin + k start at cov[sum(nb[<k])].  Formatted by host_threads() threads in windows, written in read order.
-inline void write_coverage_txt(FILE* f, int r_begin, const std::vector<int32_t>& nb, const UVec<int32_t>& cov, int reso) {
+// at != nullptr: the bins of read k start at cov[(*at)[k]] (K2's strided layout) instead of back to back.
+inline void write_coverage_txt(FILE* f, int r_begin, const std::vector<int32_t>& nb, const UVec<int32_t>& cov, int reso, const std::vector<int64_t>* at = nullptr) {
     const int64_t nr = (int64_t)nb.size();
-    std::vector<int64_t> first((size_t)nr + 1, 0);
+    std::vector<int64_t> first((size_t)nr + 1, 0);   // cumulative bins: sizes the text buffers
     for (int64_t k = 0; k < nr; k++) first[(size_t)k + 1] = first[(size_t)k] + nb[(size_t)k];
+    const std::vector<int64_t>& where = at ? *at : first;
     const int64_t chunk = 256, window = (int64_t)host_threads() * 8;
     const int64_t n_chunks = (nr + chunk - 1) / chunk;
     // uninitialised chunk buffers (a value-initialised vector<char> of the upper bound would zero and fault in three
@@ -887,7 +922,7 @@ inline void write_coverage_txt(FILE* f, int r_begin, const std::vector<int32_t>&
                     memcpy(p, "read ", 5); p += 5;
                     p = put_int(p, r_begin + k);
                     *p++ = ' ';
-                    const int32_t* c32 = cov.data() + first[(size_t)k];
+                    const int32_t* c32 = cov.data() + where[(size_t)k];
                     for (int j = 0; j < nb[(size_t)k]; j++) {
                         p = put_int(p, (long long)reso * j);
                         *p++ = ',';
@@ -944,11 +979,13 @@ struct PartLoader {
     int first_rc = 0;
     bool pairs = true;   // false in `hinge filter`: see LasPart::load
     bool paf = false;    // the (single) part is a PAF file
-    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first_rc = paf ? first->load_paf(path, rlen) : first->load(path, rlen, pairs); }
+    bool span16 = false; // `hinge filter`: also produce the 16|16 span copy (LasPart::want_span16)
+    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first->want_span16 = span16; first_rc = paf ? first->load_paf(path, rlen) : first->load(path, rlen, pairs); }
     // returns the part (ownership passes to the caller) and its load() code
     LasPart* take(size_t part, const std::string& path, const std::vector<int32_t>& rlen, int& rc) {
         if (part == 0 && first) { rc = first_rc; return first.release(); }
         LasPart* p = new LasPart();
+        p->want_span16 = span16;
         rc = paf ? p->load_paf(path, rlen) : p->load(path, rlen, pairs);
         return p;
     }

@@ -64,8 +64,10 @@ def self_match_reads(p: formats.Pileups, rlen: np.ndarray) -> set:
 
 
 def run_filter(db_name: str, las_base: str, prefix: str, config: str, mlas: bool = False, device: int = 0,
-               write_coverage: bool = True, force_exact: bool = False, ctx: Optional[Context] = None) -> int:
-    """`hinge filter --db DB --las LAS [--mlas] -x PREFIX --config INI`.  Returns the exit code."""
+               write_coverage: bool = True, force_exact: bool = False, ctx: Optional[Context] = None, packed: bool = False) -> int:
+    """`hinge filter --db DB --las LAS [--mlas] -x PREFIX --config INI`.  Returns the exit code.
+    packed = True takes the route of the executables (hinge_set_pileups_packed with the ingest's span copy and facts, the
+    coverage bins from K2); False the plain hinge_set_pileups (device sweep k_pileup_facts) and hinge_filter_coverage_bins."""
     try:
         idx = formats.read_db_index(db_name)
     except OSError:
@@ -110,7 +112,13 @@ def run_filter(db_name: str, las_base: str, prefix: str, config: str, mlas: bool
             pile = formats.pileups_from_las(recs, rlen)
             r_begin = int(recs.rec["aread"][0])
             r_end = int(recs.rec["aread"][-1])
-            ctx.set_pileups(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+            if packed:
+                from .capi import pack_spans
+                span16, max_pile, in_range = pack_spans(pile.row_ptr, pile.a_span, rlen)
+                ctx.set_pileups_packed(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag, span16, max_pile, in_range)
+            else:
+                ctx.set_pileups(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+            ctx.coverage_out(packed and write_coverage)
             ctx.filter_stats(P)
             ctx.filter_median(P, r_begin, r_end, fetch=True)
             ctx.filter_mask_annotate(P)
@@ -118,7 +126,7 @@ def run_filter(db_name: str, las_base: str, prefix: str, config: str, mlas: bool
             mask, cmask, flags = ctx.get_masks()
             off, pos, typ, ish = ctx.get_annotations()
             if write_coverage:
-                nb, cov = ctx.coverage_bins(r_begin, r_end, P.reso, 0)
+                nb, cov = ctx.get_coverage() if packed else ctx.coverage_bins(r_begin, r_end, P.reso, 0)
                 o = 0
                 for k, i in enumerate(range(r_begin, r_end + 1)):
                     c = cov[o:o + nb[k]]

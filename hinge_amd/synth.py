@@ -99,13 +99,63 @@ def d_bits_ok(n_reads: int, max_len: int) -> bool:
     return 2 * int(n_reads).bit_length() + 1 + int(max_len).bit_length() + 1 <= 62
 
 
-def generate(spec: SynthSpec) -> SynthData:
-    rng = np.random.default_rng(spec.seed)
-    G = spec.genome_len
+def _entry_map(roff, gs, ge, s, g_of_t_sign, g_of_t_off):
+    """An "entry" maps a frame interval [t0, t1) onto a read linearly: rpos(t) = c + sg * t, with
+    g(t) = g_of_t_off + g_of_t_sign * t and rpos(g) = roff + (g - gs) if s > 0 else roff + (ge - g)."""
+    sg = s * g_of_t_sign
+    c = np.where(s > 0, roff + g_of_t_off - gs, roff + ge - g_of_t_off)
+    return c, sg
 
-    # ---- repeat families: non-overlapping copies on the genome -------------------------
+
+class _Records:
+    """Directed overlap records accumulated by the generators (lists of arrays, concatenated by the caller)."""
+
+    def __init__(self, spec: SynthSpec, rng):
+        self.spec, self.rng = spec, rng
+        self.a, self.b, self.ab, self.ae, self.bb, self.be, self.comp = [], [], [], [], [], [], []
+
+    def emit(self, i, j, e_read, e_t0, e_t1, e_c, e_sg):
+        """Emit both directed records for entry pairs (i, j)."""
+        spec, rng = self.spec, self.rng
+        for (x, y) in ((i, j), (j, i)):
+            lo = np.maximum(e_t0[x], e_t0[y])
+            hi = np.minimum(e_t1[x], e_t1[y])
+            if spec.end_jitter > 0:
+                lo = lo + rng.integers(0, spec.end_jitter + 1, size=len(lo))
+                hi = hi - rng.integers(0, spec.end_jitter + 1, size=len(hi))
+            if spec.tie_quantum > 0:
+                q = spec.tie_quantum
+                lo = ((lo + q - 1) // q) * q
+                hi = (hi // q) * q
+            ok = hi - lo >= max(spec.min_ovl - 2 * spec.end_jitter - 2 * spec.tie_quantum, 200)
+            lo, hi, xx, yy = lo[ok], hi[ok], x[ok], y[ok]
+            pa0 = e_c[xx] + e_sg[xx] * lo
+            pa1 = e_c[xx] + e_sg[xx] * hi
+            pb0 = e_c[yy] + e_sg[yy] * lo
+            pb1 = e_c[yy] + e_sg[yy] * hi
+            ab = np.minimum(pa0, pa1)
+            ae = np.maximum(pa0, pa1)
+            bb = np.minimum(pb0, pb1)
+            be = np.maximum(pb0, pb1)
+            if spec.indel_max > 0:
+                d = rng.integers(0, spec.indel_max + 1, size=len(bb))
+                side = rng.random(len(bb)) < 0.5
+                bb = np.where(side, bb + d, bb)
+                be = np.where(side, be, be - d)
+            self.a.append(e_read[xx])
+            self.b.append(e_read[yy])
+            self.ab.append(ab)
+            self.ae.append(ae)
+            self.bb.append(bb)
+            self.be.append(be)
+            self.comp.append((e_sg[xx] != e_sg[yy]).astype(np.uint8))
+
+
+def plant_repeats(spec: SynthSpec, rng):
+    """Repeat families as non-overlapping copies on the genome: (fam_len, copies = [(family, pos, orient)])."""
+    G = spec.genome_len
     fam_len: List[int] = []
-    copies = []                                       # (family, pos, orient)
+    copies = []
     occupied: List[Tuple[int, int]] = []
     for f in range(spec.n_repeat_families):
         L = int(rng.integers(spec.repeat_len[0], spec.repeat_len[1] + 1))
@@ -119,6 +169,47 @@ def generate(spec: SynthSpec) -> SynthData:
                     o = 1 if (not spec.inverted_copies or rng.random() < 0.7) else -1
                     copies.append((f, p, o))
                     break
+    return fam_len, copies
+
+
+def repeat_records(rec: _Records, fam_len, copies, seg_read, seg_roff, seg_gs, seg_ge, seg_s):
+    """Cross-copy local alignments of every repeat family (frame = the family's own coordinate): what creates the coverage
+    jumps `hinge filter` annotates.  Appends to rec."""
+    spec = rec.spec
+    for f, L in enumerate(fam_len):
+        e_read, e_t0, e_t1, e_c, e_sg, e_copy = [], [], [], [], [], []
+        for ci, (ff, p, o) in enumerate(copies):
+            if ff != f:
+                continue
+            x0 = np.maximum(seg_gs, p)
+            x1 = np.minimum(seg_ge, p + L)
+            hit = np.nonzero(x1 - x0 >= spec.min_ovl)[0]
+            if len(hit) == 0:
+                continue
+            if o > 0:
+                t0 = x0[hit] - p
+                t1 = x1[hit] - p
+                cc, ss = _entry_map(seg_roff[hit], seg_gs[hit], seg_ge[hit], seg_s[hit], 1, p)
+            else:
+                t0 = p + L - x1[hit]
+                t1 = p + L - x0[hit]
+                cc, ss = _entry_map(seg_roff[hit], seg_gs[hit], seg_ge[hit], seg_s[hit], -1, p + L)
+            e_read.append(seg_read[hit]); e_t0.append(t0); e_t1.append(t1)
+            e_c.append(cc); e_sg.append(ss); e_copy.append(np.full(len(hit), ci))
+        if not e_read:
+            continue
+        e_read = np.concatenate(e_read); e_t0 = np.concatenate(e_t0); e_t1 = np.concatenate(e_t1)
+        e_c = np.concatenate(e_c); e_sg = np.concatenate(e_sg); e_copy = np.concatenate(e_copy)
+        i, j = _expand_pairs(e_t0, e_t1, spec.min_ovl)
+        keep = e_copy[i] != e_copy[j]
+        rec.emit(i[keep], j[keep], e_read, e_t0, e_t1, e_c, e_sg)
+
+
+def generate(spec: SynthSpec) -> SynthData:
+    rng = np.random.default_rng(spec.seed)
+    G = spec.genome_len
+
+    fam_len, copies = plant_repeats(spec, rng)
 
     # ---- reads ---------------------------------------------------------------------------
     mean_len = (spec.len_min + spec.len_max) / 2 if spec.len_dist == "uniform" else spec.len_mean
@@ -167,84 +258,17 @@ def generate(spec: SynthSpec) -> SynthData:
     seg_ge = np.concatenate(seg_ge)
     seg_s = np.concatenate(seg_s)
 
-    # An "entry" maps a frame interval [t0,t1) onto a read linearly: rpos(t) = c + sg * t.
-    def entry_map(roff, gs, ge, s, g_of_t_sign, g_of_t_off):
-        # g(t) = g_of_t_off + g_of_t_sign * t ; rpos(g) = roff + (g-gs) if s>0 else roff + (ge-g)
-        sg = s * g_of_t_sign
-        c = np.where(s > 0, roff + g_of_t_off - gs, roff + ge - g_of_t_off)
-        return c, sg
-
-    rec_a, rec_b, rec_ab, rec_ae, rec_bb, rec_be, rec_comp = [], [], [], [], [], [], []
-
-    def emit(i, j, e_read, e_t0, e_t1, e_c, e_sg):
-        """Emit both directed records for entry pairs (i, j)."""
-        for (x, y) in ((i, j), (j, i)):
-            lo = np.maximum(e_t0[x], e_t0[y])
-            hi = np.minimum(e_t1[x], e_t1[y])
-            if spec.end_jitter > 0:
-                lo = lo + rng.integers(0, spec.end_jitter + 1, size=len(lo))
-                hi = hi - rng.integers(0, spec.end_jitter + 1, size=len(hi))
-            if spec.tie_quantum > 0:
-                q = spec.tie_quantum
-                lo = ((lo + q - 1) // q) * q
-                hi = (hi // q) * q
-            ok = hi - lo >= max(spec.min_ovl - 2 * spec.end_jitter - 2 * spec.tie_quantum, 200)
-            lo, hi, xx, yy = lo[ok], hi[ok], x[ok], y[ok]
-            pa0 = e_c[xx] + e_sg[xx] * lo
-            pa1 = e_c[xx] + e_sg[xx] * hi
-            pb0 = e_c[yy] + e_sg[yy] * lo
-            pb1 = e_c[yy] + e_sg[yy] * hi
-            ab = np.minimum(pa0, pa1)
-            ae = np.maximum(pa0, pa1)
-            bb = np.minimum(pb0, pb1)
-            be = np.maximum(pb0, pb1)
-            if spec.indel_max > 0:
-                d = rng.integers(0, spec.indel_max + 1, size=len(bb))
-                side = rng.random(len(bb)) < 0.5
-                bb = np.where(side, bb + d, bb)
-                be = np.where(side, be, be - d)
-            rec_a.append(e_read[xx])
-            rec_b.append(e_read[yy])
-            rec_ab.append(ab)
-            rec_ae.append(ae)
-            rec_bb.append(bb)
-            rec_be.append(be)
-            rec_comp.append((e_sg[xx] != e_sg[yy]).astype(np.uint8))
+    rec = _Records(spec, rng)
 
     # ---- true overlaps: frame = genome --------------------------------------------------
-    c, sg = entry_map(seg_roff, seg_gs, seg_ge, seg_s, 1, 0)
+    c, sg = _entry_map(seg_roff, seg_gs, seg_ge, seg_s, 1, 0)
     i, j = _expand_pairs(seg_gs, seg_ge, spec.min_ovl)
     keep = seg_read[i] != seg_read[j]
-    emit(i[keep], j[keep], seg_read, seg_gs, seg_ge, c, sg)
+    rec.emit(i[keep], j[keep], seg_read, seg_gs, seg_ge, c, sg)
 
     # ---- repeat-induced overlaps: frame = repeat coordinate of each family ---------------
-    for f, L in enumerate(fam_len):
-        e_read, e_t0, e_t1, e_c, e_sg, e_copy = [], [], [], [], [], []
-        for ci, (ff, p, o) in enumerate(copies):
-            if ff != f:
-                continue
-            x0 = np.maximum(seg_gs, p)
-            x1 = np.minimum(seg_ge, p + L)
-            hit = np.nonzero(x1 - x0 >= spec.min_ovl)[0]
-            if len(hit) == 0:
-                continue
-            if o > 0:
-                t0 = x0[hit] - p
-                t1 = x1[hit] - p
-                cc, ss = entry_map(seg_roff[hit], seg_gs[hit], seg_ge[hit], seg_s[hit], 1, p)
-            else:
-                t0 = p + L - x1[hit]
-                t1 = p + L - x0[hit]
-                cc, ss = entry_map(seg_roff[hit], seg_gs[hit], seg_ge[hit], seg_s[hit], -1, p + L)
-            e_read.append(seg_read[hit]); e_t0.append(t0); e_t1.append(t1)
-            e_c.append(cc); e_sg.append(ss); e_copy.append(np.full(len(hit), ci))
-        if not e_read:
-            continue
-        e_read = np.concatenate(e_read); e_t0 = np.concatenate(e_t0); e_t1 = np.concatenate(e_t1)
-        e_c = np.concatenate(e_c); e_sg = np.concatenate(e_sg); e_copy = np.concatenate(e_copy)
-        i, j = _expand_pairs(e_t0, e_t1, spec.min_ovl)
-        keep = e_copy[i] != e_copy[j]
-        emit(i[keep], j[keep], e_read, e_t0, e_t1, e_c, e_sg)
+    repeat_records(rec, fam_len, copies, seg_read, seg_roff, seg_gs, seg_ge, seg_s)
+    rec_a, rec_b, rec_ab, rec_ae, rec_bb, rec_be, rec_comp = rec.a, rec.b, rec.ab, rec.ae, rec.bb, rec.be, rec.comp
 
     aread = np.concatenate(rec_a).astype(np.int32)
     bread = np.concatenate(rec_b).astype(np.int32)
@@ -382,6 +406,46 @@ def to_las_records(d: SynthData, sel: Optional[np.ndarray] = None) -> formats.La
     return formats.LasRecords(tspace=d.spec.tspace, rec=rec, trace=tr, trace_off=toff)
 
 
+_synthio = None
+
+
+def _synthio_lib():
+    """hinge_amd/lib/libhinge_synthio.so (hinge_amd/tools_c/synth_io.c): the same bytes as to_las_records + write_las,
+    streamed from C.  None if it has not been built."""
+    global _synthio
+    if _synthio is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhinge_synthio.so")
+        if not os.path.exists(path):
+            _synthio = False
+        else:
+            lib = ctypes.CDLL(path)
+            lib.synth_write_las.restype = ctypes.c_int
+            lib.synth_write_las.argtypes = [ctypes.c_char_p, ctypes.c_int64] + [ctypes.c_void_p] + [ctypes.c_int32] + [ctypes.c_void_p] * 8
+            _synthio = lib
+    return _synthio or None
+
+
+def write_las_file(d: SynthData, path: str, sel: Optional[np.ndarray] = None, fast: Optional[bool] = None) -> None:
+    """NAME.las of the data set (or of the records sel).  fast = None: the C writer when it is built and applies (one-byte
+    traces), else the numpy writer; both produce the same bytes (tests/test_host_ingest.py)."""
+    lib = _synthio_lib() if fast in (None, True) else None
+    if lib is not None and d.spec.tspace <= formats.TRACE_XOVR:
+        cols = [np.ascontiguousarray(v, dtype=t) for v, t in ((d.aread, np.int32), (d.bread, np.int32), (d.comp, np.uint8), (d.ab, np.int32),
+                                                             (d.ae, np.int32), (d.bb, np.int32), (d.be, np.int32), (d.rlen, np.int32))]
+        s = None if sel is None else np.ascontiguousarray(sel, dtype=np.int64)
+        n = d.novl if s is None else len(s)
+        rc = lib.synth_write_las(path.encode(), n, None if s is None else s.ctypes.data, d.spec.tspace, *[c.ctypes.data for c in cols])
+        if rc == -2:
+            raise AssertionError("trace generator cannot express this indel / trace-spacing combination")
+        if rc != 0:
+            raise OSError("cannot write %s" % path)
+        return
+    assert fast is not True, "libhinge_synthio.so is not built"
+    formats.write_las(path, to_las_records(d, sel))
+
+
 def write_dataset(d: SynthData, directory: str, name: str = "G", write_bases: bool = True) -> str:
     """Write NAME.db/.idx/.bps (+qual track), NAME.las and, for n_blocks > 1, NAME.k.las."""
     import os
@@ -390,12 +454,12 @@ def write_dataset(d: SynthData, directory: str, name: str = "G", write_bases: bo
     formats.write_db(db, d.rlen, block_first=d.block_first, write_bases=write_bases)
     if d.qv is not None:
         formats.write_qual_track(db, d.qv)
-    formats.write_las(os.path.join(directory, name + ".las"), to_las_records(d))
+    write_las_file(d, os.path.join(directory, name + ".las"))
     if d.spec.n_blocks > 1:
         for k in range(d.spec.n_blocks):
             lo, hi = d.block_first[k], d.block_first[k + 1]
             sel = np.nonzero((d.aread >= lo) & (d.aread < hi))[0]
-            formats.write_las(os.path.join(directory, "%s.%d.las" % (name, k + 1)), to_las_records(d, sel))
+            write_las_file(d, os.path.join(directory, "%s.%d.las" % (name, k + 1)), sel)
     return db
 
 
@@ -461,4 +525,11 @@ CONFIGS = {
     "cfg4_yeast": SynthSpec(genome_len=12_000_000, coverage=80, len_dist="lognormal", len_mean=8000,
                             len_min=1500, len_max=40000, seed=4, n_repeat_families=20,
                             repeat_len=(1000, 6000), repeat_copies=(2, 5), n_blocks=8),
+    # config 5 (HBM-roofline stress): generated on the device by hinge_amd.synth_device (no .las of this size is ever written).
+    # SURVEY 8(d) quotes ~10^9 overlaps for the whole 100 Mb genome; with overlaps of >= 1 kb between 7 kb reads at 100x the
+    # model gives ~170 per read, 2.4e8 in all, so "one rank's share of 10^9" (>= 1.25e8 overlaps) is the 52 Mb block below.
+    "cfg5_stress": SynthSpec(genome_len=100_000_000, coverage=100, len_dist="lognormal", len_mean=7000, len_min=1500,
+                             len_max=40000, seed=5, n_repeat_families=60, repeat_len=(1000, 8000), repeat_copies=(2, 5), n_blocks=8),
+    "cfg5_share": SynthSpec(genome_len=52_000_000, coverage=100, len_dist="lognormal", len_mean=7000, len_min=1500,
+                            len_max=40000, seed=5, n_repeat_families=30, repeat_len=(1000, 8000), repeat_copies=(2, 5)),
 }

@@ -82,6 +82,18 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
  * alive).  row_ptr always has n_reads+1 entries (empty rows outside the part).                   */
 int hinge_set_pileups(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr,
                       const int32_t* a_span, const int32_t* b_span, const uint32_t* b_flag, int on_device);
+/* The same, for an ingest that hands over what it saw while it touched every record (the replacement of the per-record work of
+ * LAInterface::getOverlap, LAInterface.cpp:1553-1634): span16[n_ovl + hinge_span16_pad()] = abpos | aepos << 16 (the stream of
+ * the two coverage passes; NULL if some read is >= 65536 bp), max_pile = the largest pile-up, spans_in_range = 1 if every
+ * (abpos, aepos) lies in [0, rlen[A]].  No device sweep over the spans runs before the first pass then.  The pad elements
+ * behind span16[n_ovl] may be read by a kernel (their values are never used).                                             */
+int hinge_set_pileups_packed(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int64_t n_ovl, const int64_t* row_ptr,
+                             const int32_t* a_span, const int32_t* b_span, const uint32_t* b_flag, const uint32_t* span16,
+                             uint32_t max_pile, int spans_in_range, int on_device);
+#define HINGE_SPAN16_PAD 256   /* = hinge_span16_pad() */
+int hinge_span16_pad(void);
+/* The two facts about the current part, whoever produced them (the caller or the library's own sweep). */
+int hinge_get_pileup_facts(hinge_ctx* ctx, uint32_t* max_pile, int* spans_in_range);
 /* Optional: use a caller-owned DEVICE buffer int32[n_reads][2] as the all-read mask table (so a
  * collective can fill other ranks' rows in place).  NULL returns to the library-owned table.      */
 int hinge_attach_mask_table(hinge_ctx* ctx, int32_t* d_mask_all);
@@ -133,6 +145,12 @@ int hinge_filter_get_annotations(hinge_ctx* ctx, int64_t* off, int32_t* pos, int
  * r0..r1 inclusive: nbins[r1-r0+1]; if cov != NULL, bins of read i start at sum(nbins[<i]).      */
 int hinge_filter_coverage_bins(hinge_ctx* ctx, int32_t r0, int32_t r1, int32_t reso, int32_t cutoff, int32_t* nbins,
                                int32_t* cov, int64_t cov_cap);
+/* .coverage.txt without a second sweep: with coverage_out(1), K2 (hinge_filter_mask_annotate*) also stores the cutoff-0 coverage
+ * bins it holds in LDS (profileCoverage(cutoff 0), LAInterface.cpp:4298-4320 as printed by filter.cpp:599-602).
+ * get_coverage: off[n + 1] (always filled; host-known layout: bins of read r_begin + k start at cov[off[k]], off[n] = ints
+ * needed), nbins[n] = bins of each read, cov[off[n]]; nbins and cov may be NULL (to size the buffer first).            */
+int hinge_filter_coverage_out(hinge_ctx* ctx, int enable);
+int hinge_filter_get_coverage(hinge_ctx* ctx, int64_t* off, int32_t* nbins, int32_t* cov, int64_t cov_cap);
 /* Counters of the last hinge pass: [0] reads that reached hinge calling, [1] annotations resolved on
  * the exact (std::sort-replaying) path, [2] total annotations, [3] total hinges.                  */
 int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
@@ -194,6 +212,18 @@ int hinge_profile_report(hinge_ctx* ctx, double* total_ms, int64_t* count);
 /* ---- device event timing helper for bench.py (HIP events on the ctx stream) -------------------- */
 int hinge_timer_start(hinge_ctx* ctx);
 int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms);
+
+/* ---- test hooks (tests/ only; no product code calls them) ---------------------------------------- */
+/* 1 = every scanned annotation through the serial k_hinge_exact, 2 = always replay the pile-up's std::sort order in LDS. */
+int hinge_debug_force_exact(hinge_ctx* ctx, int mode);
+/* Run the general k_mask_annotate even where k_mask_annotate_q20 applies. */
+int hinge_debug_force_general_mask(hinge_ctx* ctx, int on);
+/* out[0] = reads the last K2 pass handed from the fast kernel to the general one. */
+int hinge_debug_fallback_reads(hinge_ctx* ctx, int64_t* out);
+/* out[0..1] = undecided annotations the last hinge pass put through the half-size / full-size k_hinge_call. */
+int hinge_debug_heavy_items(hinge_ctx* ctx, int64_t* out);
+/* pos_out[k] = position of element k after std::sort(compare_overlap) of n keys, through the wavefront-parallel replay. */
+int hinge_debug_pileup_order(hinge_ctx* ctx, int32_t n, const int32_t* keys, int32_t* pos_out);
 
 #ifdef __cplusplus
 }

@@ -468,8 +468,14 @@ int oracle_maximal(const char* name_db, const char* las_base, int mlas, const ch
         reads[read]->effective_start = rs; reads[read]->effective_end = re; has_mask[read] = 1;
     }
     fclose(mask_file);
+    // A read without a .mas line (outside the .las' A range): the reference reads effective_start / effective_end of a
+    // freshly allocated Read uninitialised - zeroes on a fresh heap, so the read is simply inactive (length 0 <
+    // LENGTH_THRESHOLD).  Restated as (0, 0); HINGE_STRICT_MAS=1 refuses instead (-3).
     for (int i = 0; i < n_read; i++)
-        if (!has_mask[i]) return -3;    // reference reads uninitialised effective_start/end here
+        if (!has_mask[i]) {
+            if (getenv("HINGE_STRICT_MAS")) return -3;
+            reads[i]->effective_start = 0; reads[i]->effective_end = 0;
+        }
     for (int i = 0; i < n_read; i++)
         if (reads[i]->effective_end - reads[i]->effective_start < P.LENGTH_THRESHOLD) reads[i]->active = false;
 
@@ -662,7 +668,11 @@ extern "C" int oracle_layout(const char* name_db, const char* las_base, int mlas
         }
         fclose(mask_file);
     }
-    for (int i = 0; i < n_read; i++) if (!has_mask[i]) return -3;
+    for (int i = 0; i < n_read; i++)
+        if (!has_mask[i]) {   // see oracle_maximal: (0, 0) as on a fresh heap, or refuse under HINGE_STRICT_MAS=1
+            if (getenv("HINGE_STRICT_MAS")) return -3;
+            reads[i]->effective_start = 0; reads[i]->effective_end = 0;
+        }
 
     std::unordered_map<int, std::vector<IPair>> marked_repeats, marked_hinges;
     {

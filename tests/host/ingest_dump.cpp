@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
     if (paf) { if (read_fasta_lengths(argv[1], db.rlen) != 0) return 3; }
     else if (db.open(argv[1]) != 0) return 3;
     LasPart las;
+    las.want_span16 = true;
     const int rc = paf ? las.load_paf(argv[2], db.rlen) : las.load(argv[2], db.rlen);
     if (rc != 0) return rc & 255;
     printf("%s\n", las.indexed_in_pieces ? "pieces" : "sequential");
@@ -37,6 +38,9 @@ int main(int argc, char** argv) {
     fwrite(hdr, 8, 4, f);
     put(f, las.row_ptr); put(f, las.a_span); put(f, las.b_span); put(f, las.b_flag); put(f, las.trace_off); put(f, las.tlen);
     put(f, las.rec_row_ptr); put(f, las.rec_b); put(f, las.rec_kept); put(f, las.self_a); put(f, las.self_span);
+    put(f, las.span16);
+    const std::vector<int64_t> facts = {(int64_t)las.max_pile, las.spans_in_range ? 1 : 0};
+    put(f, facts);
     fclose(f);
     return 0;
 }

@@ -21,8 +21,13 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 25
     for name in declared:
         assert hasattr(lib, name), "libhinge_hip.so lacks %s" % name
-    bound = {s[0] for s in capi.SYMBOLS}
+    bound = {s[0] for s in capi.SYMBOLS + capi.EXTRA_SYMBOLS}
     assert set(declared) <= bound, "capi.py does not bind: %s" % sorted(set(declared) - bound)
+    # and the other way round: nothing is exported that the header does not declare
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("hinge_") and " T " in l}
+    assert exported <= set(declared), "exported but not declared in include/hinge_hip.h: %s" % sorted(exported - set(declared))
 
 
 def test_no_cpu_fallback_without_gpu():

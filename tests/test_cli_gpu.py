@@ -70,9 +70,22 @@ def test_cli_reads_outside_the_overlap_id_range(datasets, oracle_lib, tmp_path):
     bad = [f for f in filt if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
     assert not bad, "differs from the oracle: %s" % bad
     assert sum(1 for _ in open(os.path.join(wd_h, "G.mas"))) == d.n_reads - 6
-    assert _oracle(oracle_lib, wd_o, False, "nominal.ini")[1:] == [-3, -3]          # (maximal truncates .coverage.txt first)
-    assert run("maximal", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini") == 2
-    assert run("layout", "--db", "G", "--las", "G.las", "-x", "G", "-o", "G", "--config", "nominal.ini") == 2
+    # strict mode: both sides refuse to guess what the reference's uninitialised fields held
+    os.environ["HINGE_STRICT_MAS"] = "1"
+    try:
+        assert _oracle(oracle_lib, wd_o, False, "nominal.ini")[1:] == [-3, -3]          # (maximal truncates .coverage.txt first)
+        assert run("maximal", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini") == 2
+        assert run("layout", "--db", "G", "--las", "G.las", "-x", "G", "-o", "G", "--config", "nominal.ini") == 2
+    finally:
+        del os.environ["HINGE_STRICT_MAS"]
+    # default: such reads are inactive with mask (0, 0) - what a fresh heap gives the reference - and all stages run
+    assert run_in(wd_o, oracle_lib.oracle_filter, b"G", b"G.las", 0, b"G", b"nominal.ini", b"") == 0
+    assert _oracle(oracle_lib, wd_o, False, "nominal.ini")[1:] == [0, 0]
+    assert run("filter", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini") == 0
+    assert run("maximal", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini") == 0
+    assert run("layout", "--db", "G", "--las", "G.las", "-x", "G", "-o", "G", "--config", "nominal.ini") == 0
+    bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
 
 
 def test_cli_inputs_the_reference_cannot_process(oracle_lib, tmp_path):

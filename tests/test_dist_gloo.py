@@ -101,10 +101,30 @@ class TableBackend:
         assert np.array_equal(self.mask.numpy(), self.expect_visible), "mask table seen by hinge calling is wrong"
         self.checked.append("masks")
 
-    def hinge_rows(self):
+    FAKE_POS = 123456
+
+    def hinge_rows(self, drop_last=True):
+        """The oracle's .hinges.txt already stops before the last A read of the (merged or per-part) run, so a hinge is planted
+        on this block's last read here: the orchestration must drop it exactly where the reference's `i < r_end` would."""
         sel = (self.rows[:, 0] >= self.lo) & (self.rows[:, 0] < self.hi)
-        t = torch.from_numpy(np.ascontiguousarray(self.rows[sel]))
+        mine = np.concatenate([self.rows[sel], np.array([[self.hi - 1, self.FAKE_POS, 1]], np.int32)])
+        if drop_last:
+            mine = mine[mine[:, 0] != self.hi - 1]
+        t = torch.from_numpy(np.ascontiguousarray(mine))
         return t, int(t.shape[0])
+
+    def max_pileup(self):
+        return 100
+
+    def status_code(self):
+        self.checked.append("status")
+        return 0
+
+    def regrow(self):
+        raise AssertionError("no capacity error was reported")
+
+    def raise_status(self, codes):
+        raise AssertionError(codes)
 
 
 def _worker(rank, world, port, mode, median, first, mean_all, mask_all, rows, expect_min_cov, ret):
@@ -121,11 +141,15 @@ def _worker(rank, world, port, mode, median, first, mean_all, mask_all, rows, ex
         be = TableBackend(lo, hi, mean_all, mask_all, rows, expect_min_cov[rank], visible)
         job = ShardedFilter(be, Exchange(blocks, torch.device("cpu")), mode=mode, median=median)
         got = job.step(fetch_hinges=True)
-        assert be.checked == ["min_cov", "masks"]
+        assert be.checked == ["min_cov", "masks", "status"]
         assert np.array_equal(job.mean_cov.numpy()[lo:hi], mean_all[lo:hi].astype(np.int32))
         if mode == "merged" and median == "gather":
             assert np.array_equal(job.mean_cov.numpy(), mean_all.astype(np.int32)), "all-gather of mean coverage"
-        assert np.array_equal(got.numpy(), rows), "assembled hinge list"
+        want = rows
+        if mode == "merged":   # one merged .las keeps the hinges of every block's last read except the global last one
+            planted = np.array([[first[k + 1] - 1, TableBackend.FAKE_POS, 1] for k in range(world - 1)], np.int32).reshape(-1, 3)
+            want = np.concatenate([np.concatenate([rows[(rows[:, 0] >= first[k]) & (rows[:, 0] < first[k + 1])], planted[k:k + 1]]) for k in range(world)])
+        assert np.array_equal(got.numpy(), want), "assembled hinge list"
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

@@ -19,7 +19,8 @@ def _oracle_filter(lib, wd, mlas, ini="nominal.ini"):
 
 def _hip_filter(wd, mlas, ini="nominal.ini", **kw):
     from hinge_amd import stages
-    return run_in(wd, stages.run_filter, "G", "G" if mlas else "G.las", "G", ini, mlas, 0, True, kw.get("force_exact", False))
+    return run_in(wd, stages.run_filter, "G", "G" if mlas else "G.las", "G", ini, mlas, 0, True, kw.get("force_exact", False),
+                  kw.get("ctx"), kw.get("packed", False))
 
 
 def _compare(wd_o, wd_h):
@@ -41,6 +42,56 @@ def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas, exact
     nh = sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.hinges.txt")))
     na = sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.repeat.txt")))
     assert na > 0 and nh > 0
+
+
+@pytest.mark.parametrize("name,mlas,general", [("tiny_qv", False, 0), ("tiny_mlas", True, 0), ("ties", False, 0), ("edges", False, 0), ("tspace200", False, 0),
+                                               ("long_repeat", False, 1), ("long_reads", False, 0), ("deep", False, 0)])
+def test_filter_packed_route(datasets, oracle_lib, tmp_path, name, mlas, general):
+    """The route of the executables: hinge_set_pileups_packed (span copy and facts from the ingest, no k_pileup_facts sweep) and
+    the .coverage.txt bins stored by K2 itself (fast kernel, general kernel and the hand-back between them)."""
+    from hinge_amd import capi
+    src, _ = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, mlas) == 0
+    ctx = capi.Context(0)
+    ctx.force_general_mask(general)
+    assert _hip_filter(wd_h, mlas, ctx=ctx, packed=True) == 0
+    _compare(wd_o, wd_h)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["huge", "past_end"])
+def test_filter_packed_route_fallback_reads(datasets, oracle_lib, tmp_path, mode):
+    from hinge_amd import capi
+    src, _ = _bloated_dataset(datasets, tmp_path, mode)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle_filter(oracle_lib, wd_o, False) == 0
+    ctx = capi.Context(0)
+    assert _hip_filter(wd_h, False, ctx=ctx, packed=True) == 0
+    # past_end: the ingest sees a coordinate outside its read, so no span copy is handed over and every read of the part
+    # takes the int32 spans; the one bad pile-up still leaves the fast kernel through the fallback list
+    assert ctx.fallback_reads() == 1
+    _compare(wd_o, wd_h)
+
+
+def test_context_reuse_with_more_reads(datasets, oracle_lib, tmp_path):
+    """One context, two data sets, the second with more reads: the library-owned per-read tables are reallocated and every
+    kernel must follow them (hinge_set_reads re-points mask / mean_cov unless a caller table is attached)."""
+    from hinge_amd import capi
+    ctx = capi.Context(0)
+    sizes = []
+    for name in ("tiny", "long_repeat", "tiny"):
+        src, d = datasets(name)
+        sizes.append(d.n_reads)
+        wd_o = clone_dataset(src, str(tmp_path / (name + "_oracle%d" % len(sizes))))
+        wd_h = clone_dataset(src, str(tmp_path / (name + "_hip%d" % len(sizes))))
+        assert _oracle_filter(oracle_lib, wd_o, False) == 0
+        assert _hip_filter(wd_h, False, ctx=ctx, packed=len(sizes) % 2 == 0) == 0
+        _compare(wd_o, wd_h)
+    assert sizes[1] > sizes[0]
+    ctx.close()
 
 
 @pytest.mark.parametrize("extra", ["ec = 60\n", "coverage = false\n", "hinge_min_support = 3\nhinge_unbridged = 2\nhinge_min_pileup = 3\n",

@@ -31,7 +31,7 @@ def _read_dump(path):
     hdr = np.frombuffer(raw, np.int64, 4)
     pos = 32
     cols = []
-    for dt in (np.int64, np.int32, np.int32, np.uint32, np.int64, np.int32, np.int64, np.int32, np.int64, np.int32, np.int32):
+    for dt in (np.int64, np.int32, np.int32, np.uint32, np.int64, np.int32, np.int64, np.int32, np.int64, np.int32, np.int32, np.uint32, np.int64):
         n = int(np.frombuffer(raw, np.int64, 1, pos)[0])
         pos += 8
         cols.append(np.frombuffer(raw, dt, n, pos).copy())
@@ -53,7 +53,15 @@ def test_ingest_matches_numpy_reader(datasets, ingest_dump, tmp_path, name, las)
         assert _dump(ingest_dump, db, lasp, out, threads, how) == 0
         assert how == ["sequential" if threads == 1 else "pieces"], how
         hdr, c = _read_dump(out)
-        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span = c
+        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span, span16, facts = c
+        # what hinge_set_pileups_packed gets besides the columns: the numpy restatement (capi.pack_spans) must agree
+        from hinge_amd import capi
+        want16, want_pile, want_in_range = capi.pack_spans(pile.row_ptr, pile.a_span, d.rlen)
+        assert facts.tolist() == [want_pile, int(want_in_range)]
+        if want16 is None:
+            assert len(span16) == 0 and int(d.rlen.max()) >= 65536
+        else:
+            np.testing.assert_array_equal(span16, want16)
         assert hdr[0] == recs.novl and hdr[1] == recs.tspace
         assert hdr[2] == recs.rec["aread"][0] and hdr[3] == recs.rec["aread"][-1]
         np.testing.assert_array_equal(row_ptr, pile.row_ptr)
@@ -76,6 +84,22 @@ def test_ingest_matches_numpy_reader(datasets, ingest_dump, tmp_path, name, las)
             ref = open(out, "rb").read()
         else:
             assert open(out, "rb").read() == ref, "result depends on the number of threads"
+
+
+def test_fast_las_writer_writes_the_same_bytes(datasets, tmp_path):
+    """hinge_amd/tools_c/synth_io.c (what write_dataset uses when it is built) == to_las_records + formats.write_las."""
+    import filecmp
+    from hinge_amd import synth
+    if synth._synthio_lib() is None:
+        pytest.skip("libhinge_synthio.so not built")
+    for name in ("tiny", "edges", "chimera", "long_reads"):
+        _, d = datasets(name)
+        sel = np.nonzero(d.aread < d.n_reads // 2)[0]
+        for k, s in enumerate((None, sel)):
+            a, b = str(tmp_path / ("%s%d_c.las" % (name, k))), str(tmp_path / ("%s%d_np.las" % (name, k)))
+            synth.write_las_file(d, a, s, fast=True)
+            synth.write_las_file(d, b, s, fast=False)
+            assert filecmp.cmp(a, b, shallow=False), (name, k)
 
 
 def test_ingest_rejects_damaged_files(datasets, ingest_dump, tmp_path):
@@ -138,7 +162,7 @@ def test_fasta_and_paf_ingest_matches_the_oracle(datasets, ingest_dump, oracle_l
         out = str(tmp_path / "paf.bin")
         assert subprocess.run([ingest_dump, "--paf", fa, paf, out], stdout=subprocess.DEVNULL).returncode == 0
         hdr, c = _read_dump(out)
-        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span = c
+        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span, span16, facts = c
         assert hdr[0] == n_rec and hdr[2] == x[0, 0] and hdr[3] == x[-1, 0]
         order = np.argsort(x[:, 0], kind="stable")           # the reference files every line under its A read, in file order
         xs = x[order]

@@ -22,10 +22,13 @@ def main():
     ap.add_argument("--genome", type=int, default=1_000_000)
     ap.add_argument("--workload", default="cfg2_ecoli160")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--exact-config", action="store_true", help="at the configuration's own genome size: its own repeat model too (the data set bench.py uses)")
     args = ap.parse_args()
     import oracle
     from hinge_amd import synth
     spec = dataclasses.replace(synth.CONFIGS[args.workload], genome_len=args.genome, n_repeat_families=1, repeat_copies=(3, 3), n_blocks=1)
+    if args.exact_config and args.genome == synth.CONFIGS[args.workload].genome_len:
+        spec = dataclasses.replace(synth.CONFIGS[args.workload], n_blocks=1)
     d = synth.generate(spec)
     tmp = tempfile.mkdtemp(prefix="hinge_e2e_")
     out = {"workload": "%s at G=%d" % (args.workload, args.genome), "reads": d.n_reads, "overlaps": d.novl}
