@@ -75,6 +75,7 @@ SYMBOLS = [
     ("hinge_trim_classify", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     ("hinge_trim_classify_types", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     ("hinge_trim_classify_part", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    ("hinge_trim_classify_part_full", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     ("hinge_matching_position", C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
     ("hinge_filter_mask_annotate_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_hinges_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
@@ -379,6 +380,12 @@ class Context:
         """Match type of every overlap of the current part (storage order)."""
         out = np.zeros(max(int(n_ovl), 1), np.uint8)
         self._ck(self.lib.hinge_trim_classify_part(self.h, aln_threshold, theta, theta2, _ptr(out)))
+        return out[:int(n_ovl)]
+
+    def trim_classify_part_full(self, n_ovl: int, aln_threshold: int, theta: int, theta2: int) -> np.ndarray:
+        """All ten classification fields of every overlap of the current part (storage order)."""
+        out = np.zeros((max(int(n_ovl), 1), 10), np.int32)
+        self._ck(self.lib.hinge_trim_classify_part_full(self.h, aln_threshold, theta, theta2, _ptr(out)))
         return out[:int(n_ovl)]
 
     def set_trim(self, trim: bool):

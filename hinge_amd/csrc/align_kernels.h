@@ -241,6 +241,170 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify_rows(int r_begin, int r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The part form again, as a STREAM: k_trim_classify_rows spends 416 vector instructions per 8 overlaps evaluating "inside both
+// masks" for every trace point on eight lanes, and is bound by instruction issue at 15 % of the HBM rate.  Here ONE lane owns
+// one overlap, and the raw .las bytes of 64 consecutive overlaps (records and traces as they lie in the file) are first copied
+// into LDS with coalesced 16-byte loads - the only global traffic besides the SoA columns - so the per-lane walks that follow
+// read LDS, not 64 scattered cache lines per instruction (what held the earlier one-lane-per-overlap kernel at 4 ms).
+// A lane needs three walks, and only the first touches every point, with two instructions each:
+//   1. T = sum of the B advances of the inner points (the B coordinate of the last inner point is b_first + sign * T);
+//   2. forward from point 0 until the first point inside both masks (usually a handful of points);
+//   3. backward from the last point until the last point inside both masks.
+// "First / last index that satisfies the test" is evaluated in index order with an early exit, which is the reference's
+// definition (LAInterface.cpp:4606-4640) whatever the coordinates look like - no monotonicity is assumed.
+// One wavefront per workgroup (the stage buffer is its own), CAP bytes of LDS each.
+// ------------------------------------------------------------------------------------------------
+constexpr int STREAM_CAP = 10240;   // bytes of staged .las per wavefront: 64 overlaps of ~130 B are 8.3 KB; 16 workgroups per CU
+
+template <int TB, typename FETCH>
+__device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, const int comp, const int2 ea, const int2 eb, const int tl,
+                                              FETCH adv /*B advance of trace pair j*/, const int aln_threshold, const int theta, const int theta2,
+                                              const int trim, ClassifyOut& o) {
+    const int ninner = max(tl / 2 - 1, 0);
+    const int np = trim ? ninner + 2 : 0;
+    const int sign = 1 - 2 * comp;
+    const int b_first = comp ? bs.y : bs.x, b_last = comp ? bs.x : bs.y;
+    const int a_base = (av.x / 100) * 100;          // inner point i sits at a_base + 100 * i (hard-coded 100, LAInterface.cpp:4581-4584)
+    const int qlo = comp ? -eb.y : eb.x, qhi = comp ? -eb.x : eb.y;
+    const int q_first = sign * b_first, q_last = sign * b_last;
+    bool s_found = false, e_found = false;
+    int s_idx = np, s_a = 0, s_q = 0, e_idx = 0, e_a = 0, e_q = 0;
+    if (np > 0) {
+        int T = 0;
+        for (int j = 0; j < ninner; j++) T += adv(j);
+        // first point (ascending index) with a >= ea.x and q >= qlo
+        if (av.x >= ea.x && q_first >= qlo) { s_found = true; s_idx = 0; s_a = av.x; s_q = q_first; }
+        else {
+            int q = q_first;
+            for (int i = 1; i <= ninner; i++) {
+                q += adv(i - 1);
+                const int a = a_base + 100 * i;
+                if (a >= ea.x && q >= qlo) { s_found = true; s_idx = i; s_a = a; s_q = q; break; }
+            }
+            if (!s_found && av.y >= ea.x && q_last >= qlo) { s_found = true; s_idx = np - 1; s_a = av.y; s_q = q_last; }
+        }
+        // last point (descending index) with a <= ea.y and q <= qhi
+        if (av.y <= ea.y && q_last <= qhi) { e_found = true; e_idx = np - 1; e_a = av.y; e_q = q_last; }
+        else {
+            int q = q_first + T;
+            for (int i = ninner; i >= 1; i--) {
+                const int a = a_base + 100 * i;
+                if (a <= ea.y && q <= qhi) { e_found = true; e_idx = i; e_a = a; e_q = q; break; }
+                q -= adv(i - 1);
+            }
+            if (!e_found && av.x <= ea.y && q_first <= qhi) { e_found = true; e_idx = 0; e_a = av.x; e_q = q_first; }
+        }
+    }
+    int start_idx = s_found ? s_idx : np, end_idx = e_found ? e_idx : 0;
+    o.eff_ab = av.x; o.eff_ae = av.y; o.eff_bb = bs.x; o.eff_be = bs.y;
+    if (comp == 0) {
+        if (s_found) { o.eff_ab = s_a; o.eff_bb = sign * s_q; }
+        if (e_found) { o.eff_ae = e_a; o.eff_be = sign * e_q; }
+    } else {
+        if (s_found) { o.eff_ab = s_a; o.eff_be = sign * s_q; }
+        if (e_found) { o.eff_ae = e_a; o.eff_bb = sign * e_q; }
+    }
+    bool active = trim ? !(start_idx >= end_idx) : true;   // without trimming match->active keeps its value (maximal.cpp:97-104)
+    if (!trim) { start_idx = 0; end_idx = 0; }
+    int type;
+    if (((o.eff_be - o.eff_bb) < aln_threshold) || ((o.eff_ae - o.eff_ab) < aln_threshold) || !active) {
+        active = false;
+        type = MT_NOT_ACTIVE;
+    } else {
+        const int A_left = o.eff_ab - ea.x, A_right = ea.y - o.eff_ae;
+        int B_left = o.eff_bb - eb.x, B_right = eb.y - o.eff_be;
+        if (comp) { const int t = B_left; B_left = B_right; B_right = t; }
+        type = add_types_asymmetric(A_left, A_right, B_left, B_right, theta, theta2);
+    }
+    o.type = type;
+    o.active = active ? 1 : 0;
+    o.weight = o.eff_ae - o.eff_ab + o.eff_be - o.eff_bb;
+    o.length = av.y - av.x + bs.y - bs.x;
+    o.start_idx = start_idx;
+    o.end_idx = end_idx;
+}
+
+template <int TB>
+__global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+                                                               const int2* __restrict__ a_span, const int2* __restrict__ b_span,
+                                                               const unsigned* __restrict__ b_flag, const unsigned char* __restrict__ trace,
+                                                               int64_t trace_readable /*bytes that may be read from `trace`*/,
+                                                               const int64_t* __restrict__ trace_off, const int* __restrict__ tlen,
+                                                               const int2* __restrict__ eff, int aln_threshold, int theta, int theta2,
+                                                               unsigned char* __restrict__ type_out /*[n_ovl] or nullptr*/,
+                                                               ClassifyOut* __restrict__ full_out /*[n_ovl] or nullptr*/, int trim) {
+    __shared__ uint4 stage4[STREAM_CAP / 16];
+    const unsigned char* stage = reinterpret_cast<const unsigned char*>(stage4);
+    const int lane = threadIdx.x;
+    for (int i = r_begin + (int)blockIdx.x; i <= r_end; i += (int)gridDim.x) {
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int2 ea = eff[i];
+        for (int64_t k0 = s; k0 < e; k0 += WAVE) {
+            const int64_t k = k0 + lane;
+            const bool live = k < e;
+            int2 av = make_int2(0, 0), bs = make_int2(0, 0), eb = make_int2(0, 0);
+            int comp = 0, tl = 0;
+            int64_t t0 = 0;
+            if (live) {
+                av = a_span[k];
+                bs = b_span[k];
+                const unsigned bf = b_flag[k];
+                comp = (int)(bf >> 31);
+                eb = eff[bf & 0x7fffffffu];
+                tl = tlen[k];
+                t0 = trace_off[k];
+            }
+            const int need = (trim && tl >= 4) ? (tl - 2) * TB : 0;   // bytes of the pairs the walks read (the last pair is never read)
+            const int64_t t1 = t0 + need;
+            unsigned long long pending = ballot_of(live);
+            while (pending) {
+                const int first = __ffsll((long long)pending) - 1;
+                const int64_t base = __shfl(t0, first) & ~15ll;
+                const bool mine = ((pending >> lane) & 1ull) != 0;
+                // offsets ascend with the lane (storage order), so the lanes that fit are a prefix of the pending ones; whatever the
+                // offsets are, only the pending lanes in front of the first one that does not fit are taken
+                const unsigned long long fits = ballot_of(mine && t0 >= base && (t1 - base) <= (int64_t)STREAM_CAP);
+                const unsigned long long nofit = pending & ~fits;
+                const unsigned long long take = nofit ? (fits & ((1ull << (__ffsll((long long)nofit) - 1)) - 1ull)) : fits;
+                ClassifyOut o;
+                if (take == 0ull) {
+                    // one overlap whose trace alone exceeds the stage buffer (> 5000 trace points): its lane walks global memory
+                    if (lane == first) {
+                        const unsigned char* tp = trace + t0;
+                        classify_lane<TB>(av, bs, comp, ea, eb, tl, [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); },
+                                          aln_threshold, theta, theta2, trim, o);
+                        if (type_out) type_out[k] = (unsigned char)o.type;
+                        if (full_out) full_out[k] = o;
+                    }
+                    pending &= ~(1ull << first);
+                    continue;
+                }
+                const int last = 63 - __clzll((long long)take);
+                const int64_t end = __shfl(t1, last);
+                const int nchunk = (int)((end - base + 15) >> 4);
+                for (int c = lane; c < nchunk; c += WAVE) {
+                    const int64_t off = base + 16ll * c;
+                    uint4 w = make_uint4(0, 0, 0, 0);
+                    if (off + 16 <= trace_readable) w = *reinterpret_cast<const uint4*>(trace + off);
+                    else { unsigned char* wb = reinterpret_cast<unsigned char*>(&w); for (int q = 0; q < 16 && off + q < trace_readable; q++) wb[q] = trace[off + q]; }
+                    stage4[c] = w;
+                }
+                __syncthreads();
+                if ((take >> lane) & 1ull) {
+                    const unsigned char* tp = stage + (int)(t0 - base);
+                    classify_lane<TB>(av, bs, comp, ea, eb, tl, [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)*reinterpret_cast<const unsigned short*>(tp + 4 * j + 2); },
+                                      aln_threshold, theta, theta2, trim, o);
+                    if (type_out) type_out[k] = (unsigned char)o.type;
+                    if (full_out) full_out[k] = o;
+                }
+                __syncthreads();
+                pending &= ~take;
+            }
+        }
+    }
+}
+
 // GetMatchingPosition for a list of (overlap, pos_A) queries: one thread each (tiny lists: hinges x matches).
 template <int TB>
 __global__ void k_matching_position(int64_t nq, const int64_t* __restrict__ q_ovl, const int* __restrict__ q_pos,

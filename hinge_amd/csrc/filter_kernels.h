@@ -598,7 +598,7 @@ __device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long lo
 template <typename ZF, typename CF>
 __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
                                                    const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o,
-                                                   const long long row, const int n_pile) {
+                                                   const long long row, const int n_pile, const unsigned long long flag_words = ~0ull) {
     if (o.cov_out) {   // before anything reuses the profile's LDS (cand)
         int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
         for (int j = lane; j < K0; j += WAVE) dst[j] = z(j);
@@ -675,6 +675,8 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
         const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
         for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
+            // flag_words: bit w clear = the caller knows that no bin of [64 w, 64 w + 63] can pass the threshold (words beyond 63: always looked at)
+            if (base < 64 * WAVE && !((flag_words >> (base / WAVE)) & 1ull)) continue;
             const int j = base + lane;
             int code = -1;
             const bool in = j >= jlo && j <= jhi;
@@ -1039,6 +1041,153 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
             }
         }
         mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2, lean form: the reads that fit ONE LDS slot (class 1: up to ~16 kb, nearly all of a part), 16|16 spans, reso 40,
+// cut_off = 20 * SH, no_hinge_region >= 40, MIN_COV >= 0.  Same 20-bp begin|end histogram and the same mask / gate /
+// annotation code as k_mask_annotate_q20, with the per-read fixed cost cut down (k_mask_annotate_q20 spent ~4/5 of its
+// vector instructions outside the per-overlap loop):
+//  * No hot-bin bookkeeping.  About half of all overlaps begin in the read's first 20-bp bin and half end in its last one;
+//    neither count is needed: begins in bin 0 are B0 = n - (all other begins), known once the scan has summed the bins, and
+//    ends in the last bin only ever show up in PE[last] = n.  Those events go to a lane-private trash word (no same-address
+//    serialisation, never read, never cleared); B0 is added by the profile accessors.
+//  * The constants of the last phase (FilterDev, the 14 output pointers) live in device memory and are loaded where they are
+//    used: held in SGPRs across the whole read loop they cost 59 spills to VGPR lanes, every one a v_readlane / v_writelane.
+//  * The prefix scan takes two rows of 256 bins at a time with their DPP chains interleaved (a lone chain is half s_nop).
+// ------------------------------------------------------------------------------------------------
+struct K2Const {   // one per context in device memory, refreshed by the host when something in it changes
+    FilterDev P;
+    AnnoOut o;
+};
+
+__device__ __forceinline__ void wave_incl_scan2(int& a, int& b) {   // two independent inclusive scans, interleaved
+#define HINGE_SCAN2_STEP(CTRL, MASK)                                        \
+    {                                                                       \
+        const int ta = dpp_or_old<CTRL, MASK>(0, a), tb = dpp_or_old<CTRL, MASK>(0, b); \
+        a += ta; b += tb;                                                   \
+    }
+    HINGE_SCAN2_STEP(0x111, 0xf) HINGE_SCAN2_STEP(0x112, 0xf) HINGE_SCAN2_STEP(0x114, 0xf) HINGE_SCAN2_STEP(0x118, 0xf)
+    HINGE_SCAN2_STEP(0x142, 0xa) HINGE_SCAN2_STEP(0x143, 0xc)
+#undef HINGE_SCAN2_STEP
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __restrict__ C, const int* __restrict__ read_list, int n1,
+                                                              const int64_t* __restrict__ row_ptr, const unsigned* __restrict__ span16,
+                                                              const int* __restrict__ rlen, const int* __restrict__ nbins0,
+                                                              const int* __restrict__ d_min_cov, int slot_ints, int SH,
+                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int g1) {
+    extern __shared__ int lds[];
+    const int lane = lane_id();
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int reso = 40;
+    const int PADF = (SH + 2 + 3) & ~3, PADT = (2 * SH + 4 + 3) & ~3;
+    const int qcap = slot_ints - 4 * WAVE - PADF - PADT;   // (the slot keeps the size k_mask_annotate_q20 uses: same read classes)
+    int* const Pq = lds + (size_t)wib * slot_ints + PADF;
+    int* const trash = Pq + qcap + PADT + lane;
+    const int MIN_COV = *d_min_cov;
+    for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
+
+    for (int item = (int)blockIdx.x * 4 + wib; item < n1; item += g1 * 4) {
+        const int i = read_list[item];
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int rl = rlen[i];
+        const int K0 = nbins0[i];                     // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
+        const int64_t n64 = e - s;
+        const int qe = rl / 20;                       // last bin an event can fall in
+        if (n64 >= 65536 || K0 < 0 || qe >= qcap || MIN_COV < 0) {
+            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
+            continue;
+        }
+        const int n = (int)n64;
+        const unsigned* __restrict__ row = span16 + s;
+        const int Qn = qe + 1, Qs = (Qn + 3) & ~3;
+        // ---- phase 1: begin|end counts per 20-bp bin ---------------------------------------------------------
+        bool cleared = false;
+        for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
+            unsigned v[LOADS_IN_FLIGHT];
+            const unsigned* __restrict__ p = row + (unsigned)(base + lane);   // (padded by half a batch: no clamp)
+            if (n - base > (LOADS_IN_FLIGHT / 2) * WAVE) {
+#pragma unroll
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = p[u * WAVE];
+            } else if (n > 0) {
+#pragma unroll
+                for (int u = 0; u < LOADS_IN_FLIGHT / 2; u++) v[u] = p[u * WAVE];
+            }
+            if (!cleared) {   // cleared while the first batch is in flight
+                int4* z4 = reinterpret_cast<int4*>(Pq);
+                for (int t = lane; t < Qs / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
+                cleared = true;
+            }
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                if (base + u * WAVE >= n) break;   // wave-uniform
+                if (base + u * WAVE + lane < n) {
+                    const unsigned qb = (v[u] & 0xffffu) / 20u, qd = (v[u] >> 16) / 20u;
+                    int* pb = qb == 0u ? trash : Pq + qb;
+                    int* pe = qd == (unsigned)qe ? trash : Pq + qd;
+                    atomicAdd(pb, 1);
+                    atomicAdd(pe, 0x10000);
+                }
+            }
+        }
+        // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane, two rows of 256 bins per step ----------
+        int carry = 0;
+        for (int base = 0; base < Qn; base += 8 * WAVE) {
+            const int t0 = base + 4 * lane, t1 = t0 + 4 * WAVE;
+            int4 a = t0 < Qs ? *reinterpret_cast<const int4*>(Pq + t0) : make_int4(0, 0, 0, 0);
+            int4 b = t1 < Qs ? *reinterpret_cast<const int4*>(Pq + t1) : make_int4(0, 0, 0, 0);
+            a.y += a.x; a.z += a.y; a.w += a.z;
+            b.y += b.x; b.z += b.y; b.w += b.z;
+            int ia = a.w, ib = b.w;
+            wave_incl_scan2(ia, ib);
+            const int ea = ia - a.w + carry;
+            const int mid = carry + wave_last(ia);
+            const int eb = ib - b.w + mid;
+            a.x += ea; a.y += ea; a.z += ea; a.w += ea;
+            b.x += eb; b.y += eb; b.z += eb; b.w += eb;
+            if (t0 < Qs) *reinterpret_cast<int4*>(Pq + t0) = a;
+            if (t1 < Qs) *reinterpret_cast<int4*>(Pq + t1) = b;
+            carry = mid + wave_last(ib);
+        }
+        // begins of bin 0 and ends of bin qe were not counted: B0 = n - (the counted begins); from bin qe on every event is
+        // consumed: PB' = n - B0, PE = n
+        const int counted_b = carry & 0xffff;
+        const int B0 = n - counted_b;
+        {
+            const int tot = counted_b | (n << 16);
+            for (int t = qe + lane; t < Qs + PADT; t += WAVE) Pq[t] = tot;
+        }
+        auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return k > 0 ? (p & 0xffff) + B0 - (int)((unsigned)p >> 16) : 0; };
+        auto covc = [&](int k) {
+            const int qb = 2 * k - 1 - SH;
+            return (qb >= 0 ? (Pq[qb] & 0xffff) + B0 : 0) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16);
+        };
+        // The cutoff profile is zero from its last bin on, so any bound >= the reference's K works (see k_mask_annotate_q20)
+        const int KC = nbins_of<40>(n, rl + 20 * SH, reso);
+        // ---- coverage mask on the cutoff profile: covc(k) > MIN_COV  <=>  PB'[2k-1-SH] - PE[2k-1+SH] > MIN_COV - B0 where the
+        // begin prefix exists (2k-1-SH >= 0); before that covc = -PE <= 0 <= MIN_COV ------------------------------------
+        RunState run{0, 0ull, 0, 0};
+        const int thr = MIN_COV - B0;
+        const int kmin = (SH + 2) / 2;   // first k with 2k - 1 - SH >= 0
+        for (int base = 0; base < KC; base += WAVE) {
+            const int k = base + lane;
+            const int d = (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16);
+            const unsigned long long M = ballot_of(d > thr && k >= kmin);
+            const int left = KC - base;
+            if (left >= 64) {
+                if (M == ~0ull) { run.prev_pos = 1ull; continue; }
+                run_feed(run, base, M, ~0ull, reso);
+            } else {
+                const unsigned long long V = (1ull << left) - 1ull;
+                run_feed(run, base, M & V, V, reso);
+            }
+        }
+        // the constants of the last phase: loaded here, not held across the loop (the asm hides the pointer from the hoisting passes)
+        const K2Const* c = C;
+        asm volatile("" : "+s"(c));
+        mask_gate_annotate(c->P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, c->o, (long long)s, n);
     }
 }
 

@@ -72,6 +72,10 @@ struct hinge_ctx {
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
     int k2_rpw = 0;              // class-1 reads per wavefront of k_mask_annotate_q20 (0: chosen from the part's size)
+    int k2_lean = 1;             // HINGE_K2_LEAN=0: class-1 reads through k_mask_annotate_q20 like the longer ones (tests, A/B timing)
+    DevBuf k2c;                  // K2Const of k_mask_annotate_lean in device memory
+    K2Const k2c_host;            // what was uploaded last
+    bool k2c_valid = false;
     bool trace_padded = false;   // the trace buffer is the library's own copy with 8 spare bytes behind it
     int64_t trace_bytes = 0;
     int tbytes = 1;
@@ -221,6 +225,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
     if (const char* g = getenv("HINGE_K2_RPW")) ctx->k2_rpw = std::max(1, atoi(g));
+    if (const char* g = getenv("HINGE_K2_LEAN")) ctx->k2_lean = atoi(g);
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -238,7 +243,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
-                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb};
+                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -724,15 +729,38 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         // class-1 reads per wavefront: 3 once the part has enough reads to fill the GPU several times over with a third of the
         // wavefronts (84.1 us vs 88.8 us on 86 588 reads; 2: 87.4, 4: 84.5), 1 for small parts; HINGE_K2_RPW overrides
         const int rpw = ctx->k2_rpw > 0 ? ctx->k2_rpw : std::min(3, std::max(1, n1 / 16384));
-        const int g = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4);
-        if (ctx->use_span16)
-            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+        const bool lean = ctx->use_span16 && ctx->k2_lean != 0 && n1 > 0;
+        if (lean) {
+            // class-1 reads (one LDS slot; nearly all of a part) through the lean kernel; its constants sit in device memory
+            K2Const hc;
+            memset(&hc, 0, sizeof(hc));
+            hc.P = to_dev(p);
+            hc.o = anno_out(ctx);
+            int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
+            if (rc) return rc;
+            if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
+                ctx->k2c_host = hc;
+                CK(hipMemcpyAsync(ctx->k2c.p, &ctx->k2c_host, sizeof(K2Const), hipMemcpyHostToDevice, ctx->stream));
+                ctx->k2c_valid = true;
+            }
+            const int g1 = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw);
+            hipLaunchKernelGGL(k_mask_annotate_lean, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, (const int*)ctx->bucket_list.p, n1,
                                (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
-        else
-            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
-                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+                               (const int*)&sc(ctx)->min_cov, slot, SH, (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1);
+        }
+        const int n1q = lean ? 0 : n1;   // what is left for k_mask_annotate_q20: the reads that need two or four slots (+ class 1 without the lean kernel)
+        const int* list_q = (const int*)ctx->bucket_list.p + (lean ? n1 : 0);
+        const int g = ((n1q + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4;
+        if (g > 0) {
+            if (ctx->use_span16)
+                hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), list_q, n1q, n2, n4,
+                                   (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
+                                   (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+            else
+                hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), list_q, n1q, n2, n4,
+                                   (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
+                                   (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+        }
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is

@@ -180,6 +180,8 @@ int hinge_trim_classify_types(hinge_ctx* ctx, int64_t n_sel, const int64_t* sel,
  * them anyway (`hinge maximal`: the best one or two overlaps of every (A, B) pair): one wavefront per A read streams the part
  * with coalesced loads instead of gathering a list (a list in hash-map order costs six scattered cache lines per overlap).   */
 int hinge_trim_classify_part(hinge_ctx* ctx, int32_t aln_threshold, int32_t theta, int32_t theta2, uint8_t* type_out);
+/* The same with all ten fields of hinge_trim_classify per overlap: out[n_ovl][10], storage order.                          */
+int hinge_trim_classify_part_full(hinge_ctx* ctx, int32_t aln_threshold, int32_t theta, int32_t theta2, int32_t* out);
 /* Sequential containment resolution of `hinge maximal` (maximal.cpp:780-858), host side, no device work: reads in
  * ascending id; a read that is still active is removed if one of its containers is active at that moment (containers
  * of lower id have their final state by then, those of higher id their initial one).  pairs = n_pairs (a, b) int32 rows,

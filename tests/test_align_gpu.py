@@ -67,10 +67,40 @@ def test_trim_classify_part_equals_the_list_form(datasets, oracle_lib, tmp_path,
     thr = (1000, 300, 0)
     full = ctx.trim_classify(sel, a_of, *thr)
     types = ctx.trim_classify_types(sel, a_of, *thr)
-    part = ctx.trim_classify_part(n, *thr)
+    part = ctx.trim_classify_part(n, *thr)                 # the streaming kernel (one lane per overlap over an LDS-staged .las)
+    part_full = ctx.trim_classify_part_full(n, *thr)
+    os.environ["HINGE_K4_ROWS"] = "1"                       # the eight-lanes-per-overlap kernel
+    try:
+        part_rows = ctx.trim_classify_part(n, *thr)
+    finally:
+        del os.environ["HINGE_K4_ROWS"]
     assert np.array_equal(types, full[:, 4].astype(np.uint8))
     assert np.array_equal(part, types)
+    assert np.array_equal(part_rows, types)
+    assert np.array_equal(part_full, full), np.nonzero((part_full != full).any(axis=1))[0][:10]
     assert len(set(part.tolist())) >= 4
+    ctx.close()
+
+
+def test_trim_classify_stream_with_masks_that_cut_deep(datasets, oracle_lib, tmp_path):
+    """Masks that end in the middle of the reads (the walks of the streaming kernel then run far into the traces) and traces longer
+    than the wavefront's stage buffer can hold 64 of: the stream form against the list form, all ten fields."""
+    ctx, recs, pile, eff, a_of, toff, tlen = _setup(datasets, oracle_lib, tmp_path, "long_reads")
+    n = pile.n_ovl
+    rng = np.random.default_rng(7)
+    rl = eff[:, 1].max()
+    eff2 = eff.copy()
+    cut = rng.random(len(eff2)) < 0.5
+    eff2[cut, 0] = (eff2[cut, 0] + rng.integers(0, 6000, size=int(cut.sum()))).astype(np.int32)
+    eff2[cut, 1] = np.maximum(eff2[cut, 0], eff2[cut, 1] - rng.integers(0, 6000, size=int(cut.sum()))).astype(np.int32)
+    ctx.set_eff_reads(eff2)
+    sel = np.arange(n, dtype=np.int64)
+    thr = (1000, 300, 0)
+    full = ctx.trim_classify(sel, a_of, *thr)
+    part_full = ctx.trim_classify_part_full(n, *thr)
+    assert np.array_equal(part_full, full), np.nonzero((part_full != full).any(axis=1))[0][:10]
+    assert (tlen.astype(np.int64) * 64 > 10240).any()       # some steps cannot stage all 64 overlaps at once
+    assert rl > 0 and len(set(full[:, 4].tolist())) >= 5
     ctx.close()
 
 
