@@ -77,6 +77,7 @@ SYMBOLS = [
     ("hinge_trim_classify_part", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     ("hinge_trim_classify_part_full", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
     ("hinge_matching_position", C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
+    ("hinge_select_edges", C.c_int, [_VP, C.c_int32, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     ("hinge_filter_mask_annotate_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_hinges_async", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_check", C.c_int, [_VP]),
@@ -397,6 +398,22 @@ class Context:
         out = np.zeros(max(len(q_ovl), 1), np.int32)
         self._ck(self.lib.hinge_matching_position(self.h, len(q_ovl), _ptr(q_ovl), _ptr(q_pos), _ptr(out)))
         return out[:len(q_ovl)]
+
+    def select_edges(self, read_active, off_fwd, off_bwd, match_rec, h_off, h_rec, k_off, k_rec, hinge_tolerance: int, hinge_slack: int):
+        """hinge_select_edges: (chosen[2, n_reads], hinge_pos[2, n_reads], poison_hits[n_matches])."""
+        read_active = np.ascontiguousarray(read_active, dtype=np.uint8)
+        n = len(read_active)
+        off_fwd, off_bwd, h_off, k_off = (np.ascontiguousarray(v, dtype=np.int64) for v in (off_fwd, off_bwd, h_off, k_off))
+        match_rec = np.ascontiguousarray(match_rec, dtype=np.int32).reshape(-1, 9)
+        h_rec = np.ascontiguousarray(h_rec, dtype=np.int32).reshape(-1, 3)
+        k_rec = np.ascontiguousarray(k_rec, dtype=np.int32).reshape(-1, 2)
+        chosen = np.zeros((2, n), np.int32)
+        hpos = np.zeros((2, n), np.int32)
+        poison = np.zeros(max(len(match_rec), 1), np.int32)
+        self._ck(self.lib.hinge_select_edges(self.h, n, _ptr(read_active), len(match_rec), _ptr(off_fwd), _ptr(off_bwd), _ptr(match_rec) if len(match_rec) else None,
+                                             _ptr(h_off), _ptr(h_rec) if len(h_rec) else None, _ptr(k_off), _ptr(k_rec) if len(k_rec) else None,
+                                             int(hinge_tolerance), int(hinge_slack), _ptr(chosen), _ptr(hpos), _ptr(poison)))
+        return chosen, hpos, poison[:len(match_rec)]
 
     def filter_mask_annotate_async(self, p: FilterParams):
         self._ck(self.lib.hinge_filter_mask_annotate_async(self.h, C.byref(p)))

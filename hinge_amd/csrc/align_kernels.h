@@ -257,10 +257,10 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify_rows(int r_begin, int r
 // ------------------------------------------------------------------------------------------------
 constexpr int STREAM_CAP = 10240;   // bytes of staged .las per wavefront: 64 overlaps of ~130 B are 8.3 KB; 16 workgroups per CU
 
-template <int TB, typename FETCH>
+template <int TB, typename FETCH, typename SUM>
 __device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, const int comp, const int2 ea, const int2 eb, const int tl,
-                                              FETCH adv /*B advance of trace pair j*/, const int aln_threshold, const int theta, const int theta2,
-                                              const int trim, ClassifyOut& o) {
+                                              FETCH adv /*B advance of trace pair j*/, SUM sum_adv /*sum of adv(0 .. count - 1)*/, const int aln_threshold,
+                                              const int theta, const int theta2, const int trim, ClassifyOut& o) {
     const int ninner = max(tl / 2 - 1, 0);
     const int np = trim ? ninner + 2 : 0;
     const int sign = 1 - 2 * comp;
@@ -271,8 +271,7 @@ __device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, cons
     bool s_found = false, e_found = false;
     int s_idx = np, s_a = 0, s_q = 0, e_idx = 0, e_a = 0, e_q = 0;
     if (np > 0) {
-        int T = 0;
-        for (int j = 0; j < ninner; j++) T += adv(j);
+        const int T = sum_adv(ninner);
         // first point (ascending index) with a >= ea.x and q >= qlo
         if (av.x >= ea.x && q_first >= qlo) { s_found = true; s_idx = 0; s_a = av.x; s_q = q_first; }
         else {
@@ -372,7 +371,8 @@ __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int 
                     // one overlap whose trace alone exceeds the stage buffer (> 5000 trace points): its lane walks global memory
                     if (lane == first) {
                         const unsigned char* tp = trace + t0;
-                        classify_lane<TB>(av, bs, comp, ea, eb, tl, [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); },
+                        auto adv = [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); };
+                        classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, [&](int cnt) { int T = 0; for (int j = 0; j < cnt; j++) T += adv(j); return T; },
                                           aln_threshold, theta, theta2, trim, o);
                         if (type_out) type_out[k] = (unsigned char)o.type;
                         if (full_out) full_out[k] = o;
@@ -393,8 +393,34 @@ __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int 
                 __syncthreads();
                 if ((take >> lane) & 1ull) {
                     const unsigned char* tp = stage + (int)(t0 - base);
-                    classify_lane<TB>(av, bs, comp, ea, eb, tl, [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)*reinterpret_cast<const unsigned short*>(tp + 4 * j + 2); },
-                                      aln_threshold, theta, theta2, trim, o);
+                    auto adv = [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); };
+                    // The sum over every pair is the one walk that touches the whole trace: whole aligned words when the trace starts
+                    // on an even byte (it does in a .las: 12 + a sum of even record sizes) - the advances are then bytes 1 and 3 of
+                    // every word (one byte per value) resp. its upper half (two bytes per value) - else value by value.
+                    auto sum_words = [&](int cnt) {
+                        const unsigned lo = (unsigned)(t0 - base);
+                        int T = 0;
+                        if (cnt <= 0) return 0;
+                        if (TB == 1 && !(lo & 1u)) {
+                            const unsigned* W = reinterpret_cast<const unsigned*>(stage);
+                            const unsigned hi = lo + 2u * (unsigned)cnt;            // exclusive end, even
+                            const unsigned w0 = lo >> 2, w1 = (hi - 1u) >> 2;
+                            unsigned m0 = (lo & 2u) ? 0xff000000u : 0xff00ff00u;    // a trace that starts in the word's second half
+                            const unsigned m1 = (hi & 2u) ? 0x0000ff00u : 0xff00ff00u;   // one that ends after its first half
+                            if (w0 == w1) return (int)__builtin_amdgcn_sad_u8(W[w0] & m0 & m1, 0u, 0u);
+                            unsigned acc = __builtin_amdgcn_sad_u8(W[w0] & m0, 0u, 0u);
+                            for (unsigned w = w0 + 1; w < w1; w++) acc = __builtin_amdgcn_sad_u8(W[w] & 0xff00ff00u, 0u, acc);
+                            return (int)__builtin_amdgcn_sad_u8(W[w1] & m1, 0u, acc);
+                        }
+                        if (TB == 2 && !(lo & 3u)) {
+                            const unsigned* W = reinterpret_cast<const unsigned*>(stage) + (lo >> 2);
+                            for (int j = 0; j < cnt; j++) T += (int)(W[j] >> 16);
+                            return T;
+                        }
+                        for (int j = 0; j < cnt; j++) T += adv(j);
+                        return T;
+                    };
+                    classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, sum_words, aln_threshold, theta, theta2, trim, o);
                     if (type_out) type_out[k] = (unsigned char)o.type;
                     if (full_out) full_out[k] = o;
                 }

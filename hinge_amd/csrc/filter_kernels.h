@@ -1077,7 +1077,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
                                                               const int64_t* __restrict__ row_ptr, const unsigned* __restrict__ span16,
                                                               const int* __restrict__ rlen, const int* __restrict__ nbins0,
                                                               const int* __restrict__ d_min_cov, int slot_ints, int SH,
-                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int g1) {
+                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int g1,
+                                                              int ablate /*timing experiments only (HINGE_K2_ABLATE): leave a read after phase k; 0 = off*/) {
     extern __shared__ int lds[];
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1132,6 +1133,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
                 }
             }
         }
+        if (ablate == 1) continue;
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane, two rows of 256 bins per step ----------
         int carry = 0;
         for (int base = 0; base < Qn; base += 8 * WAVE) {
@@ -1151,6 +1153,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
             if (t1 < Qs) *reinterpret_cast<int4*>(Pq + t1) = b;
             carry = mid + wave_last(ib);
         }
+        if (ablate == 2) continue;
         // begins of bin 0 and ends of bin qe were not counted: B0 = n - (the counted begins); from bin qe on every event is
         // consumed: PB' = n - B0, PE = n
         const int counted_b = carry & 0xffff;
@@ -1184,10 +1187,20 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
                 run_feed(run, base, M & V, V, reso);
             }
         }
-        // the constants of the last phase: loaded here, not held across the loop (the asm hides the pointer from the hoisting passes)
+        if (ablate == 3) continue;
+        // the constants of the last phase: loaded here in one go, not held across the loop (the asm hides the pointer from the
+        // hoisting passes; the copies are values, so nothing is re-read after the stores that follow)
         const K2Const* c = C;
         asm volatile("" : "+s"(c));
-        mask_gate_annotate(c->P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, c->o, (long long)s, n);
+        typedef const int __attribute__((address_space(4)))* ConstWords;   // constant address space: scalar loads (s_load_dwordx8 ...)
+        const ConstWords cw = (ConstWords)(unsigned long long)c;
+        K2Const kc;
+        static_assert(sizeof(K2Const) % sizeof(int) == 0, "copied word by word");
+#pragma unroll
+        for (int t = 0; t < (int)(sizeof(K2Const) / sizeof(int)); t++) reinterpret_cast<int*>(&kc)[t] = cw[t];
+        const FilterDev& P = kc.P;
+        const AnnoOut& o = kc.o;
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n);
     }
 }
 

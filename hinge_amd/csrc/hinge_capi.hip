@@ -12,6 +12,7 @@
 #include "filter_kernels.h"
 #include "hinge_call_kernel.h"
 #include "align_kernels.h"
+#include "select_kernel.h"
 
 using namespace hinge;
 
@@ -72,6 +73,7 @@ struct hinge_ctx {
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
     int k2_rpw = 0;              // class-1 reads per wavefront of k_mask_annotate_q20 (0: chosen from the part's size)
+    int k2_ablate = 0;           // HINGE_K2_ABLATE (timing experiments): k_mask_annotate_lean leaves every read after phase k
     int k2_lean = 1;             // HINGE_K2_LEAN=0: class-1 reads through k_mask_annotate_q20 like the longer ones (tests, A/B timing)
     DevBuf k2c;                  // K2Const of k_mask_annotate_lean in device memory
     K2Const k2c_host;            // what was uploaded last
@@ -226,6 +228,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
     if (const char* g = getenv("HINGE_K2_RPW")) ctx->k2_rpw = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_K2_LEAN")) ctx->k2_lean = atoi(g);
+    if (const char* g = getenv("HINGE_K2_ABLATE")) ctx->k2_ablate = atoi(g);
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -746,7 +749,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
             const int g1 = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw);
             hipLaunchKernelGGL(k_mask_annotate_lean, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, (const int*)ctx->bucket_list.p, n1,
                                (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, SH, (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1);
+                               (const int*)&sc(ctx)->min_cov, slot, SH, (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1, ctx->k2_ablate);
         }
         const int n1q = lean ? 0 : n1;   // what is left for k_mask_annotate_q20: the reads that need two or four slots (+ class 1 without the lean kernel)
         const int* list_q = (const int*)ctx->bucket_list.p + (lean ? n1 : 0);

@@ -502,44 +502,52 @@ int main(int argc, char* argv[]) {
     }
 
     fclose(fopen("hinge_debug.txt", "w"));
-    // best-overlap selection, hinging.cpp:1911-2148
-    int hinge_pos = -1;
-    for (int i = 0; i < n_read; i++) {
-        if (!active[(size_t)i]) continue;
-        const Match* chosen = nullptr;
+    // best-overlap selection, hinging.cpp:1911-2148: one walk per (read, direction) on the GPU (k_select_edges behind
+    // hinge_select_edges); the host packs the classified matches and the hinge tables and prints what was chosen, in read order
+    {
+        std::vector<int64_t> off_f((size_t)n_read + 1, 0), off_b((size_t)n_read + 1, 0), h_off((size_t)n_read + 1, 0), k_off((size_t)n_read + 1, 0);
+        int64_t nm = 0;
+        for (int i = 0; i < n_read; i++) nm += (int64_t)matches_forward[(size_t)i].size() + (int64_t)matches_backward[(size_t)i].size();
+        std::vector<int32_t> rec((size_t)nm * 9);
+        std::vector<const Match*> who((size_t)nm);
+        int64_t w = 0;
         for (int dirn = 0; dirn < 2; dirn++) {
-            std::vector<Match>& ms = (dirn == 0 ? matches_forward : matches_backward)[(size_t)i];
-            int plain = 0, internal = 0;
-            for (auto& m : ms) {
-                if (!m.c.active || !active[(size_t)m.b]) continue;
-                if (m.c.type == (dirn == 0 ? MT_FORWARD : MT_BACKWARD) && plain == 0) {
-                    bool poisoned = false;
-                    for (auto& nk : new_killed_hinges_vec[(size_t)i]) {
-                        bool hit;
-                        if (dirn == 0)
-                            hit = ((m.comp != 1) && (nk.type == -1) && (nk.pos > m.c.eff_be)) || ((m.comp == 1) && (nk.type == 1) && (nk.pos < m.c.eff_bb));
-                        else
-                            hit = ((m.comp != 1) && (nk.type == 1) && (nk.pos < m.c.eff_bb)) || ((m.comp == 1) && (nk.type == -1) && (nk.pos > m.c.eff_be));
-                        if (hit) { print_overlap(out_skipped, m); poisoned = true; }
-                    }
-                    if (!poisoned) { chosen = &m; hinge_pos = -1; plain = 1; }
-                } else if (m.c.type == (dirn == 0 ? MT_FORWARD_INTERNAL : MT_BACKWARD_INTERNAL) && !hinges_vec[(size_t)m.b].empty() && internal == 0) {
-                    int anchor, want;
-                    if (dirn == 0) { anchor = m.comp == 1 ? m.be : m.bb; want = 1 - 2 * m.comp; }
-                    else { anchor = m.comp == 1 ? m.bb : m.be; want = -1 + 2 * m.comp; }
-                    for (auto& hb : hinges_vec[(size_t)m.b])
-                        if ((anchor > hb.pos - HINGE_TOLERANCE) && (anchor < hb.pos + HINGE_TOLERANCE) && hb.type == want && hb.active) {
-                            if (plain == 0 || m.c.weight > chosen->c.weight - 2 * HINGE_SLACK) { chosen = &m; plain = 1; internal = 1; hinge_pos = hb.pos; }
-                            break;
-                        }
+            std::vector<int64_t>& off = dirn == 0 ? off_f : off_b;
+            for (int i = 0; i < n_read; i++) {
+                off[(size_t)i] = w;
+                for (auto& m : (dirn == 0 ? matches_forward : matches_backward)[(size_t)i]) {
+                    int32_t* r = &rec[(size_t)w * 9];
+                    r[0] = m.b; r[1] = m.comp; r[2] = m.c.type; r[3] = m.c.active; r[4] = m.c.weight; r[5] = m.c.eff_bb; r[6] = m.c.eff_be; r[7] = m.bb; r[8] = m.be;
+                    who[(size_t)w++] = &m;
                 }
             }
-            if (chosen) {
-                print_overlap(out_hg, *chosen);
-                print_overlap2(out_hg2, *chosen, hinge_pos);
-                if (dirn == 0) chosen = nullptr;   // reset only after the forward pass (hinging.cpp:2026)
-            } else {
-                fprintf(deadend_out, "%d\t matches_%s size: %d\n", i, dirn == 0 ? "forward" : "backward", (int)ms.size());
+            off[(size_t)n_read] = w;
+        }
+        std::vector<int32_t> h_rec, k_rec;
+        for (int i = 0; i < n_read; i++) {
+            h_off[(size_t)i] = (int64_t)h_rec.size() / 3;
+            k_off[(size_t)i] = (int64_t)k_rec.size() / 2;
+            for (auto& h : hinges_vec[(size_t)i]) { h_rec.push_back(h.pos); h_rec.push_back(h.type); h_rec.push_back(h.active ? 1 : 0); }
+            for (auto& h : new_killed_hinges_vec[(size_t)i]) { k_rec.push_back(h.pos); k_rec.push_back(h.type); }
+        }
+        h_off[(size_t)n_read] = (int64_t)h_rec.size() / 3;
+        k_off[(size_t)n_read] = (int64_t)k_rec.size() / 2;
+        std::vector<int32_t> chosen((size_t)n_read * 2), chosen_hpos((size_t)n_read * 2), poison((size_t)std::max<int64_t>(nm, 1), 0);
+        HH_CHECK(ctx, hinge_select_edges(ctx, n_read, active.data(), nm, off_f.data(), off_b.data(), rec.data(), h_off.data(), h_rec.data(), k_off.data(),
+                                         k_rec.data(), HINGE_TOLERANCE, HINGE_SLACK, chosen.data(), chosen_hpos.data(), poison.data()));
+        for (int i = 0; i < n_read; i++) {
+            if (!active[(size_t)i]) continue;
+            for (int dirn = 0; dirn < 2; dirn++) {
+                const std::vector<int64_t>& off = dirn == 0 ? off_f : off_b;
+                for (int64_t j = off[(size_t)i]; j < off[(size_t)i + 1]; j++)        // .edges.skipped: one line per killed hinge that poisoned the match
+                    for (int t = 0; t < poison[(size_t)j]; t++) print_overlap(out_skipped, *who[(size_t)j]);
+                const int pick = chosen[(size_t)dirn * (size_t)n_read + (size_t)i];
+                if (pick >= 0) {
+                    print_overlap(out_hg, *who[(size_t)pick]);
+                    print_overlap2(out_hg2, *who[(size_t)pick], chosen_hpos[(size_t)dirn * (size_t)n_read + (size_t)i]);
+                } else {
+                    fprintf(deadend_out, "%d\t matches_%s size: %d\n", i, dirn == 0 ? "forward" : "backward", (int)(off[(size_t)i + 1] - off[(size_t)i]));
+                }
             }
         }
     }

@@ -193,6 +193,23 @@ int hinge_resolve_containment(int32_t n_reads, uint8_t* active, int64_t n_pairs,
 /* LOverlap::GetMatchingPosition (LAInterface.cpp:4498-4546) for nq (overlap, position on A) queries.        */
 int hinge_matching_position(hinge_ctx* ctx, int64_t nq, const int64_t* q_ovl, const int32_t* q_pos, int32_t* out);
 
+/* Best-overlap edge selection of `hinge layout` (hinging.cpp:1911-2148): for every active read one walk over its forward and
+ * one over its backward matches, each keeping at most one edge.  All arrays are host pointers.
+ *   read_active[n_reads]             reads[i]->active after the hinge bookkeeping
+ *   match_rec[n_matches][9]          b, reverse_complement_match_, match_type_, active, weight, eff_read_B_match_start_,
+ *                                    eff_read_B_match_end_, read_B_match_start_, read_B_match_end_ (LAInterface.h:76-110)
+ *   off_fwd / off_bwd[n_reads + 1]   matches_forward[i] / matches_backward[i] = match_rec[off[i] .. off[i + 1]), in
+ *                                    compare_overlap_weight order (hinging.cpp:1244-1256)
+ *   h_off[n_reads + 1], h_rec[][3]   hinges_vec[i]: pos, type, active        (hinging.cpp:1200-1240, 1650-1675)
+ *   k_off[n_reads + 1], k_rec[][2]   new_killed_hinges_vec[i]: pos, type     (hinging.cpp:1262-1321)
+ * Out: chosen[2][n_reads] = index into match_rec of the edge kept by the forward ([0][i]) and backward ([1][i]) walk, -1 = dead
+ * end or inactive read; chosen_hinge_pos[2][n_reads] = the hinge_pos PrintOverlapToFile2 prints with it; poison_hits[n_matches] =
+ * how many killed hinges poisoned the match (= its lines in .edges.skipped).                                                    */
+int hinge_select_edges(hinge_ctx* ctx, int32_t n_reads, const uint8_t* read_active, int64_t n_matches, const int64_t* off_fwd,
+                       const int64_t* off_bwd, const int32_t* match_rec, const int64_t* h_off, const int32_t* h_rec, const int64_t* k_off,
+                       const int32_t* k_rec, int32_t hinge_tolerance, int32_t hinge_slack, int32_t* chosen, int32_t* chosen_hinge_pos,
+                       int32_t* poison_hits);
+
 /* Staged launches with no host round trip, for pipelines that put a collective between the stages
  * (multi-GPU).  A pass starts at hinge_filter_stats (which clears the per-pass device scalars and is
  * itself asynchronous); check reports the HINGE_E_* flags raised since then.                       */

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--genome", type=int, default=1_000_000)
     ap.add_argument("--workload", default="cfg2_ecoli160")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--dir", default="", help="work in this directory and keep it (e.g. to profile the executables on the data set afterwards)")
     ap.add_argument("--exact-config", action="store_true", help="at the configuration's own genome size: its own repeat model too (the data set bench.py uses)")
     args = ap.parse_args()
     import oracle
@@ -30,7 +31,10 @@ def main():
     if args.exact_config and args.genome == synth.CONFIGS[args.workload].genome_len:
         spec = dataclasses.replace(synth.CONFIGS[args.workload], n_blocks=1)
     d = synth.generate(spec)
-    tmp = tempfile.mkdtemp(prefix="hinge_e2e_")
+    tmp = args.dir or tempfile.mkdtemp(prefix="hinge_e2e_")
+    if args.dir:
+        os.makedirs(tmp, exist_ok=True)
+        args.keep = True
     out = {"workload": "%s at G=%d" % (args.workload, args.genome), "reads": d.n_reads, "overlaps": d.novl}
     try:
         dirs = {}

@@ -20,6 +20,10 @@ VARIANTS = [
     ("lean rpw=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "3"}),
     ("lean rpw=4", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "4"}),
     ("lean rpw=6", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "6"}),
+    # cumulative cost of the phases of the lean kernel: every read is left after phase k (results are garbage: not compared)
+    ("lean abl=1", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "1"}),   # histogram
+    ("lean abl=2", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "2"}),   # + prefix scan
+    ("lean abl=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "3"}),   # + mask pass
 ]
 
 
@@ -45,7 +49,7 @@ def main():
         parts.append((d.rlen.copy(), d.n_reads, pile.n_ovl, tens, max_pile, in_range))
     base = None
     for name, env in VARIANTS:
-        for k in ("HINGE_K2_LEAN", "HINGE_K2_RPW", "HINGE_NO_SPAN16"):
+        for k in ("HINGE_K2_LEAN", "HINGE_K2_RPW", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctxs = []
@@ -60,8 +64,11 @@ def main():
             ctx.filter_median(P, 0, n - 1, fetch=True)
             ctx.filter_mask_annotate(P)      # synchronous: sizes the annotation buffer
             ctxs.append(ctx)
-        res = [(c.get_masks(), c.get_annotations()[:3]) for c in ctxs]
-        if base is None:
+        ablated = "HINGE_K2_ABLATE" in env
+        res = None if ablated else [(c.get_masks(), c.get_annotations()[:3]) for c in ctxs]
+        if ablated:
+            pass
+        elif base is None:
             base = res
         else:
             for (m0, a0), (m1, a1) in zip(base, res):

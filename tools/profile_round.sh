@@ -8,8 +8,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-PMCB="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"      # counter passes serialise the kernels: few steps
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e"
+PMCB="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e"      # counter passes serialise the kernels: few steps
 (cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
