@@ -135,14 +135,27 @@ template <> struct SpanLoad<true> {
     static __device__ __forceinline__ int2 get(raw v) { return make_int2((int)(v & 0xffffu), (int)(v >> 16)); }
 };
 
+// What k_mask_annotate_lean needs to start on a read, written by k_cov_stats in the order of K2's read list (pos_of[]): one
+// 32-byte scalar load instead of the chain read_list -> row_ptr / rlen / nbins0 / cov_off (two dependent round trips to HBM per read).
+struct alignas(32) K2Rec {
+    long long row;        // row_ptr[i]
+    int n;                // pile-up size (clipped to INT_MAX)
+    int rl;               // rlen[i]
+    int i;                // read id
+    int K0;               // bins of the plain profile, -1: not a read for the fast kernels (nbins0[i])
+    long long cov_off;    // where K2 stores the read's coverage bins (0 when they are not wanted)
+};
+
 template <int RESO, bool PACKED>
-__global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+__device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                      const int2* __restrict__ a_span, const unsigned* __restrict__ span16,
                                                      const int* __restrict__ rlen, int reso,
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
                                                      unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/,
                                                      int* __restrict__ pass_scalars, int n_pass_scalars, int* __restrict__ d_min_cov,
-                                                     int set_min_cov, int min_cov_value) {
+                                                     int set_min_cov, int min_cov_value,
+                                                     const int* __restrict__ pos_of /*nullptr, or [r_end - r_begin + 1]: slot of the read in k2rec, -1 none*/,
+                                                     K2Rec* __restrict__ k2rec, const long long* __restrict__ cov_off /*nullptr or by read - r_begin*/) {
     // This is the first kernel of a pass and touches none of the pass scalars itself, so workgroup 0 clears
     // them (and applies a pending MIN_COV) instead of two 4-us memset launches in front of it.
     if (blockIdx.x == 0) {
@@ -153,25 +166,65 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);   // tell the compiler it is wave-uniform: row bounds become scalar loads
     const int nwaves = (gridDim.x * BLOCK) >> 6;
     long long blk_cov = 0, blk_slot = 0;
-    // (no hand-written prefetch of the next row: measured 7x slower - it serialises the wave's loads)
-    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        const int rl = rlen[i];
+    typedef SpanLoad<PACKED> SL;
+    typedef typename SL::raw Raw;
+    const Raw* __restrict__ spans = PACKED ? (const Raw*)(const void*)span16 : (const Raw*)(const void*)a_span;
+    // A pass over a part that is not in the Infinity Cache is bound by memory latency, not bandwidth: a wavefront that loads its
+    // row's bounds, then the row, then reduces it has bytes in flight for only part of the time.  So the chain is software-pipelined:
+    // while read i is reduced, the first batch of read i + nwaves is already in flight (registers nxt[]) and the bounds of read
+    // i + 2 nwaves are being fetched.  Only rows of fewer than 65536 overlaps take part (the others are streamed as before).
+    auto issue = [&](int64_t s, int n, Raw (&v)[LOADS_IN_FLIGHT]) {   // unconditional loads from a clamped index off the scalar row base
+        const Raw* __restrict__ row = spans + s;
+        const unsigned last = (unsigned)(n - 1);
+#pragma unroll
+        for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(u * WAVE + lane), last)];
+    };
+    int i = r_begin + wave, i1 = i + nwaves;
+    int64_t s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+    int rl0 = 0, rl1 = 0, pos0 = -1, pos1 = -1;          // (the slot in k2rec and the bin offset travel with the bounds: no load at the end of a read)
+    long long co0 = 0, co1 = 0;
+    auto meta = [&](int r, int64_t& ms, int64_t& me, int& mrl, int& mpos, long long& mco) {
+        ms = row_ptr[r]; me = row_ptr[r + 1]; mrl = rlen[r];
+        mpos = pos_of ? pos_of[r - r_begin] : -1;
+        mco = cov_off ? cov_off[r - r_begin] : 0;
+    };
+    if (i <= r_end) meta(i, s0, e0, rl0, pos0, co0);
+    if (i1 <= r_end) meta(i1, s1, e1, rl1, pos1, co1);
+    Raw pre[LOADS_IN_FLIGHT];
+#pragma unroll
+    for (int u = 0; u < LOADS_IN_FLIGHT; u++) pre[u] = Raw();
+    if (i <= r_end && e0 - s0 < 65536 && e0 > s0) issue(s0, (int)(e0 - s0), pre);
+    while (i <= r_end) {
+        const int i2 = i1 + nwaves;
+        int64_t s2 = 0, e2 = 0;
+        int rl2 = 0, pos2 = -1;
+        long long co2 = 0;
+        if (i2 <= r_end) meta(i2, s2, e2, rl2, pos2, co2);
+        Raw nxt[LOADS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < LOADS_IN_FLIGHT; u++) nxt[u] = Raw();
+        if (i1 <= r_end && e1 - s1 < 65536 && e1 > s1) issue(s1, (int)(e1 - s1), nxt);
+        const int64_t s = s0, e = e0;
+        const int rl = rl0;
         long long tot;
         int mx = INT_MIN;
-        bool q20_ok = false;     // every coordinate in [0, rl] and fewer than 65536 overlaps: k_mask_annotate_q20 may take the read
+        bool q20_ok = false;     // every coordinate in [0, rl] and fewer than 65536 overlaps: the fast K2 kernels may take the read
         if (e - s < 65536) {
             // common case: 32-bit lane offsets from the scalar row base, unconditional loads from a clamped index (no
             // exec-mask branch and no 64-bit address arithmetic per load), one 32-bit sum (n * K < 2^32 for n < 65536)
             const int n = (int)(e - s);
-            typedef SpanLoad<PACKED> SL;
-            const typename SL::raw* __restrict__ row = (PACKED ? (const typename SL::raw*)(const void*)span16 : (const typename SL::raw*)(const void*)a_span) + s;
+            const Raw* __restrict__ row = spans + s;
             const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
             unsigned sum = 0, umx = 0;   // max as unsigned: a negative coordinate shows up as a huge one
             for (int base = 0; base < n; base += LOADS_IN_FLIGHT * WAVE) {
-                typename SL::raw v[LOADS_IN_FLIGHT];
+                Raw v[LOADS_IN_FLIGHT];
+                if (base == 0) {
 #pragma unroll
-                for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
+                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = pre[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
+                }
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                     if (base + u * WAVE >= n) break;   // wave-uniform
@@ -224,8 +277,14 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
             mx = wave_max(mx);
         }
         if (lane == 0) {
-            const int K = nbins_of<RESO>((int)(e - s), mx, reso);
-            nbins0[i] = q20_ok ? K : -1;   // bins of the plain profile for k_mask_annotate_q20, -1 = not a read for that kernel
+            const int K = nbins_of<RESO>((int)min<int64_t>(e - s, 0x7fffffff), mx, reso);
+            const int K0 = q20_ok ? K : -1;
+            nbins0[i] = K0;   // bins of the plain profile for the fast K2 kernels, -1 = not a read for them
+            if (pos0 >= 0) {
+                K2Rec r;
+                r.row = s; r.n = (int)min<int64_t>(e - s, 0x7fffffff); r.rl = rl; r.i = i; r.K0 = K0; r.cov_off = co0;
+                k2rec[pos0] = r;
+            }
             if (rl >= 5000) {
                 const long long m = tot / (long long)max(1, K);   // C division, filter.cpp:654
                 mean_cov[i] = (int)m;
@@ -235,6 +294,10 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
                 mean_cov[i] = MEAN_SENTINEL;
             }
         }
+        i = i1; s0 = s1; e0 = e1; rl0 = rl1; pos0 = pos1; co0 = co1;
+        i1 = i2; s1 = s2; e1 = e2; rl1 = rl2; pos1 = pos2; co1 = co2;
+#pragma unroll
+        for (int u = 0; u < LOADS_IN_FLIGHT; u++) pre[u] = nxt[u];
     }
     // one slot per wave: thousands of atomics on one address cost ~12 ns each (they would dominate the kernel)
     if (lane == 0) {
@@ -242,6 +305,26 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
         wave_totals[2 * wave + 1] = (unsigned long long)blk_slot;
     }
 }
+
+#define HINGE_COV_STATS_PARAMS                                                                                                          \
+    int r_begin, int r_end, const int64_t *__restrict__ row_ptr, const int2 *__restrict__ a_span, const unsigned *__restrict__ span16,  \
+        const int *__restrict__ rlen, int reso, int *__restrict__ mean_cov, int *__restrict__ nbins0,                                    \
+        unsigned long long *__restrict__ wave_totals, int *__restrict__ pass_scalars, int n_pass_scalars, int *__restrict__ d_min_cov,   \
+        int set_min_cov, int min_cov_value, const int *__restrict__ pos_of, K2Rec *__restrict__ k2rec, const long long *__restrict__ cov_off
+#define HINGE_COV_STATS_ARGS                                                                                                            \
+    r_begin, r_end, row_ptr, a_span, span16, rlen, reso, mean_cov, nbins0, wave_totals, pass_scalars, n_pass_scalars, d_min_cov,        \
+        set_min_cov, min_cov_value, pos_of, k2rec, cov_off
+template <int RESO, bool PACKED>
+__global__ __launch_bounds__(BLOCK) void k_cov_stats(HINGE_COV_STATS_PARAMS) {
+    cov_stats_body<RESO, PACKED>(HINGE_COV_STATS_ARGS);
+}
+// the same with the register budget of eight wavefronts per SIMD (HINGE_K1_W8=1: A/B timing)
+template <int RESO, bool PACKED>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cov_stats_w8(HINGE_COV_STATS_PARAMS) {
+    cov_stats_body<RESO, PACKED>(HINGE_COV_STATS_ARGS);
+}
+#undef HINGE_COV_STATS_PARAMS
+#undef HINGE_COV_STATS_ARGS
 
 // General median (any int32 values): one workgroup, 4-pass 8-bit radix select.  Run by the last block of
 // k_median_hist when some mean coverage falls outside [0, MED_BINS).
@@ -598,9 +681,11 @@ __device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long lo
 template <typename ZF, typename CF>
 __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
                                                    const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o,
-                                                   const long long row, const int n_pile, const unsigned long long flag_words = ~0ull) {
+                                                   const long long row, const int n_pile, const unsigned long long flag_words = ~0ull,
+                                                   const long long cov_at = -1 /*>= 0: the caller already has o.cov_off[i - o.cov_base]*/,
+                                                   const int2* qv_known = nullptr /*the caller already has o.qv_mask[i]*/) {
     if (o.cov_out) {   // before anything reuses the profile's LDS (cand)
-        int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
+        int* __restrict__ dst = o.cov_out + (cov_at >= 0 ? cov_at : o.cov_off[i - o.cov_base]);
         for (int j = lane; j < K0; j += WAVE) dst[j] = z(j);
         if (lane == 0) o.cov_nbins[i - o.cov_base] = K0;
     }
@@ -626,7 +711,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
     }
     int2 mk;
     {
-        int2 q = o.qv_mask ? o.qv_mask[i] : make_int2(0, 0);
+        int2 q = qv_known ? *qv_known : (o.qv_mask ? o.qv_mask[i] : make_int2(0, 0));
         if (o.keep && !o.keep[i]) { maxend = maxstart; q.y = q.x; }   // filter.cpp:767-773
         if (P.use_qv && P.use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
         else if (P.use_cov && !P.use_qv) mk = make_int2(maxstart, maxend);
@@ -1073,9 +1158,8 @@ __device__ __forceinline__ void wave_incl_scan2(int& a, int& b) {   // two indep
 #undef HINGE_SCAN2_STEP
 }
 
-__global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __restrict__ C, const int* __restrict__ read_list, int n1,
-                                                              const int64_t* __restrict__ row_ptr, const unsigned* __restrict__ span16,
-                                                              const int* __restrict__ rlen, const int* __restrict__ nbins0,
+__global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __restrict__ C, const K2Rec* __restrict__ k2rec, int n1,
+                                                              const unsigned* __restrict__ span16, const int2* __restrict__ qv_mask /*nullptr: no QV track*/,
                                                               const int* __restrict__ d_min_cov, int slot_ints, int SH,
                                                               int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int g1,
                                                               int ablate /*timing experiments only (HINGE_K2_ABLATE): leave a read after phase k; 0 = off*/) {
@@ -1090,12 +1174,22 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
     const int MIN_COV = *d_min_cov;
     for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
 
-    for (int item = (int)blockIdx.x * 4 + wib; item < n1; item += g1 * 4) {
-        const int i = read_list[item];
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        const int rl = rlen[i];
-        const int K0 = nbins0[i];                     // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
-        const int64_t n64 = e - s;
+    // One pass over a cold part is bound by memory latency (every wavefront has bytes in flight only while it waits for its own
+    // row), so the chain is pipelined: the record of the next read is fetched (one scalar load) under phase 1 of the current one,
+    // and its rows are then pulled into L2 by one load per 128-byte line whose value is never used, under phases 2-5.
+    const int step = g1 * 4;
+    int item = (int)blockIdx.x * 4 + wib;
+    if (item >= n1) return;
+    K2Rec cur = k2rec[item], nx = cur;
+    unsigned touch = 0;
+    for (; item < n1; item += step, cur = nx) {   // `continue` leaves a read
+        nx = k2rec[min(item + step, n1 - 1)];     // (used after phase 1 and as the next `cur`: never waited for here)
+        const int i = cur.i;
+        const long long s = cur.row;
+        const int rl = cur.rl;
+        const int K0 = cur.K0;                        // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
+        const long long n64 = cur.n;
+        const int2 qv = qv_mask ? qv_mask[i] : make_int2(0, 0);
         const int qe = rl / 20;                       // last bin an event can fall in
         if (n64 >= 65536 || K0 < 0 || qe >= qcap || MIN_COV < 0) {
             if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
@@ -1132,6 +1226,14 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
                     atomicAdd(pe, 0x10000);
                 }
             }
+        }
+        if (item + step < n1 && lane * 32 < nx.n) {
+            // One dword of every 128-byte line of the NEXT read's spans: brings them into L2 while phases 2-5 of this read run.
+            // Inline assembly because the value is dead: a C++ load would be sunk to its (only, artificial) use or dropped.
+            // `touch` stays allocated to the end of the iteration (the asm there), so the returning load cannot clobber a
+            // register that holds something else by then.
+            const unsigned* tp = span16 + nx.row + lane * 32;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(tp));
         }
         if (ablate == 1) continue;
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane, two rows of 256 bins per step ----------
@@ -1200,7 +1302,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
         for (int t = 0; t < (int)(sizeof(K2Const) / sizeof(int)); t++) reinterpret_cast<int*>(&kc)[t] = cw[t];
         const FilterDev& P = kc.P;
         const AnnoOut& o = kc.o;
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n);
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n, ~0ull, cur.cov_off, &qv);
+        asm volatile("" ::"v"(touch));   // (the prefetch load's register lives until here)
     }
 }
 

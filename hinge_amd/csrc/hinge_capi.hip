@@ -73,8 +73,13 @@ struct hinge_ctx {
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
     int k2_rpw = 0;              // class-1 reads per wavefront of k_mask_annotate_q20 (0: chosen from the part's size)
+    int k1_w8 = 0;               // HINGE_K1_W8=1: k_cov_stats compiled for eight wavefronts per SIMD (A/B timing)
     int k2_ablate = 0;           // HINGE_K2_ABLATE (timing experiments): k_mask_annotate_lean leaves every read after phase k
     int k2_lean = 1;             // HINGE_K2_LEAN=0: class-1 reads through k_mask_annotate_q20 like the longer ones (tests, A/B timing)
+    DevBuf k2rec, pos_of;        // K2Rec per class-1 read in K2's list order (written by k_cov_stats), and read -> slot (-1: none)
+    bool k2rec_fresh = false;    // k_cov_stats of this pass filled k2rec for the current pile-ups
+    bool k2rec_cov = false;      // ... with the coverage-bin offsets of this cut_off in them
+    int k2rec_cut = 0;
     DevBuf k2c;                  // K2Const of k_mask_annotate_lean in device memory
     K2Const k2c_host;            // what was uploaded last
     bool k2c_valid = false;
@@ -229,6 +234,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_K2_RPW")) ctx->k2_rpw = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_K2_LEAN")) ctx->k2_lean = atoi(g);
     if (const char* g = getenv("HINGE_K2_ABLATE")) ctx->k2_ablate = atoi(g);
+    if (const char* g = getenv("HINGE_K1_W8")) ctx->k1_w8 = atoi(g);
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -246,7 +252,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
-                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c};
+                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c, &ctx->k2rec, &ctx->pos_of};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -368,6 +374,15 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
         if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)nr))) return rc;
         CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
+        {   // read -> position among the class-1 reads (the order k_mask_annotate_lean works in), -1 for the other classes
+            std::vector<int> pos((size_t)nr, -1);
+            for (int t = 0; t < n1; t++) pos[(size_t)(lst[(size_t)t] - r_begin)] = t;
+            if ((rc = ensure(ctx, ctx->pos_of, sizeof(int) * (size_t)nr))) return rc;
+            if ((rc = ensure(ctx, ctx->k2rec, sizeof(K2Rec) * (size_t)std::max(n1, 1)))) return rc;
+            CK(hipMemcpyAsync(ctx->pos_of.p, pos.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
+            CK(hipStreamSynchronize(ctx->stream));   // pos is a local
+            ctx->k2rec_fresh = false;
+        }
         CK(hipStreamSynchronize(ctx->stream));   // lst is a local
         const bool pack_ok = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
         if (facts_given) {
@@ -532,6 +547,27 @@ static int flush_min_cov(hinge_ctx* ctx) {
     return HINGE_OK;
 }
 
+// Layout of K2's coverage-bin output: read i of the part gets (rlen + cut_off) / reso + 3 slots, the most bins a profile the
+// kernels accept can have (more raises ST_RANGE).  Host-computable, so no device prefix sum and no second launch.
+static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
+    if (!ctx->cov_out_on) return HINGE_OK;
+    const int key[4] = {ctx->r_begin, ctx->r_end, p->reso, p->cut_off};
+    const int nr = ctx->r_end - ctx->r_begin + 1;
+    if (memcmp(key, ctx->cov_key, sizeof(key)) != 0 || ctx->h_cov_off.size() != (size_t)nr + 1) {
+        ctx->h_cov_off.assign((size_t)nr + 1, 0);
+        for (int k = 0; k < nr; k++)
+            ctx->h_cov_off[(size_t)k + 1] = ctx->h_cov_off[(size_t)k] + ((int64_t)std::max(ctx->h_rlen[(size_t)(ctx->r_begin + k)], 0) + std::max(p->cut_off, 0)) / p->reso + 3;
+        int rc;
+        if ((rc = ensure(ctx, ctx->cov_off_d, sizeof(int64_t) * ((size_t)nr + 1)))) return rc;
+        if ((rc = ensure(ctx, ctx->cov_nb, sizeof(int) * (size_t)nr))) return rc;
+        if ((rc = ensure(ctx, ctx->cov_buf, sizeof(int) * (size_t)std::max<int64_t>(ctx->h_cov_off[(size_t)nr], 1)))) return rc;
+        CK(hipMemcpyAsync(ctx->cov_off_d.p, ctx->h_cov_off.data(), sizeof(int64_t) * ((size_t)nr + 1), hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        memcpy(ctx->cov_key, key, sizeof(key));
+    }
+    return HINGE_OK;
+}
+
 static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int nr = ctx->r_end - ctx->r_begin + 1;
     const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
@@ -545,18 +581,34 @@ static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int n_reset = (int)(SCALARS_RESET_BYTES / sizeof(int));
     const int set_mc = ctx->min_cov_pending ? 1 : 0, mc = ctx->min_cov_value;
     ctx->min_cov_pending = false;
+    {   // the K2 records carry each read's offset in the coverage-bin output: its layout must exist before this kernel runs
+        int rc = prepare_cov_out(ctx, p);
+        if (rc) return rc;
+    }
+    const long long* cov_off_arg = ctx->cov_out_on ? (const long long*)ctx->cov_off_d.p : (const long long*)nullptr;
     ProfScope _ps(ctx, KID_STATS);
-#define LAUNCH_COV_STATS(RESO, PACKED)                                                                                                 \
-    hipLaunchKernelGGL((k_cov_stats<RESO, PACKED>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end,                   \
+#define LAUNCH_COV_STATS(KERNEL, RESO, PACKED)                                                                                          \
+    hipLaunchKernelGGL((KERNEL<RESO, PACKED>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end,                        \
                        (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, \
                        p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p, (int*)ctx->scalars.p, n_reset, \
-                       &sc(ctx)->min_cov, set_mc, mc)
-    if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(40, true);
-    else if (p->reso == 40) LAUNCH_COV_STATS(40, false);
-    else if (ctx->use_span16) LAUNCH_COV_STATS(0, true);
-    else LAUNCH_COV_STATS(0, false);
+                       &sc(ctx)->min_cov, set_mc, mc, (const int*)ctx->pos_of.p, (K2Rec*)ctx->k2rec.p, cov_off_arg)
+    if (ctx->k1_w8) {
+        if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats_w8, 40, true);
+        else if (p->reso == 40) LAUNCH_COV_STATS(k_cov_stats_w8, 40, false);
+        else if (ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats_w8, 0, true);
+        else LAUNCH_COV_STATS(k_cov_stats_w8, 0, false);
+    } else {
+        if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats, 40, true);
+        else if (p->reso == 40) LAUNCH_COV_STATS(k_cov_stats, 40, false);
+        else if (ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats, 0, true);
+        else LAUNCH_COV_STATS(k_cov_stats, 0, false);
+    }
+#undef LAUNCH_COV_STATS
     CK(hipGetLastError());
     ctx->nbins0_reso = p->reso;   // nbins0[] now describes these pile-ups at this reso
+    ctx->k2rec_fresh = true;
+    ctx->k2rec_cov = ctx->cov_out_on;
+    ctx->k2rec_cut = p->cut_off;
     return HINGE_OK;
 }
 
@@ -679,33 +731,12 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
                        (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,                     \
                        (const int*)&sc(ctx)->min_cov, kcap, anno_out(ctx), LIST, COUNT)
 
-// Layout of K2's coverage-bin output: read i of the part gets (rlen + cut_off) / reso + 3 slots, the most bins a profile the
-// kernels accept can have (more raises ST_RANGE).  Host-computable, so no device prefix sum and no second launch.
-static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
-    if (!ctx->cov_out_on) return HINGE_OK;
-    const int key[4] = {ctx->r_begin, ctx->r_end, p->reso, p->cut_off};
-    const int nr = ctx->r_end - ctx->r_begin + 1;
-    if (memcmp(key, ctx->cov_key, sizeof(key)) != 0 || ctx->h_cov_off.size() != (size_t)nr + 1) {
-        ctx->h_cov_off.assign((size_t)nr + 1, 0);
-        for (int k = 0; k < nr; k++)
-            ctx->h_cov_off[(size_t)k + 1] = ctx->h_cov_off[(size_t)k] + ((int64_t)std::max(ctx->h_rlen[(size_t)(ctx->r_begin + k)], 0) + std::max(p->cut_off, 0)) / p->reso + 3;
-        int rc;
-        if ((rc = ensure(ctx, ctx->cov_off_d, sizeof(int64_t) * ((size_t)nr + 1)))) return rc;
-        if ((rc = ensure(ctx, ctx->cov_nb, sizeof(int) * (size_t)nr))) return rc;
-        if ((rc = ensure(ctx, ctx->cov_buf, sizeof(int) * (size_t)std::max<int64_t>(ctx->h_cov_off[(size_t)nr], 1)))) return rc;
-        CK(hipMemcpyAsync(ctx->cov_off_d.p, ctx->h_cov_off.data(), sizeof(int64_t) * ((size_t)nr + 1), hipMemcpyHostToDevice, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-        memcpy(ctx->cov_key, key, sizeof(key));
-    }
-    ctx->cov_valid = true;
-    return HINGE_OK;
-}
-
 static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     {
         int rc = flush_min_cov(ctx);
         if (rc) return rc;
         if ((rc = prepare_cov_out(ctx, p))) return rc;
+        ctx->cov_valid = ctx->cov_out_on;   // this pass stores the bins
     }
     const int kcap = kcap_for(ctx, p);
     const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
@@ -732,7 +763,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         // class-1 reads per wavefront: 3 once the part has enough reads to fill the GPU several times over with a third of the
         // wavefronts (84.1 us vs 88.8 us on 86 588 reads; 2: 87.4, 4: 84.5), 1 for small parts; HINGE_K2_RPW overrides
         const int rpw = ctx->k2_rpw > 0 ? ctx->k2_rpw : std::min(3, std::max(1, n1 / 16384));
-        const bool lean = ctx->use_span16 && ctx->k2_lean != 0 && n1 > 0;
+        const bool lean = ctx->use_span16 && ctx->k2_lean != 0 && n1 > 0 && ctx->k2rec_fresh && ctx->k2rec_cov == ctx->cov_out_on &&
+                          (!ctx->cov_out_on || ctx->k2rec_cut == p->cut_off);
         if (lean) {
             // class-1 reads (one LDS slot; nearly all of a part) through the lean kernel; its constants sit in device memory
             K2Const hc;
@@ -747,8 +779,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
                 ctx->k2c_valid = true;
             }
             const int g1 = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw);
-            hipLaunchKernelGGL(k_mask_annotate_lean, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, (const int*)ctx->bucket_list.p, n1,
-                               (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
+            hipLaunchKernelGGL(k_mask_annotate_lean, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, (const K2Rec*)ctx->k2rec.p, n1,
+                               (const unsigned*)ctx->span16.p, ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr,
                                (const int*)&sc(ctx)->min_cov, slot, SH, (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1, ctx->k2_ablate);
         }
         const int n1q = lean ? 0 : n1;   // what is left for k_mask_annotate_q20: the reads that need two or four slots (+ class 1 without the lean kernel)

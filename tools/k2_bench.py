@@ -18,12 +18,13 @@ VARIANTS = [
     ("lean rpw=1", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "1"}),
     ("lean rpw=2", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "2"}),
     ("lean rpw=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "3"}),
-    ("lean rpw=4", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "4"}),
     ("lean rpw=6", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "6"}),
+    ("lean rpw=12", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "12"}),
+    ("lean K1w8", {"HINGE_K2_LEAN": "1", "HINGE_K1_W8": "1"}),
     # cumulative cost of the phases of the lean kernel: every read is left after phase k (results are garbage: not compared)
-    ("lean abl=1", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "1"}),   # histogram
-    ("lean abl=2", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "2"}),   # + prefix scan
-    ("lean abl=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "3"}),   # + mask pass
+    ("lean abl=1", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "1", "HINGE_K2_RPW": "6"}),   # histogram
+    ("lean abl=2", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "2", "HINGE_K2_RPW": "6"}),   # + prefix scan
+    ("lean abl=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "3", "HINGE_K2_RPW": "6"}),   # + mask pass
 ]
 
 
@@ -49,7 +50,7 @@ def main():
         parts.append((d.rlen.copy(), d.n_reads, pile.n_ovl, tens, max_pile, in_range))
     base = None
     for name, env in VARIANTS:
-        for k in ("HINGE_K2_LEAN", "HINGE_K2_RPW", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE"):
+        for k in ("HINGE_K2_LEAN", "HINGE_K2_RPW", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctxs = []
