@@ -190,19 +190,18 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
     };
     if (i <= r_end) meta(i, s0, e0, rl0, pos0, co0);
     if (i1 <= r_end) meta(i1, s1, e1, rl1, pos1, co1);
-    Raw pre[LOADS_IN_FLIGHT];
+    Raw bufA[LOADS_IN_FLIGHT], bufB[LOADS_IN_FLIGHT];
 #pragma unroll
-    for (int u = 0; u < LOADS_IN_FLIGHT; u++) pre[u] = Raw();
-    if (i <= r_end && e0 - s0 < 65536 && e0 > s0) issue(s0, (int)(e0 - s0), pre);
-    while (i <= r_end) {
+    for (int u = 0; u < LOADS_IN_FLIGHT; u++) { bufA[u] = Raw(); bufB[u] = Raw(); }
+    if (i <= r_end && e0 - s0 < 65536 && e0 > s0) issue(s0, (int)(e0 - s0), bufA);
+    // one read: `pre` holds its first batch (in flight since the previous call), `nxt` receives the next read's.  Called with the
+    // two buffers swapped every other time: copying nxt into pre would wait for the loads it has just issued.
+    auto one_read = [&](Raw (&pre)[LOADS_IN_FLIGHT], Raw (&nxt)[LOADS_IN_FLIGHT]) {
         const int i2 = i1 + nwaves;
         int64_t s2 = 0, e2 = 0;
         int rl2 = 0, pos2 = -1;
         long long co2 = 0;
         if (i2 <= r_end) meta(i2, s2, e2, rl2, pos2, co2);
-        Raw nxt[LOADS_IN_FLIGHT];
-#pragma unroll
-        for (int u = 0; u < LOADS_IN_FLIGHT; u++) nxt[u] = Raw();
         if (i1 <= r_end && e1 - s1 < 65536 && e1 > s1) issue(s1, (int)(e1 - s1), nxt);
         const int64_t s = s0, e = e0;
         const int rl = rl0;
@@ -296,8 +295,11 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
         }
         i = i1; s0 = s1; e0 = e1; rl0 = rl1; pos0 = pos1; co0 = co1;
         i1 = i2; s1 = s2; e1 = e2; rl1 = rl2; pos1 = pos2; co1 = co2;
-#pragma unroll
-        for (int u = 0; u < LOADS_IN_FLIGHT; u++) pre[u] = nxt[u];
+    };
+    while (i <= r_end) {
+        one_read(bufA, bufB);
+        if (i > r_end) break;
+        one_read(bufB, bufA);
     }
     // one slot per wave: thousands of atomics on one address cost ~12 ns each (they would dominate the kernel)
     if (lane == 0) {
@@ -1158,11 +1160,14 @@ __device__ __forceinline__ void wave_incl_scan2(int& a, int& b) {   // two indep
 #undef HINGE_SCAN2_STEP
 }
 
+template <bool TIMING>
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __restrict__ C, const K2Rec* __restrict__ k2rec, int n1,
                                                               const unsigned* __restrict__ span16, const int2* __restrict__ qv_mask /*nullptr: no QV track*/,
                                                               const int* __restrict__ d_min_cov, int slot_ints, int SH,
                                                               int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int g1,
-                                                              int ablate /*timing experiments only (HINGE_K2_ABLATE): leave a read after phase k; 0 = off*/) {
+                                                              int ablate /*timing experiments only (HINGE_K2_ABLATE): leave a read after phase k; 0 = off;
+                                                                           100 = per-phase shader-clock totals into tdbg*/,
+                                                              unsigned long long* __restrict__ tdbg /*[8], HINGE_K2_ABLATE=100 only*/) {
     extern __shared__ int lds[];
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1182,8 +1187,20 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
     if (item >= n1) return;
     K2Rec cur = k2rec[item], nx = cur;
     unsigned touch = 0;
+    constexpr bool timing = TIMING;   // (its own instantiation: the accumulators would cost the normal kernel 16 SGPRs)
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto tick = [&](int k) {   // (wave-uniform; waits for everything outstanding so that a phase is charged with its own latencies)
+        if constexpr (TIMING) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tacc[k] += now - tprev;
+            tprev = now;
+        }
+    };
+    if constexpr (TIMING) tprev = __builtin_amdgcn_s_memtime();
     for (; item < n1; item += step, cur = nx) {   // `continue` leaves a read
         nx = k2rec[min(item + step, n1 - 1)];     // (used after phase 1 and as the next `cur`: never waited for here)
+        tick(0);                                  // [0] loop overhead + the record loads
         const int i = cur.i;
         const long long s = cur.row;
         const int rl = cur.rl;
@@ -1215,6 +1232,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
                 for (int t = lane; t < Qs / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
                 cleared = true;
             }
+            tick(1);                               // [1] span loads (+ clearing the bins)
 #pragma unroll
             for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                 if (base + u * WAVE >= n) break;   // wave-uniform
@@ -1227,12 +1245,13 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
                 }
             }
         }
-        if (item + step < n1 && lane * 32 < nx.n) {
-            // One dword of every 128-byte line of the NEXT read's spans: brings them into L2 while phases 2-5 of this read run.
+        tick(2);                                   // [2] LDS atomics of the histogram
+        if (item + step < n1 && lane * 16 < nx.n) {
+            // One dword of every 64 bytes of the NEXT read's spans: brings them into L2 while phases 2-5 of this read run.
             // Inline assembly because the value is dead: a C++ load would be sunk to its (only, artificial) use or dropped.
             // `touch` stays allocated to the end of the iteration (the asm there), so the returning load cannot clobber a
             // register that holds something else by then.
-            const unsigned* tp = span16 + nx.row + lane * 32;
+            const unsigned* tp = span16 + nx.row + lane * 16;
             asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(tp));
         }
         if (ablate == 1) continue;
@@ -1255,6 +1274,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
             if (t1 < Qs) *reinterpret_cast<int4*>(Pq + t1) = b;
             carry = mid + wave_last(ib);
         }
+        tick(3);                                   // [3] prefix scan
         if (ablate == 2) continue;
         // begins of bin 0 and ends of bin qe were not counted: B0 = n - (the counted begins); from bin qe on every event is
         // consumed: PB' = n - B0, PE = n
@@ -1289,6 +1309,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
                 run_feed(run, base, M & V, V, reso);
             }
         }
+        tick(4);                                   // [4] totals + mask pass
         if (ablate == 3) continue;
         // the constants of the last phase: loaded here in one go, not held across the loop (the asm hides the pointer from the
         // hoisting passes; the copies are values, so nothing is re-read after the stores that follow)
@@ -1304,6 +1325,12 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
         const AnnoOut& o = kc.o;
         mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n, ~0ull, cur.cov_off, &qv);
         asm volatile("" ::"v"(touch));   // (the prefetch load's register lives until here)
+        tick(5);                                   // [5] mask / gate / annotation / outputs (incl. the constants' loads)
+    }
+    if (timing && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) atomicAdd(&tdbg[k], tacc[k]);
+        atomicAdd(&tdbg[6], 1ull);
     }
 }
 

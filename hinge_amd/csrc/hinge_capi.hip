@@ -158,6 +158,7 @@ struct Scalars {
     unsigned facts[2];                  // k_pileup_facts: largest pile-up, out-of-range flag
     int bins_status;                    // hinge_filter_coverage_bins' own range flag
     int pad2;
+    unsigned long long tdbg[8];         // HINGE_K2_ABLATE=100: shader-clock totals per phase of k_mask_annotate_lean, [6] = wavefronts
     unsigned dbg[16];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
@@ -517,6 +518,17 @@ int hinge_debug_heavy_items(hinge_ctx* ctx, int64_t* out) {
     return HINGE_OK;
 }
 
+// timing experiments (HINGE_K2_ABLATE=100): out[0..5] = shader clocks per phase of k_mask_annotate_lean summed over wavefronts
+// since the context was created, out[6] = wavefronts
+int hinge_debug_k2_phase_clocks(hinge_ctx* ctx, int64_t* out) {
+    if (!ctx || !out) return HINGE_E_ARG;
+    unsigned long long v[8];
+    CK(hipStreamSynchronize(ctx->stream));
+    CK(hipMemcpy(v, sc(ctx)->tdbg, sizeof(v), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; k++) out[k] = (int64_t)v[k];
+    return HINGE_OK;
+}
+
 // hidden knob for tests: 1 = route every scanned annotation through k_hinge_exact,
 // 2 = force the in-kernel exact pile-up order for every scanned annotation
 int hinge_debug_force_exact(hinge_ctx* ctx, int on) {
@@ -779,9 +791,13 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
                 ctx->k2c_valid = true;
             }
             const int g1 = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw);
-            hipLaunchKernelGGL(k_mask_annotate_lean, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, (const K2Rec*)ctx->k2rec.p, n1,
-                               (const unsigned*)ctx->span16.p, ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr,
-                               (const int*)&sc(ctx)->min_cov, slot, SH, (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1, ctx->k2_ablate);
+#define LAUNCH_LEAN(TIMING)                                                                                                              \
+            hipLaunchKernelGGL(k_mask_annotate_lean<TIMING>, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p,             \
+                               (const K2Rec*)ctx->k2rec.p, n1, (const unsigned*)ctx->span16.p,                                                  \
+                               ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr, (const int*)&sc(ctx)->min_cov, slot, SH,        \
+                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1, ctx->k2_ablate, (unsigned long long*)sc(ctx)->tdbg)
+            if (ctx->k2_ablate == 100) LAUNCH_LEAN(true); else LAUNCH_LEAN(false);
+#undef LAUNCH_LEAN
         }
         const int n1q = lean ? 0 : n1;   // what is left for k_mask_annotate_q20: the reads that need two or four slots (+ class 1 without the lean kernel)
         const int* list_q = (const int*)ctx->bucket_list.p + (lean ? n1 : 0);

@@ -80,9 +80,10 @@ def test_select_edges_matches_the_reference_loop(seed):
         hinges.append([(int(rng.integers(0, 9000)), int(rng.choice([-1, 1])), int(rng.random() < 0.7)) for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.4 else 0)])
         killed.append([(int(rng.integers(0, 9000)), int(rng.choice([-1, 1]))) for _ in range(int(rng.integers(1, 3)) if rng.random() < 0.25 else 0)])
     recs, fwd, bwd = [], [], []
-    off = {0: [0], 1: [0]}
+    off = {0: [], 1: []}
     lists = {0: fwd, 1: bwd}
     for dirn in (0, 1):                  # the kernel takes one record array: all forward lists, then all backward lists
+        off[dirn].append(len(recs))
         for i in range(n):
             ms = []
             w = int(rng.integers(8000, 20000))

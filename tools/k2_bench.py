@@ -25,6 +25,7 @@ VARIANTS = [
     ("lean abl=1", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "1", "HINGE_K2_RPW": "6"}),   # histogram
     ("lean abl=2", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "2", "HINGE_K2_RPW": "6"}),   # + prefix scan
     ("lean abl=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "3", "HINGE_K2_RPW": "6"}),   # + mask pass
+    ("lean clocks", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "100", "HINGE_K2_RPW": "3"}),   # serialised phases, shader clocks per phase
 ]
 
 
@@ -33,6 +34,7 @@ def main():
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cov-out", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated variant names (default: all)")
     ap.add_argument("--parts", type=int, default=3, help="distinct parts rotated between timed launches (cold Infinity Cache)")
     args = ap.parse_args()
     import torch
@@ -49,7 +51,10 @@ def main():
         tens = [torch.from_numpy(x).to(dev) for x in (pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag.view(np.int32), span16.view(np.int32))]
         parts.append((d.rlen.copy(), d.n_reads, pile.n_ovl, tens, max_pile, in_range))
     base = None
+    only = [x.strip() for x in args.only.split(",") if x.strip()]
     for name, env in VARIANTS:
+        if only and name not in only:
+            continue
         for k in ("HINGE_K2_LEAN", "HINGE_K2_RPW", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -65,7 +70,7 @@ def main():
             ctx.filter_median(P, 0, n - 1, fetch=True)
             ctx.filter_mask_annotate(P)      # synchronous: sizes the annotation buffer
             ctxs.append(ctx)
-        ablated = "HINGE_K2_ABLATE" in env
+        ablated = env.get("HINGE_K2_ABLATE", "0") not in ("0", "100")
         res = None if ablated else [(c.get_masks(), c.get_annotations()[:3]) for c in ctxs]
         if ablated:
             pass
@@ -83,6 +88,11 @@ def main():
                 c.filter_stats(P)
                 c.filter_mask_annotate_async(P)
         tot = {}
+        if env.get("HINGE_K2_ABLATE") == "100":
+            clk = sum(c.k2_phase_clocks() for c in ctxs)
+            reads = sum(p[1] for p in parts) * (args.reps + 1)
+            print("   clocks per read by phase [record, span loads, histogram atomics, scan, mask, annotate+outputs]:",
+                  [round(float(x) / reads, 1) for x in clk[:6]], "(wavefronts %d)" % clk[6], flush=True)
         for c in ctxs:
             for k, (ms, cnt) in c.profile_report().items():
                 if cnt:
