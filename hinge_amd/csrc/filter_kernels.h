@@ -169,40 +169,14 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
     typedef SpanLoad<PACKED> SL;
     typedef typename SL::raw Raw;
     const Raw* __restrict__ spans = PACKED ? (const Raw*)(const void*)span16 : (const Raw*)(const void*)a_span;
-    // A pass over a part that is not in the Infinity Cache is bound by memory latency, not bandwidth: a wavefront that loads its
-    // row's bounds, then the row, then reduces it has bytes in flight for only part of the time.  So the chain is software-pipelined:
-    // while read i is reduced, the first batch of read i + nwaves is already in flight (registers nxt[]) and the bounds of read
-    // i + 2 nwaves are being fetched.  Only rows of fewer than 65536 overlaps take part (the others are streamed as before).
-    auto issue = [&](int64_t s, int n, Raw (&v)[LOADS_IN_FLIGHT]) {   // unconditional loads from a clamped index off the scalar row base
-        const Raw* __restrict__ row = spans + s;
-        const unsigned last = (unsigned)(n - 1);
-#pragma unroll
-        for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(u * WAVE + lane), last)];
-    };
-    int i = r_begin + wave, i1 = i + nwaves;
-    int64_t s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-    int rl0 = 0, rl1 = 0, pos0 = -1, pos1 = -1;          // (the slot in k2rec and the bin offset travel with the bounds: no load at the end of a read)
-    long long co0 = 0, co1 = 0;
-    auto meta = [&](int r, int64_t& ms, int64_t& me, int& mrl, int& mpos, long long& mco) {
-        ms = row_ptr[r]; me = row_ptr[r + 1]; mrl = rlen[r];
-        mpos = pos_of ? pos_of[r - r_begin] : -1;
-        mco = cov_off ? cov_off[r - r_begin] : 0;
-    };
-    if (i <= r_end) meta(i, s0, e0, rl0, pos0, co0);
-    if (i1 <= r_end) meta(i1, s1, e1, rl1, pos1, co1);
-    Raw bufA[LOADS_IN_FLIGHT], bufB[LOADS_IN_FLIGHT];
-#pragma unroll
-    for (int u = 0; u < LOADS_IN_FLIGHT; u++) { bufA[u] = Raw(); bufB[u] = Raw(); }
-    if (i <= r_end && e0 - s0 < 65536 && e0 > s0) issue(s0, (int)(e0 - s0), bufA);
-    // one read: `pre` holds its first batch (in flight since the previous call), `nxt` receives the next read's.  Called with the
-    // two buffers swapped every other time: copying nxt into pre would wait for the loads it has just issued.
-    auto one_read = [&](Raw (&pre)[LOADS_IN_FLIGHT], Raw (&nxt)[LOADS_IN_FLIGHT]) {
-        const int i2 = i1 + nwaves;
-        int64_t s2 = 0, e2 = 0;
-        int rl2 = 0, pos2 = -1;
-        long long co2 = 0;
-        if (i2 <= r_end) meta(i2, s2, e2, rl2, pos2, co2);
-        if (i1 <= r_end && e1 - s1 < 65536 && e1 > s1) issue(s1, (int)(e1 - s1), nxt);
+    // (Software-pipelining this loop - the next row's first batch and the bounds of the row after it in flight while the current
+    // row is reduced, ping-pong register buffers - was measured on parts that are not in the Infinity Cache: 34.6 -> 47.9 us; with
+    // the register budget of eight wavefronts per SIMD 41.8 us.  The extra registers cost more wavefronts than the overlap wins.)
+    for (int i = r_begin + wave; i <= r_end; i += nwaves) {
+        const int64_t s0 = row_ptr[i], e0 = row_ptr[i + 1];
+        const int rl0 = rlen[i];
+        const int pos0 = pos_of ? pos_of[i - r_begin] : -1;
+        const long long co0 = cov_off ? cov_off[i - r_begin] : 0;
         const int64_t s = s0, e = e0;
         const int rl = rl0;
         long long tot;
@@ -217,13 +191,8 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
             unsigned sum = 0, umx = 0;   // max as unsigned: a negative coordinate shows up as a huge one
             for (int base = 0; base < n; base += LOADS_IN_FLIGHT * WAVE) {
                 Raw v[LOADS_IN_FLIGHT];
-                if (base == 0) {
 #pragma unroll
-                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = pre[u];
-                } else {
-#pragma unroll
-                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
-                }
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                     if (base + u * WAVE >= n) break;   // wave-uniform
@@ -293,13 +262,6 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
                 mean_cov[i] = MEAN_SENTINEL;
             }
         }
-        i = i1; s0 = s1; e0 = e1; rl0 = rl1; pos0 = pos1; co0 = co1;
-        i1 = i2; s1 = s2; e1 = e2; rl1 = rl2; pos1 = pos2; co1 = co2;
-    };
-    while (i <= r_end) {
-        one_read(bufA, bufB);
-        if (i > r_end) break;
-        one_read(bufB, bufA);
     }
     // one slot per wave: thousands of atomics on one address cost ~12 ns each (they would dominate the kernel)
     if (lane == 0) {
@@ -1163,6 +1125,7 @@ __device__ __forceinline__ void wave_incl_scan2(int& a, int& b) {   // two indep
 template <bool TIMING>
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __restrict__ C, const K2Rec* __restrict__ k2rec, int n1,
                                                               const unsigned* __restrict__ span16, const int2* __restrict__ qv_mask /*nullptr: no QV track*/,
+                                                              int* __restrict__ cov_out /*nullptr, or the coverage-bin output*/, int* __restrict__ cov_nbins, int cov_base,
                                                               const int* __restrict__ d_min_cov, int slot_ints, int SH,
                                                               int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int g1,
                                                               int ablate /*timing experiments only (HINGE_K2_ABLATE): leave a read after phase k; 0 = off;
@@ -1289,6 +1252,14 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __r
             const int qb = 2 * k - 1 - SH;
             return (qb >= 0 ? (Pq[qb] & 0xffff) + B0 : 0) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16);
         };
+        // The .coverage.txt bins go out NOW, not with the other outputs at the end of the read: on this architecture stores count in
+        // vmcnt like loads and retire in order, so the next read's first wait for its spans is also a wait for every store issued
+        // before it.  Issued here, the bins (the bulk of the stores) have the mask pass and the annotation phase to drain.
+        if (cov_out) {
+            int* __restrict__ dst = cov_out + cur.cov_off;
+            for (int j = lane; j < K0; j += WAVE) dst[j] = cov0(j);
+            if (lane == 0) cov_nbins[i - cov_base] = K0;
+        }
         // The cutoff profile is zero from its last bin on, so any bound >= the reference's K works (see k_mask_annotate_q20)
         const int KC = nbins_of<40>(n, rl + 20 * SH, reso);
         // ---- coverage mask on the cutoff profile: covc(k) > MIN_COV  <=>  PB'[2k-1-SH] - PE[2k-1+SH] > MIN_COV - B0 where the

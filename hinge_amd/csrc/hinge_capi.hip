@@ -783,6 +783,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
             memset(&hc, 0, sizeof(hc));
             hc.P = to_dev(p);
             hc.o = anno_out(ctx);
+            hc.o.cov_out = nullptr;   // (the lean kernel stores the bins itself, early: see there)
             int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
             if (rc) return rc;
             if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
@@ -794,7 +795,9 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
 #define LAUNCH_LEAN(TIMING)                                                                                                              \
             hipLaunchKernelGGL(k_mask_annotate_lean<TIMING>, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p,             \
                                (const K2Rec*)ctx->k2rec.p, n1, (const unsigned*)ctx->span16.p,                                                  \
-                               ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr, (const int*)&sc(ctx)->min_cov, slot, SH,        \
+                               ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr,                                                \
+                               ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr, (int*)ctx->cov_nb.p, ctx->r_begin,                        \
+                               (const int*)&sc(ctx)->min_cov, slot, SH,                                                                        \
                                (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1, ctx->k2_ablate, (unsigned long long*)sc(ctx)->tdbg)
             if (ctx->k2_ablate == 100) LAUNCH_LEAN(true); else LAUNCH_LEAN(false);
 #undef LAUNCH_LEAN

@@ -1084,6 +1084,35 @@ long oracle_load_las(const char* name_db, const char* las_path, int* out, long c
     return n;
 }
 
+// trimmed read lengths (Open_DB + Trim_DB) and the qual track (getQV) through the oracle's readers: what the pins compare
+int oracle_read_lengths(const char* name_db, int* out, int cap) {
+    DB db;
+    if (open_db(name_db, db) != 0) return -1;
+    const int n = (int)db.rlen.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = db.rlen[(size_t)i];
+    return n;
+}
+long oracle_qv(const char* name_db, long* offsets, int* values, long cap) {
+    DB db;
+    if (open_db(name_db, db) != 0) return -1;
+    std::vector<std::vector<int>> QV;
+    if (load_qv(db, QV) != 0) return -1;
+    long k = 0;
+    const int n = (int)db.rlen.size();
+    if ((int)QV.size() != n) return -2;
+    for (int i = 0; i < n; i++) {
+        offsets[i] = k;
+        for (size_t j = 0; j < QV[(size_t)i].size(); j++) { if (k < cap) values[k] = QV[(size_t)i][j]; k++; }
+    }
+    offsets[n] = k;
+    return k;
+}
+int oracle_tspace(const char* las_path) {
+    LasHeader h;
+    if (las_header(las_path, h) != 0) return -1;
+    return h.tspace;
+}
+
 // ---- FASTA + PAF input: the same three stages, reads from loadFASTA, alignments from loadPAF, no trace points ----
 int oracle_filter_paf(const char* fasta, const char* paf, const char* prefix, const char* name_config) {
     return oracle_filter((std::string("fasta:") + fasta).c_str(), (std::string("paf:") + paf).c_str(), 0, prefix, name_config, "");

@@ -257,3 +257,126 @@ def test_fasta_and_paf_parsers_golden(oracle_lib, tmp_path):
     assert oracle_lib.oracle_load_las(b"fasta:" + fa.encode(), b"paf:" + paf.encode(), P(x), ctypes.c_long(8)) == 5
     assert x[:5].tolist() == [[0, 1, 1, 9, 3, 11, 0, 0], [1, 4, 0, 20, 2, 12, 1, 0], [2, 0, 0, 7, 0, 7, 0, 0], [4, 4, 4, 12, 0, 8, 1, 0],
                               [3, 1, 0, 0, 5, 5, 0, 0]]
+
+
+# ---- round 2: the pinned surface widened to what else the reference's LIBRARY can reach -------------------------------------
+def _trimmed_dataset(tmp_path, with_qv, track_over="untrimmed"):
+    """A DB whose stub says cutoff = 2500, all = 0 with reads below the cutoff and reads that are not DB_BEST: Trim_DB drops both
+    (DB.c:585-683) and the .las / the trimmed qual track use the ids that are left.  Returns (dir, kept rlen,
+    per-untrimmed keep mask, SynthData over the TRIMMED ids)."""
+    import dataclasses
+    from hinge_amd import formats, synth
+    d = synth.generate(dataclasses.replace(synth.CONFIGS["tiny_qv" if with_qv else "tiny"], seed=77))
+    rng = np.random.default_rng(5)
+    n_t = d.n_reads
+    # untrimmed read table: the data set's reads (ids = trimmed ids) with dropped reads spliced in between
+    extra = int(n_t * 0.3)
+    pos = np.sort(rng.choice(n_t + extra, size=extra, replace=False))
+    keep = np.ones(n_t + extra, bool)
+    keep[pos] = False
+    rlen_u = np.zeros(n_t + extra, np.int32)
+    rlen_u[keep] = d.rlen
+    flags = np.full(n_t + extra, formats.DB_BEST | 850, np.int32)
+    short = rng.random(extra) < 0.5
+    rlen_u[pos[short]] = rng.integers(200, 2500, size=int(short.sum()))               # below the cutoff
+    rlen_u[pos[~short]] = rng.integers(3000, 9000, size=int((~short).sum()))
+    flags[pos[~short]] = 850                                                          # long enough, but not DB_BEST
+    assert int(d.rlen.min()) >= 2500
+    wd = str(tmp_path / ("trim_qv" if with_qv else "trim"))
+    os.makedirs(wd, exist_ok=True)
+    db = os.path.join(wd, "G")
+    formats.write_db(db, rlen_u, cutoff=2500, all_flag=0, flags=flags, write_bases=True)
+    synth.write_las_file(d, db + ".las")
+    if with_qv:
+        if track_over == "untrimmed":     # one entry per untrimmed read (tracklen == ureads): getQV skips the dropped ones
+            qv_u, it = [], iter(d.qv)
+            for k in range(n_t + extra):
+                qv_u.append(next(it) if keep[k] else rng.integers(5, 38, size=max(1, (int(rlen_u[k]) + 99) // 100)).astype(np.uint8))
+            formats.write_qual_track(db, qv_u)
+        else:                             # one entry per trimmed read (tracklen == treads)
+            formats.write_qual_track(db, d.qv)
+    return wd, d, keep
+
+
+@pytest.mark.parametrize("with_qv,track_over", [(False, ""), (True, "untrimmed"), (True, "trimmed")])
+def test_live_reference_trimmed_db(oracle_lib, ref_lib, tmp_path, with_qv, track_over):
+    """Trim_DB (cutoff > 0, all = 0): read lengths, the .las under trimmed ids (strand flip needs the trimmed lengths) and getQV
+    on the trimmed DB - reference library vs oracle vs the Python / C++ host readers.
+    A qual track with one entry per UNTRIMMED read on a trimmed DB makes the reference's getQV crash (Load_Track of this DB.c reads
+    nreads + 1 offsets of a table laid out for ureads and then indexes the data with them: observed segfault), so there is nothing to
+    pin there: the oracle and the product readers skip the dropped reads, and only agree with each other."""
+    from hinge_amd import formats
+    wd, d, keep = _trimmed_dataset(tmp_path, with_qv, track_over)
+    db = os.path.join(wd, "G").encode()
+    a = np.zeros(d.n_reads + 8, np.int32)
+    b = np.zeros(d.n_reads + 8, np.int32)
+    oracle_lib.oracle_read_lengths.argtypes = [ctypes.c_char_p, ip, ctypes.c_int]
+    assert ref_lib.ref_read_lengths(db, P(b), len(b)) == d.n_reads
+    assert oracle_lib.oracle_read_lengths(db, P(a), len(a)) == d.n_reads
+    assert np.array_equal(a, b) and np.array_equal(a[:d.n_reads], d.rlen)
+    assert np.array_equal(formats.read_db_index(os.path.join(wd, "G"))["rlen"], d.rlen)
+    x = np.zeros((d.novl, 8), np.int32)
+    y = np.zeros((d.novl, 8), np.int32)
+    assert oracle_lib.oracle_load_las(db, db + b".las", P(x), d.novl) == d.novl
+    assert ref_lib.ref_load_las(db, db + b".las", P(y), d.novl) == d.novl
+    assert np.array_equal(x, y) and x[:, 6].sum() > 0
+    if with_qv:
+        lp = ctypes.POINTER(ctypes.c_long)
+        for lib, name in ((ref_lib, "ref_qv"), (oracle_lib, "oracle_qv")):
+            getattr(lib, name).argtypes = [ctypes.c_char_p, lp, ip, ctypes.c_long]
+            getattr(lib, name).restype = ctypes.c_long
+        tot = sum(len(q) for q in d.qv)
+        o1, o2 = np.zeros(d.n_reads + 1, np.int64), np.zeros(d.n_reads + 1, np.int64)
+        v1, v2 = np.zeros(tot, np.int32), np.zeros(tot, np.int32)
+        assert oracle_lib.oracle_qv(db, o2.ctypes.data_as(lp), P(v2), tot) == tot
+        if track_over == "trimmed":
+            assert ref_lib.ref_qv(db, o1.ctypes.data_as(lp), P(v1), tot) == tot
+            assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
+        else:
+            o1, v1 = o2, v2
+        py = formats.read_qual_track(os.path.join(wd, "G"))
+        assert all(np.array_equal(v1[o1[i]:o1[i + 1]], py[i].astype(np.int32)) for i in range(d.n_reads))
+
+
+def test_trimmed_db_through_the_host_ingest(tmp_path):
+    """The executables' DB reader (hinge_amd/host/host_common.h ReadDB) on the same trimmed DB: ids and lengths as above (the
+    reference's values are asserted by the live test; here the data set's own)."""
+    import subprocess
+    wd, d, keep = _trimmed_dataset(tmp_path, True, "untrimmed")
+    exe = str(tmp_path / "ingest_dump")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(root, "tests", "host", "ingest_dump.cpp"), "-lz"], check=True)
+    out = str(tmp_path / "dump.bin")
+    assert subprocess.run([exe, os.path.join(wd, "G"), os.path.join(wd, "G.las"), out], stdout=subprocess.DEVNULL).returncode == 0
+    from test_host_ingest import _read_dump
+    from hinge_amd import formats
+    hdr, c = _read_dump(out)
+    pile = formats.pileups_from_las(formats.read_las(os.path.join(wd, "G.las")), d.rlen)
+    assert hdr[0] == d.novl and np.array_equal(c[0], pile.row_ptr) and np.array_equal(c[2], pile.b_span.ravel())
+
+
+def test_live_reference_two_byte_traces(oracle_lib, ref_lib, datasets):
+    """tspace > 125: two bytes per trace value on disk (LAInterface.cpp:607-614).  The reference's getOverlap against the oracle's
+    reader, and every record's trace through ProcessAlignment / GetMatchingPosition of both."""
+    from hinge_amd import formats
+    wd, d = datasets("tspace200")
+    db = os.path.join(wd, "G").encode()
+    oracle_lib.oracle_tspace.argtypes = [ctypes.c_char_p]
+    assert ref_lib.ref_tspace(db + b".las") == oracle_lib.oracle_tspace(db + b".las") == 200
+    x = np.zeros((d.novl, 8), np.int32)
+    y = np.zeros((d.novl, 8), np.int32)
+    assert oracle_lib.oracle_load_las(db, db + b".las", P(x), d.novl) == d.novl
+    assert ref_lib.ref_load_las(db, db + b".las", P(y), d.novl) == d.novl
+    assert np.array_equal(x, y)
+    recs = formats.read_las(os.path.join(wd, "G.las"))
+    assert recs.tspace == 200 and np.array_equal(recs.rec["tlen"], x[:, 7])
+    rng = np.random.default_rng(9)
+    tr16 = recs.trace.view("<u2")
+    for k in rng.integers(0, d.novl, size=400):
+        t0 = int(recs.trace_off[k]) // 2
+        trace = tr16[t0:t0 + int(recs.rec["tlen"][k])]
+        a, b = int(x[k, 0]), int(x[k, 1])
+        hdr = np.array([x[k, 2], x[k, 3], x[k, 4], x[k, 5], x[k, 6], 300, d.rlen[a] - 300, 300, d.rlen[b] - 300], np.int32)
+        assert np.array_equal(_pa(oracle_lib, "oracle", hdr, trace, 1000, 300, 0), _pa(ref_lib, "ref", hdr, trace, 1000, 300, 0))
+        for pos in rng.integers(hdr[0] - 20, hdr[1] + 20, size=3):
+            assert _mp(oracle_lib, "oracle", hdr, trace, pos) == _mp(ref_lib, "ref", hdr, trace, pos)
