@@ -143,7 +143,6 @@ EXTRA_SYMBOLS = [
     ("hinge_debug_fallback_reads", C.c_int, [_VP, _VP]),
     ("hinge_debug_heavy_items", C.c_int, [_VP, _VP]),
     ("hinge_debug_pileup_order", C.c_int, [_VP, C.c_int32, _VP, _VP]),
-    ("hinge_debug_k2_phase_clocks", C.c_int, [_VP, _VP]),
 ]
 
 
@@ -279,11 +278,6 @@ class Context:
         out = np.zeros(2, np.int64)
         self._ck(self.lib.hinge_debug_heavy_items(self.h, _ptr(out)))
         return int(out[0]), int(out[1])
-
-    def k2_phase_clocks(self) -> np.ndarray:
-        out = np.zeros(8, np.int64)
-        self._ck(self.lib.hinge_debug_k2_phase_clocks(self.h, _ptr(out)))
-        return out
 
     def debug_pileup_order(self, keys: np.ndarray) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.int32)

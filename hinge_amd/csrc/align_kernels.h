@@ -255,7 +255,8 @@ __global__ __launch_bounds__(BLOCK) void k_trim_classify_rows(int r_begin, int r
 // definition (LAInterface.cpp:4606-4640) whatever the coordinates look like - no monotonicity is assumed.
 // One wavefront per workgroup (the stage buffer is its own), CAP bytes of LDS each.
 // ------------------------------------------------------------------------------------------------
-constexpr int STREAM_CAP = 10240;   // bytes of staged .las per wavefront: 64 overlaps of ~130 B are 8.3 KB; 16 workgroups per CU
+// STREAM_CAP = bytes of staged .las per wavefront: 64 overlaps of ~130 B are 8.3 KB.  10240 -> 16 workgroups (wavefronts) per CU,
+// 8192 -> 20 (a step then often needs a second sub-step for its last few overlaps); HINGE_K4_CAP picks the instantiation.
 
 template <int TB, typename FETCH, typename SUM>
 __device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, const int comp, const int2 ea, const int2 eb, const int tl,
@@ -324,7 +325,7 @@ __device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, cons
     o.end_idx = end_idx;
 }
 
-template <int TB>
+template <int TB, int STREAM_CAP>
 __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                                const int2* __restrict__ a_span, const int2* __restrict__ b_span,
                                                                const unsigned* __restrict__ b_flag, const unsigned char* __restrict__ trace,
@@ -409,7 +410,15 @@ __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int 
                             const unsigned m1 = (hi & 2u) ? 0x0000ff00u : 0xff00ff00u;   // one that ends after its first half
                             if (w0 == w1) return (int)__builtin_amdgcn_sad_u8(W[w0] & m0 & m1, 0u, 0u);
                             unsigned acc = __builtin_amdgcn_sad_u8(W[w0] & m0, 0u, 0u);
-                            for (unsigned w = w0 + 1; w < w1; w++) acc = __builtin_amdgcn_sad_u8(W[w] & 0xff00ff00u, 0u, acc);
+                            unsigned w = w0 + 1;
+                            for (; w + 4 <= w1; w += 4) {   // four independent LDS reads in flight per round trip
+                                const unsigned x0 = W[w], x1 = W[w + 1], x2 = W[w + 2], x3 = W[w + 3];
+                                acc = __builtin_amdgcn_sad_u8(x0 & 0xff00ff00u, 0u, acc);
+                                acc = __builtin_amdgcn_sad_u8(x1 & 0xff00ff00u, 0u, acc);
+                                acc = __builtin_amdgcn_sad_u8(x2 & 0xff00ff00u, 0u, acc);
+                                acc = __builtin_amdgcn_sad_u8(x3 & 0xff00ff00u, 0u, acc);
+                            }
+                            for (; w < w1; w++) acc = __builtin_amdgcn_sad_u8(W[w] & 0xff00ff00u, 0u, acc);
                             return (int)__builtin_amdgcn_sad_u8(W[w1] & m1, 0u, acc);
                         }
                         if (TB == 2 && !(lo & 3u)) {

@@ -135,27 +135,14 @@ template <> struct SpanLoad<true> {
     static __device__ __forceinline__ int2 get(raw v) { return make_int2((int)(v & 0xffffu), (int)(v >> 16)); }
 };
 
-// What k_mask_annotate_lean needs to start on a read, written by k_cov_stats in the order of K2's read list (pos_of[]): one
-// 32-byte scalar load instead of the chain read_list -> row_ptr / rlen / nbins0 / cov_off (two dependent round trips to HBM per read).
-struct alignas(32) K2Rec {
-    long long row;        // row_ptr[i]
-    int n;                // pile-up size (clipped to INT_MAX)
-    int rl;               // rlen[i]
-    int i;                // read id
-    int K0;               // bins of the plain profile, -1: not a read for the fast kernels (nbins0[i])
-    long long cov_off;    // where K2 stores the read's coverage bins (0 when they are not wanted)
-};
-
 template <int RESO, bool PACKED>
-__device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+__global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                      const int2* __restrict__ a_span, const unsigned* __restrict__ span16,
                                                      const int* __restrict__ rlen, int reso,
                                                      int* __restrict__ mean_cov, int* __restrict__ nbins0,
                                                      unsigned long long* __restrict__ wave_totals /*[2 * nwaves]*/,
                                                      int* __restrict__ pass_scalars, int n_pass_scalars, int* __restrict__ d_min_cov,
-                                                     int set_min_cov, int min_cov_value,
-                                                     const int* __restrict__ pos_of /*nullptr, or [r_end - r_begin + 1]: slot of the read in k2rec, -1 none*/,
-                                                     K2Rec* __restrict__ k2rec, const long long* __restrict__ cov_off /*nullptr or by read - r_begin*/) {
+                                                     int set_min_cov, int min_cov_value) {
     // This is the first kernel of a pass and touches none of the pass scalars itself, so workgroup 0 clears
     // them (and applies a pending MIN_COV) instead of two 4-us memset launches in front of it.
     if (blockIdx.x == 0) {
@@ -166,31 +153,23 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);   // tell the compiler it is wave-uniform: row bounds become scalar loads
     const int nwaves = (gridDim.x * BLOCK) >> 6;
     long long blk_cov = 0, blk_slot = 0;
-    typedef SpanLoad<PACKED> SL;
-    typedef typename SL::raw Raw;
-    const Raw* __restrict__ spans = PACKED ? (const Raw*)(const void*)span16 : (const Raw*)(const void*)a_span;
-    // (Software-pipelining this loop - the next row's first batch and the bounds of the row after it in flight while the current
-    // row is reduced, ping-pong register buffers - was measured on parts that are not in the Infinity Cache: 34.6 -> 47.9 us; with
-    // the register budget of eight wavefronts per SIMD 41.8 us.  The extra registers cost more wavefronts than the overlap wins.)
+    // (no hand-written prefetch of the next row: measured 7x slower - it serialises the wave's loads)
     for (int i = r_begin + wave; i <= r_end; i += nwaves) {
-        const int64_t s0 = row_ptr[i], e0 = row_ptr[i + 1];
-        const int rl0 = rlen[i];
-        const int pos0 = pos_of ? pos_of[i - r_begin] : -1;
-        const long long co0 = cov_off ? cov_off[i - r_begin] : 0;
-        const int64_t s = s0, e = e0;
-        const int rl = rl0;
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        const int rl = rlen[i];
         long long tot;
         int mx = INT_MIN;
-        bool q20_ok = false;     // every coordinate in [0, rl] and fewer than 65536 overlaps: the fast K2 kernels may take the read
+        bool q20_ok = false;     // every coordinate in [0, rl] and fewer than 65536 overlaps: k_mask_annotate_q20 may take the read
         if (e - s < 65536) {
             // common case: 32-bit lane offsets from the scalar row base, unconditional loads from a clamped index (no
             // exec-mask branch and no 64-bit address arithmetic per load), one 32-bit sum (n * K < 2^32 for n < 65536)
             const int n = (int)(e - s);
-            const Raw* __restrict__ row = spans + s;
+            typedef SpanLoad<PACKED> SL;
+            const typename SL::raw* __restrict__ row = (PACKED ? (const typename SL::raw*)(const void*)span16 : (const typename SL::raw*)(const void*)a_span) + s;
             const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
             unsigned sum = 0, umx = 0;   // max as unsigned: a negative coordinate shows up as a huge one
             for (int base = 0; base < n; base += LOADS_IN_FLIGHT * WAVE) {
-                Raw v[LOADS_IN_FLIGHT];
+                typename SL::raw v[LOADS_IN_FLIGHT];
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
 #pragma unroll
@@ -245,14 +224,8 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
             mx = wave_max(mx);
         }
         if (lane == 0) {
-            const int K = nbins_of<RESO>((int)min<int64_t>(e - s, 0x7fffffff), mx, reso);
-            const int K0 = q20_ok ? K : -1;
-            nbins0[i] = K0;   // bins of the plain profile for the fast K2 kernels, -1 = not a read for them
-            if (pos0 >= 0) {
-                K2Rec r;
-                r.row = s; r.n = (int)min<int64_t>(e - s, 0x7fffffff); r.rl = rl; r.i = i; r.K0 = K0; r.cov_off = co0;
-                k2rec[pos0] = r;
-            }
+            const int K = nbins_of<RESO>((int)(e - s), mx, reso);
+            nbins0[i] = q20_ok ? K : -1;   // bins of the plain profile for k_mask_annotate_q20, -1 = not a read for that kernel
             if (rl >= 5000) {
                 const long long m = tot / (long long)max(1, K);   // C division, filter.cpp:654
                 mean_cov[i] = (int)m;
@@ -269,26 +242,6 @@ __device__ __forceinline__ void cov_stats_body(int r_begin, int r_end, const int
         wave_totals[2 * wave + 1] = (unsigned long long)blk_slot;
     }
 }
-
-#define HINGE_COV_STATS_PARAMS                                                                                                          \
-    int r_begin, int r_end, const int64_t *__restrict__ row_ptr, const int2 *__restrict__ a_span, const unsigned *__restrict__ span16,  \
-        const int *__restrict__ rlen, int reso, int *__restrict__ mean_cov, int *__restrict__ nbins0,                                    \
-        unsigned long long *__restrict__ wave_totals, int *__restrict__ pass_scalars, int n_pass_scalars, int *__restrict__ d_min_cov,   \
-        int set_min_cov, int min_cov_value, const int *__restrict__ pos_of, K2Rec *__restrict__ k2rec, const long long *__restrict__ cov_off
-#define HINGE_COV_STATS_ARGS                                                                                                            \
-    r_begin, r_end, row_ptr, a_span, span16, rlen, reso, mean_cov, nbins0, wave_totals, pass_scalars, n_pass_scalars, d_min_cov,        \
-        set_min_cov, min_cov_value, pos_of, k2rec, cov_off
-template <int RESO, bool PACKED>
-__global__ __launch_bounds__(BLOCK) void k_cov_stats(HINGE_COV_STATS_PARAMS) {
-    cov_stats_body<RESO, PACKED>(HINGE_COV_STATS_ARGS);
-}
-// the same with the register budget of eight wavefronts per SIMD (HINGE_K1_W8=1: A/B timing)
-template <int RESO, bool PACKED>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cov_stats_w8(HINGE_COV_STATS_PARAMS) {
-    cov_stats_body<RESO, PACKED>(HINGE_COV_STATS_ARGS);
-}
-#undef HINGE_COV_STATS_PARAMS
-#undef HINGE_COV_STATS_ARGS
 
 // General median (any int32 values): one workgroup, 4-pass 8-bit radix select.  Run by the last block of
 // k_median_hist when some mean coverage falls outside [0, MED_BINS).
@@ -645,11 +598,9 @@ __device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long lo
 template <typename ZF, typename CF>
 __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
                                                    const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o,
-                                                   const long long row, const int n_pile, const unsigned long long flag_words = ~0ull,
-                                                   const long long cov_at = -1 /*>= 0: the caller already has o.cov_off[i - o.cov_base]*/,
-                                                   const int2* qv_known = nullptr /*the caller already has o.qv_mask[i]*/) {
-    if (o.cov_out) {   // before anything reuses the profile's LDS (cand)
-        int* __restrict__ dst = o.cov_out + (cov_at >= 0 ? cov_at : o.cov_off[i - o.cov_base]);
+                                                   const long long row, const int n_pile, const bool cov_done = false) {
+    if (o.cov_out && !cov_done) {   // before anything reuses the profile's LDS (cand)
+        int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
         for (int j = lane; j < K0; j += WAVE) dst[j] = z(j);
         if (lane == 0) o.cov_nbins[i - o.cov_base] = K0;
     }
@@ -675,7 +626,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
     }
     int2 mk;
     {
-        int2 q = qv_known ? *qv_known : (o.qv_mask ? o.qv_mask[i] : make_int2(0, 0));
+        int2 q = o.qv_mask ? o.qv_mask[i] : make_int2(0, 0);
         if (o.keep && !o.keep[i]) { maxend = maxstart; q.y = q.x; }   // filter.cpp:767-773
         if (P.use_qv && P.use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
         else if (P.use_cov && !P.use_qv) mk = make_int2(maxstart, maxend);
@@ -724,8 +675,6 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
         const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
         for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
-            // flag_words: bit w clear = the caller knows that no bin of [64 w, 64 w + 63] can pass the threshold (words beyond 63: always looked at)
-            if (base < 64 * WAVE && !((flag_words >> (base / WAVE)) & 1ull)) continue;
             const int j = base + lane;
             int code = -1;
             const bool in = j >= jlo && j <= jhi;
@@ -1071,6 +1020,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         }
         auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
         auto covc = [&](int k) { return (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16); };
+        // The .coverage.txt bins go out NOW, not with the other outputs at the end of the read: on this architecture stores count in
+        // vmcnt like loads and retire in order, so the next read's first wait for its spans also waits for every store issued
+        // before it.  Issued here, the bins (the bulk of the stores) have the mask pass and the annotation phase to drain.
+        if (o.cov_out) {
+            int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
+            for (int j = lane; j < K0; j += WAVE) dst[j] = cov0(j);
+            if (lane == 0) o.cov_nbins[i - o.cov_base] = K0;
+        }
 
         // ---- coverage mask on the cutoff profile ------------------------------------------------------
         RunState run{0, 0ull, 0, 0};
@@ -1089,219 +1046,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
                 run_feed(run, base, M & V, V, reso);
             }
         }
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2, lean form: the reads that fit ONE LDS slot (class 1: up to ~16 kb, nearly all of a part), 16|16 spans, reso 40,
-// cut_off = 20 * SH, no_hinge_region >= 40, MIN_COV >= 0.  Same 20-bp begin|end histogram and the same mask / gate /
-// annotation code as k_mask_annotate_q20, with the per-read fixed cost cut down (k_mask_annotate_q20 spent ~4/5 of its
-// vector instructions outside the per-overlap loop):
-//  * No hot-bin bookkeeping.  About half of all overlaps begin in the read's first 20-bp bin and half end in its last one;
-//    neither count is needed: begins in bin 0 are B0 = n - (all other begins), known once the scan has summed the bins, and
-//    ends in the last bin only ever show up in PE[last] = n.  Those events go to a lane-private trash word (no same-address
-//    serialisation, never read, never cleared); B0 is added by the profile accessors.
-//  * The constants of the last phase (FilterDev, the 14 output pointers) live in device memory and are loaded where they are
-//    used: held in SGPRs across the whole read loop they cost 59 spills to VGPR lanes, every one a v_readlane / v_writelane.
-//  * The prefix scan takes two rows of 256 bins at a time with their DPP chains interleaved (a lone chain is half s_nop).
-// ------------------------------------------------------------------------------------------------
-struct K2Const {   // one per context in device memory, refreshed by the host when something in it changes
-    FilterDev P;
-    AnnoOut o;
-};
-
-__device__ __forceinline__ void wave_incl_scan2(int& a, int& b) {   // two independent inclusive scans, interleaved
-#define HINGE_SCAN2_STEP(CTRL, MASK)                                        \
-    {                                                                       \
-        const int ta = dpp_or_old<CTRL, MASK>(0, a), tb = dpp_or_old<CTRL, MASK>(0, b); \
-        a += ta; b += tb;                                                   \
-    }
-    HINGE_SCAN2_STEP(0x111, 0xf) HINGE_SCAN2_STEP(0x112, 0xf) HINGE_SCAN2_STEP(0x114, 0xf) HINGE_SCAN2_STEP(0x118, 0xf)
-    HINGE_SCAN2_STEP(0x142, 0xa) HINGE_SCAN2_STEP(0x143, 0xc)
-#undef HINGE_SCAN2_STEP
-}
-
-template <bool TIMING>
-__global__ __launch_bounds__(BLOCK) void k_mask_annotate_lean(const K2Const* __restrict__ C, const K2Rec* __restrict__ k2rec, int n1,
-                                                              const unsigned* __restrict__ span16, const int2* __restrict__ qv_mask /*nullptr: no QV track*/,
-                                                              int* __restrict__ cov_out /*nullptr, or the coverage-bin output*/, int* __restrict__ cov_nbins, int cov_base,
-                                                              const int* __restrict__ d_min_cov, int slot_ints, int SH,
-                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int g1,
-                                                              int ablate /*timing experiments only (HINGE_K2_ABLATE): leave a read after phase k; 0 = off;
-                                                                           100 = per-phase shader-clock totals into tdbg*/,
-                                                              unsigned long long* __restrict__ tdbg /*[8], HINGE_K2_ABLATE=100 only*/) {
-    extern __shared__ int lds[];
-    const int lane = lane_id();
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int reso = 40;
-    const int PADF = (SH + 2 + 3) & ~3, PADT = (2 * SH + 4 + 3) & ~3;
-    const int qcap = slot_ints - 4 * WAVE - PADF - PADT;   // (the slot keeps the size k_mask_annotate_q20 uses: same read classes)
-    int* const Pq = lds + (size_t)wib * slot_ints + PADF;
-    int* const trash = Pq + qcap + PADT + lane;
-    const int MIN_COV = *d_min_cov;
-    for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
-
-    // One pass over a cold part is bound by memory latency (every wavefront has bytes in flight only while it waits for its own
-    // row), so the chain is pipelined: the record of the next read is fetched (one scalar load) under phase 1 of the current one,
-    // and its rows are then pulled into L2 by one load per 128-byte line whose value is never used, under phases 2-5.
-    const int step = g1 * 4;
-    int item = (int)blockIdx.x * 4 + wib;
-    if (item >= n1) return;
-    K2Rec cur = k2rec[item], nx = cur;
-    unsigned touch = 0;
-    constexpr bool timing = TIMING;   // (its own instantiation: the accumulators would cost the normal kernel 16 SGPRs)
-    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto tick = [&](int k) {   // (wave-uniform; waits for everything outstanding so that a phase is charged with its own latencies)
-        if constexpr (TIMING) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            tacc[k] += now - tprev;
-            tprev = now;
-        }
-    };
-    if constexpr (TIMING) tprev = __builtin_amdgcn_s_memtime();
-    for (; item < n1; item += step, cur = nx) {   // `continue` leaves a read
-        nx = k2rec[min(item + step, n1 - 1)];     // (used after phase 1 and as the next `cur`: never waited for here)
-        tick(0);                                  // [0] loop overhead + the record loads
-        const int i = cur.i;
-        const long long s = cur.row;
-        const int rl = cur.rl;
-        const int K0 = cur.K0;                        // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
-        const long long n64 = cur.n;
-        const int2 qv = qv_mask ? qv_mask[i] : make_int2(0, 0);
-        const int qe = rl / 20;                       // last bin an event can fall in
-        if (n64 >= 65536 || K0 < 0 || qe >= qcap || MIN_COV < 0) {
-            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
-            continue;
-        }
-        const int n = (int)n64;
-        const unsigned* __restrict__ row = span16 + s;
-        const int Qn = qe + 1, Qs = (Qn + 3) & ~3;
-        // ---- phase 1: begin|end counts per 20-bp bin ---------------------------------------------------------
-        bool cleared = false;
-        for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
-            unsigned v[LOADS_IN_FLIGHT];
-            const unsigned* __restrict__ p = row + (unsigned)(base + lane);   // (padded by half a batch: no clamp)
-            if (n - base > (LOADS_IN_FLIGHT / 2) * WAVE) {
-#pragma unroll
-                for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = p[u * WAVE];
-            } else if (n > 0) {
-#pragma unroll
-                for (int u = 0; u < LOADS_IN_FLIGHT / 2; u++) v[u] = p[u * WAVE];
-            }
-            if (!cleared) {   // cleared while the first batch is in flight
-                int4* z4 = reinterpret_cast<int4*>(Pq);
-                for (int t = lane; t < Qs / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
-                cleared = true;
-            }
-            tick(1);                               // [1] span loads (+ clearing the bins)
-#pragma unroll
-            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
-                if (base + u * WAVE >= n) break;   // wave-uniform
-                if (base + u * WAVE + lane < n) {
-                    const unsigned qb = (v[u] & 0xffffu) / 20u, qd = (v[u] >> 16) / 20u;
-                    int* pb = qb == 0u ? trash : Pq + qb;
-                    int* pe = qd == (unsigned)qe ? trash : Pq + qd;
-                    atomicAdd(pb, 1);
-                    atomicAdd(pe, 0x10000);
-                }
-            }
-        }
-        tick(2);                                   // [2] LDS atomics of the histogram
-        if (item + step < n1 && lane * 16 < nx.n) {
-            // One dword of every 64 bytes of the NEXT read's spans: brings them into L2 while phases 2-5 of this read run.
-            // Inline assembly because the value is dead: a C++ load would be sunk to its (only, artificial) use or dropped.
-            // `touch` stays allocated to the end of the iteration (the asm there), so the returning load cannot clobber a
-            // register that holds something else by then.
-            const unsigned* tp = span16 + nx.row + lane * 16;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(tp));
-        }
-        if (ablate == 1) continue;
-        // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane, two rows of 256 bins per step ----------
-        int carry = 0;
-        for (int base = 0; base < Qn; base += 8 * WAVE) {
-            const int t0 = base + 4 * lane, t1 = t0 + 4 * WAVE;
-            int4 a = t0 < Qs ? *reinterpret_cast<const int4*>(Pq + t0) : make_int4(0, 0, 0, 0);
-            int4 b = t1 < Qs ? *reinterpret_cast<const int4*>(Pq + t1) : make_int4(0, 0, 0, 0);
-            a.y += a.x; a.z += a.y; a.w += a.z;
-            b.y += b.x; b.z += b.y; b.w += b.z;
-            int ia = a.w, ib = b.w;
-            wave_incl_scan2(ia, ib);
-            const int ea = ia - a.w + carry;
-            const int mid = carry + wave_last(ia);
-            const int eb = ib - b.w + mid;
-            a.x += ea; a.y += ea; a.z += ea; a.w += ea;
-            b.x += eb; b.y += eb; b.z += eb; b.w += eb;
-            if (t0 < Qs) *reinterpret_cast<int4*>(Pq + t0) = a;
-            if (t1 < Qs) *reinterpret_cast<int4*>(Pq + t1) = b;
-            carry = mid + wave_last(ib);
-        }
-        tick(3);                                   // [3] prefix scan
-        if (ablate == 2) continue;
-        // begins of bin 0 and ends of bin qe were not counted: B0 = n - (the counted begins); from bin qe on every event is
-        // consumed: PB' = n - B0, PE = n
-        const int counted_b = carry & 0xffff;
-        const int B0 = n - counted_b;
-        {
-            const int tot = counted_b | (n << 16);
-            for (int t = qe + lane; t < Qs + PADT; t += WAVE) Pq[t] = tot;
-        }
-        auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return k > 0 ? (p & 0xffff) + B0 - (int)((unsigned)p >> 16) : 0; };
-        auto covc = [&](int k) {
-            const int qb = 2 * k - 1 - SH;
-            return (qb >= 0 ? (Pq[qb] & 0xffff) + B0 : 0) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16);
-        };
-        // The .coverage.txt bins go out NOW, not with the other outputs at the end of the read: on this architecture stores count in
-        // vmcnt like loads and retire in order, so the next read's first wait for its spans is also a wait for every store issued
-        // before it.  Issued here, the bins (the bulk of the stores) have the mask pass and the annotation phase to drain.
-        if (cov_out) {
-            int* __restrict__ dst = cov_out + cur.cov_off;
-            for (int j = lane; j < K0; j += WAVE) dst[j] = cov0(j);
-            if (lane == 0) cov_nbins[i - cov_base] = K0;
-        }
-        // The cutoff profile is zero from its last bin on, so any bound >= the reference's K works (see k_mask_annotate_q20)
-        const int KC = nbins_of<40>(n, rl + 20 * SH, reso);
-        // ---- coverage mask on the cutoff profile: covc(k) > MIN_COV  <=>  PB'[2k-1-SH] - PE[2k-1+SH] > MIN_COV - B0 where the
-        // begin prefix exists (2k-1-SH >= 0); before that covc = -PE <= 0 <= MIN_COV ------------------------------------
-        RunState run{0, 0ull, 0, 0};
-        const int thr = MIN_COV - B0;
-        const int kmin = (SH + 2) / 2;   // first k with 2k - 1 - SH >= 0
-        for (int base = 0; base < KC; base += WAVE) {
-            const int k = base + lane;
-            const int d = (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16);
-            const unsigned long long M = ballot_of(d > thr && k >= kmin);
-            const int left = KC - base;
-            if (left >= 64) {
-                if (M == ~0ull) { run.prev_pos = 1ull; continue; }
-                run_feed(run, base, M, ~0ull, reso);
-            } else {
-                const unsigned long long V = (1ull << left) - 1ull;
-                run_feed(run, base, M & V, V, reso);
-            }
-        }
-        tick(4);                                   // [4] totals + mask pass
-        if (ablate == 3) continue;
-        // the constants of the last phase: loaded here in one go, not held across the loop (the asm hides the pointer from the
-        // hoisting passes; the copies are values, so nothing is re-read after the stores that follow)
-        const K2Const* c = C;
-        asm volatile("" : "+s"(c));
-        typedef const int __attribute__((address_space(4)))* ConstWords;   // constant address space: scalar loads (s_load_dwordx8 ...)
-        const ConstWords cw = (ConstWords)(unsigned long long)c;
-        K2Const kc;
-        static_assert(sizeof(K2Const) % sizeof(int) == 0, "copied word by word");
-#pragma unroll
-        for (int t = 0; t < (int)(sizeof(K2Const) / sizeof(int)); t++) reinterpret_cast<int*>(&kc)[t] = cw[t];
-        const FilterDev& P = kc.P;
-        const AnnoOut& o = kc.o;
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n, ~0ull, cur.cov_off, &qv);
-        asm volatile("" ::"v"(touch));   // (the prefetch load's register lives until here)
-        tick(5);                                   // [5] mask / gate / annotation / outputs (incl. the constants' loads)
-    }
-    if (timing && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) atomicAdd(&tdbg[k], tacc[k]);
-        atomicAdd(&tdbg[6], 1ull);
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n, true);
     }
 }
 

@@ -73,16 +73,6 @@ struct hinge_ctx {
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
     int k2_rpw = 0;              // class-1 reads per wavefront of k_mask_annotate_q20 (0: chosen from the part's size)
-    int k1_w8 = 0;               // HINGE_K1_W8=1: k_cov_stats compiled for eight wavefronts per SIMD (A/B timing)
-    int k2_ablate = 0;           // HINGE_K2_ABLATE (timing experiments): k_mask_annotate_lean leaves every read after phase k
-    int k2_lean = 1;             // HINGE_K2_LEAN=0: class-1 reads through k_mask_annotate_q20 like the longer ones (tests, A/B timing)
-    DevBuf k2rec, pos_of;        // K2Rec per class-1 read in K2's list order (written by k_cov_stats), and read -> slot (-1: none)
-    bool k2rec_fresh = false;    // k_cov_stats of this pass filled k2rec for the current pile-ups
-    bool k2rec_cov = false;      // ... with the coverage-bin offsets of this cut_off in them
-    int k2rec_cut = 0;
-    DevBuf k2c;                  // K2Const of k_mask_annotate_lean in device memory
-    K2Const k2c_host;            // what was uploaded last
-    bool k2c_valid = false;
     bool trace_padded = false;   // the trace buffer is the library's own copy with 8 spare bytes behind it
     int64_t trace_bytes = 0;
     int tbytes = 1;
@@ -158,7 +148,6 @@ struct Scalars {
     unsigned facts[2];                  // k_pileup_facts: largest pile-up, out-of-range flag
     int bins_status;                    // hinge_filter_coverage_bins' own range flag
     int pad2;
-    unsigned long long tdbg[8];         // HINGE_K2_ABLATE=100: shader-clock totals per phase of k_mask_annotate_lean, [6] = wavefronts
     unsigned dbg[16];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
@@ -233,9 +222,6 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
     if (const char* g = getenv("HINGE_K2_RPW")) ctx->k2_rpw = std::max(1, atoi(g));
-    if (const char* g = getenv("HINGE_K2_LEAN")) ctx->k2_lean = atoi(g);
-    if (const char* g = getenv("HINGE_K2_ABLATE")) ctx->k2_ablate = atoi(g);
-    if (const char* g = getenv("HINGE_K1_W8")) ctx->k1_w8 = atoi(g);
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -253,7 +239,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
-                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c, &ctx->k2rec, &ctx->pos_of};
+                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -375,15 +361,6 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
         if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)nr))) return rc;
         CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
-        {   // read -> position among the class-1 reads (the order k_mask_annotate_lean works in), -1 for the other classes
-            std::vector<int> pos((size_t)nr, -1);
-            for (int t = 0; t < n1; t++) pos[(size_t)(lst[(size_t)t] - r_begin)] = t;
-            if ((rc = ensure(ctx, ctx->pos_of, sizeof(int) * (size_t)nr))) return rc;
-            if ((rc = ensure(ctx, ctx->k2rec, sizeof(K2Rec) * (size_t)std::max(n1, 1)))) return rc;
-            CK(hipMemcpyAsync(ctx->pos_of.p, pos.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
-            CK(hipStreamSynchronize(ctx->stream));   // pos is a local
-            ctx->k2rec_fresh = false;
-        }
         CK(hipStreamSynchronize(ctx->stream));   // lst is a local
         const bool pack_ok = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
         if (facts_given) {
@@ -518,17 +495,6 @@ int hinge_debug_heavy_items(hinge_ctx* ctx, int64_t* out) {
     return HINGE_OK;
 }
 
-// timing experiments (HINGE_K2_ABLATE=100): out[0..5] = shader clocks per phase of k_mask_annotate_lean summed over wavefronts
-// since the context was created, out[6] = wavefronts
-int hinge_debug_k2_phase_clocks(hinge_ctx* ctx, int64_t* out) {
-    if (!ctx || !out) return HINGE_E_ARG;
-    unsigned long long v[8];
-    CK(hipStreamSynchronize(ctx->stream));
-    CK(hipMemcpy(v, sc(ctx)->tdbg, sizeof(v), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; k++) out[k] = (int64_t)v[k];
-    return HINGE_OK;
-}
-
 // hidden knob for tests: 1 = route every scanned annotation through k_hinge_exact,
 // 2 = force the in-kernel exact pile-up order for every scanned annotation
 int hinge_debug_force_exact(hinge_ctx* ctx, int on) {
@@ -559,27 +525,6 @@ static int flush_min_cov(hinge_ctx* ctx) {
     return HINGE_OK;
 }
 
-// Layout of K2's coverage-bin output: read i of the part gets (rlen + cut_off) / reso + 3 slots, the most bins a profile the
-// kernels accept can have (more raises ST_RANGE).  Host-computable, so no device prefix sum and no second launch.
-static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
-    if (!ctx->cov_out_on) return HINGE_OK;
-    const int key[4] = {ctx->r_begin, ctx->r_end, p->reso, p->cut_off};
-    const int nr = ctx->r_end - ctx->r_begin + 1;
-    if (memcmp(key, ctx->cov_key, sizeof(key)) != 0 || ctx->h_cov_off.size() != (size_t)nr + 1) {
-        ctx->h_cov_off.assign((size_t)nr + 1, 0);
-        for (int k = 0; k < nr; k++)
-            ctx->h_cov_off[(size_t)k + 1] = ctx->h_cov_off[(size_t)k] + ((int64_t)std::max(ctx->h_rlen[(size_t)(ctx->r_begin + k)], 0) + std::max(p->cut_off, 0)) / p->reso + 3;
-        int rc;
-        if ((rc = ensure(ctx, ctx->cov_off_d, sizeof(int64_t) * ((size_t)nr + 1)))) return rc;
-        if ((rc = ensure(ctx, ctx->cov_nb, sizeof(int) * (size_t)nr))) return rc;
-        if ((rc = ensure(ctx, ctx->cov_buf, sizeof(int) * (size_t)std::max<int64_t>(ctx->h_cov_off[(size_t)nr], 1)))) return rc;
-        CK(hipMemcpyAsync(ctx->cov_off_d.p, ctx->h_cov_off.data(), sizeof(int64_t) * ((size_t)nr + 1), hipMemcpyHostToDevice, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-        memcpy(ctx->cov_key, key, sizeof(key));
-    }
-    return HINGE_OK;
-}
-
 static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int nr = ctx->r_end - ctx->r_begin + 1;
     const int grid = grid_for_reads(ctx, nr, WAVES_PER_BLOCK);
@@ -593,34 +538,18 @@ static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int n_reset = (int)(SCALARS_RESET_BYTES / sizeof(int));
     const int set_mc = ctx->min_cov_pending ? 1 : 0, mc = ctx->min_cov_value;
     ctx->min_cov_pending = false;
-    {   // the K2 records carry each read's offset in the coverage-bin output: its layout must exist before this kernel runs
-        int rc = prepare_cov_out(ctx, p);
-        if (rc) return rc;
-    }
-    const long long* cov_off_arg = ctx->cov_out_on ? (const long long*)ctx->cov_off_d.p : (const long long*)nullptr;
     ProfScope _ps(ctx, KID_STATS);
-#define LAUNCH_COV_STATS(KERNEL, RESO, PACKED)                                                                                          \
-    hipLaunchKernelGGL((KERNEL<RESO, PACKED>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end,                        \
+#define LAUNCH_COV_STATS(RESO, PACKED)                                                                                                 \
+    hipLaunchKernelGGL((k_cov_stats<RESO, PACKED>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->r_begin, ctx->r_end,                   \
                        (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, \
                        p->reso, ctx->mean_cov, (int*)ctx->nbins0.p, (unsigned long long*)ctx->wave_totals.p, (int*)ctx->scalars.p, n_reset, \
-                       &sc(ctx)->min_cov, set_mc, mc, (const int*)ctx->pos_of.p, (K2Rec*)ctx->k2rec.p, cov_off_arg)
-    if (ctx->k1_w8) {
-        if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats_w8, 40, true);
-        else if (p->reso == 40) LAUNCH_COV_STATS(k_cov_stats_w8, 40, false);
-        else if (ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats_w8, 0, true);
-        else LAUNCH_COV_STATS(k_cov_stats_w8, 0, false);
-    } else {
-        if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats, 40, true);
-        else if (p->reso == 40) LAUNCH_COV_STATS(k_cov_stats, 40, false);
-        else if (ctx->use_span16) LAUNCH_COV_STATS(k_cov_stats, 0, true);
-        else LAUNCH_COV_STATS(k_cov_stats, 0, false);
-    }
-#undef LAUNCH_COV_STATS
+                       &sc(ctx)->min_cov, set_mc, mc)
+    if (p->reso == 40 && ctx->use_span16) LAUNCH_COV_STATS(40, true);
+    else if (p->reso == 40) LAUNCH_COV_STATS(40, false);
+    else if (ctx->use_span16) LAUNCH_COV_STATS(0, true);
+    else LAUNCH_COV_STATS(0, false);
     CK(hipGetLastError());
     ctx->nbins0_reso = p->reso;   // nbins0[] now describes these pile-ups at this reso
-    ctx->k2rec_fresh = true;
-    ctx->k2rec_cov = ctx->cov_out_on;
-    ctx->k2rec_cut = p->cut_off;
     return HINGE_OK;
 }
 
@@ -743,12 +672,33 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
                        (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,                     \
                        (const int*)&sc(ctx)->min_cov, kcap, anno_out(ctx), LIST, COUNT)
 
+// Layout of K2's coverage-bin output: read i of the part gets (rlen + cut_off) / reso + 3 slots, the most bins a profile the
+// kernels accept can have (more raises ST_RANGE).  Host-computable, so no device prefix sum and no second launch.
+static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
+    if (!ctx->cov_out_on) return HINGE_OK;
+    const int key[4] = {ctx->r_begin, ctx->r_end, p->reso, p->cut_off};
+    const int nr = ctx->r_end - ctx->r_begin + 1;
+    if (memcmp(key, ctx->cov_key, sizeof(key)) != 0 || ctx->h_cov_off.size() != (size_t)nr + 1) {
+        ctx->h_cov_off.assign((size_t)nr + 1, 0);
+        for (int k = 0; k < nr; k++)
+            ctx->h_cov_off[(size_t)k + 1] = ctx->h_cov_off[(size_t)k] + ((int64_t)std::max(ctx->h_rlen[(size_t)(ctx->r_begin + k)], 0) + std::max(p->cut_off, 0)) / p->reso + 3;
+        int rc;
+        if ((rc = ensure(ctx, ctx->cov_off_d, sizeof(int64_t) * ((size_t)nr + 1)))) return rc;
+        if ((rc = ensure(ctx, ctx->cov_nb, sizeof(int) * (size_t)nr))) return rc;
+        if ((rc = ensure(ctx, ctx->cov_buf, sizeof(int) * (size_t)std::max<int64_t>(ctx->h_cov_off[(size_t)nr], 1)))) return rc;
+        CK(hipMemcpyAsync(ctx->cov_off_d.p, ctx->h_cov_off.data(), sizeof(int64_t) * ((size_t)nr + 1), hipMemcpyHostToDevice, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        memcpy(ctx->cov_key, key, sizeof(key));
+    }
+    ctx->cov_valid = true;
+    return HINGE_OK;
+}
+
 static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     {
         int rc = flush_min_cov(ctx);
         if (rc) return rc;
         if ((rc = prepare_cov_out(ctx, p))) return rc;
-        ctx->cov_valid = ctx->cov_out_on;   // this pass stores the bins
     }
     const int kcap = kcap_for(ctx, p);
     const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
@@ -775,46 +725,15 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         // class-1 reads per wavefront: 3 once the part has enough reads to fill the GPU several times over with a third of the
         // wavefronts (84.1 us vs 88.8 us on 86 588 reads; 2: 87.4, 4: 84.5), 1 for small parts; HINGE_K2_RPW overrides
         const int rpw = ctx->k2_rpw > 0 ? ctx->k2_rpw : std::min(3, std::max(1, n1 / 16384));
-        const bool lean = ctx->use_span16 && ctx->k2_lean != 0 && n1 > 0 && ctx->k2rec_fresh && ctx->k2rec_cov == ctx->cov_out_on &&
-                          (!ctx->cov_out_on || ctx->k2rec_cut == p->cut_off);
-        if (lean) {
-            // class-1 reads (one LDS slot; nearly all of a part) through the lean kernel; its constants sit in device memory
-            K2Const hc;
-            memset(&hc, 0, sizeof(hc));
-            hc.P = to_dev(p);
-            hc.o = anno_out(ctx);
-            hc.o.cov_out = nullptr;   // (the lean kernel stores the bins itself, early: see there)
-            int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
-            if (rc) return rc;
-            if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
-                ctx->k2c_host = hc;
-                CK(hipMemcpyAsync(ctx->k2c.p, &ctx->k2c_host, sizeof(K2Const), hipMemcpyHostToDevice, ctx->stream));
-                ctx->k2c_valid = true;
-            }
-            const int g1 = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw);
-#define LAUNCH_LEAN(TIMING)                                                                                                              \
-            hipLaunchKernelGGL(k_mask_annotate_lean<TIMING>, dim3(g1), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p,             \
-                               (const K2Rec*)ctx->k2rec.p, n1, (const unsigned*)ctx->span16.p,                                                  \
-                               ctx->has_qv ? (const int2*)ctx->qv_mask.p : (const int2*)nullptr,                                                \
-                               ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr, (int*)ctx->cov_nb.p, ctx->r_begin,                        \
-                               (const int*)&sc(ctx)->min_cov, slot, SH,                                                                        \
-                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, g1, ctx->k2_ablate, (unsigned long long*)sc(ctx)->tdbg)
-            if (ctx->k2_ablate == 100) LAUNCH_LEAN(true); else LAUNCH_LEAN(false);
-#undef LAUNCH_LEAN
-        }
-        const int n1q = lean ? 0 : n1;   // what is left for k_mask_annotate_q20: the reads that need two or four slots (+ class 1 without the lean kernel)
-        const int* list_q = (const int*)ctx->bucket_list.p + (lean ? n1 : 0);
-        const int g = ((n1q + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4;
-        if (g > 0) {
-            if (ctx->use_span16)
-                hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), list_q, n1q, n2, n4,
-                                   (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                                   (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
-            else
-                hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), list_q, n1q, n2, n4,
-                                   (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                                   (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
-        }
+        const int g = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4);
+        if (ctx->use_span16)
+            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+                               (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
+                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+        else
+            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
+                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is

@@ -188,7 +188,17 @@ def read_qual_track(db_name: str) -> Optional[List[np.ndarray]]:
         tracklen, size = struct.unpack("<ii", f.read(8))
         offs = np.frombuffer(f.read(8 * (tracklen + 1)), dtype=np.int64)
     data = np.fromfile(pre + ".qual.data", dtype=np.uint8)
-    return [data[offs[i]:offs[i + 1]] for i in range(tracklen)]
+    out = [data[offs[i]:offs[i + 1]] for i in range(tracklen)]
+    # A track with one entry per UNTRIMMED read on a trimmed DB: the entries of the reads Trim_DB drops are skipped (what the
+    # oracle and the C++ host reader do; the reference's own getQV crashes on this combination, tests/test_oracle_pinned.py)
+    try:
+        idx = read_db_index(db_name)
+    except OSError:
+        return out
+    keep = idx.get("keep")
+    if keep is not None and tracklen == len(keep) and int(np.sum(keep)) != tracklen:
+        out = [q for q, k in zip(out, keep) if k]
+    return out
 
 
 # --------------------------------------------------------------------------------------

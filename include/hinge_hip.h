@@ -241,8 +241,6 @@ int hinge_debug_force_general_mask(hinge_ctx* ctx, int on);
 int hinge_debug_fallback_reads(hinge_ctx* ctx, int64_t* out);
 /* out[0..1] = undecided annotations the last hinge pass put through the half-size / full-size k_hinge_call. */
 int hinge_debug_heavy_items(hinge_ctx* ctx, int64_t* out);
-/* HINGE_K2_ABLATE=100 builds a timing run: out[0..5] = shader clocks per phase of k_mask_annotate_lean, out[6] = wavefronts. */
-int hinge_debug_k2_phase_clocks(hinge_ctx* ctx, int64_t* out);
 /* pos_out[k] = position of element k after std::sort(compare_overlap) of n keys, through the wavefront-parallel replay. */
 int hinge_debug_pileup_order(hinge_ctx* ctx, int32_t n, const int32_t* keys, int32_t* pos_out);
 

@@ -319,19 +319,6 @@ def test_filter_int32_spans(datasets, oracle_lib, tmp_path, monkeypatch):
         _compare(wd_o, wd_h)
 
 
-def test_filter_class1_reads_through_the_q20_kernel(datasets, oracle_lib, tmp_path, monkeypatch):
-    """HINGE_K2_LEAN=0: the reads that fit one LDS slot go through k_mask_annotate_q20 (hot-bin words, per-read fold) instead of
-    k_mask_annotate_lean, which every other test of this file runs by default."""
-    monkeypatch.setenv("HINGE_K2_LEAN", "0")
-    for name in ("tiny_qv", "long_repeat", "edges"):
-        src, _ = datasets(name)
-        wd_o = clone_dataset(src, str(tmp_path / (name + "_oracle")))
-        wd_h = clone_dataset(src, str(tmp_path / (name + "_hip")))
-        assert _oracle_filter(oracle_lib, wd_o, False) == 0
-        assert _hip_filter(wd_h, False, packed=True) == 0
-        _compare(wd_o, wd_h)
-
-
 @pytest.mark.parametrize("name,genome,mlas", [("cfg3_nctc", 400_000, False), ("cfg4_yeast", 600_000, True), ("cfg2_ecoli160", 250_000, False)])
 def test_baseline_configs_scaled_down(oracle_lib, tmp_path, name, genome, mlas):
     """BASELINE.json's other configurations (repeat-rich NCTC-like with chimeras; 8-block yeast-like with --mlas; the bench

@@ -2,7 +2,7 @@
 """A/B timing of the K2 kernels (coverage mask + repeat annotation) on the bench workload: every variant runs on its own
 context over the same resident part, its masks / annotations are compared with the first variant's, and K2 alone is timed
 with HIP events (hinge_profile_*).  Variants are environment settings read when a context is created
-(HINGE_K2_LEAN, HINGE_K2_RPW, HINGE_NO_SPAN16 ...).    python tools/k2_bench.py [--genome 4600000] [--cov-out]"""
+(HINGE_K2_RPW, HINGE_NO_SPAN16 ...).    python tools/k2_bench.py [--genome 4600000] [--cov-out]"""
 import argparse
 import dataclasses
 import os
@@ -14,18 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = [
-    ("q20 rpw=3", {"HINGE_K2_LEAN": "0"}),
-    ("lean rpw=1", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "1"}),
-    ("lean rpw=2", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "2"}),
-    ("lean rpw=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "3"}),
-    ("lean rpw=6", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "6"}),
-    ("lean rpw=12", {"HINGE_K2_LEAN": "1", "HINGE_K2_RPW": "12"}),
-    ("lean K1w8", {"HINGE_K2_LEAN": "1", "HINGE_K1_W8": "1"}),
-    # cumulative cost of the phases of the lean kernel: every read is left after phase k (results are garbage: not compared)
-    ("lean abl=1", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "1", "HINGE_K2_RPW": "6"}),   # histogram
-    ("lean abl=2", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "2", "HINGE_K2_RPW": "6"}),   # + prefix scan
-    ("lean abl=3", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "3", "HINGE_K2_RPW": "6"}),   # + mask pass
-    ("lean clocks", {"HINGE_K2_LEAN": "1", "HINGE_K2_ABLATE": "100", "HINGE_K2_RPW": "3"}),   # serialised phases, shader clocks per phase
+    ("rpw=1", {"HINGE_K2_RPW": "1"}),
+    ("rpw=2", {"HINGE_K2_RPW": "2"}),
+    ("rpw=3", {"HINGE_K2_RPW": "3"}),
+    ("rpw=4", {"HINGE_K2_RPW": "4"}),
+    ("int32 spans", {"HINGE_NO_SPAN16": "1"}),
 ]
 
 
@@ -70,7 +63,7 @@ def main():
             ctx.filter_median(P, 0, n - 1, fetch=True)
             ctx.filter_mask_annotate(P)      # synchronous: sizes the annotation buffer
             ctxs.append(ctx)
-        ablated = env.get("HINGE_K2_ABLATE", "0") not in ("0", "100")
+        ablated = False
         res = None if ablated else [(c.get_masks(), c.get_annotations()[:3]) for c in ctxs]
         if ablated:
             pass
@@ -88,11 +81,6 @@ def main():
                 c.filter_stats(P)
                 c.filter_mask_annotate_async(P)
         tot = {}
-        if env.get("HINGE_K2_ABLATE") == "100":
-            clk = sum(c.k2_phase_clocks() for c in ctxs)
-            reads = sum(p[1] for p in parts) * (args.reps + 1)
-            print("   clocks per read by phase [record, span loads, histogram atomics, scan, mask, annotate+outputs]:",
-                  [round(float(x) / reads, 1) for x in clk[:6]], "(wavefronts %d)" % clk[6], flush=True)
         for c in ctxs:
             for k, (ms, cnt) in c.profile_report().items():
                 if cnt:

@@ -54,11 +54,13 @@ def main():
     n = pile.n_ovl
     alg = 24.0 * n + float(tlen.sum()) + 8.0 * n
     out = {}
-    for name, env in (("stream", None), ("rows", "1")):
-        if env:
+    for name, env in (("stream", None), ("stream cap 8192", "cap8192"), ("stream cap 12288", "cap12288"), ("rows", "1")):
+        os.environ.pop("HINGE_K4_ROWS", None)
+        os.environ.pop("HINGE_K4_CAP", None)
+        if env == "1":
             os.environ["HINGE_K4_ROWS"] = env
-        else:
-            os.environ.pop("HINGE_K4_ROWS", None)
+        elif env:
+            os.environ["HINGE_K4_CAP"] = env[3:]
         types = ctx.trim_classify_part(n, 1000, 300, 0)
         ctx.profile_select(["k_trim_classify"])
         ctx.profile_enable(2 * args.reps + 4)
@@ -68,10 +70,11 @@ def main():
         ctx.profile_enable(0)
         out[name] = types
         t = ms / cnt
-        print("%-7s %.3f ms per launch, %d overlaps, mean tlen %.1f B, algorithmic %.2f GB -> %.2f TB/s = %.2f of the HBM peak" %
+        print("%-16s %.3f ms per launch, %d overlaps, mean tlen %.1f B, algorithmic %.2f GB -> %.2f TB/s = %.2f of the HBM peak" %
               (name, t, n, float(tlen.mean()), alg / 1e9, alg / (t * 1e-3) / 1e12, alg / (t * 1e-3) / 8e12), flush=True)
     os.environ.pop("HINGE_K4_ROWS", None)
-    assert np.array_equal(out["stream"], out["rows"]), "the two kernels disagree"
+    os.environ.pop("HINGE_K4_CAP", None)
+    assert all(np.array_equal(out["stream"], v) for v in out.values()), "the kernels disagree"
     print("types identical; histogram:", np.bincount(out["stream"], minlength=14).tolist())
 
 
