@@ -40,6 +40,7 @@ class CovEstimate(C.Structure):
 # every symbol include/hinge_hip.h declares: (name, restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = [
+    ("hinge_device_count", C.c_int, []),
     ("hinge_ctx_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
     ("hinge_ctx_destroy", None, [_VP]),
     ("hinge_last_error", C.c_char_p, [_VP]),
@@ -52,6 +53,7 @@ SYMBOLS = [
     ("hinge_get_pileup_facts", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     ("hinge_attach_mask_table", C.c_int, [_VP, _VP]),
     ("hinge_attach_mean_cov", C.c_int, [_VP, _VP]),
+    ("hinge_set_mask_rows", C.c_int, [_VP, C.c_int32, C.c_int32, _VP]),
     ("hinge_clear_masks", C.c_int, [_VP]),
     ("hinge_filter_stats", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_median", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, C.POINTER(CovEstimate)]),

@@ -434,6 +434,19 @@ int hinge_attach_mean_cov(hinge_ctx* ctx, int32_t* d) {
     ctx->mean_attached = d != nullptr;
     return HINGE_OK;
 }
+int hinge_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int hinge_set_mask_rows(hinge_ctx* ctx, int32_t r0, int32_t r1, const int32_t* rows) {
+    if (!ctx || !ctx->mask || !rows || r0 < 0 || r1 >= ctx->n_reads || r1 < r0) return fail(ctx, HINGE_E_ARG, "hinge_set_mask_rows: bad arguments");
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpyAsync(ctx->mask + r0, rows, sizeof(int2) * (size_t)(r1 - r0 + 1), hipMemcpyHostToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return HINGE_OK;
+}
+
 int hinge_clear_masks(hinge_ctx* ctx) {
     if (!ctx || !ctx->mask) return HINGE_E_ARG;
     CK(hipMemsetAsync(ctx->mask, 0, sizeof(int2) * (size_t)ctx->n_reads, ctx->stream));

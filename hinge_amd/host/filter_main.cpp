@@ -1,6 +1,7 @@
 // Reads_filter  ==  `hinge filter --db DB --las LAS[.las] [--mlas] -x PREFIX --config nominal.ini`
 // Same flags, same inputs, same output files, same exit codes as src/filter/filter.cpp; the pile-up
 // arithmetic (filter.cpp:529-1070) runs in the HIP kernels behind include/hinge_hip.h.
+#include <functional>
 #include <set>
 #include "host_common.h"
 
@@ -74,16 +75,37 @@ int main(int argc, char* argv[]) {
         if (rf) fclose(rf);
         console.info("Restricting to %zu reads", reads_to_keep.size());
     }
+    // ---- how many ranks: one per visible GPU for a --mlas run (HINGE_RANKS overrides; more ranks than devices share them) -----
+    // A rank = one host thread + one hinge_ctx.  The parts of a --mlas run go to the ranks in waves of n_ranks consecutive parts;
+    // what the reference's sequential loop carries from part to part is exchanged between the ranks of a wave (see run_wave):
+    // the running MIN_COV (a prefix maximum over the parts) and the mask table (a part sees the masks of the parts before it).
+    int n_ranks = 1;
+    {
+        const char* e = getenv("HINGE_RANKS");
+        const int ndev = hinge_device_count();
+        n_ranks = e ? atoi(e) : ndev;
+        n_ranks = std::max(1, std::min(n_ranks, (int)las_list.size()));
+        if (!reads_to_keep.empty() || fa_and_paf) n_ranks = 1;   // --restrictreads grows its read set from part to part: sequential
+    }
     PartLoader loader;
     loader.pairs = !reads_to_keep.empty();   // the neighbours of the listed reads need the per-record B column
     loader.paf = fa_and_paf;
     loader.span16 = true;
-    if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
+    if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
-    hinge_ctx* ctx = gpu.ctx;
-    HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), has_qv ? qvm.data() : nullptr));
-    HH_CHECK(ctx, hinge_filter_set_min_cov(ctx, P.min_cov));
+    std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
+    ctxs[0] = gpu.ctx;
+    {
+        const int ndev = std::max(1, hinge_device_count());
+        for (int r = 1; r < n_ranks; r++)
+            if (hinge_ctx_create(r % ndev, &ctxs[(size_t)r]) != HINGE_OK) { console.error("cannot create a context on device %d", r % ndev); return 2; }
+    }
+    hinge_ctx* ctx = ctxs[0];
+    for (int r = 0; r < n_ranks; r++) {
+        HH_CHECK(ctxs[(size_t)r], hinge_set_reads(ctxs[(size_t)r], n_read, db.rlen.data(), has_qv ? qvm.data() : nullptr));
+        HH_CHECK(ctxs[(size_t)r], hinge_filter_set_min_cov(ctxs[(size_t)r], P.min_cov));
+    }
 
     tm.mark("ctx_create + set_reads");
     FILE* f_cov = fopen((out + ".coverage.txt").c_str(), "w");
@@ -97,27 +119,46 @@ int main(int argc, char* argv[]) {
     FILE* f_selfflag = fopen((out + ".self.flag").c_str(), "w");
     if (!f_cov || !f_rep || !f_hg || !f_mask || !f_cmask || !f_covflag || !f_selfflag) { console.error("cannot open output files with prefix %s", out.c_str()); return 2; }
 
-    for (size_t part = 0; part < las_list.size(); part++) {
-        console.info("part: %zu  name of las: %s", part, las_list[part].c_str());
-        int lrc = 0;
-        std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
-        LasPart& las = *las_owner;
-        if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
-        if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
-        if (lrc != 0) { fprintf(stderr, "Reads_filter: cannot read %s\n", las_list[part].c_str()); quit(1); }
-        tm.mark("las ingest");
-        console.info("# Alignments: %lld", (long long)las.novl);
-        if (las.novl == 0) { console.error("No alignments!"); return 1; }
-        const int r_begin = las.r_begin, r_end = las.r_end;
-        const size_t nr = (size_t)(r_end - r_begin + 1);
-        HH_CHECK(ctx, hinge_set_pileups_packed(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(),
-                                               las.span16_ptr(), las.max_pile, las.spans_in_range ? 1 : 0, 0));
-        HH_CHECK(ctx, hinge_filter_coverage_out(ctx, 1));   // K2 also stores the cutoff-0 bins: .coverage.txt needs no sweep of its own
-
-        tm.mark("set_pileups (H2D)");
-        // self_match_reads, filter.cpp:552-561 (float accumulation in record order)
+    // Everything one part produces, kept until its turn to be written comes (files are written in part order).
+    struct PartOut {
+        int code = 0;                 // 0 ok, else the exit code of the program
+        std::string error;            // console.error text for a non-zero code
+        std::unique_ptr<LasPart> las;
+        int r_begin = 0, r_end = -1;
+        hinge_cov_estimate est{};
         std::set<int> self_match;
-        if (P.delete_telomere) {
+        std::vector<int32_t> mask, cmask, nb, pos, type;
+        std::vector<uint8_t> flags, is_hinge;
+        std::vector<int64_t> coff, off;
+        UVec<int32_t> cov;
+    };
+    int running_min_cov = P.min_cov;   // MIN_COV as the sequential loop carries it (filter.cpp:677-678)
+#define PART_FAIL(o, c, ...)                                            \
+    do {                                                                 \
+        char _b[512];                                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                           \
+        (o).code = (c); (o).error = _b;                                  \
+        return;                                                          \
+    } while (0)
+#define PART_CHECK(o, cx, call)                                                                                  \
+    do {                                                                                                          \
+        int _rc = (call);                                                                                         \
+        if (_rc != HINGE_OK) PART_FAIL(o, _rc == HINGE_E_UNDEFINED ? 1 : 2, "%s failed (%d): %s", #call, _rc, hinge_last_error(cx)); \
+    } while (0)
+    // phase A of a part: ingest, upload, coverage statistics, the part's own median
+    auto phase_a = [&](hinge_ctx* cx, size_t part, PartOut& o) {
+        int lrc = 0;
+        o.las.reset(loader.take(part, las_list[part], db.rlen, lrc));
+        LasPart& las = *o.las;
+        if (lrc == -2) PART_FAIL(o, 2, "%s is not sorted by A read", las_list[part].c_str());
+        if (lrc == -3) PART_FAIL(o, 1, "%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str());
+        if (lrc != 0) PART_FAIL(o, -1, "Reads_filter: cannot read %s", las_list[part].c_str());
+        if (las.novl == 0) PART_FAIL(o, 1, "No alignments!");
+        o.r_begin = las.r_begin; o.r_end = las.r_end;
+        PART_CHECK(o, cx, hinge_set_pileups_packed(cx, las.r_begin, las.r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(),
+                                                   las.b_flag.data(), las.span16_ptr(), las.max_pile, las.spans_in_range ? 1 : 0, 0));
+        PART_CHECK(o, cx, hinge_filter_coverage_out(cx, 1));   // K2 also stores the cutoff-0 bins: .coverage.txt needs no sweep of its own
+        if (P.delete_telomere) {   // self_match_reads, filter.cpp:552-561 (float accumulation in record order)
             std::map<int, float> cov;
             for (size_t k = 0; k < las.self_a.size(); k++) {
                 float& c = cov[las.self_a[k]];
@@ -126,11 +167,9 @@ int main(int argc, char* argv[]) {
             }
             for (auto& it : cov) {
                 float c = it.second / float(db.rlen[(size_t)it.first]);
-                if ((c > 4.5) && (db.rlen[(size_t)it.first] > 10000)) self_match.insert(it.first);
+                if ((c > 4.5) && (db.rlen[(size_t)it.first] > 10000)) o.self_match.insert(it.first);
             }
         }
-
-        tm.mark("self matches");
         if (!reads_to_keep.empty()) {   // + every B the listed reads have an alignment with (idx_ab, filter.cpp:680-694); cumulative over parts
             const std::set<int> initial = reads_to_keep;
             for (int i : initial) {
@@ -140,52 +179,57 @@ int main(int argc, char* argv[]) {
             console.info("After accounting for neighbours of reads selected, have %zu reads", reads_to_keep.size());
             std::vector<uint8_t> keep((size_t)n_read, 0);
             for (int i : reads_to_keep) if (i >= 0 && i < n_read) keep[(size_t)i] = 1;
-            HH_CHECK(ctx, hinge_set_read_restriction(ctx, keep.data()));
+            PART_CHECK(o, cx, hinge_set_read_restriction(cx, keep.data()));
         }
-        hinge_cov_estimate est;
-        HH_CHECK(ctx, hinge_filter_stats(ctx, &P));
-        HH_CHECK(ctx, hinge_filter_median(ctx, &P, r_begin, r_end, &est));
-        console.info("Estimated mean coverage: %lld", (long long)(est.num_slot ? est.total_cov / est.num_slot : 0));
-        console.info("Estimated median coverage: %d", P.est_cov != 0 ? P.est_cov : est.cov_est);
-        HH_CHECK(ctx, hinge_filter_mask_annotate(ctx, &P));
-        HH_CHECK(ctx, hinge_filter_hinges(ctx, &P));
-
-        tm.mark("kernels (4 passes)");
-        // .coverage.txt, filter.cpp:599-602: the bins K2 stored
-        {
-            std::vector<int64_t> coff(nr + 1);
-            HH_CHECK(ctx, hinge_filter_get_coverage(ctx, coff.data(), nullptr, nullptr, 0));
-            std::vector<int32_t> nb(nr);
-            UVec<int32_t> cov;   // filled by the copy from the device: no zero fill, huge pages
-            cov.resize((size_t)std::max<int64_t>(coff[nr], 1));
-            HH_CHECK(ctx, hinge_filter_get_coverage(ctx, coff.data(), nb.data(), cov.data(), coff[nr]));
-            write_coverage_txt(f_cov, r_begin, nb, cov, P.reso, &coff);
-        }
+        PART_CHECK(o, cx, hinge_filter_stats(cx, &P));
+        PART_CHECK(o, cx, hinge_filter_median(cx, &P, las.r_begin, las.r_end, &o.est));
+    };
+    // phase B: the mask / annotation pass under the MIN_COV this part sees; its mask rows come back to the host
+    auto phase_b = [&](hinge_ctx* cx, int min_cov_seen, PartOut& o) {
+        const size_t nr = (size_t)(o.r_end - o.r_begin + 1);
+        PART_CHECK(o, cx, hinge_filter_set_min_cov(cx, min_cov_seen));
+        PART_CHECK(o, cx, hinge_filter_mask_annotate(cx, &P));
+        o.mask.resize(2 * nr); o.cmask.resize(2 * nr); o.flags.resize(nr);
+        PART_CHECK(o, cx, hinge_filter_get_masks(cx, o.mask.data(), o.cmask.data(), o.flags.data()));
+    };
+    // phase C: hinge calling (every mask this part may see is in the context's table by now) and the rest of the results
+    auto phase_c = [&](hinge_ctx* cx, PartOut& o) {
+        const size_t nr = (size_t)(o.r_end - o.r_begin + 1);
+        PART_CHECK(o, cx, hinge_filter_hinges(cx, &P));
+        o.coff.resize(nr + 1); o.nb.resize(nr);
+        PART_CHECK(o, cx, hinge_filter_get_coverage(cx, o.coff.data(), nullptr, nullptr, 0));
+        o.cov.resize((size_t)std::max<int64_t>(o.coff[nr], 1));   // filled by the copy from the device: no zero fill, huge pages
+        PART_CHECK(o, cx, hinge_filter_get_coverage(cx, o.coff.data(), o.nb.data(), o.cov.data(), o.coff[nr]));
+        o.off.resize(nr + 1);
+        PART_CHECK(o, cx, hinge_filter_get_annotations(cx, o.off.data(), nullptr, nullptr, nullptr));
+        const size_t na = (size_t)std::max<int64_t>(o.off[nr], 1);
+        o.pos.resize(na); o.type.resize(na); o.is_hinge.resize(na);
+        PART_CHECK(o, cx, hinge_filter_get_annotations(cx, o.off.data(), o.pos.data(), o.type.data(), o.is_hinge.data()));
+    };
+    // the text of one part, in the reference's order (filter.cpp:599-602,775-788,1076-1098)
+    auto write_part = [&](size_t part, PartOut& o) {
+        console.info("part: %zu  name of las: %s", part, las_list[part].c_str());
+        console.info("# Alignments: %lld", (long long)o.las->novl);
+        console.info("Estimated mean coverage: %lld", (long long)(o.est.num_slot ? o.est.total_cov / o.est.num_slot : 0));
+        console.info("Estimated median coverage: %d", P.est_cov != 0 ? P.est_cov : o.est.cov_est);
+        const int r_begin = o.r_begin;
+        const size_t nr = (size_t)(o.r_end - o.r_begin + 1);
+        write_coverage_txt(f_cov, r_begin, o.nb, o.cov, P.reso, &o.coff);
         tm.mark("coverage.txt");
-        std::vector<int32_t> mask(2 * nr), cmask(2 * nr);
-        std::vector<uint8_t> flags(nr);
-        HH_CHECK(ctx, hinge_filter_get_masks(ctx, mask.data(), cmask.data(), flags.data()));
         for (size_t k = 0; k < nr; k++) {
             const int i = r_begin + (int)k;
             if (P.delete_telomere) {
-                if (flags[k] & 1) fprintf(f_covflag, "%d\n", i);
-                if (self_match.count(i)) fprintf(f_selfflag, "%d\n", i);
+                if (o.flags[k] & 1) fprintf(f_covflag, "%d\n", i);
+                if (o.self_match.count(i)) fprintf(f_selfflag, "%d\n", i);
             }
-            fprintf(f_cmask, "%d %d %d\n", i, cmask[2 * k], cmask[2 * k + 1]);
-            fprintf(f_mask, "%d %d %d\n", i, mask[2 * k], mask[2 * k + 1]);
+            fprintf(f_cmask, "%d %d %d\n", i, o.cmask[2 * k], o.cmask[2 * k + 1]);
+            fprintf(f_mask, "%d %d %d\n", i, o.mask[2 * k], o.mask[2 * k + 1]);
         }
         fclose(fopen("debug.txt", "w"));   // filter.cpp:837
-
-        std::vector<int64_t> off(nr + 1);
-        HH_CHECK(ctx, hinge_filter_get_annotations(ctx, off.data(), nullptr, nullptr, nullptr));
-        const size_t na = (size_t)std::max<int64_t>(off[nr], 1);
-        std::vector<int32_t> pos(na), type(na);
-        std::vector<uint8_t> is_hinge(na);
-        HH_CHECK(ctx, hinge_filter_get_annotations(ctx, off.data(), pos.data(), type.data(), is_hinge.data()));
         if (f_rep) {   // closed inside the part loop, filter.cpp:1086: later parts write nothing
             for (size_t k = 0; k < nr; k++) {
                 fprintf(f_rep, "%d ", r_begin + (int)k);
-                for (int64_t t = off[k]; t < off[k + 1]; t++) fprintf(f_rep, "%d %d ", pos[(size_t)t], type[(size_t)t]);
+                for (int64_t t = o.off[k]; t < o.off[k + 1]; t++) fprintf(f_rep, "%d %d ", o.pos[(size_t)t], o.type[(size_t)t]);
                 fprintf(f_rep, "\n");
             }
             fclose(f_rep);
@@ -194,13 +238,66 @@ int main(int argc, char* argv[]) {
         int hg_cnt = 0;
         for (size_t k = 0; k + 1 < nr; k++) {   // i < r_end, filter.cpp:1091
             fprintf(f_hg, "%d ", r_begin + (int)k);
-            for (int64_t t = off[k]; t < off[k + 1]; t++)
-                if (is_hinge[(size_t)t]) { fprintf(f_hg, "%d %d ", pos[(size_t)t], type[(size_t)t]); hg_cnt++; }
+            for (int64_t t = o.off[k]; t < o.off[k + 1]; t++)
+                if (o.is_hinge[(size_t)t]) { fprintf(f_hg, "%d %d ", o.pos[(size_t)t], o.type[(size_t)t]); hg_cnt++; }
             fprintf(f_hg, "\n");
         }
         tm.mark("mas/cmas/repeat/hinges txt");
-        console.info("Number of hinges before filtering: %lld", (long long)off[nr]);
+        console.info("Number of hinges before filtering: %lld", (long long)o.off[nr]);
         console.info("Number of hinges: %d", hg_cnt);
+    };
+    auto report = [&](const PartOut& o) -> int {   // a failed part ends the program the way the sequential loop did
+        if (o.code == 0) return 0;
+        if (o.code == -1) { fprintf(stderr, "%s\n", o.error.c_str()); quit(1); }
+        console.error("%s", o.error.c_str());
+        return o.code;
+    };
+    auto seen_min_cov = [&](const PartOut& o) {   // filter.cpp:671-678
+        const int cov_est = P.est_cov != 0 ? P.est_cov : o.est.cov_est;
+        if (running_min_cov < cov_est / 3) running_min_cov = cov_est / 3;
+        return running_min_cov;
+    };
+
+    for (size_t w0 = 0; w0 < las_list.size(); w0 += (size_t)n_ranks) {
+        const size_t w1 = std::min(las_list.size(), w0 + (size_t)n_ranks);
+        const size_t nw = w1 - w0;
+        std::vector<PartOut> outs(nw);
+        auto on_ranks = [&](const std::function<void(size_t)>& f) {   // f(k) for the parts of the wave, rank k on its own thread
+            if (nw == 1) { f(0); return; }
+            std::vector<std::thread> th;
+            for (size_t k = 0; k < nw; k++) th.emplace_back(f, k);
+            for (auto& t : th) t.join();
+        };
+        on_ranks([&](size_t k) { phase_a(ctxs[k], w0 + k, outs[k]); });
+        tm.mark("wave: ingest + H2D + statistics + median");
+        // exchange 1: the MIN_COV each part sees is a running maximum in part order (8 bytes per part; in one process: a host loop)
+        std::vector<int> seen(nw, running_min_cov);
+        size_t n_good = 0;
+        for (; n_good < nw && outs[n_good].code == 0; n_good++) seen[n_good] = seen_min_cov(outs[n_good]);
+        on_ranks([&](size_t k) { if (k < n_good) phase_b(ctxs[k], seen[k], outs[k]); });
+        for (size_t k = 0; k < n_good; k++) if (outs[k].code != 0) { n_good = k; break; }
+        // exchange 2: mask rows.  While part p is in hinge calling, the table holds the masks of the parts up to p and (0, 0) for
+        // the later ones (filter.cpp:534 / :778-787 in a sequential loop); afterwards every context gets the rest of the wave.
+        if (n_ranks > 1) {
+            on_ranks([&](size_t k) {
+                if (k >= n_good) return;
+                for (size_t q = 0; q < k; q++)
+                    PART_CHECK(outs[k], ctxs[k], hinge_set_mask_rows(ctxs[k], outs[q].r_begin, outs[q].r_end, outs[q].mask.data()));
+            });
+        }
+        on_ranks([&](size_t k) { if (k < n_good && outs[k].code == 0) phase_c(ctxs[k], outs[k]); });
+        if (n_ranks > 1) {
+            on_ranks([&](size_t k) {
+                for (size_t q = k + 1; q < n_good; q++)
+                    if (outs[k].code == 0) PART_CHECK(outs[k], ctxs[k], hinge_set_mask_rows(ctxs[k], outs[q].r_begin, outs[q].r_end, outs[q].mask.data()));
+            });   // (ranks without a part in this - the last - wave are not used again)
+        }
+        tm.mark("wave: masks, exchange, hinges, results");
+        for (size_t k = 0; k < nw; k++) {
+            const int rc = report(outs[k]);
+            if (rc) return rc;
+            write_part(w0 + k, outs[k]);
+        }
     }
     if (f_rep) fclose(f_rep);
     fclose(f_cov); fclose(f_hg); fclose(f_mask); fclose(f_cmask); fclose(f_covflag); fclose(f_selfflag);

@@ -83,50 +83,89 @@ int main(int argc, char* argv[]) {
         if (eff[(size_t)i * 2 + 1] - eff[(size_t)i * 2] < LENGTH_THRESHOLD) active[(size_t)i] = 0;
 
     tm.mark("db + ini + mas");
+    // ---- ranks: one host thread + one context per visible GPU for a --mlas run (HINGE_RANKS overrides) --------------------------
+    // Everything a part needs up to its list of containment candidates depends on that part only (a read's pile-up lies in its
+    // own part; whether a read is examined at all depends on its INITIAL activity), so the parts of a wave run side by side,
+    // each on its own GPU.  What the reference does sequentially - a read is dropped only if one of its containers is still
+    // active at that moment - stays one host pass over the candidate rows in part order (exchange 4 of the sharded path).
+    int n_ranks = 1;
+    {
+        const char* e = getenv("HINGE_RANKS");
+        n_ranks = e ? atoi(e) : hinge_device_count();
+        n_ranks = std::max(1, std::min(n_ranks, (int)las_list.size()));
+        if (fa_and_paf) n_ranks = 1;
+    }
     PartLoader loader;
     loader.paf = fa_and_paf;
-    if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
+    if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
-    hinge_ctx* ctx = gpu.ctx;
-    HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), nullptr));
-    HH_CHECK(ctx, hinge_set_eff_reads(ctx, eff.data()));
+    std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
+    ctxs[0] = gpu.ctx;
+    {
+        const int ndev = std::max(1, hinge_device_count());
+        for (int r = 1; r < n_ranks; r++)
+            if (hinge_ctx_create(r % ndev, &ctxs[(size_t)r]) != HINGE_OK) { console.error("cannot create a context on device %d", r % ndev); return 2; }
+    }
+    hinge_ctx* ctx = ctxs[0];
+    for (int r = 0; r < n_ranks; r++) {
+        HH_CHECK(ctxs[(size_t)r], hinge_set_reads(ctxs[(size_t)r], n_read, db.rlen.data(), nullptr));
+        HH_CHECK(ctxs[(size_t)r], hinge_set_eff_reads(ctxs[(size_t)r], eff.data()));
+    }
     tm.mark("ctx_create + set_reads");
 
-    for (size_t part = 0; part < las_list.size(); part++) {
-        console.info("name of las: %s", las_list[part].c_str());
+    struct PartOut {
+        int code = 0;
+        std::string error;
+        int r_begin = 0, r_end = -1;
+        int64_t novl = 0, n_classified = 0;
+        std::vector<int32_t> nb;      // .coverage.txt
+        UVec<int32_t> cov;
+        std::vector<int32_t> pairs;   // (a, b) rows of the selected overlaps in which B covers A, in selection order
+    };
+#define PART_FAIL(o, c, ...)                                            \
+    do {                                                                 \
+        char _b[512];                                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                           \
+        (o).code = (c); (o).error = _b;                                  \
+        return;                                                          \
+    } while (0)
+#define PART_CHECK(o, cx, call)                                                                                  \
+    do {                                                                                                          \
+        int _rc = (call);                                                                                         \
+        if (_rc != HINGE_OK) PART_FAIL(o, _rc == HINGE_E_UNDEFINED ? 1 : 2, "%s failed (%d): %s", #call, _rc, hinge_last_error(cx)); \
+    } while (0)
+    auto part_work = [&](hinge_ctx* cx, size_t part, PartOut& o, bool timed) {
         int lrc = 0;
         std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
         LasPart& las = *las_owner;
-        if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
-        if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
-        if (lrc != 0) { fprintf(stderr, "get_maximal_reads: cannot read %s\n", las_list[part].c_str()); quit(1); }
-        tm.mark("las ingest");
-        if (las.novl == 0) { console.error("No alignments!"); return 1; }
+        if (lrc == -2) PART_FAIL(o, 2, "%s is not sorted by A read", las_list[part].c_str());
+        if (lrc == -3) PART_FAIL(o, 1, "%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str());
+        if (lrc != 0) PART_FAIL(o, -1, "get_maximal_reads: cannot read %s", las_list[part].c_str());
+        if (timed) tm.mark("las ingest");
+        if (las.novl == 0) PART_FAIL(o, 1, "No alignments!");
+        o.novl = las.novl;
         const int r_begin = las.r_begin, r_end = las.r_end;
+        o.r_begin = r_begin; o.r_end = r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
-        HH_CHECK(ctx, hinge_set_pileups_packed(ctx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(),
-                                               nullptr, las.max_pile, las.spans_in_range ? 1 : 0, 0));   // no coverage passes here: no span copy
+        PART_CHECK(o, cx, hinge_set_pileups_packed(cx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(),
+                                                   nullptr, las.max_pile, las.spans_in_range ? 1 : 0, 0));   // no coverage passes here: no span copy
         {
             static const uint8_t no_trace[1] = {0};   // PAF: no trace points, ProcessAlignment(trim = false)
-            HH_CHECK(ctx, hinge_set_trim(ctx, las.is_paf ? 0 : 1));
-            HH_CHECK(ctx, hinge_set_traces(ctx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
+            PART_CHECK(o, cx, hinge_set_trim(cx, las.is_paf ? 0 : 1));
+            PART_CHECK(o, cx, hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
         }
-
-        tm.mark("set_pileups + set_traces (H2D)");
+        if (timed) tm.mark("set_pileups + set_traces (H2D)");
         // .coverage.txt is truncated and rewritten with the same content (maximal.cpp:517,659-685)
         {
-            std::vector<int32_t> nb(nr);
-            HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, reso, 0, nb.data(), nullptr, 0));
+            o.nb.resize(nr);
+            PART_CHECK(o, cx, hinge_filter_coverage_bins(cx, r_begin, r_end, reso, 0, o.nb.data(), nullptr, 0));
             int64_t tot = 0;
-            for (size_t k = 0; k < nr; k++) tot += nb[k];
-            UVec<int32_t> cov;   // filled by the copy from the device: no zero fill, huge pages
-            cov.resize((size_t)std::max<int64_t>(tot, 1));
-            HH_CHECK(ctx, hinge_filter_coverage_bins(ctx, r_begin, r_end, reso, 0, nb.data(), cov.data(), tot));
-            write_coverage_txt(f_cov, r_begin, nb, cov, reso);
+            for (size_t k = 0; k < nr; k++) tot += o.nb[k];
+            o.cov.resize((size_t)std::max<int64_t>(tot, 1));   // filled by the copy from the device: no zero fill, huge pages
+            PART_CHECK(o, cx, hinge_filter_coverage_bins(cx, r_begin, r_end, reso, 0, o.nb.data(), o.cov.data(), tot));
         }
-
-        tm.mark("coverage.txt");
+        if (timed) tm.mark("coverage bins");
         // pairs of every read that is active when its turn comes (activity only changes at a read's own turn).
         // Every read's grouping is independent: chunks of 64 reads go to host threads, each chunk emits its selected
         // overlaps (best one or two per (A,B) pair, in the map's iteration order) into its own buffer; the buffers
@@ -161,30 +200,29 @@ int main(int argc, char* argv[]) {
         sel.resize((size_t)std::max<int64_t>(n_sel, 1)); a_of.resize((size_t)std::max<int64_t>(n_sel, 1)); mtype.resize((size_t)std::max<int64_t>(n_sel, 1));
         parallel_dynamic(n_chunks, 16, [&](int64_t c0, int64_t c1) {
             for (int64_t c = c0; c < c1; c++) {
-                int64_t o = chunk_base[(size_t)c];
-                if (!chunk_sel[(size_t)c].empty()) memcpy(sel.data() + o, chunk_sel[(size_t)c].data(), chunk_sel[(size_t)c].size() * sizeof(int64_t));
+                int64_t o2 = chunk_base[(size_t)c];
+                if (!chunk_sel[(size_t)c].empty()) memcpy(sel.data() + o2, chunk_sel[(size_t)c].data(), chunk_sel[(size_t)c].size() * sizeof(int64_t));
                 const int64_t k0 = c * CH, k1 = std::min<int64_t>((int64_t)nr, k0 + CH);
                 for (int64_t k = k0; k < k1; k++)
-                    for (int t = 0; t < n_sel_of[(size_t)k]; t++) a_of[(size_t)o++] = r_begin + (int)k;
+                    for (int t = 0; t < n_sel_of[(size_t)k]; t++) a_of[(size_t)o2++] = r_begin + (int)k;
                 std::vector<int64_t>().swap(chunk_sel[(size_t)c]);
             }
         });
-        tm.mark("pick_pairs");
+        if (timed) tm.mark("pick_pairs");
         // Nearly every overlap is selected (one or two per (A, B) pair), so the whole part is classified in storage order -
         // coalesced, nothing to upload - and the selected ones are picked out of the result.
         {
             UVec<uint8_t> all_types;
             all_types.resize((size_t)std::max<int64_t>(las.n_kept(), 1));
-            HH_CHECK(ctx, hinge_trim_classify_part(ctx, ALN_THRESHOLD, THETA, THETA2, all_types.data()));
+            PART_CHECK(o, cx, hinge_trim_classify_part(cx, ALN_THRESHOLD, THETA, THETA2, all_types.data()));
             parallel_chunks(n_sel, host_threads(), [&](int, int64_t b, int64_t e) {
                 for (int64_t c = b; c < e; c++) mtype[(size_t)c] = all_types[(size_t)sel[(size_t)c]];
             });
         }
-
-        tm.mark("trim_classify (GPU)");
-        // sequential containment resolution, maximal.cpp:780-858: one (a, b) row per overlap that classified as BCOVERA
-        const int64_t n_classified = n_sel;
-        // (the rows keep the order of `sel`: counted and written in contiguous pieces by the host threads)
+        if (timed) tm.mark("trim_classify (GPU)");
+        // one (a, b) row per selected overlap that classified as BCOVERA (the rows keep the order of `sel`: counted and
+        // written in contiguous pieces by the host threads)
+        o.n_classified = n_sel;
         const int T = host_threads();
         std::vector<int64_t> piece_rows((size_t)T + 1, 0);
         parallel_chunks(n_sel, T, [&](int c, int64_t b, int64_t e) {
@@ -193,27 +231,50 @@ int main(int argc, char* argv[]) {
             piece_rows[(size_t)c + 1] = m;
         });
         for (int c = 0; c < T; c++) piece_rows[(size_t)c + 1] += piece_rows[(size_t)c];
-        std::vector<int32_t> pairs((size_t)(2 * piece_rows[(size_t)T]));
+        o.pairs.resize((size_t)(2 * piece_rows[(size_t)T]));
         parallel_chunks(n_sel, T, [&](int c, int64_t b, int64_t e) {
-            int32_t* out = pairs.data() + 2 * piece_rows[(size_t)c];
+            int32_t* out = o.pairs.data() + 2 * piece_rows[(size_t)c];
             for (int64_t k = b; k < e; k++)
                 if (mtype[(size_t)k] == MT_BCOVERA) {
                     *out++ = a_of[(size_t)k];
                     *out++ = (int32_t)(las.b_flag[(size_t)sel[(size_t)k]] & 0x7fffffffu);
                 }
         });
-        std::vector<int32_t> containing((size_t)n_read);
-        if (hinge_resolve_containment(n_read, active.data(), (int64_t)(pairs.size() / 2), pairs.data(), containing.data()) != HINGE_OK) {
-            console.error("containment resolution: malformed candidate list");
-            return 2;
+    };
+
+    for (size_t w0 = 0; w0 < las_list.size(); w0 += (size_t)n_ranks) {
+        const size_t w1 = std::min(las_list.size(), w0 + (size_t)n_ranks), nw = w1 - w0;
+        std::vector<PartOut> outs(nw);
+        if (nw == 1) part_work(ctxs[0], w0, outs[0], true);
+        else {
+            std::vector<std::thread> th;
+            for (size_t k = 0; k < nw; k++) th.emplace_back([&, k] { part_work(ctxs[k], w0 + k, outs[k], false); });
+            for (auto& t : th) t.join();
+            tm.mark("wave: ingest + H2D + bins + pick_pairs + classify");
         }
-        for (int i = r_begin; i <= r_end; i++)
-            if (containing[(size_t)i] >= 0) fprintf(f_contained, "%d\t%d\n", i, containing[(size_t)i]);
-        int n_active = 0;
-        for (int i = r_begin; i <= r_end; i++)
-            if (active[(size_t)i]) { n_active++; fprintf(f_max, "%d\n", i); }
-        tm.mark("containment + max txt");
-        console.info("classified %lld overlaps; removed contained reads, active reads: %d / %zu", (long long)n_classified, n_active, nr);
+        for (size_t k = 0; k < nw; k++) {
+            PartOut& o = outs[k];
+            console.info("name of las: %s", las_list[w0 + k].c_str());
+            if (o.code == -1) { fprintf(stderr, "%s\n", o.error.c_str()); quit(1); }
+            if (o.code != 0) { console.error("%s", o.error.c_str()); return o.code; }
+            const int r_begin = o.r_begin, r_end = o.r_end;
+            const size_t nr = (size_t)(r_end - r_begin + 1);
+            write_coverage_txt(f_cov, r_begin, o.nb, o.cov, reso);
+            tm.mark("coverage.txt");
+            // sequential containment resolution, maximal.cpp:780-858
+            std::vector<int32_t> containing((size_t)n_read);
+            if (hinge_resolve_containment(n_read, active.data(), (int64_t)(o.pairs.size() / 2), o.pairs.data(), containing.data()) != HINGE_OK) {
+                console.error("containment resolution: malformed candidate list");
+                return 2;
+            }
+            for (int i = r_begin; i <= r_end; i++)
+                if (containing[(size_t)i] >= 0) fprintf(f_contained, "%d\t%d\n", i, containing[(size_t)i]);
+            int n_active = 0;
+            for (int i = r_begin; i <= r_end; i++)
+                if (active[(size_t)i]) { n_active++; fprintf(f_max, "%d\n", i); }
+            tm.mark("containment + max txt");
+            console.info("classified %lld overlaps; removed contained reads, active reads: %d / %zu", (long long)o.n_classified, n_active, nr);
+        }
     }
     fclose(f_cov); fclose(f_contained); fclose(f_max);
     return finish(ctx, tm);

@@ -66,6 +66,7 @@ typedef struct hinge_cov_estimate {
 } hinge_cov_estimate;
 
 /* ---- context ------------------------------------------------------------------------------- */
+int hinge_device_count(void);       /* visible HIP devices (0 if the runtime cannot be initialised) */
 int hinge_ctx_create(int device, hinge_ctx** out);
 void hinge_ctx_destroy(hinge_ctx* ctx);
 const char* hinge_last_error(const hinge_ctx* ctx);
@@ -98,6 +99,9 @@ int hinge_get_pileup_facts(hinge_ctx* ctx, uint32_t* max_pile, int* spans_in_ran
  * collective can fill other ranks' rows in place).  NULL returns to the library-owned table.      */
 int hinge_attach_mask_table(hinge_ctx* ctx, int32_t* d_mask_all);
 int hinge_attach_mean_cov(hinge_ctx* ctx, int32_t* d_mean_cov);
+/* Rows r0..r1 of the mask table from the host (masks another context computed: the parts of a --mlas run on several GPUs see
+ * the masks of the parts before them, filter.cpp:778-787 in the reference's sequential loop).                                */
+int hinge_set_mask_rows(hinge_ctx* ctx, int32_t r0, int32_t r1, const int32_t* rows);
 /* Reset the mask table to (0,0) (the state maskvec has before the first part, filter.cpp:534).   */
 int hinge_clear_masks(hinge_ctx* ctx);
 

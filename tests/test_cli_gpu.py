@@ -198,3 +198,31 @@ def test_cli_filter_restrictreads(datasets, oracle_lib, tmp_path, name, mlas):
     assert not bad, "differs from the oracle: %s" % bad
     emptied = sum(1 for l in open(os.path.join(wd_h, "G.mas")) if l.split()[1] == l.split()[2])
     assert 0 < emptied < d.n_reads
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_cli_mlas_on_several_ranks(oracle_lib, tmp_path, ranks):
+    """`hinge filter --mlas` with the parts spread over HINGE_RANKS ranks (one host thread + one context each; on a node with
+    several GPUs one per device, here all on the one GPU): waves of `ranks` parts run concurrently, the running MIN_COV and the
+    mask table are exchanged between them, and every output file equals the oracle's sequential --mlas loop byte for byte.
+    8 blocks (BASELINE config 4's shape, scaled down), so 2 and 3 ranks need several waves and 3 leaves a ragged last wave."""
+    import dataclasses
+    from hinge_amd import synth
+    d = synth.generate(dataclasses.replace(synth.CONFIGS["cfg4_yeast"], genome_len=500_000))
+    assert d.spec.n_blocks == 8
+    src = str(tmp_path / "src")
+    synth.write_dataset(d, src, "G", write_bases=False)
+    write_ini(os.path.join(src, "nominal.ini"))
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert run_in(wd_o, oracle_lib.oracle_filter, b"G", b"G", 1, b"G", b"nominal.ini", b"") == 0
+    assert run_in(wd_o, oracle_lib.oracle_maximal, b"G", b"G", 1, b"G", b"nominal.ini") == 0
+    for sub in ("filter", "maximal"):     # get_maximal_reads: the parts' classification side by side, containment in part order
+        r = subprocess.run([HINGE, sub, "--db", "G", "--las", "G", "--mlas", "-x", "G", "--config", "nominal.ini"], cwd=wd_h,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, HINGE_RANKS=str(ranks)))
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+    filt = ["G.mas", "G.cmas", "G.repeat.txt", "G.hinges.txt", "G.coverage.txt", "G.cov.flag", "G.self.flag", "G.max", "G.contained.txt"]
+    bad = [f for f in filt if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
+    assert 0 < sum(1 for _ in open(os.path.join(wd_o, "G.max"))) < d.n_reads
+    assert sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.hinges.txt"))) > 0
