@@ -221,14 +221,36 @@ int main(int argc, char* argv[]) {
     std::vector<std::string> las_list;
     if (fa_and_paf) las_list.push_back(name_paf);
     else if (mlas) las_list = las_parts(name_las); else las_list.push_back(name_las);
+    // ---- ranks: one host thread + one context per visible GPU for a --mlas run (HINGE_RANKS overrides) --------------------------
+    // The front half of a part - ingest, the (A, B) grouping of the active x active pairs, packing, trim + classify on the GPU -
+    // runs for the parts of a wave side by side.  The reference's loop carries one thing from part to part: a read found
+    // contained ("Should not happen", hinging.cpp:590-600) is inactive for the parts after it.  The front halves therefore work on
+    // the activity at the start of the wave and are consumed in part order; should a part deactivate a read, the front halves of
+    // the wave's later parts are simply run again (on the then current activity), one after the other.
+    int n_ranks = 1;
+    {
+        const char* e = getenv("HINGE_RANKS");
+        n_ranks = e ? atoi(e) : hinge_device_count();
+        n_ranks = std::max(1, std::min(n_ranks, (int)las_list.size()));
+        if (fa_and_paf) n_ranks = 1;
+    }
     PartLoader loader;
     loader.paf = fa_and_paf;
-    if (!las_list.empty()) loader.preload(las_list[0], db.rlen);
+    if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
     tm.mark("setup + las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
-    hinge_ctx* ctx = gpu.ctx;
-    HH_CHECK(ctx, hinge_set_reads(ctx, n_read, db.rlen.data(), nullptr));
-    HH_CHECK(ctx, hinge_set_eff_reads(ctx, eff.data()));
+    std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
+    ctxs[0] = gpu.ctx;
+    {
+        const int ndev = std::max(1, hinge_device_count());
+        for (int r = 1; r < n_ranks; r++)
+            if (hinge_ctx_create(r % ndev, &ctxs[(size_t)r]) != HINGE_OK) { console.error("cannot create a context on device %d", r % ndev); return 2; }
+    }
+    hinge_ctx* ctx = ctxs[0];
+    for (int r = 0; r < n_ranks; r++) {
+        HH_CHECK(ctxs[(size_t)r], hinge_set_reads(ctxs[(size_t)r], n_read, db.rlen.data(), nullptr));
+        HH_CHECK(ctxs[(size_t)r], hinge_set_eff_reads(ctxs[(size_t)r], eff.data()));
+    }
     tm.mark("setup + ctx_create + set_reads");
 
     // ---- GetAlignment, hinging.cpp:347-610 ---------------------------------------------------------------
@@ -240,62 +262,94 @@ int main(int argc, char* argv[]) {
         for (int i = 0; i < n_read; i++) active[(size_t)i] = active[(size_t)i] && maximal[(size_t)i];
     }
     std::vector<std::vector<Match>> matches_forward((size_t)n_read), matches_backward((size_t)n_read);
-    std::vector<LasPart*> parts;
-    std::vector<PackedPart*> packed;   // the selected overlaps of every part (GetMatchingPosition needs their traces again)
-    int resident_part = -1;            // which packed part the GPU context currently holds
-    for (size_t part = 0; part < las_list.size(); part++) {
-        int lrc = 0;
-        LasPart* lp = loader.take(part, las_list[part], db.rlen, lrc);
-        parts.push_back(lp);
-        LasPart& las = *lp;
-        if (lrc == -2) { console.error("%s is not sorted by A read", las_list[part].c_str()); return 2; }
-        if (lrc == -3) { console.error("%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str()); return 1; }
-        if (lrc != 0) { fprintf(stderr, "hinging: cannot read %s\n", las_list[part].c_str()); quit(1); }
-        tm.mark("las ingest");
-        if (las.novl == 0) { console.error("No alignments!"); return 2; }
+    std::vector<LasPart*> parts(las_list.size(), nullptr);
+    std::vector<PackedPart*> packed(las_list.size(), nullptr);   // the selected overlaps of every part (GetMatchingPosition needs their traces again)
+    int resident_part = -1;            // which packed part the GPU context `ctx` currently holds
+    struct Front {   // the front half of one part
+        int code = 0;
+        std::string error;
+        std::vector<std::vector<PairPick>> picks;
+        std::vector<Classified> cls;
+        size_t n_sel = 0;
+    };
+#define PART_FAIL(o, c, ...)                                            \
+    do {                                                                 \
+        char _b[512];                                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                           \
+        (o).code = (c); (o).error = _b;                                  \
+        return;                                                          \
+    } while (0)
+    auto front_half = [&](hinge_ctx* cx, size_t part, Front& f, bool timed) {
+        f = Front();
+        if (!parts[part]) {
+            int lrc = 0;
+            parts[part] = loader.take(part, las_list[part], db.rlen, lrc);
+            if (lrc == -2) PART_FAIL(f, 2, "%s is not sorted by A read", las_list[part].c_str());
+            if (lrc == -3) PART_FAIL(f, 1, "%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str());
+            if (lrc != 0) PART_FAIL(f, -1, "hinging: cannot read %s", las_list[part].c_str());
+            if (timed) tm.mark("las ingest");
+        }
+        LasPart& las = *parts[part];
+        if (las.novl == 0) PART_FAIL(f, 2, "No alignments!");
         const int r_begin = las.r_begin, r_end = las.r_end;
         const size_t nr = (size_t)(r_end - r_begin + 1);
         // pairs between reads that are active now (the map only ever receives active x active records, hinging.cpp:478-490)
-        std::vector<std::vector<PairPick>> picks(nr);
+        f.picks.assign(nr, std::vector<PairPick>());
         std::vector<int64_t> sel;
         std::vector<int32_t> a_of;
         parallel_dynamic((int64_t)nr, 64, [&](int64_t k0, int64_t k1) {
             for (int64_t k = k0; k < k1; k++) {
                 const int i = r_begin + (int)k;
                 if (!active[(size_t)i]) continue;
-                pick_pairs(las, i, USE_TWO_MATCHES, 1, [&](int b) { return active[(size_t)b] && KEEP_ONLY_MAX; }, picks[(size_t)k]);
+                pick_pairs(las, i, USE_TWO_MATCHES, 1, [&](int b) { return active[(size_t)b] && KEEP_ONLY_MAX; }, f.picks[(size_t)k]);
             }
         });
         for (int i = r_begin; i <= r_end; i++) {
             if (!active[(size_t)i]) continue;
-            for (auto& p : picks[(size_t)(i - r_begin)])
+            for (auto& p : f.picks[(size_t)(i - r_begin)])
                 for (int w = 0; w < 2; w++)
                     if (p.pick[w] >= 0) { sel.push_back(p.pick[w]); a_of.push_back(i); }
         }
-        tm.mark("pick_pairs");
+        if (timed) tm.mark("pick_pairs");
         // Only the selected overlaps (active x active pairs, best one or two each: thousands out of tens of millions) go to
         // the GPU: their SoA rows and trace bytes are packed here; Match.k is the index into this packed part.
+        delete packed[part];
         PackedPart* pk = new PackedPart();
-        packed.push_back(pk);
+        packed[part] = pk;
         pk->build(las, sel, a_of, n_read);
-        if (!sel.empty()) { HH_CHECK(ctx, pk->upload(ctx)); resident_part = (int)part; }
-        tm.mark("pack + upload selected overlaps");
+        f.n_sel = sel.size();
+        if (!sel.empty()) {
+            int rc = pk->upload(cx);
+            if (rc != HINGE_OK) PART_FAIL(f, 2, "upload of the selected overlaps failed (%d): %s", rc, hinge_last_error(cx));
+            if (cx == ctx) resident_part = (int)part;
+        }
+        if (timed) tm.mark("pack + upload selected overlaps");
         std::vector<int64_t> sel_packed(sel.size());
         for (size_t t = 0; t < sel.size(); t++) sel_packed[t] = (int64_t)t;
-        std::vector<Classified> cls(std::max<size_t>(sel.size(), 1));
-        if (!sel.empty()) HH_CHECK(ctx, hinge_trim_classify(ctx, (int64_t)sel.size(), sel_packed.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)cls.data()));
-        tm.mark("trim_classify (GPU)");
+        f.cls.assign(std::max<size_t>(sel.size(), 1), Classified());
+        if (!sel.empty()) {
+            int rc = hinge_trim_classify(cx, (int64_t)sel.size(), sel_packed.data(), a_of.data(), ALN_THRESHOLD, THETA, THETA2, (int32_t*)f.cls.data());
+            if (rc != HINGE_OK) PART_FAIL(f, 2, "hinge_trim_classify failed (%d): %s", rc, hinge_last_error(cx));
+        }
+        if (timed) tm.mark("trim_classify (GPU)");
+    };
+    // the back half: matches of the part's reads, in read order; returns true if it deactivated a read
+    auto consume = [&](size_t part, Front& f) -> bool {
+        LasPart& las = *parts[part];
+        const int r_begin = las.r_begin, r_end = las.r_end;
+        bool dropped = false;
         size_t c = 0;
         for (int i = r_begin; i <= r_end; i++) {
             // NOTE: `active` is the state BEFORE this loop for the pair filter above (the reference fills idx_ab for the
             // whole part first, hinging.cpp:478-490), but a read dropped here is inactive for the reads after it.
-            if (picks[(size_t)(i - r_begin)].empty() && !active[(size_t)i]) continue;
-            if (!active[(size_t)i]) { for (auto& p : picks[(size_t)(i - r_begin)]) for (int w = 0; w < 2; w++) if (p.pick[w] >= 0) c++; continue; }
+            auto& pk = f.picks[(size_t)(i - r_begin)];
+            if (pk.empty() && !active[(size_t)i]) continue;
+            if (!active[(size_t)i]) { for (auto& p : pk) for (int w = 0; w < 2; w++) if (p.pick[w] >= 0) c++; continue; }
             bool contained = false;
-            for (auto& p : picks[(size_t)(i - r_begin)])
+            for (auto& p : pk)
                 for (int w = 0; w < 2; w++) {
                     if (p.pick[w] < 0) continue;
-                    const Classified& r = cls[c++];
+                    const Classified& r = f.cls[c++];
                     const int64_t k = p.pick[w];
                     Match m;
                     m.a = i; m.b = p.b; m.comp = (int)(las.b_flag[(size_t)k] >> 31);
@@ -308,9 +362,30 @@ int main(int argc, char* argv[]) {
                     if (r.type == MT_FORWARD || r.type == MT_FORWARD_INTERNAL) matches_forward[(size_t)i].push_back(m);
                     else if (r.type == MT_BACKWARD || r.type == MT_BACKWARD_INTERNAL) matches_backward[(size_t)i].push_back(m);
                 }
-            if (contained) active[(size_t)i] = 0;   // "[contained] Should not happen"
+            if (contained) { active[(size_t)i] = 0; dropped = true; }   // "[contained] Should not happen"
+        }
+        return dropped;
+    };
+    for (size_t w0 = 0; w0 < las_list.size(); w0 += (size_t)n_ranks) {
+        const size_t w1 = std::min(las_list.size(), w0 + (size_t)n_ranks), nw = w1 - w0;
+        std::vector<Front> fronts(nw);
+        if (nw == 1) front_half(ctxs[0], w0, fronts[0], true);
+        else {
+            std::vector<std::thread> th;
+            for (size_t k = 0; k < nw; k++) th.emplace_back([&, k] { front_half(ctxs[k], w0 + k, fronts[k], false); });
+            for (auto& t : th) t.join();
+            tm.mark("wave: ingest + pick_pairs + upload + classify");
+        }
+        bool stale = false;   // a part of this wave deactivated a read: the later fronts were made for an activity that no longer holds
+        for (size_t k = 0; k < nw; k++) {
+            if (stale) front_half(ctxs[0], w0 + k, fronts[k], false);
+            Front& f = fronts[k];
+            if (f.code == -1) { fprintf(stderr, "%s\n", f.error.c_str()); quit(1); }
+            if (f.code != 0) { console.error("%s", f.error.c_str()); return f.code; }
+            if (consume(w0 + k, f)) stale = true;
         }
     }
+#undef PART_FAIL
 
     tm.mark("matches");
     auto by_weight = [](const Match& x, const Match& y) { return x.c.weight > y.c.weight; };   // compare_overlap_weight

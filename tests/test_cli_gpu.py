@@ -217,12 +217,15 @@ def test_cli_mlas_on_several_ranks(oracle_lib, tmp_path, ranks):
     wd_h = clone_dataset(src, str(tmp_path / "hip"))
     assert run_in(wd_o, oracle_lib.oracle_filter, b"G", b"G", 1, b"G", b"nominal.ini", b"") == 0
     assert run_in(wd_o, oracle_lib.oracle_maximal, b"G", b"G", 1, b"G", b"nominal.ini") == 0
-    for sub in ("filter", "maximal"):     # get_maximal_reads: the parts' classification side by side, containment in part order
-        r = subprocess.run([HINGE, sub, "--db", "G", "--las", "G", "--mlas", "-x", "G", "--config", "nominal.ini"], cwd=wd_h,
+    assert run_in(wd_o, oracle_lib.oracle_layout, b"G", b"G", 1, b"G", b"G", b"nominal.ini") == 0
+    # get_maximal_reads: the parts' classification side by side, containment in part order; hinging: the parts' front halves
+    # (grouping, packing, classification) side by side, matches consumed in part order, selection in one K5 launch
+    for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+        r = subprocess.run([HINGE, sub, "--db", "G", "--las", "G", "--mlas", "-x", "G", "--config", "nominal.ini"] + extra, cwd=wd_h,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, HINGE_RANKS=str(ranks)))
         assert r.returncode == 0, r.stdout.decode()[-2000:]
-    filt = ["G.mas", "G.cmas", "G.repeat.txt", "G.hinges.txt", "G.coverage.txt", "G.cov.flag", "G.self.flag", "G.max", "G.contained.txt"]
-    bad = [f for f in filt if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
     assert not bad, "differs from the oracle: %s" % bad
     assert 0 < sum(1 for _ in open(os.path.join(wd_o, "G.max"))) < d.n_reads
+    assert os.path.getsize(os.path.join(wd_o, "G.edges.hinges")) > 0
     assert sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.hinges.txt"))) > 0
