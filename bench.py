@@ -69,7 +69,7 @@ def pmc_traffic(kname):
     """
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprofv3_pmc_summary.csv")))
     if not files:
         return None, None
     fetch = write = None

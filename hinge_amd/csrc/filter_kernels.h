@@ -49,7 +49,7 @@ struct FilterDev {   // device copy of hinge_filter_params + derived values
     int sup, pil, unb, tol, bin_len;
     int use_qv, use_cov, del_telo;
     int est_cov;
-    int ablate;   // scratch/ablation builds only (HINGE_ABLATE): stop k_mask_annotate after phase k
+    int ablate;   // ablation builds only (-DHINGE_ABLATE): stop k_mask_annotate after phase k
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
@@ -930,6 +930,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];
         const int K0 = nbins0[i];                     // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
+        const long long cov_at = o.cov_out ? o.cov_off[i - o.cov_base] : 0;   // (fetched with the row bounds, used after phase 1)
         const int64_t n64 = e - s;
         const int qe = rl / 20;                       // last bin an event can fall in
         if (n64 >= 65536 || K0 < 0 || qe >= qcap) {   // 16-bit counts would overflow / malformed / too long: general kernel
@@ -1001,6 +1002,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
 
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
         int carry = 0;
+        int* __restrict__ const cov_dst = o.cov_out ? o.cov_out + cov_at : (int*)nullptr;
 #ifdef HINGE_ABLATE
         if (P.ablate != 6 && P.ablate != 8)
 #endif
@@ -1012,7 +1014,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
             const int excl = incl - v.w + carry;
             v.x += excl; v.y += excl; v.z += excl; v.w += excl;
             if (t < Qn) *reinterpret_cast<int4*>(Pq + t) = v;
+            if (cov_dst) {
+                // the .coverage.txt bins straight from the registers of the scan: cov0[k] = PB[2k-1] - PE[2k-1], and this lane holds
+                // the prefixes of bins t .. t+3, i.e. 2k-1 = t+1 and t+3 (k = t/2 + 1, t/2 + 2).  Stored here - not with the other
+                // outputs at the end of the read - they also have the rest of the read's work to drain: stores count in vmcnt like
+                // loads on this architecture, so the next read's first wait for its spans waits for every store issued before it.
+                const int k1 = (t >> 1) + 1;
+                if (k1 < K0) cov_dst[k1] = (v.y & 0xffff) - (int)((unsigned)v.y >> 16);
+                if (k1 + 1 < K0) cov_dst[k1 + 1] = (v.w & 0xffff) - (int)((unsigned)v.w >> 16);
+            }
             carry += wave_last(incl);
+        }
+        if (cov_dst && lane == 0) {
+            if (K0 > 0) cov_dst[0] = 0;                      // cov0[0]: nothing is consumed before position 0
+            o.cov_nbins[i - o.cov_base] = K0;
         }
         {   // copies of the totals behind the scanned bins (the scan ran over [0, round-up-to-4 of Qn))
             const int Qs = (Qn + 3) & ~3;
@@ -1020,15 +1035,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         }
         auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
         auto covc = [&](int k) { return (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16); };
-        // The .coverage.txt bins go out NOW, not with the other outputs at the end of the read: on this architecture stores count in
-        // vmcnt like loads and retire in order, so the next read's first wait for its spans also waits for every store issued
-        // before it.  Issued here, the bins (the bulk of the stores) have the mask pass and the annotation phase to drain.
-        if (o.cov_out) {
-            int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
-            for (int j = lane; j < K0; j += WAVE) dst[j] = cov0(j);
-            if (lane == 0) o.cov_nbins[i - o.cov_base] = K0;
-        }
-
         // ---- coverage mask on the cutoff profile ------------------------------------------------------
         RunState run{0, 0ull, 0, 0};
 #ifdef HINGE_ABLATE

@@ -214,8 +214,9 @@ int main(int argc, char* argv[]) {
         console.info("Estimated median coverage: %d", P.est_cov != 0 ? P.est_cov : o.est.cov_est);
         const int r_begin = o.r_begin;
         const size_t nr = (size_t)(o.r_end - o.r_begin + 1);
-        write_coverage_txt(f_cov, r_begin, o.nb, o.cov, P.reso, &o.coff);
-        tm.mark("coverage.txt");
+        // .coverage.txt (150 MB of text for an E. coli part) is formatted and written by its own thread (which fans out to the
+        // host threads) while this one writes the small files
+        std::thread cov_writer([&] { write_coverage_txt(f_cov, r_begin, o.nb, o.cov, P.reso, &o.coff); });
         for (size_t k = 0; k < nr; k++) {
             const int i = r_begin + (int)k;
             if (P.delete_telomere) {
@@ -243,6 +244,8 @@ int main(int argc, char* argv[]) {
             fprintf(f_hg, "\n");
         }
         tm.mark("mas/cmas/repeat/hinges txt");
+        cov_writer.join();
+        tm.mark("coverage.txt (rest)");
         console.info("Number of hinges before filtering: %lld", (long long)o.off[nr]);
         console.info("Number of hinges: %d", hg_cnt);
     };

@@ -54,10 +54,13 @@ def main():
     n = pile.n_ovl
     alg = 24.0 * n + float(tlen.sum()) + 8.0 * n
     out = {}
-    for name, env in (("stream", None), ("stream cap 8192", "cap8192"), ("stream cap 12288", "cap12288"), ("rows", "1")):
+    for name, env in (("stream", None), ("stream 16 w/CU", "wpc16"), ("stream 32 w/CU", "wpc32"), ("stream cap 8192", "cap8192"), ("rows", "1")):
         os.environ.pop("HINGE_K4_ROWS", None)
         os.environ.pop("HINGE_K4_CAP", None)
-        if env == "1":
+        os.environ.pop("HINGE_K4_WAVES_PER_CU", None)
+        if env and env.startswith("wpc"):
+            os.environ["HINGE_K4_WAVES_PER_CU"] = env[3:]
+        elif env == "1":
             os.environ["HINGE_K4_ROWS"] = env
         elif env:
             os.environ["HINGE_K4_CAP"] = env[3:]
@@ -74,6 +77,7 @@ def main():
               (name, t, n, float(tlen.mean()), alg / 1e9, alg / (t * 1e-3) / 1e12, alg / (t * 1e-3) / 8e12), flush=True)
     os.environ.pop("HINGE_K4_ROWS", None)
     os.environ.pop("HINGE_K4_CAP", None)
+    os.environ.pop("HINGE_K4_WAVES_PER_CU", None)
     assert all(np.array_equal(out["stream"], v) for v in out.values()), "the kernels disagree"
     print("types identical; histogram:", np.bincount(out["stream"], minlength=14).tolist())
 

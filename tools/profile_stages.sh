@@ -25,7 +25,9 @@ python tools/e2e_bench.py --genome 4600000 --exact-config --dir $D > $OUT/${TAG}
 cd /tmp
 for st in filter maximal layout; do
   extra=""; [ $st = layout ] && extra="-o G"
-  (cd $D/hip && rocprofv3 --kernel-trace --stats -d $OUT/cli_$st -o $TAG --output-format csv -- $R/hinge_amd/bin/hinge $st --db G --las G.las -x G --config nominal.ini $extra > $OUT/cli_$st.log 2>&1)
+  case $st in filter) exe=Reads_filter;; maximal) exe=get_maximal_reads;; layout) exe=hinging;; esac
+  # (HINGE_SLOW_EXIT=1: the executables normally leave through _exit(), which would skip the profiler's output)
+  (cd $D/hip && HINGE_SLOW_EXIT=1 rocprofv3 --kernel-trace --stats -d $OUT/cli_$st -o $TAG --output-format csv -- $R/hinge_amd/bin/$exe --db G --las G.las -x G --config nominal.ini $extra > $OUT/cli_$st.log 2>&1)
   cp $(find $OUT/cli_$st -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_stages_cli_${st}_kernel_stats.csv 2>/dev/null
 done
 rm -rf $D
