@@ -37,10 +37,10 @@ constexpr int ST_MEDIAN_RANGE = 32;   // sharded median: a mean coverage outside
 
 #ifdef HINGE_ABLATE
 #define HINGE_ABLATE_POINT(k) if (P.ablate == (k)) continue;
-#define HINGE_ABLATE_RETURN(k) if (P.ablate == (k) || ((k) == 2 && P.ablate >= 6)) return;
+#define HINGE_ABLATE_RETURN_V(k) if (P.ablate == (k) || ((k) == 2 && P.ablate >= 6)) return 0;
 #else
 #define HINGE_ABLATE_POINT(k)
-#define HINGE_ABLATE_RETURN(k)
+#define HINGE_ABLATE_RETURN_V(k)
 #endif
 
 struct FilterDev {   // device copy of hinge_filter_params + derived values
@@ -596,9 +596,11 @@ __device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long lo
 // outputs.  z(j) = cutoff-0 coverage of bin j (j < K0), c(j) = cutoff coverage; cand = LDS scratch for the
 // packed candidates (pos << 1 | (type == +1)): slot t is written only after z(j) was read for every j <= t.
 template <typename ZF, typename CF>
-__device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
+__device__ __forceinline__ int mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
                                                    const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o,
-                                                   const long long row, const int n_pile, const bool cov_done = false) {
+                                                   const long long row, const int n_pile, const bool cov_done = false,
+                                                   const bool cand_in_profile = true /*cand[] overwrites what z() reads*/,
+                                                   const unsigned long long flag_words = ~0ull /*bit w clear: no bin of [64 w, 64 w + 63] can be an annotation*/) {
     if (o.cov_out && !cov_done) {   // before anything reuses the profile's LDS (cand)
         int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
         for (int j = lane; j < K0; j += WAVE) dst[j] = z(j);
@@ -637,11 +639,13 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         o.cmask[i] = make_int2(msc, mec);
         o.rflags[i] = fl;
     }
-    HINGE_ABLATE_RETURN(2)
+    HINGE_ABLATE_RETURN_V(2)
     // ---- gate sums over the two NO_HINGE_REGION windows only (filter.cpp:842-865) -----------------
+    // Only a read that keeps an annotation after the merge needs them (about 3 % of the reads): they are taken lazily, after the
+    // merge, unless the candidate list shares its LDS with the profile (then the windows may be overwritten by it: taken first).
     int ncand = 0;
     int S = 0, nS = 0, E = 0, nE = 0;
-    {
+    auto gate_sums = [&]() {
         // bins j with lo <= reso*j <= hi, clipped to [0, K0)
         auto jfirst = [&](int lo) { return lo <= 0 ? 0 : (lo + reso - 1) / reso; };
         auto jlast = [&](int hi) { return hi < 0 ? -1 : min(hi / reso, K0 - 1); };
@@ -663,8 +667,9 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
             for (int j = e0 + lane; j <= e1; j += WAVE) E += z(j);
             S = wave_sum(S); E = wave_sum(E);
         }
-    }
-    HINGE_ABLATE_RETURN(3)
+    };
+    if (cand_in_profile) gate_sums();
+    HINGE_ABLATE_RETURN_V(3)
     // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
     {
         const int wlo = mk.x + P.nhr, whi = mk.y - P.nhr;
@@ -675,6 +680,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
         const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
         for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
+            if (base < 64 * WAVE && !((flag_words >> (base / WAVE)) & 1ull)) continue;   // (words beyond the 64th: always looked at)
             const int j = base + lane;
             int code = -1;
             const bool in = j >= jlo && j <= jhi;
@@ -698,7 +704,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
             ncand += __popcll(bal);
         }
     }
-    HINGE_ABLATE_RETURN(4)
+    HINGE_ABLATE_RETURN_V(4)
     // merge (filter.cpp:817-829) - sequential on a short list, in place
     int m = 0;
     if (lane == 0 && ncand > 0) {
@@ -718,6 +724,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         cand[m++] = cur;
     }
     m = __builtin_amdgcn_readfirstlane(m);
+    if (m > 0 && !cand_in_profile) gate_sums();
     // gate: fp32, IEEE divide, NaN compares false (filter.cpp:861-865)
     bool gate_skip;
     {
@@ -749,6 +756,7 @@ __device__ __forceinline__ void mask_gate_annotate(const FilterDev& P, const int
         o.anno_buf[off + t] = make_int2(cd >> 1, (cd & 1) ? 1 : -1);
         o.hinge_flag[off + t] = 0;
     }
+    return ncand;   // slots of cand[] that were written
 }
 
 // General kernel.  LDS per wave: h0[kcap] (cutoff-0 difference histogram -> coverage), hc[kcap] (cutoff
@@ -876,7 +884,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
             run_feed(run, base, __ballot(c > MIN_COV) & V, V, reso);   // c[j] > 0 after subtracting MIN_COV
         }
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, [&](int j) { return h0[j]; }, [&](int j) { return hc[j]; }, hc, o, (long long)s, n);
+        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, [&](int j) { return h0[j]; }, [&](int j) { return hc[j]; }, hc, o, (long long)s, n, false,
+                           false /*the candidates go where the cutoff profile was: the gate reads the plain one*/);
     }
 }
 
@@ -923,6 +932,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
     int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
     int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1}
     const int MIN_COV = *d_min_cov;
+    // the division-free annotation test of mask_gate_annotate applies (then |gradient| > min(MIN_RA, MAX_RA) is necessary): -1 = no
+    const int mulpath_thr = (P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0) ? min(P.min_ra, P.max_ra) : -1;
     for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
 
     for (; item < item_end; item += item_step) {   // `continue` leaves a read
@@ -1006,9 +1017,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
 #ifdef HINGE_ABLATE
         if (P.ablate != 6 && P.ablate != 8)
 #endif
+        // Which 64-bin words of the plain profile can hold an annotation at all: an annotation needs |cov0[k+1] - cov0[k]| above
+        // min(MIN_RA, MAX_RA), and that difference is simply the begins minus the ends of the two 20-bp bins 2k, 2k+1 - the raw
+        // counts this loop holds before it sums them.  A typical read has no such bin between its ends' pile-ups.
+        unsigned long long flag_words = mulpath_thr >= 0 ? 0ull : ~0ull;
         for (int base = 0; base < Qn; base += 4 * WAVE) {
             const int t = base + 4 * lane;
             int4 v = t < Qn ? *reinterpret_cast<const int4*>(Pq + t) : make_int4(0, 0, 0, 0);
+            if (mulpath_thr >= 0) {
+                const int s01 = v.x + v.y, s23 = v.z + v.w;   // (16|16 packed: the halves cannot carry, the counts are below 65536)
+                const int g0 = (s01 & 0xffff) - (int)((unsigned)s01 >> 16), g1 = (s23 & 0xffff) - (int)((unsigned)s23 >> 16);
+                const unsigned long long bal = ballot_of(max(abs(g0), abs(g1)) > mulpath_thr);
+                const int w = base >> 7;                       // this step covers the 40-bp bins [base / 2, base / 2 + 127]: words w, w + 1
+                if (w < 63) flag_words |= ((unsigned long long)((unsigned)bal != 0u) << w) | ((unsigned long long)((unsigned)(bal >> 32) != 0u) << (w + 1));
+                else flag_words |= 1ull << 63;   // (bins beyond word 62: looked at unconditionally)
+            }
             v.y += v.x; v.z += v.y; v.w += v.z;
             const int incl = wave_incl_scan(v.w);
             const int excl = incl - v.w + carry;
@@ -1052,7 +1075,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
                 run_feed(run, base, M & V, V, reso);
             }
         }
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, Pq, o, (long long)s, n, true);
+        // the candidate list goes to the (now free) hot words when it is sure to fit - at most K0 - 2 candidates - so that the
+        // gate sums need not be taken before it is known that the read keeps an annotation; else it overwrites the profile in place
+        const bool cand_apart = K0 - 2 <= HOT * WAVE;
+        const int used = __builtin_amdgcn_readfirstlane(mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, cand_apart ? hot : Pq, o, (long long)s, n, true,
+                                                                           !cand_apart, flag_words));
+        if (cand_apart && used > 0) {   // the hot words start every read at zero
+#pragma unroll
+            for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
+        }
     }
 }
 
