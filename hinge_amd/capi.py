@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhinge_hip.so")
+LIB_PATH = os.environ.get("HINGE_LIB") or os.path.join(_HERE, "lib", "libhinge_hip.so")   # HINGE_LIB: another build of the library (tools/ablate_k2.sh)
 
 HINGE_OK = 0
 ERR_NAMES = {-1: "HINGE_E_ARG", -2: "HINGE_E_DEVICE", -3: "HINGE_E_CAPACITY", -4: "HINGE_E_UNDEFINED", -5: "HINGE_E_RANGE"}

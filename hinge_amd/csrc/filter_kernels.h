@@ -986,11 +986,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
                     const unsigned de = (unsigned)qe - qd;
                     int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;
                     int* pe = de < 2u ? hot_e + de * WAVE : Pq + qd;
+#ifdef HINGE_ABLATE
+                    if (P.ablate == 10) { asm volatile("" ::"v"(pb), "v"(pe)); continue; }   // 10 = loads and bin arithmetic, no LDS atomics
+#endif
                     atomicAdd(pb, 1);
                     atomicAdd(pe, 0x10000);
                 }
             }
         }
+#ifdef HINGE_ABLATE
+        if (P.ablate == 10) continue;
+#endif
+        HINGE_ABLATE_POINT(9)    // (ablation builds: 9 = stop after the histogram, before the hot-word fold)
         {   // fold the lane-private hot words into their bins (and zero them for the next read)
             int hv[HOT];
 #pragma unroll
@@ -1014,13 +1021,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
         int carry = 0;
         int* __restrict__ const cov_dst = o.cov_out ? o.cov_out + cov_at : (int*)nullptr;
-#ifdef HINGE_ABLATE
-        if (P.ablate != 6 && P.ablate != 8)
-#endif
         // Which 64-bin words of the plain profile can hold an annotation at all: an annotation needs |cov0[k+1] - cov0[k]| above
         // min(MIN_RA, MAX_RA), and that difference is simply the begins minus the ends of the two 20-bp bins 2k, 2k+1 - the raw
         // counts this loop holds before it sums them.  A typical read has no such bin between its ends' pile-ups.
         unsigned long long flag_words = mulpath_thr >= 0 ? 0ull : ~0ull;
+#ifdef HINGE_ABLATE
+        if (P.ablate != 6 && P.ablate != 8)
+#endif
         for (int base = 0; base < Qn; base += 4 * WAVE) {
             const int t = base + 4 * lane;
             int4 v = t < Qn ? *reinterpret_cast<const int4*>(Pq + t) : make_int4(0, 0, 0, 0);

@@ -194,6 +194,9 @@ static FilterDev to_dev(const hinge_filter_params* p) {
     d.use_qv = p->use_qv_mask; d.use_cov = p->use_coverage_mask; d.del_telo = p->delete_telomere;
     d.est_cov = p->est_cov;
     d.ablate = 0;
+#ifdef HINGE_ABLATE
+    if (const char* a = getenv("HINGE_ABLATE_PHASE")) d.ablate = atoi(a);   // ablation builds only (tools/ablate_k2.sh)
+#endif
     return d;
 }
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cov-out", action="store_true")
     ap.add_argument("--only", default="", help="comma-separated variant names (default: all)")
+    ap.add_argument("--no-check", action="store_true", help="do not compare results between variants (ablation builds produce garbage)")
     ap.add_argument("--parts", type=int, default=3, help="distinct parts rotated between timed launches (cold Infinity Cache)")
     args = ap.parse_args()
     import torch
@@ -63,7 +64,7 @@ def main():
             ctx.filter_median(P, 0, n - 1, fetch=True)
             ctx.filter_mask_annotate(P)      # synchronous: sizes the annotation buffer
             ctxs.append(ctx)
-        ablated = False
+        ablated = args.no_check
         res = None if ablated else [(c.get_masks(), c.get_annotations()[:3]) for c in ctxs]
         if ablated:
             pass
