@@ -595,9 +595,11 @@ __device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long lo
 // Everything after the coverage profiles exist: mask, telomere flag, gate sums, annotation candidates, merge,
 // outputs.  z(j) = cutoff-0 coverage of bin j (j < K0), c(j) = cutoff coverage; cand = LDS scratch for the
 // packed candidates (pos << 1 | (type == +1)): slot t is written only after z(j) was read for every j <= t.
-template <typename ZF, typename CF>
-__device__ __forceinline__ int mask_gate_annotate(const FilterDev& P, const int reso, const int MIN_COV, const int i, const int lane,
-                                                   const int K0, const RunState& run, ZF z, CF c, int* cand, const AnnoOut& o,
+// PT / OT: FilterDev / AnnoOut, possibly qualified with the constant address space (k_mask_annotate_q20 passes them in device
+// memory: every field is then a scalar load at its point of use instead of an SGPR that is live - or spilled - across the read loop).
+template <typename PT, typename OT, typename ZF, typename CF>
+__device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, const int MIN_COV, const int i, const int lane,
+                                                   const int K0, const RunState& run, ZF z, CF c, int* cand, const OT& o,
                                                    const long long row, const int n_pile, const bool cov_done = false,
                                                    const bool cand_in_profile = true /*cand[] overwrites what z() reads*/,
                                                    const unsigned long long flag_words = ~0ull /*bit w clear: no bin of [64 w, 64 w + 63] can be an annotation*/) {
@@ -898,11 +900,25 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
 // words (hot[4][64]) so they never collide; they are summed once per read.
 // A read goes to the fallback list (run by k_mask_annotate afterwards) when its pile-up has 65536+ overlaps
 // or any coordinate lies outside [0, rlen], or the read is too long even for a whole workgroup's LDS.
+// The constants of the read's last phase (FilterDev, the output pointers) are passed in device memory behind one pointer and read
+// through the constant address space where they are used (scalar loads, a field at a time): as by-value kernel arguments they are
+// live across the whole read loop and cost 58 SGPR spills to VGPR lanes - the reloads alone were ~90 v_readlane per read,
+// 15 % of the kernel's time (ablation build, tools/ablate_k2.sh).
+struct K2Const {
+    FilterDev P;
+    AnnoOut o;
+};
+
 template <bool PACKED>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(64))) void k_mask_annotate_q20(FilterDev P, const int* __restrict__ read_list, int n1, int n2, int n4,
+__global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off, int mulpath_thr /*min(MIN_RA, MAX_RA) when the
+                                                             division-free annotation test applies, else -1*/,
+                                                             int nhr /*NO_HINGE_REGION*/, int use_cov /*the coverage mask takes part in the mask*/,
+                                                             const int* __restrict__ read_list, int n1, int n2, int n4,
                                                              const int64_t* __restrict__ row_ptr,
                                                              const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
-                                                             const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints, AnnoOut o,
+                                                             const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints,
+                                                             int* __restrict__ cov_out /*nullptr, or the coverage-bin output*/,
+                                                             const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int rpw) {
     extern __shared__ int lds[];
     constexpr int HOT = 4;
@@ -920,7 +936,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
     else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g1) * 2 + (wib >> 1); if (item >= n2) return; item += n1; item_end = item + 1; }
     else { width = 4; if (wib != 0) return; item = n1 + n2 + ((int)blockIdx.x - g1 - g2); item_end = item + 1; }
     constexpr int reso = 40;
-    const int SH = P.cut_off / 20;
+    const int SH = cut_off / 20;
     // Zero words in front of the prefix array and copies of the totals behind it make PB[q < 0] = 0 and P[q > last] = P[last]
     // plain loads: the profile accessors below need no clamps and issue their LDS reads back to back.
     const int PADF = (SH + 2 + 3) & ~3, PADT = (2 * SH + 4 + 3) & ~3;
@@ -932,8 +948,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
     int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
     int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1}
     const int MIN_COV = *d_min_cov;
-    // the division-free annotation test of mask_gate_annotate applies (then |gradient| > min(MIN_RA, MAX_RA) is necessary): -1 = no
-    const int mulpath_thr = (P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0) ? min(P.min_ra, P.max_ra) : -1;
+#ifdef HINGE_ABLATE
+    struct { int ablate; } P = {C->P.ablate};
+#endif
     for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
 
     for (; item < item_end; item += item_step) {   // `continue` leaves a read
@@ -941,7 +958,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];
         const int K0 = nbins0[i];                     // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
-        const long long cov_at = o.cov_out ? o.cov_off[i - o.cov_base] : 0;   // (fetched with the row bounds, used after phase 1)
+        const long long cov_at = cov_out ? cov_off[i - cov_base] : 0;   // (fetched with the row bounds, used after phase 1)
         const int64_t n64 = e - s;
         const int qe = rl / 20;                       // last bin an event can fall in
         if (n64 >= 65536 || K0 < 0 || qe >= qcap) {   // 16-bit counts would overflow / malformed / too long: general kernel
@@ -1016,15 +1033,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         // The cutoff profile is zero from its last bin on (every event consumed: begins - ends = 0), and a zero bin that
         // follows a zero bin changes nothing in the run search, so any bound >= the reference's K works: the largest a
         // well-formed pile-up can have needs no reduction.
-        const int KC = nbins_of<40>(n, rl + P.cut_off, reso);
+        const int KC = nbins_of<40>(n, rl + cut_off, reso);
 
         // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
         int carry = 0;
-        int* __restrict__ const cov_dst = o.cov_out ? o.cov_out + cov_at : (int*)nullptr;
+        int* __restrict__ const cov_dst = cov_out ? cov_out + cov_at : (int*)nullptr;
         // Which 64-bin words of the plain profile can hold an annotation at all: an annotation needs |cov0[k+1] - cov0[k]| above
         // min(MIN_RA, MAX_RA), and that difference is simply the begins minus the ends of the two 20-bp bins 2k, 2k+1 - the raw
         // counts this loop holds before it sums them.  A typical read has no such bin between its ends' pile-ups.
         unsigned long long flag_words = mulpath_thr >= 0 ? 0ull : ~0ull;
+        // ... and only between the bounds every annotation window respects: 40 j >= mask.first + NHR >= NHR, j <= K0 - 3, and with
+        // the coverage mask 40 j <= mask.second - NHR <= rl - cut_off - NHR (a bin of the cutoff profile is positive only while an
+        // overlap still has cut_off bases to go, so the mask ends at rl - cut_off at the latest).  The pile-ups of begins at the
+        // read's start and of ends at its end - which exceed the threshold in every read - lie outside them.
+        const int jlo_b = max(nhr, 0) / reso;
+        const int jhi_b = use_cov ? min(K0 - 3, rl - cut_off - nhr < 0 ? -1 : (rl - cut_off - nhr) / reso) : K0 - 3;
 #ifdef HINGE_ABLATE
         if (P.ablate != 6 && P.ablate != 8)
 #endif
@@ -1034,7 +1057,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
             if (mulpath_thr >= 0) {
                 const int s01 = v.x + v.y, s23 = v.z + v.w;   // (16|16 packed: the halves cannot carry, the counts are below 65536)
                 const int g0 = (s01 & 0xffff) - (int)((unsigned)s01 >> 16), g1 = (s23 & 0xffff) - (int)((unsigned)s23 >> 16);
-                const unsigned long long bal = ballot_of(max(abs(g0), abs(g1)) > mulpath_thr);
+                const int k0 = t >> 1;                         // this lane's two 40-bp bins: k0, k0 + 1
+                const unsigned long long bal = ballot_of(max(abs(g0), abs(g1)) > mulpath_thr && k0 + 1 >= jlo_b && k0 <= jhi_b);
                 const int w = base >> 7;                       // this step covers the 40-bp bins [base / 2, base / 2 + 127]: words w, w + 1
                 if (w < 63) flag_words |= ((unsigned long long)((unsigned)bal != 0u) << w) | ((unsigned long long)((unsigned)(bal >> 32) != 0u) << (w + 1));
                 else flag_words |= 1ull << 63;   // (bins beyond word 62: looked at unconditionally)
@@ -1057,7 +1081,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         }
         if (cov_dst && lane == 0) {
             if (K0 > 0) cov_dst[0] = 0;                      // cov0[0]: nothing is consumed before position 0
-            o.cov_nbins[i - o.cov_base] = K0;
+            cov_nbins[i - cov_base] = K0;
         }
         {   // copies of the totals behind the scanned bins (the scan ran over [0, round-up-to-4 of Qn))
             const int Qs = (Qn + 3) & ~3;
@@ -1085,8 +1109,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96), amdgpu_n
         // the candidate list goes to the (now free) hot words when it is sure to fit - at most K0 - 2 candidates - so that the
         // gate sums need not be taken before it is known that the read keeps an annotation; else it overwrites the profile in place
         const bool cand_apart = K0 - 2 <= HOT * WAVE;
-        const int used = __builtin_amdgcn_readfirstlane(mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, cov0, covc, cand_apart ? hot : Pq, o, (long long)s, n, true,
-                                                                           !cand_apart, flag_words));
+        const K2Const* c = C;
+        asm volatile("" : "+s"(c));   // (hides the pointer from the hoisting passes: the loads below stay inside this phase)
+        typedef const K2Const __attribute__((address_space(4))) K2ConstK;   // constant address space: scalar loads
+        K2ConstK& kc = *(K2ConstK*)(unsigned long long)c;
+        const int used = __builtin_amdgcn_readfirstlane(mask_gate_annotate(kc.P, reso, MIN_COV, i, lane, K0, run, cov0, covc, cand_apart ? hot : Pq, kc.o, (long long)s, n,
+                                                                           true, !cand_apart, flag_words));
         if (cand_apart && used > 0) {   // the hot words start every read at zero
 #pragma unroll
             for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;

@@ -73,6 +73,9 @@ struct hinge_ctx {
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
     int k2_rpw = 0;              // class-1 reads per wavefront of k_mask_annotate_q20 (0: chosen from the part's size)
+    DevBuf k2c;                  // K2Const of k_mask_annotate_q20 in device memory
+    K2Const k2c_host;            // what was uploaded last
+    bool k2c_valid = false;
     bool trace_padded = false;   // the trace buffer is the library's own copy with 8 spare bytes behind it
     int64_t trace_bytes = 0;
     int tbytes = 1;
@@ -242,7 +245,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
-                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb};
+                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -742,14 +745,35 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         // wavefronts (84.1 us vs 88.8 us on 86 588 reads; 2: 87.4, 4: 84.5), 1 for small parts; HINGE_K2_RPW overrides
         const int rpw = ctx->k2_rpw > 0 ? ctx->k2_rpw : std::min(3, std::max(1, n1 / 16384));
         const int g = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4);
+        {   // the kernel's constants (parameters, output pointers): a 200-byte block in device memory, uploaded when it changes
+            K2Const hc;
+            memset(&hc, 0, sizeof(hc));
+            hc.P = to_dev(p);
+            hc.o = anno_out(ctx);
+            int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
+            if (rc) return rc;
+            if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
+                ctx->k2c_host = hc;
+                CK(hipMemcpyAsync(ctx->k2c.p, &ctx->k2c_host, sizeof(K2Const), hipMemcpyHostToDevice, ctx->stream));
+                ctx->k2c_valid = true;
+            }
+        }
+        int* cov_out = ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr;
+        // the division-free annotation test of mask_gate_annotate applies: then |gradient| > min(MIN_RA, MAX_RA) is necessary
+        const int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
+                                    ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
         if (ctx->use_span16)
-            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
+                               p->no_hinge_region, (p->use_coverage_mask != 0) ? 1 : 0, (const int*)ctx->bucket_list.p, n1, n2, n4,
                                (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+                               (const int*)&sc(ctx)->min_cov, slot, cov_out, (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin,
+                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
         else
-            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, to_dev(p), (const int*)ctx->bucket_list.p, n1, n2, n4,
+            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
+                               p->no_hinge_region, (p->use_coverage_mask != 0) ? 1 : 0, (const int*)ctx->bucket_list.p, n1, n2, n4,
                                (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, anno_out(ctx), (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+                               (const int*)&sc(ctx)->min_cov, slot, cov_out, (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin,
+                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is
