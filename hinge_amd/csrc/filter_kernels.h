@@ -908,6 +908,16 @@ struct K2Const {
     FilterDev P;
     AnnoOut o;
 };
+constexpr int K2_MAX_HEADS = 64;
+struct K2Heads { unsigned base[K2_MAX_HEADS]; };   // value of every item counter before this launch
+#ifdef HINGE_ABLATE
+// Ablation builds: per-read time stamps (100 MHz s_memrealtime) of k_mask_annotate_q20, five per list item: read start, histogram
+// done, scan done, mask pass done, read done (tools/k2_trace.py).
+__device__ unsigned long long* g_k2_trace = nullptr;
+#define HINGE_K2_STAMP(k) do { if (k2tr && lane == 0) k2tr[5 * (size_t)item + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HINGE_K2_STAMP(k) do { } while (0)
+#endif
 
 template <bool PACKED>
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off, int mulpath_thr /*min(MIN_RA, MAX_RA) when the
@@ -919,22 +929,43 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
                                                              const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints,
                                                              int* __restrict__ cov_out /*nullptr, or the coverage-bin output*/,
                                                              const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
-                                                             int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count, int rpw) {
+                                                             int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count,
+                                                             unsigned* __restrict__ heads, int n_heads, K2Heads bases) {
     extern __shared__ int lds[];
     constexpr int HOT = 4;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // A workgroup has four LDS slots of slot_ints words.  read_list = [n1 reads that fit one slot | n2 reads that need two |
-    // n4 reads that need all four]; the first ceil(n1/4) workgroups run four reads, the next ceil(n2/2) two (wavefronts 0
-    // and 2, each over two slots), the last n4 one.  One launch, LDS sized for the common short read, and the few long
-    // reads of a part overlap with everything else instead of costing every read its occupancy.
-    // rpw: class-1 reads per wavefront (the per-wavefront set-up below is ~1/8 of a read's scalar instructions; a wavefront that
-    // runs `rpw` reads pays it once; the reads of a wavefront are g1 * 4 apart in the list)
-    const int g1 = ((n1 + 3) / 4 + rpw - 1) / rpw, g2 = (n2 + 1) / 2;
-    int width, item, item_end, item_step = 1;
-    if ((int)blockIdx.x < g1) { width = 1; item = (int)blockIdx.x * 4 + wib; if (item >= n1) return; item_end = n1; item_step = g1 * 4; }
-    else if ((int)blockIdx.x < g1 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g1) * 2 + (wib >> 1); if (item >= n2) return; item += n1; item_end = item + 1; }
-    else { width = 4; if (wib != 0) return; item = n1 + n2 + ((int)blockIdx.x - g1 - g2); item_end = item + 1; }
+    // A workgroup has four LDS slots of slot_ints words.  read_list = [n1 reads that fit one slot, longest first | n2 reads that
+    // need two | n4 reads that need all four].  The grid is [n4 workgroups that run one long read each | ceil(n2/2) that run two
+    // (wavefronts 0 and 2, each over two slots) | the PERSISTENT workgroups of the n1 short reads, as many as the GPU holds at
+    // once]: the long reads - the most expensive items of the launch - start first, and the wavefronts of the persistent
+    // workgroups take the short reads one at a time, the next one fetched while the current one is worked on.
+    // Where from: ONE device counter serialises - a returning device-scope atomic on one word takes 11.7 ns, 1.1 ms for the
+    // 87 k reads of the bench part (measured; the guide's "one word saturates at 88 dequeues / us").  So there are n_heads (<= 64)
+    // counters, 128 bytes apart; persistent workgroup pb draws from head pb % n_heads, whose items are h, h + n_heads, ... of the
+    // sorted list (every head the same mix of lengths, every head the same number of workgroups: n_heads divides their count).
+    // The counters only ever grow: a launch advances head h by its wavefronts + its items, the host keeps the sums and passes
+    // where this launch starts (`bases`).
+    // Round 1 gave every wavefront a fixed number of reads and every four such wavefronts a workgroup, in list order with the long
+    // reads last: the per-read time stamps of an ablation build (tools/k2_trace.py) showed 18 % of the resident wavefront slots
+    // idle behind their workgroup's slowest wavefront and the last 15 % of the launch at falling occupancy.  Dealing the reads to
+    // the workgroups on the host by estimated cost (least-loaded-first, dynamic only inside a workgroup) was worse than that: a
+    // read's time is not predictable enough from its length (117 us; the workgroups ended between 50 % and 100 % of the launch).
+    const int g4 = n4, g2 = (n2 + 1) / 2;
+    int width, item, item_end;
+    bool dyn = false;
+    unsigned grab = 0, head_base = 0;
+    int head = 0;
+    unsigned* head_ptr = nullptr;
+    if ((int)blockIdx.x < g4) { width = 4; if (wib != 0) return; item = n1 + n2 + (int)blockIdx.x; item_end = item + 1; }
+    else if ((int)blockIdx.x < g4 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g4) * 2 + (wib >> 1); if (item >= n2) return; item += n1; item_end = item + 1; }
+    else {
+        width = 1; dyn = true; item = 0; item_end = n1;
+        head = ((int)blockIdx.x - g4 - g2) % n_heads;
+        head_ptr = heads + head * 32;
+        head_base = bases.base[head];
+        if (lane == 0) grab = atomicAdd(head_ptr, 1u);   // (its latency is covered by the set-up below)
+    }
     constexpr int reso = 40;
     const int SH = cut_off / 20;
     // Zero words in front of the prefix array and copies of the totals behind it make PB[q < 0] = 0 and P[q > last] = P[last]
@@ -950,10 +981,15 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
     const int MIN_COV = *d_min_cov;
 #ifdef HINGE_ABLATE
     struct { int ablate; } P = {C->P.ablate};
+    unsigned long long* const k2tr = g_k2_trace;
 #endif
     for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
+    auto drawn = [&]() { return head + n_heads * (int)((unsigned)__builtin_amdgcn_readfirstlane((int)grab) - head_base); };
+    if (dyn) item = drawn();
 
-    for (; item < item_end; item += item_step) {   // `continue` leaves a read
+    for (; (unsigned)item < (unsigned)item_end; item = dyn ? drawn() : item_end) {   // `continue` leaves a read
+        if (dyn && lane == 0) grab = atomicAdd(head_ptr, 1u);   // the item after this one
+        HINGE_K2_STAMP(0);
         const int i = read_list[item];
         const int64_t s = row_ptr[i], e = row_ptr[i + 1];
         const int rl = rlen[i];
@@ -1014,6 +1050,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
 #ifdef HINGE_ABLATE
         if (P.ablate == 10) continue;
 #endif
+        HINGE_K2_STAMP(1);
         HINGE_ABLATE_POINT(9)    // (ablation builds: 9 = stop after the histogram, before the hot-word fold)
         {   // fold the lane-private hot words into their bins (and zero them for the next read)
             int hv[HOT];
@@ -1087,6 +1124,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
             const int Qs = (Qn + 3) & ~3;
             for (int t = lane; t < PADT; t += WAVE) Pq[Qs + t] = carry;
         }
+        HINGE_K2_STAMP(2);
         auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
         auto covc = [&](int k) { return (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16); };
         // ---- coverage mask on the cutoff profile ------------------------------------------------------
@@ -1108,6 +1146,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
         }
         // the candidate list goes to the (now free) hot words when it is sure to fit - at most K0 - 2 candidates - so that the
         // gate sums need not be taken before it is known that the read keeps an annotation; else it overwrites the profile in place
+        HINGE_K2_STAMP(3);
         const bool cand_apart = K0 - 2 <= HOT * WAVE;
         const K2Const* c = C;
         asm volatile("" : "+s"(c));   // (hides the pointer from the hoisting passes: the loads below stay inside this phase)
@@ -1119,6 +1158,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
 #pragma unroll
             for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
         }
+        HINGE_K2_STAMP(4);
     }
 }
 

@@ -48,7 +48,7 @@ struct hinge_ctx {
     bool use_span16 = false;   // every read < 65536 bp and every coordinate inside its read (k_pileup_facts)
     int no_span16 = 0;         // HINGE_NO_SPAN16=1: keep the streaming kernels on the int32 spans
     bool has_keep = false;
-    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list;
+    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list, k2_heads;
     unsigned anno_cap = 0;
     DevBuf exact_queue;
     unsigned exact_cap = 0;
@@ -68,11 +68,15 @@ struct hinge_ctx {
     std::vector<int> h_rlen;      // host copy of the read lengths (length buckets of K2)
     unsigned max_pile = 0;        // facts about the current part's pile-ups (k_pileup_facts)
     bool spans_in_range = false;
-    int n_class[3] = {0, 0, 0};   // bucket_list = [reads needing 1 | 2 | 4 LDS slots of a K2 workgroup] of the current part   // tests: run the general K2 kernel where the q20 kernel would be chosen
+    // tests: run the general K2 kernel where the q20 kernel would be chosen
 
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
-    int k2_rpw = 0;              // class-1 reads per wavefront of k_mask_annotate_q20 (0: chosen from the part's size)
+    int k2_wgs = 0;              // workgroups of k_mask_annotate_q20 (0: as many as the GPU holds at once, capped by the part's reads); HINGE_K2_WGS
+    int k2_occ_lds = -1, k2_occ = 0;          // occupancy calculator: workgroups per CU at that many bytes of dynamic LDS
+    std::vector<int> k2_list;                 // host copy of bucket_list (the upload is asynchronous)
+    int n_class[3] = {0, 0, 0};               // bucket_list = [reads needing 1 (longest first) | 2 | 4 LDS slots of a K2 workgroup] of the current part
+    unsigned k2_head_base[K2_MAX_HEADS] = {}; // value of every item counter of k_mask_annotate_q20 (DevBuf k2_heads) before its next launch
     DevBuf k2c;                  // K2Const of k_mask_annotate_q20 in device memory
     K2Const k2c_host;            // what was uploaded last
     bool k2c_valid = false;
@@ -123,7 +127,8 @@ struct ProfScope {
 };
 
 static_assert(HINGE_SPAN16_PAD == (LOADS_IN_FLIGHT / 2) * WAVE, "elements behind span16[n_ovl] a kernel may read (never uses)");
-static const int K2_SHORT_RLEN = 16000;   // 20-bp bins of a 16 kb read + hot words + pads = 1120 ints per wavefront, 17.5 KiB per workgroup: 8 workgroups per CU
+static const int K2_SHORT_RLEN = 21000;   // 20-bp bins of a 21 kb read + hot words + pads = 1372 ints per wavefront, 21.4 KiB per workgroup: seven
+                                          // workgroups per CU, which is what the kernel's registers allow anyway (97.5 % of the bench part's reads)
 
 // words of LDS per wavefront slot of k_mask_annotate_q20: 20-bp bins of the longest "short" read + the hot words
 static int k2_slot_ints(const hinge_ctx* ctx) {
@@ -227,7 +232,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     (void)hipMemset(ctx->scalars.p, 0, sizeof(Scalars));
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
-    if (const char* g = getenv("HINGE_K2_RPW")) ctx->k2_rpw = std::max(1, atoi(g));
+    if (const char* g = getenv("HINGE_K2_WGS")) ctx->k2_wgs = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -244,7 +249,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
-                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
+                     &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -355,19 +360,24 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
         const int nr = r_end - r_begin + 1;
         const int slot = k2_slot_ints(ctx);
         const int len1 = (slot - 4 * WAVE - 1) * 20 + 19, len2 = (2 * slot - 4 * WAVE - 1) * 20 + 19;   // longest read per class
-        std::vector<int> lst((size_t)nr);
+        ctx->k2_list.assign((size_t)std::max(nr, 1), 0);
+        std::vector<int>& lst = ctx->k2_list;   // (lives in the context: the upload is asynchronous)
         int n1 = 0, n2 = 0, n4 = 0;
         for (int i = r_begin; i <= r_end; i++) { const int l = ctx->h_rlen[(size_t)i]; n1 += l <= len1; n2 += l > len1 && l <= len2; }
         n4 = nr - n1 - n2;
-        int p1 = 0, p2 = n1, p4 = n1 + n2;
+        // class 1 longest first (counting sort on rlen / 64): the wavefronts of k_mask_annotate_q20 draw these items one at a time,
+        // and a launch whose last items are its cheapest ends with all wavefronts within a short read's time of each other
+        std::vector<int> at((size_t)(std::max(len1, 0) / 64 + 2), 0);
+        for (int i = r_begin; i <= r_end; i++) { const int l = ctx->h_rlen[(size_t)i]; if (l <= len1) at[(size_t)(std::max(l, 0) / 64)]++; }
+        for (int b = (int)at.size() - 1, run = 0; b >= 0; b--) { const int c = at[(size_t)b]; at[(size_t)b] = run; run += c; }
+        int p2 = n1, p4 = n1 + n2;
         for (int i = r_begin; i <= r_end; i++) {
             const int l = ctx->h_rlen[(size_t)i];
-            if (l <= len1) lst[(size_t)p1++] = i; else if (l <= len2) lst[(size_t)p2++] = i; else lst[(size_t)p4++] = i;
+            if (l <= len1) lst[(size_t)at[(size_t)(std::max(l, 0) / 64)]++] = i; else if (l <= len2) lst[(size_t)p2++] = i; else lst[(size_t)p4++] = i;
         }
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
-        if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)nr))) return rc;
-        CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));   // lst is a local
+        if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)std::max(nr, 1)))) return rc;
+        if (nr > 0) CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
         const bool pack_ok = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
         if (facts_given) {
             // The ingest touched every record anyway: it hands over the facts and (when every coordinate fits 16 bits and
@@ -740,11 +750,39 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         const int slot = k2_slot_ints(ctx) + ((SH + 2 + 3) & ~3) + ((2 * SH + 4 + 3) & ~3);
         const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // ~17.5 KiB for 16 kb reads: eight workgroups (32 waves) per CU
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
+        const size_t lds_all = lds20;
+        if (ctx->k2_occ_lds != (int)lds_all) {
+            int nb = 0;
+            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true>, BLOCK, lds_all));
+            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false>, BLOCK, lds_all));
+            ctx->k2_occ = std::max(nb, 1);
+            ctx->k2_occ_lds = (int)lds_all;
+        }
         const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
-        // class-1 reads per wavefront: 3 once the part has enough reads to fill the GPU several times over with a third of the
-        // wavefronts (84.1 us vs 88.8 us on 86 588 reads; 2: 87.4, 4: 84.5), 1 for small parts; HINGE_K2_RPW overrides
-        const int rpw = ctx->k2_rpw > 0 ? ctx->k2_rpw : std::min(3, std::max(1, n1 / 16384));
-        const int g = std::max(1, ((n1 + 3) / 4 + rpw - 1) / rpw + (n2 + 1) / 2 + n4);
+        // persistent workgroups for the short reads: as many as are resident at once (HINGE_K2_WGS overrides), in a multiple of the
+        // number of item counters so that every counter serves the same number of workgroups
+        int gp = n1 > 0 ? std::min((n1 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->k2_wgs > 0 ? ctx->k2_wgs : ctx->k2_occ * ctx->n_cu) : 0;
+        int n_heads = 1;
+        if (gp >= 2 * K2_MAX_HEADS) { n_heads = K2_MAX_HEADS; gp -= gp % K2_MAX_HEADS; }
+        else for (int h = std::min(gp, K2_MAX_HEADS); h >= 1; h--) if (gp % h == 0) { n_heads = h; break; }
+        const int g = std::max(1, n4 + (n2 + 1) / 2 + gp);
+        K2Heads bases;
+        {
+            if (!ctx->k2_heads.p) {
+                int rc = ensure(ctx, ctx->k2_heads, sizeof(unsigned) * 32 * K2_MAX_HEADS);
+                if (rc) return rc;
+                CK(hipMemsetAsync(ctx->k2_heads.p, 0, sizeof(unsigned) * 32 * K2_MAX_HEADS, ctx->stream));
+            }
+            const int gp_run = g - n4 - (n2 + 1) / 2;   // (g >= 1: an empty part still launches one workgroup)
+            for (int h = 0; h < K2_MAX_HEADS; h++) {
+                bases.base[h] = ctx->k2_head_base[h];
+                if (h >= n_heads) continue;
+                // one draw per wavefront of the head's workgroups + one per item of the head
+                const unsigned wgs_h = (unsigned)(gp_run / n_heads + (h < gp_run % n_heads));
+                const unsigned items_h = (unsigned)(n1 / n_heads + (h < n1 % n_heads));
+                ctx->k2_head_base[h] += wgs_h * WAVES_PER_BLOCK + items_h;
+            }
+        }
         {   // the kernel's constants (parameters, output pointers): a 200-byte block in device memory, uploaded when it changes
             K2Const hc;
             memset(&hc, 0, sizeof(hc));
@@ -763,17 +801,17 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         const int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
                                     ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
         if (ctx->use_span16)
-            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
+            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
                                p->no_hinge_region, (p->use_coverage_mask != 0) ? 1 : 0, (const int*)ctx->bucket_list.p, n1, n2, n4,
                                (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
                                (const int*)&sc(ctx)->min_cov, slot, cov_out, (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin,
-                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, (unsigned*)ctx->k2_heads.p, n_heads, bases);
         else
-            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds20, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
+            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
                                p->no_hinge_region, (p->use_coverage_mask != 0) ? 1 : 0, (const int*)ctx->bucket_list.p, n1, n2, n4,
                                (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
                                (const int*)&sc(ctx)->min_cov, slot, cov_out, (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin,
-                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, rpw);
+                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, (unsigned*)ctx->k2_heads.p, n_heads, bases);
         CK(hipGetLastError());
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is
@@ -1123,3 +1161,23 @@ int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms) {
 }  // extern "C"
 
 #include "align_capi.inc"
+
+#ifdef HINGE_ABLATE
+// Ablation builds only (tools/k2_trace.py): a device buffer of 5 * n_items time stamps for k_mask_annotate_q20.
+extern "C" int hinge_debug_k2_trace_begin(long long n_items) {
+    unsigned long long* p = nullptr;
+    if (hipMalloc(&p, (size_t)n_items * 5 * 8) != hipSuccess) return -1;
+    hipMemset(p, 0, (size_t)n_items * 5 * 8);
+    return hipMemcpyToSymbol(HIP_SYMBOL(hinge::g_k2_trace), &p, sizeof p) == hipSuccess ? 0 : -1;
+}
+extern "C" int hinge_debug_k2_trace_end(unsigned long long* out, long long n_items) {
+    unsigned long long* p = nullptr;
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(&p, HIP_SYMBOL(hinge::g_k2_trace), sizeof p) != hipSuccess || !p) return -1;
+    hipMemcpy(out, p, (size_t)n_items * 5 * 8, hipMemcpyDeviceToHost);
+    unsigned long long* z = nullptr;
+    hipMemcpyToSymbol(HIP_SYMBOL(hinge::g_k2_trace), &z, sizeof z);
+    hipFree(p);
+    return 0;
+}
+#endif

@@ -9,9 +9,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -I$R/include -DHINGE_ABLATE -shared -o $OUT/libhinge_hip_ablate.so $R/hinge_amd/csrc/hinge_capi.hip || exit 1
+HINGE_LIB=$OUT/libhinge_hip_ablate.so python $R/tools/k2_trace.py > $OUT/k2_trace.txt 2>&1; cat $OUT/k2_trace.txt
+[ "${2:-}" = trace ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 for ph in 10 9 1 6 7 2 3 4 0; do
-  HINGE_LIB=$OUT/libhinge_hip_ablate.so HINGE_ABLATE_PHASE=$ph rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/abl_$ph -o $TAG --output-format csv -- python $R/tools/k2_bench.py --cov-out --reps 3 --only "rpw=3" --no-check > $OUT/abl_$ph.log 2>&1
-  echo "phase $ph: $(grep 'rpw=3' $OUT/abl_$ph.log | tail -1)"
+  HINGE_LIB=$OUT/libhinge_hip_ablate.so HINGE_ABLATE_PHASE=$ph rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/abl_$ph -o $TAG --output-format csv -- python $R/tools/k2_bench.py --cov-out --reps 3 --only "default" --no-check > $OUT/abl_$ph.log 2>&1
+  echo "phase $ph: $(grep "^default" $OUT/abl_$ph.log | tail -1)"
   python $R/tools/pmc_summary.py $(find $OUT/abl_$ph -name "*counter_collection.csv") | grep q20 | sed "s/^/  /"
 done

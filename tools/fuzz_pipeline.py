@@ -81,7 +81,7 @@ def random_paths(rng, spec):
     if rng.random() < 0.3:
         env["HINGE_THREADS"] = str(int(rng.choice([1, 3, 16])))
     if rng.random() < 0.3:
-        env["HINGE_K2_RPW"] = str(int(rng.choice([2, 3, 5])))   # several class-1 reads per wavefront of k_mask_annotate_q20 (small parts default to 1)
+        env["HINGE_K2_WGS"] = str(int(rng.choice([1, 2, 5])))   # few persistent workgroups: every wavefront of k_mask_annotate_q20 takes several reads
     paf = spec.n_blocks == 1 and rng.random() < 0.2
     return env, paf
 

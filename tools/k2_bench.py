@@ -2,7 +2,7 @@
 """A/B timing of the K2 kernels (coverage mask + repeat annotation) on the bench workload: every variant runs on its own
 context over the same resident part, its masks / annotations are compared with the first variant's, and K2 alone is timed
 with HIP events (hinge_profile_*).  Variants are environment settings read when a context is created
-(HINGE_K2_RPW, HINGE_NO_SPAN16 ...).    python tools/k2_bench.py [--genome 4600000] [--cov-out]"""
+(HINGE_K2_WGS, HINGE_NO_SPAN16 ...).    python tools/k2_bench.py [--genome 4600000] [--cov-out]"""
 import argparse
 import dataclasses
 import os
@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = [
-    ("rpw=1", {"HINGE_K2_RPW": "1"}),
-    ("rpw=2", {"HINGE_K2_RPW": "2"}),
-    ("rpw=3", {"HINGE_K2_RPW": "3"}),
-    ("rpw=4", {"HINGE_K2_RPW": "4"}),
+    ("default", {}),
+    ("wgs=5/cu", {"HINGE_K2_WGS": "1280"}),
+    ("wgs=6/cu", {"HINGE_K2_WGS": "1536"}),
+    ("wgs=7/cu", {"HINGE_K2_WGS": "1792"}),
     ("int32 spans", {"HINGE_NO_SPAN16": "1"}),
 ]
 
@@ -49,7 +49,7 @@ def main():
     for name, env in VARIANTS:
         if only and name not in only:
             continue
-        for k in ("HINGE_K2_LEAN", "HINGE_K2_RPW", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
+        for k in ("HINGE_K2_LEAN", "HINGE_K2_WGS", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctxs = []
