@@ -681,6 +681,7 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
         // |g| > min(max(x / F, lo), hi) with x = c + MIN_COV  <=>  |g| > hi  ||  (|g| > lo && |g| > x / F), and for
         // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
         const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
+        if (flag_words == 0ull) jhi = -1;   // (no word can hold an annotation: not even the loop's set-up, a division by cov_frac)
         for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
             if (base < 64 * WAVE && !((flag_words >> (base / WAVE)) & 1ull)) continue;   // (words beyond the 64th: always looked at)
             const int j = base + lane;
@@ -728,8 +729,8 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
     m = __builtin_amdgcn_readfirstlane(m);
     if (m > 0 && !cand_in_profile) gate_sums();
     // gate: fp32, IEEE divide, NaN compares false (filter.cpp:861-865)
-    bool gate_skip;
-    {
+    bool gate_skip = true;
+    if (m > 0) {   // (only read below when the read keeps an annotation: two IEEE divisions, 27 vector instructions)
         const float avg_end = __fdiv_rn((float)E, (float)nE);
         const float avg_start = __fdiv_rn((float)S, (float)nS);
         gate_skip = fabsf(avg_end - avg_start) < 10.0f;
@@ -1029,10 +1030,11 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
                 for (int t = lane; t < (Qn + 3) / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
                 cleared = true;
             }
+            const int rem = n - base - lane;       // this lane has an overlap in batch u iff u * 64 < rem
 #pragma unroll
             for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
                 if (base + u * WAVE >= n) break;   // wave-uniform
-                if (base + u * WAVE + lane < n) {
+                if (u * WAVE < rem) {
                     // k_cov_stats vouches for 0 <= abpos, aepos <= rl: the bins need no clamp
                     const int2 w = SL::get(v[u]);
                     const unsigned qb = (unsigned)w.x / 20u, qd = (unsigned)w.y / 20u;
@@ -1085,22 +1087,38 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
         // read's start and of ends at its end - which exceed the threshold in every read - lie outside them.
         const int jlo_b = max(nhr, 0) / reso;
         const int jhi_b = use_cov ? min(K0 - 3, rl - cut_off - nhr < 0 ? -1 : (rl - cut_off - nhr) / reso) : K0 - 3;
+        // as one unsigned range test per lane: 2 lane - (b_lo - hb) <= b_span, hb = first 40-bp bin of the step (no bin at all: b_lo
+        // beyond every lane)
+        const bool no_bins = jhi_b - jlo_b + 1 < 0;
+        const int b_lo = no_bins ? (1 << 30) : jlo_b - 1;
+        const unsigned b_span = no_bins ? 0u : (unsigned)(jhi_b - jlo_b + 1);
 #ifdef HINGE_ABLATE
         if (P.ablate != 6 && P.ablate != 8)
 #endif
         for (int base = 0; base < Qn; base += 4 * WAVE) {
             const int t = base + 4 * lane;
             int4 v = t < Qn ? *reinterpret_cast<const int4*>(Pq + t) : make_int4(0, 0, 0, 0);
+            v.y += v.x;                                        // (= begins|ends of this lane's first 40-bp bin, both halves below 65536)
             if (mulpath_thr >= 0) {
-                const int s01 = v.x + v.y, s23 = v.z + v.w;   // (16|16 packed: the halves cannot carry, the counts are below 65536)
-                const int g0 = (s01 & 0xffff) - (int)((unsigned)s01 >> 16), g1 = (s23 & 0xffff) - (int)((unsigned)s23 >> 16);
-                const int k0 = t >> 1;                         // this lane's two 40-bp bins: k0, k0 + 1
-                const unsigned long long bal = ballot_of(max(abs(g0), abs(g1)) > mulpath_thr && k0 + 1 >= jlo_b && k0 <= jhi_b);
-                const int w = base >> 7;                       // this step covers the 40-bp bins [base / 2, base / 2 + 127]: words w, w + 1
-                if (w < 63) flag_words |= ((unsigned long long)((unsigned)bal != 0u) << w) | ((unsigned long long)((unsigned)(bal >> 32) != 0u) << (w + 1));
-                else flag_words |= 1ull << 63;   // (bins beyond word 62: looked at unconditionally)
+                // |begins - ends| > thr  <=>  (unsigned)(begins - ends + thr) > 2 thr (thr < 2^28, the host sees to it); this lane's two
+                // 40-bp bins are hb + 2 lane and the next one, inside the window bounds iff 2 lane in [jlo_b - 1 - hb, jhi_b - hb]
+                const int s23 = v.z + v.w;
+                const unsigned u0 = (unsigned)((v.y & 0xffff) - (int)((unsigned)v.y >> 16) + mulpath_thr);
+                const unsigned u1 = (unsigned)((s23 & 0xffff) - (int)((unsigned)s23 >> 16) + mulpath_thr);
+                const int hb = base >> 1;
+                // (two ballots and a scalar AND: the ballot of `a && b` re-materialises the predicate on the vector side)
+                const unsigned long long bal = ballot_of((unsigned)(2 * lane - (b_lo - hb)) <= b_span) & ballot_of(max(u0, u1) > 2u * (unsigned)mulpath_thr);
+                // one bit per 64-bin word, words w and w + 1 of this step.  Scalar minima written as such: from `x != 0` or from
+                // min(x, 1) the compiler makes a zero-extended boolean, selects it on the vector side and drags the whole flag word
+                // into vector registers (25 vector instructions per step, seen in the ISA)
+                unsigned f0, f1;
+                asm("s_min_u32 %0, %1, 1" : "=s"(f0) : "s"((unsigned)bal) : "scc");
+                asm("s_min_u32 %0, %1, 1" : "=s"(f1) : "s"((unsigned)(bal >> 32)) : "scc");
+                const unsigned f = f0 | (f1 << 1);
+                const int w = base >> 7;
+                flag_words |= w < 63 ? (unsigned long long)f << w : 1ull << 63;   // (bins beyond word 62: looked at unconditionally)
             }
-            v.y += v.x; v.z += v.y; v.w += v.z;
+            v.z += v.y; v.w += v.z;
             const int incl = wave_incl_scan(v.w);
             const int excl = incl - v.w + carry;
             v.x += excl; v.y += excl; v.z += excl; v.w += excl;
@@ -1129,11 +1147,13 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
         auto covc = [&](int k) { return (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16); };
         // ---- coverage mask on the cutoff profile ------------------------------------------------------
         RunState run{0, 0ull, 0, 0};
+        const int* pcb = Pq + 2 * lane - 1 - SH;   // covc(base + lane) = begins below pcb[2 base] - ends below pce[2 base]
+        const int* pce = Pq + 2 * lane - 1 + SH;
 #ifdef HINGE_ABLATE
         if (P.ablate != 7 && P.ablate != 8)
 #endif
-        for (int base = 0; base < KC; base += WAVE) {
-            const unsigned long long M = ballot_of(covc(base + lane) > MIN_COV);
+        for (int base = 0; base < KC; base += WAVE, pcb += 2 * WAVE, pce += 2 * WAVE) {
+            const unsigned long long M = ballot_of((*pcb & 0xffff) - (int)((unsigned)*pce >> 16) > MIN_COV);
             const int left = KC - base;
             if (left >= 64) {
                 // 64 bins above MIN_COV (the interior of nearly every read) open or continue a run and close none

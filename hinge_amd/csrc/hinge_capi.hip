@@ -798,8 +798,9 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         }
         int* cov_out = ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr;
         // the division-free annotation test of mask_gate_annotate applies: then |gradient| > min(MIN_RA, MAX_RA) is necessary
-        const int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
+        int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
                                     ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
+        if (mulpath_thr >= (1 << 28)) mulpath_thr = -1;   // (the kernel's range test adds it to a count: every word is looked at instead)
         if (ctx->use_span16)
             hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
                                p->no_hinge_region, (p->use_coverage_mask != 0) ? 1 : 0, (const int*)ctx->bucket_list.p, n1, n2, n4,
