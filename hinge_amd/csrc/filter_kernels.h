@@ -1014,13 +1014,18 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
                 // the 16|16 copy is padded by half a batch, so the loads need neither a clamp nor a branch each: scalar row base
                 // + one lane offset + immediates, the whole batch or its first half
                 const typename SL::raw* __restrict__ p = row + (unsigned)(base + lane);
-                if (n - base > (LOADS_IN_FLIGHT / 2) * WAVE) {
-#pragma unroll
-                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = p[u * WAVE];
-                } else if (n > 0) {
-#pragma unroll
-                    for (int u = 0; u < LOADS_IN_FLIGHT / 2; u++) v[u] = p[u * WAVE];
-                }
+                // as many loads as the row has batches left, in seven tiers (three uniform branches): the reads are not visited in
+                // storage order, so what a wavefront loads past its row's end is fetched from HBM for nothing - with "the whole batch
+                // or its first half" FETCH_SIZE was twice the rows' bytes
+                static_assert(LOADS_IN_FLIGHT == 8, "load tiers below");
+                const int left = n - base;
+#define HINGE_K2_LOADS(CNT) _Pragma("unroll") for (int u = 0; u < (CNT); u++) v[u] = p[u * WAVE];
+                if (left > 4 * WAVE) {
+                    if (left > 6 * WAVE) { HINGE_K2_LOADS(8) } else if (left > 5 * WAVE) { HINGE_K2_LOADS(6) } else { HINGE_K2_LOADS(5) }
+                } else if (left > 2 * WAVE) {
+                    if (left > 3 * WAVE) { HINGE_K2_LOADS(4) } else { HINGE_K2_LOADS(3) }
+                } else if (left > WAVE) { HINGE_K2_LOADS(2) } else if (n > 0) { HINGE_K2_LOADS(1) }
+#undef HINGE_K2_LOADS
             } else if (n > 0) {   // (the int32 spans may be the caller's buffer: clamped index)
 #pragma unroll
                 for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];

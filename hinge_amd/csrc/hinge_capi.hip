@@ -73,6 +73,7 @@ struct hinge_ctx {
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
     int k2_wgs = 0;              // workgroups of k_mask_annotate_q20 (0: as many as the GPU holds at once, capped by the part's reads); HINGE_K2_WGS
+    int k2_order_bp = 1024;                   // bucket width of the longest-first order of the one-slot reads (HINGE_K2_ORDER_BP)
     int k2_occ_lds = -1, k2_occ = 0;          // occupancy calculator: workgroups per CU at that many bytes of dynamic LDS
     std::vector<int> k2_list;                 // host copy of bucket_list (the upload is asynchronous)
     int n_class[3] = {0, 0, 0};               // bucket_list = [reads needing 1 (longest first) | 2 | 4 LDS slots of a K2 workgroup] of the current part
@@ -233,6 +234,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_DEBUG_GENERAL_MASK")) ctx->force_general_mask = atoi(g);
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
     if (const char* g = getenv("HINGE_K2_WGS")) ctx->k2_wgs = std::max(1, atoi(g));
+    if (const char* g = getenv("HINGE_K2_ORDER_BP")) ctx->k2_order_bp = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -365,15 +367,17 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
         int n1 = 0, n2 = 0, n4 = 0;
         for (int i = r_begin; i <= r_end; i++) { const int l = ctx->h_rlen[(size_t)i]; n1 += l <= len1; n2 += l > len1 && l <= len2; }
         n4 = nr - n1 - n2;
-        // class 1 longest first (counting sort on rlen / 64): the wavefronts of k_mask_annotate_q20 draw these items one at a time,
+        // class 1 longest first (counting sort on rlen / K2_ORDER_BP, reads of one bucket in storage order so that neighbours in the
+        // list still share cache lines of the per-read tables): the wavefronts of k_mask_annotate_q20 draw these items one at a time,
         // and a launch whose last items are its cheapest ends with all wavefronts within a short read's time of each other
-        std::vector<int> at((size_t)(std::max(len1, 0) / 64 + 2), 0);
-        for (int i = r_begin; i <= r_end; i++) { const int l = ctx->h_rlen[(size_t)i]; if (l <= len1) at[(size_t)(std::max(l, 0) / 64)]++; }
+        const int ob = ctx->k2_order_bp;
+        std::vector<int> at((size_t)(std::max(len1, 0) / ob + 2), 0);
+        for (int i = r_begin; i <= r_end; i++) { const int l = ctx->h_rlen[(size_t)i]; if (l <= len1) at[(size_t)(std::max(l, 0) / ob)]++; }
         for (int b = (int)at.size() - 1, run = 0; b >= 0; b--) { const int c = at[(size_t)b]; at[(size_t)b] = run; run += c; }
         int p2 = n1, p4 = n1 + n2;
         for (int i = r_begin; i <= r_end; i++) {
             const int l = ctx->h_rlen[(size_t)i];
-            if (l <= len1) lst[(size_t)at[(size_t)(std::max(l, 0) / 64)]++] = i; else if (l <= len2) lst[(size_t)p2++] = i; else lst[(size_t)p4++] = i;
+            if (l <= len1) lst[(size_t)at[(size_t)(std::max(l, 0) / ob)]++] = i; else if (l <= len2) lst[(size_t)p2++] = i; else lst[(size_t)p4++] = i;
         }
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
         if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)std::max(nr, 1)))) return rc;

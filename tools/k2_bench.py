@@ -17,7 +17,9 @@ VARIANTS = [
     ("default", {}),
     ("wgs=5/cu", {"HINGE_K2_WGS": "1280"}),
     ("wgs=6/cu", {"HINGE_K2_WGS": "1536"}),
-    ("wgs=7/cu", {"HINGE_K2_WGS": "1792"}),
+    ("order=64", {"HINGE_K2_ORDER_BP": "64"}),
+    ("order=4096", {"HINGE_K2_ORDER_BP": "4096"}),
+    ("order=none", {"HINGE_K2_ORDER_BP": "1000000"}),
     ("int32 spans", {"HINGE_NO_SPAN16": "1"}),
 ]
 
@@ -49,7 +51,7 @@ def main():
     for name, env in VARIANTS:
         if only and name not in only:
             continue
-        for k in ("HINGE_K2_LEAN", "HINGE_K2_WGS", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
+        for k in ("HINGE_K2_ORDER_BP", "HINGE_K2_WGS", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctxs = []
