@@ -11,7 +11,8 @@ coverage statistics -> median / MIN_COV -> coverage mask + repeat annotation (wh
 hinge calling.  R parts rotate so that nothing a pass reads was left in the 256 MiB Infinity Cache by the previous pass over the
 same part (R x ~0.4 GB are streamed between two visits); within one pass the second sweep may hit what the first one brought in,
 exactly as it does in production.  With N > 1 every rank owns one DAZZ_DB block of every part (weak scaling) and the path's
-exchange steps run as RCCL collectives between the kernels (hinge_amd/dist.py).
+exchange steps run as RCCL collectives between the kernels, enqueued asynchronously so that a part's exchanges run under the next
+part's kernels (hinge_amd/dist.py, step_pipelined).
 
 At N = 1 rank 0 also reports
   * "e2e": `hinge filter / maximal / layout` (the C++ executables over libhinge_hip, .las ingest and text output included) on the
@@ -162,7 +163,7 @@ def main():
 
     from hinge_amd import capi, synth
     from hinge_amd.config import default_filter_params
-    from hinge_amd.dist import BlockTable, Exchange, HipBackend, ShardedFilter
+    from hinge_amd.dist import BlockTable, Exchange, HipBackend, ShardedFilter, step_pipelined
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -241,8 +242,9 @@ def main():
         torch.cuda.synchronize()
 
     def one_step():
-        for job in jobs:
-            job.step(fetch_hinges=False, check=False)
+        # the parts of this rank, software-pipelined: a part's exchanges run under the next part's kernels (one rank without
+        # collectives: simply part after part)
+        step_pipelined(jobs)
 
     # ---- warmup (the synchronous variants also size the library's annotation / exact-path buffers) ------------
     for job, ctx in zip(jobs, ctxs):

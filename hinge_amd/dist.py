@@ -73,16 +73,19 @@ class Exchange:
     def my_range(self) -> Tuple[int, int]:
         return self.blocks.first[self.rank], self.blocks.first[self.rank + 1]
 
-    def all_gather_rows(self, table: torch.Tensor) -> None:
+    def all_gather_rows(self, table: torch.Tensor, async_op: bool = False):
         """table[n_reads, ...]: every rank has filled the rows of its own block; on return every rank
         holds all rows.  Equal blocks: ONE in-place all_gather_into_tensor on the table itself.  Unequal blocks:
-        copy-in to a cached padded shard, all-gather, one indexed copy-out (buffers and index maps are built once)."""
+        copy-in to a cached padded shard, all-gather, one indexed copy-out (buffers and index maps are built once).
+        async_op: with equal blocks the collective is only enqueued and its work handle returned (wait() orders the
+        calling stream behind it); otherwise None is returned and the exchange is complete."""
         if self.world == 1 and not self.force:
-            return
+            return None
         lo, hi = self.my_range
         if all(self.blocks.size(k) == self.S for k in range(self.world)):
-            dist.all_gather_into_tensor(table, table[lo:hi], group=self.group)   # in place: rank r's rows sit at r * S
-            return
+            # in place: rank r's rows sit at r * S
+            return dist.all_gather_into_tensor(table, table[lo:hi], group=self.group, async_op=async_op) if async_op else \
+                dist.all_gather_into_tensor(table, table[lo:hi], group=self.group)
         key = (table.dtype, tuple(table.shape[1:]), table.device)
         buf = self._buffers.get(key)
         if buf is None:
@@ -98,11 +101,12 @@ class Exchange:
         dist.all_gather_into_tensor(recv, send, group=self.group)
         if src.numel():
             table.index_copy_(0, dst, recv.index_select(0, src))
+        return None
 
-    def all_reduce_sum(self, t: torch.Tensor) -> None:
+    def all_reduce_sum(self, t: torch.Tensor, async_op: bool = False):
         if self.world == 1 and not self.force:
-            return
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def all_gather_scalar(self, v: int) -> List[int]:
         return [r[0] for r in self.all_gather_ints([v])]
@@ -224,6 +228,44 @@ class ShardedFilter:
         drop_last = self.mode == "mlas" or x.rank == x.world - 1
         rows, count = b.hinge_rows(drop_last)       # (read, pos, type) int32 rows on the device
         return x.gather_lists(rows, count)          # exchange 3
+
+
+def step_pipelined(jobs: Sequence["ShardedFilter"]) -> None:
+    """One pass of several independent sharded jobs of this rank (e.g. the .las parts it holds; every job is its own sharded
+    run over the same ranks), without status exchange or hinge fetch - the chain bench.py times.
+
+    A job's two exchanges sit between its kernels (stats -> exchange 1 -> median -> mask/annotate -> exchange 2 -> hinges), so run
+    job by job every collective is exposed: eight latency-bound RCCL calls per four-part step, about as long as a part's kernels.
+    Here the jobs are software-pipelined: every exchange is enqueued asynchronously as soon as its input exists and waited for
+    (a stream-side wait, no host block with RCCL) only where its output is read, so exchange 1 of job j runs under the stats sweep
+    of job j + 1 and exchange 2 under the next job's mask/annotate kernel; only the last one of each kind is exposed.
+    Same kernels, same collectives, same results as [j.step(False, False) for j in jobs] (tests/test_dist_gloo.py).
+    Jobs in "mlas" mode or with the all-gather form of exchange 1 (host decisions in between) are run one after the other."""
+    if not jobs:
+        return
+    x0 = jobs[0].x
+    if not (all(j.mode == "merged" and j.median == "hist" for j in jobs) and (x0.world > 1 or x0.force)):
+        for j in jobs:
+            j.step(fetch_hinges=False, check=False)
+        return
+    pending = []
+    for j in jobs:
+        lo, hi = j.x.my_range
+        j.b.begin()
+        j.b.stats()
+        h = j.b.median_hist(lo, hi - 1)
+        pending.append((h, j.x.all_reduce_sum(h, async_op=True)))      # exchange 1
+    gathers = []
+    for j, (h, w) in zip(jobs, pending):
+        if w is not None:
+            w.wait()
+        j.b.median_from_hist(h)
+        j.b.mask_annotate()
+        gathers.append(j.x.all_gather_rows(j.mask, async_op=True))     # exchange 2
+    for j, w in zip(jobs, gathers):
+        if w is not None:
+            w.wait()
+        j.b.hinges()
 
 
 class HipBackend:

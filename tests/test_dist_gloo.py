@@ -155,6 +155,51 @@ def _worker(rank, world, port, mode, median, first, mean_all, mask_all, rows, ex
         dist.destroy_process_group()
 
 
+def _pipelined_worker(rank, world, port, first, tables, ret):
+    """Three jobs per rank through dist.step_pipelined: every job must see its own global median and its own full mask table."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hinge_amd.dist import BlockTable, Exchange, ShardedFilter, step_pipelined
+        lo, hi = first[rank], first[rank + 1]
+        jobs, bes = [], []
+        for mean_all, mask_all, expect in tables:
+            be = TableBackend(lo, hi, mean_all, mask_all, np.zeros((0, 3), np.int32), expect, mask_all)
+            jobs.append(ShardedFilter(be, Exchange(BlockTable(first), torch.device("cpu")), mode="merged", median="hist"))
+            bes.append(be)
+        step_pipelined(jobs)
+        for be, job, (mean_all, mask_all, _) in zip(bes, jobs, tables):
+            assert be.checked == ["min_cov", "masks"]
+            assert np.array_equal(job.mask.numpy(), mask_all)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_pipelined_keeps_jobs_apart():
+    import torch.multiprocessing as mp
+    world, n = 2, 600
+    first = [0, n // 2, n]            # equal blocks: the in-place asynchronous all-gather
+    rng = np.random.default_rng(5)
+    tables = []
+    for k in range(3):
+        mean_all = rng.integers(30 + 60 * k, 90 + 60 * k, n).astype(np.int32)
+        mean_all[rng.integers(0, n, 20)] = MEAN_SENTINEL
+        mask_all = np.stack([rng.integers(0, 100, n), rng.integers(100, 9000, n)], axis=1).astype(np.int32) + 1000 * k
+        v = np.sort(mean_all[mean_all != MEAN_SENTINEL])
+        tables.append((mean_all, mask_all, max(5, int(v[len(v) // 2]) // 3)))
+    port = 29500 + (os.getpid() % 400) + 7
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, first, tables, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs) and len(ret) == world
+
+
 @pytest.mark.parametrize("mode,median,equal_blocks", [("merged", "hist", False), ("merged", "gather", False), ("merged", "hist", True),
                                                        ("mlas", "gather", False)])
 def test_sharded_filter_exchanges(oracle_lib, tmp_path, mode, median, equal_blocks):
