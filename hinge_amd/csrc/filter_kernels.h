@@ -1134,8 +1134,11 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
                 // outputs at the end of the read - they also have the rest of the read's work to drain: stores count in vmcnt like
                 // loads on this architecture, so the next read's first wait for its spans waits for every store issued before it.
                 const int k1 = (t >> 1) + 1;
-                if (k1 < K0) cov_dst[k1] = (v.y & 0xffff) - (int)((unsigned)v.y >> 16);
-                if (k1 + 1 < K0) cov_dst[k1 + 1] = (v.w & 0xffff) - (int)((unsigned)v.w >> 16);
+                const int c1 = (v.y & 0xffff) - (int)((unsigned)v.y >> 16), c2 = (v.w & 0xffff) - (int)((unsigned)v.w >> 16);
+                // both bins in one 8-byte store (4-byte aligned: k1 is odd); the read's last bin alone when K0 is even
+                struct __attribute__((packed, aligned(4))) Bins2 { int a, b; };
+                if (k1 + 1 < K0) *reinterpret_cast<Bins2*>(cov_dst + k1) = Bins2{c1, c2};
+                else if (k1 < K0) cov_dst[k1] = c1;
             }
             carry += wave_last(incl);
         }
