@@ -55,6 +55,21 @@ struct FilterDev {   // device copy of hinge_filter_params + derived values
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 // ballot of a predicate as the compiler holds it (a lane mask in SGPRs): __ballot(int) materialises 0/1 per lane and compares again
 __device__ __forceinline__ unsigned long long ballot_of(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Per-read table look-ups with a 32-bit BYTE offset (tables of at most 4 GiB: read ids below 2^28).  A uniform offset becomes the
+// scalar load's offset register and a per-lane one the store's 32-bit offset register, next to the table's base pointer - instead
+// of a sign extension, a 64-bit shift and a 64-bit add on the scalar unit per access (it is the busiest unit of
+// k_mask_annotate_q20: one per CU, 75 % occupied).
+template <typename T> __device__ __forceinline__ T load_at32(const T* p, unsigned byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + byte_off);
+}
+template <typename T> __device__ __forceinline__ void store_at32(T* p, unsigned byte_off, const T& v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(p) + byte_off) = v;
+}
+__device__ __forceinline__ unsigned in_vgpr(unsigned x) {   // a uniform value the compiler must treat as per-lane: what is computed from it runs on the vector unit
+    unsigned r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
 
 template <int RESO>
 __device__ __forceinline__ int bin_of(int v, int reso) {
@@ -628,18 +643,19 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
         }
         if ((sc >= 10 * ec) || (ec >= 10 * sc)) fl |= 1;
     }
+    const unsigned iv = in_vgpr((unsigned)i);   // the read's index for the lane-0 stores below (vector-side address arithmetic)
     int2 mk;
     {
-        int2 q = o.qv_mask ? o.qv_mask[i] : make_int2(0, 0);
-        if (o.keep && !o.keep[i]) { maxend = maxstart; q.y = q.x; }   // filter.cpp:767-773
+        int2 q = o.qv_mask ? load_at32(o.qv_mask, (unsigned)i << 3) : make_int2(0, 0);
+        if (o.keep && !load_at32(o.keep, (unsigned)i)) { maxend = maxstart; q.y = q.x; }   // filter.cpp:767-773
         if (P.use_qv && P.use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
         else if (P.use_cov && !P.use_qv) mk = make_int2(maxstart, maxend);
         else mk = q;
     }
     if (lane == 0) {
-        o.mask[i] = mk;
-        o.cmask[i] = make_int2(msc, mec);
-        o.rflags[i] = fl;
+        store_at32(o.mask, iv << 3, mk);
+        store_at32(o.cmask, iv << 3, make_int2(msc, mec));
+        store_at32(o.rflags, iv, fl);
     }
     HINGE_ABLATE_RETURN_V(2)
     // ---- gate sums over the two NO_HINGE_REGION windows only (filter.cpp:842-865) -----------------
@@ -673,7 +689,8 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
     if (cand_in_profile) gate_sums();
     HINGE_ABLATE_RETURN_V(3)
     // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
-    {
+    // (nothing of this - window bounds, parameter loads - when no word can hold an annotation: the usual case in k_mask_annotate_q20)
+    if (flag_words != 0ull) {
         const int wlo = mk.x + P.nhr, whi = mk.y - P.nhr;
         int jlo = wlo <= 0 ? 0 : (wlo + reso - 1) / reso;
         int jhi = whi < 0 ? -1 : whi / reso;
@@ -681,7 +698,6 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
         // |g| > min(max(x / F, lo), hi) with x = c + MIN_COV  <=>  |g| > hi  ||  (|g| > lo && |g| > x / F), and for
         // x >= 0, F > 0:  |g| > x / F  <=>  |g| * F > x  -- no division on the common path
         const bool mulpath = P.cov_frac > 0 && P.cov_frac < 8192 && P.min_ra >= 0 && P.max_ra >= 0;
-        if (flag_words == 0ull) jhi = -1;   // (no word can hold an annotation: not even the loop's set-up, a division by cov_frac)
         for (int base = (jlo / WAVE) * WAVE; base <= jhi; base += WAVE) {
             if (base < 64 * WAVE && !((flag_words >> (base / WAVE)) & 1ull)) continue;   // (words beyond the 64th: always looked at)
             const int j = base + lane;
@@ -708,9 +724,16 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
         }
     }
     HINGE_ABLATE_RETURN_V(4)
+    if (ncand == 0) {   // (wave-uniform; most reads: no merge, no gate, no work item)
+        if (lane == 0) {
+            store_at32(o.anno_off, iv << 2, 0u);
+            store_at32(o.anno_cnt, iv << 2, 0);
+        }
+        return 0;
+    }
     // merge (filter.cpp:817-829) - sequential on a short list, in place
     int m = 0;
-    if (lane == 0 && ncand > 0) {
+    if (lane == 0) {
         int cur = cand[0];
         for (int t = 1; t < ncand; t++) {
             const int nx = cand[t];
@@ -741,8 +764,8 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
             off = atomicAdd(&o.counters[0], (unsigned)m);
             if (off + (unsigned)m > o.anno_cap) { atomicOr(o.status, ST_ANNO_CAP); m = 0; }
         }
-        o.anno_off[i] = off;
-        o.anno_cnt[i] = m;
+        store_at32(o.anno_off, iv << 2, off);
+        store_at32(o.anno_cnt, iv << 2, m);
         if (m > 0 && !gate_skip) {
             const unsigned w = atomicAdd(&o.counters[1], 1u);
             WorkItem it;
@@ -911,9 +934,10 @@ struct K2Const {
 };
 constexpr int K2_MAX_HEADS = 64;
 struct K2Heads { unsigned base[K2_MAX_HEADS]; };   // value of every item counter before this launch
-#ifdef HINGE_ABLATE
-// Ablation builds: per-read time stamps (100 MHz s_memrealtime) of k_mask_annotate_q20, five per list item: read start, histogram
-// done, scan done, mask pass done, read done (tools/k2_trace.py).
+#ifdef HINGE_K2_TRACE
+// Trace builds (-DHINGE_ABLATE -DHINGE_K2_TRACE): per-read time stamps (100 MHz s_memrealtime) of k_mask_annotate_q20, five per
+// list item: read start, histogram done, scan done, mask pass done, read done (tools/k2_trace.py).  Not part of the plain ablation
+// build: the stamps change the kernel's register allocation and instruction counts.
 __device__ unsigned long long* g_k2_trace = nullptr;
 #define HINGE_K2_STAMP(k) do { if (k2tr && lane == 0) k2tr[5 * (size_t)item + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -982,6 +1006,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
     const int MIN_COV = *d_min_cov;
 #ifdef HINGE_ABLATE
     struct { int ablate; } P = {C->P.ablate};
+#endif
+#ifdef HINGE_K2_TRACE
     unsigned long long* const k2tr = g_k2_trace;
 #endif
     for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
@@ -991,14 +1017,16 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
     for (; (unsigned)item < (unsigned)item_end; item = dyn ? drawn() : item_end) {   // `continue` leaves a read
         if (dyn && lane == 0) grab = atomicAdd(head_ptr, 1u);   // the item after this one
         HINGE_K2_STAMP(0);
-        const int i = read_list[item];
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        const int rl = rlen[i];
-        const int K0 = nbins0[i];                     // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
-        const long long cov_at = cov_out ? cov_off[i - cov_base] : 0;   // (fetched with the row bounds, used after phase 1)
+        const int i = load_at32(read_list, (unsigned)item << 2);
+        struct Bounds { int64_t s, e; };
+        const Bounds rb = load_at32(reinterpret_cast<const Bounds*>(row_ptr), (unsigned)i << 3);   // row_ptr[i], row_ptr[i + 1]
+        const int64_t s = rb.s, e = rb.e;
+        const int rl = load_at32(rlen, (unsigned)i << 2);
+        const int K0 = load_at32(nbins0, (unsigned)i << 2);   // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
+        const long long cov_at = cov_out ? load_at32(cov_off, (unsigned)(i - cov_base) << 3) : 0;   // (fetched with the row bounds, used after phase 1)
         const int64_t n64 = e - s;
         const int qe = rl / 20;                       // last bin an event can fall in
-        if (n64 >= 65536 || K0 < 0 || qe >= qcap) {   // 16-bit counts would overflow / malformed / too long: general kernel
+        if (n64 >= 65536 || K0 < 0 || qe >= qcap || rl >= 600000) {   // 16-bit counts would overflow / malformed / too long: general kernel
             if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
             continue;
         }
@@ -1046,17 +1074,11 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
                     const unsigned de = (unsigned)qe - qd;
                     int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;
                     int* pe = de < 2u ? hot_e + de * WAVE : Pq + qd;
-#ifdef HINGE_ABLATE
-                    if (P.ablate == 10) { asm volatile("" ::"v"(pb), "v"(pe)); continue; }   // 10 = loads and bin arithmetic, no LDS atomics
-#endif
                     atomicAdd(pb, 1);
                     atomicAdd(pe, 0x10000);
                 }
             }
         }
-#ifdef HINGE_ABLATE
-        if (P.ablate == 10) continue;
-#endif
         HINGE_K2_STAMP(1);
         HINGE_ABLATE_POINT(9)    // (ablation builds: 9 = stop after the histogram, before the hot-word fold)
         {   // fold the lane-private hot words into their bins (and zero them for the next read)
@@ -1120,8 +1142,9 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
                 asm("s_min_u32 %0, %1, 1" : "=s"(f0) : "s"((unsigned)bal) : "scc");
                 asm("s_min_u32 %0, %1, 1" : "=s"(f1) : "s"((unsigned)(bal >> 32)) : "scc");
                 const unsigned f = f0 | (f1 << 1);
-                const int w = base >> 7;
-                flag_words |= w < 63 ? (unsigned long long)f << w : 1ull << 63;   // (bins beyond word 62: looked at unconditionally)
+                // (w = base / 128 is even; beyond word 63 the shift wraps and flags a low word for nothing, which is only a look too
+                // many: the candidate pass looks at every word from the 64th on anyway)
+                flag_words |= (unsigned long long)f << ((base >> 7) & 63);
             }
             v.z += v.y; v.w += v.z;
             const int incl = wave_incl_scan(v.w);
@@ -1144,7 +1167,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
         }
         if (cov_dst && lane == 0) {
             if (K0 > 0) cov_dst[0] = 0;                      // cov0[0]: nothing is consumed before position 0
-            cov_nbins[i - cov_base] = K0;
+            store_at32(cov_nbins, in_vgpr((unsigned)(i - cov_base)) << 2, K0);
         }
         {   // copies of the totals behind the scanned bins (the scan ran over [0, round-up-to-4 of Qn))
             const int Qs = (Qn + 3) & ~3;
@@ -1153,24 +1176,47 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __re
         HINGE_K2_STAMP(2);
         auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
         auto covc = [&](int k) { return (Pq[2 * k - 1 - SH] & 0xffff) - (int)((unsigned)Pq[2 * k - 1 + SH] >> 16); };
-        // ---- coverage mask on the cutoff profile ------------------------------------------------------
-        RunState run{0, 0ull, 0, 0};
-        const int* pcb = Pq + 2 * lane - 1 - SH;   // covc(base + lane) = begins below pcb[2 base] - ends below pce[2 base]
-        const int* pce = Pq + 2 * lane - 1 + SH;
+        // ---- coverage mask on the cutoff profile: the first longest run of bins above MIN_COV (filter.cpp:696-728) ------------
+        // On the VECTOR side.  run_feed (the general kernel's form) walks the set bits of a ballot on the scalar unit, ~55 scalar
+        // instructions for a word that is not all ones - and a read's first and last word never are.  The scalar unit is what
+        // bounds this kernel (one per CU: 455 scalar against 290 vector instructions per read, 75 % against 47 % busy), so here a
+        // lane owns bin j = base + lane:
+        //   z(j)  = largest non-positive bin <= j, 0 if none      (inclusive max-scan of `positive ? 0 : j`, carried across words)
+        //   bin j closes a run iff it is valid, non-positive and bin j - 1 is positive; the run has j - z(j - 1) - 2 bins
+        //   key   = bins << 14 | (16383 - j): the largest key is the longest run and, among equals, the first (j < 16384: reads
+        //           beyond 600 kb are handed back above); every lane keeps the largest key it saw, ONE wave maximum at the end.
+        // A run still open at the last valid bin is not counted, as in the reference's loop.
+        int key_best = 0;
+        {
+            int zc = 0, pc = 0;                        // carries: z and positivity of the previous word's last bin
+            const int* pcb = Pq + 2 * lane - 1 - SH;   // covc(base + lane) = begins below pcb[2 base] - ends below pce[2 base]
+            const int* pce = Pq + 2 * lane - 1 + SH;
 #ifdef HINGE_ABLATE
-        if (P.ablate != 7 && P.ablate != 8)
+            if (P.ablate != 7 && P.ablate != 8)
 #endif
-        for (int base = 0; base < KC; base += WAVE, pcb += 2 * WAVE, pce += 2 * WAVE) {
-            const unsigned long long M = ballot_of((*pcb & 0xffff) - (int)((unsigned)*pce >> 16) > MIN_COV);
-            const int left = KC - base;
-            if (left >= 64) {
+            for (int base = 0; base < KC; base += WAVE, pcb += 2 * WAVE, pce += 2 * WAVE) {
+                const int j = base + lane;
+                const bool valid = j < KC;
+                // (loaded by every lane: past the last bin that is the pad, the next slot or nothing - LDS reads do not fault)
+                const int cvj = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16);
+                const bool p = valid && cvj > MIN_COV;
+                const unsigned long long M = ballot_of(p);
                 // 64 bins above MIN_COV (the interior of nearly every read) open or continue a run and close none
-                if (M == ~0ull) { run.prev_pos = 1ull; continue; }
-                run_feed(run, base, M, ~0ull, reso);
-            } else {
-                const unsigned long long V = (1ull << left) - 1ull;
-                run_feed(run, base, M & V, V, reso);
+                if (M == ~0ull) { pc = 1; continue; }
+                const int z = max(wave_incl_max_scan(valid && !p ? j : 0), zc);
+                const int zprev = shfl_up1(z, zc);
+                const int pprev = shfl_up1(p ? 1 : 0, pc);
+                const int bins = j - zprev - 2;
+                const int key = (bins << 14) | (16383 - j);
+                key_best = max(key_best, (valid && !p && pprev != 0 && bins > 0) ? key : 0);
+                zc = wave_last(z);
+                pc = (int)(M >> 63);
             }
+        }
+        RunState run{0, 0ull, 0, 0};
+        {
+            const int kmax = wave_max(key_best);
+            if (kmax > 0) { run.best_len = reso * (kmax >> 14); run.best_j = 16383 - (kmax & 16383); }
         }
         // the candidate list goes to the (now free) hot words when it is sure to fit - at most K0 - 2 candidates - so that the
         // gate sums need not be taken before it is known that the read keeps an annotation; else it overwrites the profile in place

@@ -1167,8 +1167,8 @@ int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms) {
 
 #include "align_capi.inc"
 
-#ifdef HINGE_ABLATE
-// Ablation builds only (tools/k2_trace.py): a device buffer of 5 * n_items time stamps for k_mask_annotate_q20.
+#ifdef HINGE_K2_TRACE
+// Trace builds only (tools/k2_trace.py): a device buffer of 5 * n_items time stamps for k_mask_annotate_q20.
 extern "C" int hinge_debug_k2_trace_begin(long long n_items) {
     unsigned long long* p = nullptr;
     if (hipMalloc(&p, (size_t)n_items * 5 * 8) != hipSuccess) return -1;
