@@ -944,8 +944,10 @@ __device__ unsigned long long* g_k2_trace = nullptr;
 #define HINGE_K2_STAMP(k) do { } while (0)
 #endif
 
+// (eight wavefronts per SIMD: with the scalar and the vector unit both ~60 % busy the kernel is latency-sensitive again - 84.7 us at
+// six (77 VGPRs, the compiler's choice), 79.7 at seven, 78.3 at eight with a one-VGPR scratch spill and 52 SGPR spills)
 template <bool PACKED>
-__global__ __launch_bounds__(BLOCK) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off, int mulpath_thr /*min(MIN_RA, MAX_RA) when the
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off, int mulpath_thr /*min(MIN_RA, MAX_RA) when the
                                                              division-free annotation test applies, else -1*/,
                                                              int nhr /*NO_HINGE_REGION*/, int use_cov /*the coverage mask takes part in the mask*/,
                                                              const int* __restrict__ read_list, int n1, int n2, int n4,

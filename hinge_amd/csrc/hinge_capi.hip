@@ -128,8 +128,8 @@ struct ProfScope {
 };
 
 static_assert(HINGE_SPAN16_PAD == (LOADS_IN_FLIGHT / 2) * WAVE, "elements behind span16[n_ovl] a kernel may read (never uses)");
-static const int K2_SHORT_RLEN = 21000;   // 20-bp bins of a 21 kb read + hot words + pads = 1372 ints per wavefront, 21.4 KiB per workgroup: seven
-                                          // workgroups per CU, which is what the kernel's registers allow anyway (97.5 % of the bench part's reads)
+static const int K2_SHORT_RLEN = 19000;   // 20-bp bins of a 19 kb read + hot words + pads = 1268 ints per wavefront, 19.8 KiB per workgroup: eight
+                                          // workgroups per CU, the kernel's register budget (99 % of the bench part's reads need one slot)
 
 // words of LDS per wavefront slot of k_mask_annotate_q20: 20-bp bins of the longest "short" read + the hot words
 static int k2_slot_ints(const hinge_ctx* ctx) {

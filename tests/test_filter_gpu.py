@@ -293,8 +293,8 @@ def test_filter_long_reads_all_lds_classes(datasets, oracle_lib, tmp_path):
     """Reads of 4 kb .. 120 kb: one, two and four LDS slots per read, and reads too long for a workgroup's LDS."""
     from hinge_amd import capi, stages
     src, d = datasets("long_reads")
-    assert (d.rlen <= 21000).any() and ((d.rlen > 23000) & (d.rlen <= 46000)).any() and ((d.rlen > 50000) & (d.rlen <= 95000)).any()
-    slot = (21000 // 20 + 1 + 3) // 4 * 4 + 4 + 4 * 64 + 20 + 36     # bins + hot words + zero / total pads (cut_off 300)
+    assert (d.rlen <= 19000).any() and ((d.rlen > 21000) & (d.rlen <= 41000)).any() and ((d.rlen > 45000) & (d.rlen <= 85000)).any()
+    slot = (19000 // 20 + 1 + 3) // 4 * 4 + 4 + 4 * 64 + 20 + 36     # bins + hot words + zero / total pads (cut_off 300)
     n_too_long = int((d.rlen // 20 >= 4 * slot - 4 * 64 - 20 - 36).sum())   # 20-bp bins beyond a workgroup's four slots
     assert n_too_long > 0
     wd_o = clone_dataset(src, str(tmp_path / "oracle"))
