@@ -264,7 +264,10 @@ int main(int argc, char* argv[]) {
     for (size_t w0 = 0; w0 < las_list.size(); w0 += (size_t)n_ranks) {
         const size_t w1 = std::min(las_list.size(), w0 + (size_t)n_ranks);
         const size_t nw = w1 - w0;
-        std::vector<PartOut> outs(nw);
+        // (on the heap, and the LAST wave's is never freed: the process leaves through _exit() right after its text is written, and
+        // unmapping a part's columns, bins and .las first costs ~70 ms of a 0.4-s run)
+        std::vector<PartOut>* outs_heap = new std::vector<PartOut>(nw);
+        std::vector<PartOut>& outs = *outs_heap;
         auto on_ranks = [&](const std::function<void(size_t)>& f) {   // f(k) for the parts of the wave, rank k on its own thread
             if (nw == 1) { f(0); return; }
             std::vector<std::thread> th;
@@ -301,6 +304,7 @@ int main(int argc, char* argv[]) {
             if (rc) return rc;
             write_part(w0 + k, outs[k]);
         }
+        if (w1 < las_list.size() || getenv("HINGE_SLOW_EXIT")) delete outs_heap;
     }
     if (f_rep) fclose(f_rep);
     fclose(f_cov); fclose(f_hg); fclose(f_mask); fclose(f_cmask); fclose(f_covflag); fclose(f_selfflag);
