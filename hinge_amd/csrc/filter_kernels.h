@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // well-formed pile-up can have needs no reduction.
         const int KC = nbins_of<40>(n, rl + cut_off, reso);
 
-        // ---- inclusive prefixes of begins|ends, 4 consecutive bins per lane ---------------------------
+        // ---- inclusive prefixes of begins|ends, 8 consecutive bins per lane (512 per step: one step for reads of up to 10 kb) -----
         int carry = 0;
         int* __restrict__ const cov_dst = cov_out ? cov_out + cov_at : (int*)nullptr;
         // Which 64-bin words of the plain profile can hold an annotation at all: an annotation needs |cov0[k+1] - cov0[k]| above
@@ -1116,54 +1116,59 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // read's start and of ends at its end - which exceed the threshold in every read - lie outside them.
         const int jlo_b = max(nhr, 0) / reso;
         const int jhi_b = use_cov ? min(K0 - 3, rl - cut_off - nhr < 0 ? -1 : (rl - cut_off - nhr) / reso) : K0 - 3;
-        // as one unsigned range test per lane: 2 lane - (b_lo - hb) <= b_span, hb = first 40-bp bin of the step (no bin at all: b_lo
-        // beyond every lane)
-        const bool no_bins = jhi_b - jlo_b + 1 < 0;
-        const int b_lo = no_bins ? (1 << 30) : jlo_b - 1;
-        const unsigned b_span = no_bins ? 0u : (unsigned)(jhi_b - jlo_b + 1);
+        // as one unsigned range test per lane: a lane's four 40-bp bins are hb + 4 lane .. + 3 (hb = first 40-bp bin of the step),
+        // some of them inside [jlo_b, jhi_b] iff 4 lane - (b_lo - hb) <= b_span (no bin at all: b_lo beyond every lane)
+        const bool no_bins = jhi_b - jlo_b + 1 <= 0;
+        const int b_lo = no_bins ? (1 << 30) : jlo_b - 3;
+        const unsigned b_span = no_bins ? 0u : (unsigned)(jhi_b - jlo_b + 3);
 #ifdef HINGE_ABLATE
         if (P.ablate != 6 && P.ablate != 8)
 #endif
-        for (int base = 0; base < Qn; base += 4 * WAVE) {
-            const int t = base + 4 * lane;
+        for (int base = 0; base < Qn; base += 8 * WAVE) {
+            const int t = base + 8 * lane;
             int4 v = t < Qn ? *reinterpret_cast<const int4*>(Pq + t) : make_int4(0, 0, 0, 0);
+            int4 w = t + 4 < Qn ? *reinterpret_cast<const int4*>(Pq + t + 4) : make_int4(0, 0, 0, 0);
             v.y += v.x;                                        // (= begins|ends of this lane's first 40-bp bin, both halves below 65536)
+            w.y += w.x;
             if (mulpath_thr >= 0) {
-                // |begins - ends| > thr  <=>  (unsigned)(begins - ends + thr) > 2 thr (thr < 2^28, the host sees to it); this lane's two
-                // 40-bp bins are hb + 2 lane and the next one, inside the window bounds iff 2 lane in [jlo_b - 1 - hb, jhi_b - hb]
-                const int s23 = v.z + v.w;
-                const unsigned u0 = (unsigned)((v.y & 0xffff) - (int)((unsigned)v.y >> 16) + mulpath_thr);
-                const unsigned u1 = (unsigned)((s23 & 0xffff) - (int)((unsigned)s23 >> 16) + mulpath_thr);
+                // |begins - ends| > thr  <=>  (unsigned)(begins - ends + thr) > 2 thr (thr < 2^28, the host sees to it)
+                const int s1 = v.z + v.w, s3 = w.z + w.w;
+                auto excess = [&](int pair) { return (unsigned)((pair & 0xffff) - (int)((unsigned)pair >> 16) + mulpath_thr); };
+                const unsigned um = max(max(excess(v.y), excess(s1)), max(excess(w.y), excess(s3)));
                 const int hb = base >> 1;
                 // (two ballots and a scalar AND: the ballot of `a && b` re-materialises the predicate on the vector side)
-                const unsigned long long bal = ballot_of((unsigned)(2 * lane - (b_lo - hb)) <= b_span) & ballot_of(max(u0, u1) > 2u * (unsigned)mulpath_thr);
-                // one bit per 64-bin word, words w and w + 1 of this step.  Scalar minima written as such: from `x != 0` or from
-                // min(x, 1) the compiler makes a zero-extended boolean, selects it on the vector side and drags the whole flag word
-                // into vector registers (25 vector instructions per step, seen in the ISA)
+                const unsigned long long bal = ballot_of((unsigned)(4 * lane - (b_lo - hb)) <= b_span) & ballot_of(um > 2u * (unsigned)mulpath_thr);
+                // a step covers four 64-bin words (16 lanes each); flagged two at a time: lanes 0-31 -> words w, w + 1, lanes 32-63 ->
+                // w + 2, w + 3.  Scalar minima written as such: from `x != 0` or from min(x, 1) the compiler makes a zero-extended
+                // boolean, selects it on the vector side and drags the whole flag word into vector registers (25 vector instructions
+                // per step, seen in the ISA)
                 unsigned f0, f1;
                 asm("s_min_u32 %0, %1, 1" : "=s"(f0) : "s"((unsigned)bal) : "scc");
                 asm("s_min_u32 %0, %1, 1" : "=s"(f1) : "s"((unsigned)(bal >> 32)) : "scc");
-                const unsigned f = f0 | (f1 << 1);
-                // (w = base / 128 is even; beyond word 63 the shift wraps and flags a low word for nothing, which is only a look too
-                // many: the candidate pass looks at every word from the 64th on anyway)
+                const unsigned f = f0 * 3u + f1 * 12u;
+                // (w = base / 128 is a multiple of 4; beyond word 63 the shift wraps and flags low words for nothing, which is only
+                // a look too many: the candidate pass looks at every word from the 64th on anyway)
                 flag_words |= (unsigned long long)f << ((base >> 7) & 63);
             }
             v.z += v.y; v.w += v.z;
-            const int incl = wave_incl_scan(v.w);
-            const int excl = incl - v.w + carry;
+            w.x += v.w; w.y += v.w; w.z += w.y; w.w += w.z;
+            const int incl = wave_incl_scan(w.w);
+            const int excl = incl - w.w + carry;
             v.x += excl; v.y += excl; v.z += excl; v.w += excl;
+            w.x += excl; w.y += excl; w.z += excl; w.w += excl;
             if (t < Qn) *reinterpret_cast<int4*>(Pq + t) = v;
+            if (t + 4 < Qn) *reinterpret_cast<int4*>(Pq + t + 4) = w;
             if (cov_dst) {
                 // the .coverage.txt bins straight from the registers of the scan: cov0[k] = PB[2k-1] - PE[2k-1], and this lane holds
-                // the prefixes of bins t .. t+3, i.e. 2k-1 = t+1 and t+3 (k = t/2 + 1, t/2 + 2).  Stored here - not with the other
-                // outputs at the end of the read - they also have the rest of the read's work to drain: stores count in vmcnt like
-                // loads on this architecture, so the next read's first wait for its spans waits for every store issued before it.
+                // the prefixes of bins t .. t+7, i.e. 2k-1 = t+1, t+3, t+5, t+7 (k = t/2 + 1 .. t/2 + 4): one 16-byte store (4-byte
+                // aligned; a read's area has room for the up to three values it writes past the read's last bin).  Stored here - not
+                // with the other outputs at the end of the read - they also have the rest of the read's work to drain: stores count
+                // in vmcnt like loads on this architecture, so the next read's first wait for its spans waits for every store issued
+                // before it.
                 const int k1 = (t >> 1) + 1;
-                const int c1 = (v.y & 0xffff) - (int)((unsigned)v.y >> 16), c2 = (v.w & 0xffff) - (int)((unsigned)v.w >> 16);
-                // both bins in one 8-byte store (4-byte aligned: k1 is odd); the read's last bin alone when K0 is even
-                struct __attribute__((packed, aligned(4))) Bins2 { int a, b; };
-                if (k1 + 1 < K0) *reinterpret_cast<Bins2*>(cov_dst + k1) = Bins2{c1, c2};
-                else if (k1 < K0) cov_dst[k1] = c1;
+                auto cv = [&](int pre) { return (pre & 0xffff) - (int)((unsigned)pre >> 16); };
+                struct __attribute__((packed, aligned(4))) Bins4 { int a, b, c, d; };
+                if (k1 < K0) *reinterpret_cast<Bins4*>(cov_dst + k1) = Bins4{cv(v.y), cv(v.w), cv(w.y), cv(w.w)};
             }
             carry += wave_last(incl);
         }

@@ -714,7 +714,7 @@ static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
     if (memcmp(key, ctx->cov_key, sizeof(key)) != 0 || ctx->h_cov_off.size() != (size_t)nr + 1) {
         ctx->h_cov_off.assign((size_t)nr + 1, 0);
         for (int k = 0; k < nr; k++)
-            ctx->h_cov_off[(size_t)k + 1] = ctx->h_cov_off[(size_t)k] + ((int64_t)std::max(ctx->h_rlen[(size_t)(ctx->r_begin + k)], 0) + std::max(p->cut_off, 0)) / p->reso + 3;
+            ctx->h_cov_off[(size_t)k + 1] = ctx->h_cov_off[(size_t)k] + ((int64_t)std::max(ctx->h_rlen[(size_t)(ctx->r_begin + k)], 0) + std::max(p->cut_off, 0)) / p->reso + 6;   // (the bins, + room for what k_mask_annotate_q20's 16-byte stores write past the last one)
         int rc;
         if ((rc = ensure(ctx, ctx->cov_off_d, sizeof(int64_t) * ((size_t)nr + 1)))) return rc;
         if ((rc = ensure(ctx, ctx->cov_nb, sizeof(int) * (size_t)nr))) return rc;
