@@ -336,3 +336,104 @@ def test_baseline_configs_scaled_down(oracle_lib, tmp_path, name, genome, mlas):
     assert _hip_filter(wd_h, mlas) == 0
     _compare(wd_o, wd_h)
     assert sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.repeat.txt"))) > 0
+
+
+def _island_pileups(rng, n_reads):
+    """Pile-ups whose cutoff-300 coverage is a set of islands above MIN_COV of chosen lengths and positions: the shapes the
+    longest-run search has to get right (equal runs, runs across the 64-bin word boundaries, at the read's ends, none, one bin)."""
+    rlen, rows = [], []
+    for r in range(n_reads):
+        kind = r % 8
+        if kind == 0:      # the cutoff profile has exactly 64 / 65 / 128 / 129 bins
+            rl = int(rng.choice([2219, 2220, 2259, 2260, 4779, 4780, 4819, 4820]))
+        else:
+            rl = int(rng.integers(2600, 16000))
+        isl = []
+        if kind == 1:      # two or three runs of exactly the same length: the first must win
+            L = 40 * int(rng.integers(2, 12))
+            x = 40 * int(rng.integers(8, 20))
+            for _ in range(int(rng.integers(2, 4))):
+                if x + L + 700 < rl:
+                    isl.append((x, L))
+                x += L + 40 * int(rng.integers(16, 30))
+        elif kind == 2:    # runs that straddle bins 63 | 64, 127 | 128, 191 | 192
+            for edge in (64, 128, 192):
+                a = 40 * (edge - int(rng.integers(1, 6)))
+                L = 40 * int(rng.integers(2, 12))
+                if a + L + 700 < rl:
+                    isl.append((a, L))
+        elif kind == 3:    # a run that reaches the read's end, one that starts at 0
+            isl.append((0, 40 * int(rng.integers(3, 20))))
+            isl.append((max(rl - 40 * int(rng.integers(10, 30)), 1200), rl))
+        elif kind == 4:    # none at all
+            pass
+        elif kind == 5:    # many short ones, every few bins
+            x = 400
+            while x + 1200 < rl:
+                isl.append((x, 40 * int(rng.integers(1, 4))))
+                x += 40 * int(rng.integers(18, 40))
+        else:              # random
+            x = 40 * int(rng.integers(0, 30))
+            while x + 900 < rl:
+                L = 40 * int(rng.integers(1, 60))
+                isl.append((x, L))
+                x += L + 40 * int(rng.integers(16, 50))
+        ab, ae = [], []
+        for a, L in isl:
+            depth = int(rng.integers(7, 12))          # above MIN_COV = 5 (+ a few that are not: depth 4)
+            if rng.random() < 0.15:
+                depth = 4
+            for _ in range(depth):
+                ab.append(max(a - 300, 0))
+                ae.append(min(a + L + 300, rl))
+        # a thin background so that the profile has bins everywhere
+        for _ in range(3):
+            ab.append(0)
+            ae.append(rl)
+        rlen.append(rl)
+        rows.append((np.array(ab, np.int32), np.array(ae, np.int32)))
+    return np.array(rlen, np.int32), rows
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_coverage_mask_run_shapes(seed):
+    """The first longest run of bins above MIN_COV: the fast kernel (a DPP max-scan on the vector unit), the general kernel (a walk
+    over ballot bits on the scalar unit) and the specification-level model (tests/spec_model.py) on adversarial profiles."""
+    from hinge_amd import capi
+    from hinge_amd.config import default_filter_params
+    import spec_model
+    rng = np.random.default_rng(seed)
+    n = 240
+    rlen, rows = _island_pileups(rng, n)
+    row_ptr = np.zeros(n + 1, np.int64)
+    for i, (ab, _) in enumerate(rows):
+        row_ptr[i + 1] = row_ptr[i] + len(ab)
+    m = int(row_ptr[-1])
+    a_span = np.zeros((m, 2), np.int32)
+    for i, (ab, ae) in enumerate(rows):
+        a_span[row_ptr[i]:row_ptr[i + 1], 0] = ab
+        a_span[row_ptr[i]:row_ptr[i + 1], 1] = ae
+    b_span = a_span.copy()
+    b_flag = ((np.arange(m) % n).astype(np.uint32))          # some other read, forward strand (hinge calling is not run)
+    P = default_filter_params()
+    got = {}
+    for general in (0, 1):
+        ctx = capi.Context(0)
+        ctx.force_general_mask(general)
+        ctx.set_reads(rlen, None)
+        ctx.set_pileups(0, n - 1, row_ptr, a_span, b_span, b_flag)
+        ctx.set_min_cov(P.min_cov)
+        ctx.filter_stats(P)
+        ctx.filter_median(P, 0, n - 1, fetch=True)
+        min_cov = ctx.get_min_cov()
+        ctx.filter_mask_annotate(P)
+        assert ctx.fallback_reads() == 0
+        got[general] = (ctx.get_masks(), min_cov)
+        ctx.close()
+    (mask_q, cmask_q, _), mc = got[0]
+    (mask_g, cmask_g, _), mc_g = got[1]
+    assert mc == mc_g
+    assert np.array_equal(mask_q, mask_g) and np.array_equal(cmask_q, cmask_g)
+    for i, (ab, ae) in enumerate(rows):
+        want_mask, want_cmask = spec_model.coverage_mask(spec_model.coverage(ab, ae, P.cut_off), mc)
+        assert tuple(mask_q[i]) == want_mask and tuple(cmask_q[i]) == want_cmask, (i, i % 8, tuple(mask_q[i]), want_mask, tuple(cmask_q[i]), want_cmask)
