@@ -437,3 +437,76 @@ def test_coverage_mask_run_shapes(seed):
     for i, (ab, ae) in enumerate(rows):
         want_mask, want_cmask = spec_model.coverage_mask(spec_model.coverage(ab, ae, P.cut_off), mc)
         assert tuple(mask_q[i]) == want_mask and tuple(cmask_q[i]) == want_cmask, (i, i % 8, tuple(mask_q[i]), want_mask, tuple(cmask_q[i]), want_cmask)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_annotation_window_edges(seed):
+    """Coverage steps placed on the edges the candidate pass must get right: the first and last bin of the annotation window
+    (mask +- NO_HINGE_REGION, K0 - 3), the 64-bin word boundaries of the flag words, steps just below / above the threshold.
+    Fast kernel == general kernel == specification-level model (masks, merged annotations)."""
+    from hinge_amd import capi
+    from hinge_amd.config import default_filter_params
+    import spec_model
+    rng = np.random.default_rng(seed)
+    n = 200
+    rlen, rows = [], []
+    for r in range(n):
+        rl = int(rng.integers(3200, 15000))
+        base_depth = int(rng.integers(18, 40))
+        ab = [0] * base_depth
+        ae = [rl] * base_depth
+        spots = [820 + 40 * int(rng.integers(-3, 4)), 40 * 63, 40 * 64, 40 * 127, 40 * 128, 40 * 191, 40 * 192,
+                 rl - 800 + 40 * int(rng.integers(-3, 4)), 40 * (rl // 40 - 2), 40 * (rl // 40 - 3)]
+        spots += [40 * int(rng.integers(1, rl // 40)) for _ in range(4)]
+        for x in rng.choice(spots, size=int(rng.integers(1, 5)), replace=False):
+            x = int(x) + int(rng.choice([0, 0, 1, 39, -1]))
+            if not (0 < x < rl - 50):
+                continue
+            extra = int(rng.choice([8, 10, 11, 14, 20, 21, 30, 60]))      # around min / max_repeat_annotation and the coverage fraction
+            if rng.random() < 0.5:      # a step up: reads that begin at x
+                ab += [x] * extra
+                ae += [rl] * extra
+            else:                       # a step down: reads that end at x
+                ab += [0] * extra
+                ae += [x] * extra
+        rlen.append(rl)
+        rows.append((np.array(ab, np.int32), np.array(ae, np.int32)))
+    rlen = np.array(rlen, np.int32)
+    row_ptr = np.zeros(n + 1, np.int64)
+    for i, (ab, _) in enumerate(rows):
+        row_ptr[i + 1] = row_ptr[i] + len(ab)
+    m = int(row_ptr[-1])
+    a_span = np.zeros((m, 2), np.int32)
+    for i, (ab, ae) in enumerate(rows):
+        a_span[row_ptr[i]:row_ptr[i + 1], 0] = ab
+        a_span[row_ptr[i]:row_ptr[i + 1], 1] = ae
+    b_flag = ((np.arange(m) % n).astype(np.uint32))
+    P = default_filter_params()
+    PM = {"NHR": P.no_hinge_region, "CF": P.coverage_fraction, "MINRA": P.min_repeat_annotation, "MAXRA": P.max_repeat_annotation, "GAP": P.repeat_annotation_gap}
+    got = {}
+    for general in (0, 1):
+        ctx = capi.Context(0)
+        ctx.force_general_mask(general)
+        ctx.set_reads(rlen, None)
+        ctx.set_pileups(0, n - 1, row_ptr, a_span, a_span.copy(), b_flag)
+        ctx.set_min_cov(P.min_cov)
+        ctx.filter_stats(P)
+        ctx.filter_median(P, 0, n - 1, fetch=True)
+        mc = ctx.get_min_cov()
+        ctx.filter_mask_annotate(P)
+        off, pos, typ, _ = ctx.get_annotations()
+        got[general] = (ctx.get_masks()[0], off.copy(), pos.copy(), typ.copy(), mc)
+        ctx.close()
+    mask_q, off_q, pos_q, typ_q, mc = got[0]
+    mask_g, off_g, pos_g, typ_g, _ = got[1]
+    assert np.array_equal(mask_q, mask_g) and np.array_equal(off_q, off_g)
+    assert np.array_equal(pos_q[:off_q[-1]], pos_g[:off_g[-1]]) and np.array_equal(typ_q[:off_q[-1]], typ_g[:off_g[-1]])
+    n_anno = 0
+    for i, (ab, ae) in enumerate(rows):
+        want_mask, _ = spec_model.coverage_mask(spec_model.coverage(ab, ae, P.cut_off), mc)
+        assert tuple(mask_q[i]) == want_mask, (i, tuple(mask_q[i]), want_mask)
+        want = spec_model.annotate(spec_model.coverage(ab, ae, 0), want_mask, mc, PM)
+        have = list(zip(pos_q[off_q[i]:off_q[i + 1]].tolist(), typ_q[off_q[i]:off_q[i + 1]].tolist()))
+        assert have == want, (i, have, want)
+        n_anno += len(want)
+    assert n_anno > n // 2      # the steps do produce annotations
