@@ -742,8 +742,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         ctx->lds_attr_set = lds;
     }
     const int nr = ctx->r_end - ctx->r_begin + 1;
-    // one read per wavefront, no grid cap: the hardware dispatcher balances uneven pile-ups better than a
-    // grid-stride loop does (measured 137 -> 119 us at 87 k reads)
+    // the general kernel: one read per wavefront, no grid cap - the hardware dispatcher balances uneven pile-ups better than a
+    // grid-stride loop does (measured 137 -> 119 us at 87 k reads; the fast kernel below draws its reads instead)
     const int grid = std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
     // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
     // (it takes the bin count and the well-formedness of each pile-up from k_cov_stats<40> of this pass)
@@ -752,7 +752,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         // bins + hot words (the read classes of hinge_set_pileups are cut for this much) + the zero / total pads of this cut_off
         const int SH = p->cut_off / 20;
         const int slot = k2_slot_ints(ctx) + ((SH + 2 + 3) & ~3) + ((2 * SH + 4 + 3) & ~3);
-        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // ~17.5 KiB for 16 kb reads: eight workgroups (32 waves) per CU
+        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // 19.8 KiB for reads of up to 19 kb: eight workgroups (32 wavefronts) per CU
         ProfScope _ps(ctx, KID_MASK_ANNOTATE);
         const size_t lds_all = lds20;
         if (ctx->k2_occ_lds != (int)lds_all) {
