@@ -10,9 +10,11 @@ span copy + the two pile-up facts), processed back to back.  Every per-part devi
 coverage statistics -> median / MIN_COV -> coverage mask + repeat annotation (which also stores the `.coverage.txt` bins) ->
 hinge calling.  R parts rotate so that nothing a pass reads was left in the 256 MiB Infinity Cache by the previous pass over the
 same part (R x ~0.4 GB are streamed between two visits); within one pass the second sweep may hit what the first one brought in,
-exactly as it does in production.  With N > 1 every rank owns one DAZZ_DB block of every part (weak scaling) and the path's
-exchange steps run as RCCL collectives between the kernels, enqueued asynchronously so that a part's exchanges run under the next
-part's kernels (hinge_amd/dist.py, step_pipelined).
+exactly as it does in production.  With N > 1 every rank owns one DAZZ_DB block of every part (weak scaling; teams of two ranks
+share a 2-block data set, so half of every pile-up's B reads live on the team mate: hinge_amd/benchsets.py) and the path's
+exchange steps run as RCCL collectives between the kernels, batched over the parts: ONE all-reduce (coverage histograms) and
+ONE all-gather (masks) per step (hinge_amd/dist.py, PartBatch).  At every N the hinges of every part of every rank - count and
+a digest of the (read, position, type) rows - are asserted against the CPU oracle's (tests/golden/bench_expect.json).
 
 At N = 1 rank 0 also reports
   * "e2e": `hinge filter / maximal / layout` (the C++ executables over libhinge_hip, .las ingest and text output included) on the
@@ -56,6 +58,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2_ecoli160")
     ap.add_argument("--parts", type=int, default=4, help="distinct resident read sets a step passes over (>= 3 keeps the Infinity Cache cold)")
+    ap.add_argument("--gather-groups", type=int, default=1, help="all-gathers of the masks per step (1: all parts at once; 2: the first half's runs under the second half's kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     return ap.parse_args()
@@ -168,9 +171,9 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from hinge_amd import capi, synth
+    from hinge_amd import benchsets, capi, synth
     from hinge_amd.config import default_filter_params
-    from hinge_amd.dist import BlockTable, Exchange, HipBackend, ShardedFilter, step_pipelined
+    from hinge_amd.dist import resident_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -180,67 +183,57 @@ def main():
             raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not benchsets.supported_world(world):
+        raise SystemExit("bench.py: 1 GPU or an even number of GPUs (the ranks work in teams of two, hinge_amd/benchsets.py)")
+    # test rig for a 1-GPU box: HINGE_BENCH_ONE_DEVICE=1 puts every rank on device 0 and HINGE_BENCH_BACKEND=gloo moves the
+    # collectives through host memory (RCCL refuses two ranks on one device).  Results are asserted as usual; times mean nothing.
+    one_device = os.environ.get("HINGE_BENCH_ONE_DEVICE", "0") == "1"
+    pg_backend = os.environ.get("HINGE_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_pg = world > 1 or ("RANK" in os.environ and os.environ.get("HINGE_FORCE_COLLECTIVES", "0") == "1")
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev)
+        if pg_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(pg_backend)
+
+    def host_all_gather(vals):
+        if not use_pg:
+            return [list(vals)]
+        d_ = dev if pg_backend == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(vals), dtype=torch.int64, device=d_)
+        out = torch.empty(world * len(vals), dtype=torch.int64, device=d_)
+        dist.all_gather_into_tensor(out, t)
+        flat = out.cpu().tolist()
+        return [flat[k * len(vals):(k + 1) * len(vals)] for k in range(world)]
 
     P = default_filter_params()
     R = max(1, args.parts)
     base = synth.CONFIGS[args.workload]
-    jobs, ctxs, part_ovl, part_reads, part_bins, first_data = [], [], [], [], [], None
     t_gen = time.perf_counter()
+    first_data = None
+    parts = []
     for p in range(R):
-        # part p of rank r: its own seed (part 0 of rank 0 is the configuration's data set itself)
-        spec = dataclasses.replace(base, n_blocks=1, seed=base.seed + 1000 * rank + 17 * p)
+        spec, _ = benchsets.part_spec(base, world, rank, p)
         d = synth.generate(spec)
-        pile = synth.to_pileups(d)
-        if p == 0:
+        if p == 0 and world == 1:
             first_data = d
-        # block table over ranks (block sizes differ slightly through the seed): every block gets the same number of read ids
-        # (the largest block's; the extra ids are reads of length 0 without overlaps), so the per-read tables are exchanged by
-        # ONE in-place all-gather.  Only the id space is padded.
-        sizes = [d.n_reads]
-        if use_pg:
-            t = torch.tensor([d.n_reads], dtype=torch.int64, device=dev)
-            out = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(out, t)
-            sizes = [int(v) for v in out.cpu().tolist()]
-        S = max(sizes) + int(os.environ.get("HINGE_BENCH_PAD", "0"))   # HINGE_BENCH_PAD: exercise the padding with one rank
-        first = [k * S for k in range(world + 1)]
-        lo = first[rank]
-        hi = lo + d.n_reads          # real reads of this rank: [lo, hi); ids [hi, lo + S) are padding
-        n_total = first[-1]
-        rlen_all = np.zeros(n_total, np.int32)
-        if use_pg:
-            t = torch.zeros(n_total, dtype=torch.int32, device=dev)
-            t[lo:hi] = torch.from_numpy(d.rlen).to(dev)
-            dist.all_reduce(t)
-            rlen_all = t.cpu().numpy()
-        else:
-            rlen_all[lo:hi] = d.rlen
-        row_ptr = np.zeros(n_total + 1, np.int64)
-        row_ptr[lo:hi + 1] = pile.row_ptr
-        row_ptr[hi + 1:] = pile.row_ptr[-1]
-        b_flag = ((pile.b_flag & np.uint32(0x7FFFFFFF)) + np.uint32(lo)) | (pile.b_flag & np.uint32(0x80000000))
-        # what the ingest hands over besides the columns (hinge_amd/host/host_common.h LasPart::load does the same per record)
-        span16, max_pile, in_range = capi.pack_spans(pile.row_ptr, pile.a_span, d.rlen)
-        assert span16 is not None
-        tens = (torch.from_numpy(row_ptr).to(dev), torch.from_numpy(pile.a_span).to(dev), torch.from_numpy(pile.b_span).to(dev),
-                torch.from_numpy(b_flag.view(np.int32)).to(dev), torch.from_numpy(span16.view(np.int32)).to(dev))
-        ctx = capi.Context(local_rank)
-        last_a = lo + int(d.aread[-1])
-        backend = HipBackend(ctx, P, rlen_all, None, lo, lo + S - 1, tens[0], tens[1], tens[2], tens[3], span16=tens[4],
-                             facts=(max_pile, in_range), last_a=last_a, coverage_out=True)
-        job = ShardedFilter(backend, Exchange(BlockTable(first), dev), mode="merged")
-        jobs.append(job); ctxs.append(ctx)
-        part_ovl.append(int(pile.n_ovl)); part_reads.append(int(d.n_reads))
-        part_bins.append(int(np.sum(d.rlen.astype(np.int64) // P.reso + 2)))
-        del pile, d
+        parts.append(benchsets.rank_part(base, world, rank, p, data=d))
+        del d
     t_gen = time.perf_counter() - t_gen
+    # every block gets the same number of read ids (the largest block's over all ranks and parts; the ids behind a block's
+    # reads are reads of length 0 without overlaps), so the mask tables are exchanged by in-place all-gathers
+    batch, ctxs = resident_batch(parts, P, dev, gather_groups=args.gather_groups, pad=int(os.environ.get("HINGE_BENCH_PAD", "0")))
+    S = batch.S
+    part_ovl = [rp.n_ovl for rp in parts]
+    part_reads = [rp.n_reads for rp in parts]
+    part_records = [rp.n_records for rp in parts]
+    part_bins = [int(np.sum(rp.rlen.astype(np.int64) // P.reso + 2)) for rp in parts]
+    del parts
     n_ovl = sum(part_ovl)
 
     def sync():
@@ -248,25 +241,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
-        # the parts of this rank, software-pipelined: a part's exchanges run under the next part's kernels (one rank without
-        # collectives: simply part after part)
-        step_pipelined(jobs)
+    one_step = batch.step      # all parts of this rank, exchanges batched (hinge_amd/dist.py PartBatch)
 
-    # ---- warmup (the synchronous variants also size the library's annotation / exact-path buffers) ------------
-    for job, ctx in zip(jobs, ctxs):
+    # ---- warmup: the synchronous entry points size the library's annotation / exact-path buffers, then whole steps until no
+    # rank reports a full buffer ---------------------------------------------------------------------------------------
+    for p, ctx in enumerate(ctxs):
+        lo = batch.id_base(p)
         ctx.filter_stats(P)
-        if use_pg:
-            job.x.all_gather_rows(job.mean_cov)
-        ctx.filter_median(P, 0, job.x.blocks.n_reads - 1, fetch=True)
+        ctx.filter_median(P, lo, lo + S - 1, fetch=True)
         ctx.filter_mask_annotate(P)
-        if use_pg:
-            job.x.all_gather_rows(job.mask)
         ctx.filter_hinges(P)
+    batch.settle()
     for _ in range(args.warmup):
         one_step()
-    for ctx in ctxs:
-        ctx.check()
+    batch.status()
 
     # ---- untimed breakdown pass: events around EVERY kernel (they cost stream time, so the timed region below brackets
     # only the kernel it prices) --------------------------------------------------------------------------------------
@@ -296,26 +284,41 @@ def main():
         one_step()
     sync()
     elapsed = time.perf_counter() - t0
+    batch.status()
     prof_ms, prof_cnt = 0.0, 0
     for ctx in ctxs:
-        ctx.check()
         ms, cnt = ctx.profile_report()[dominant]
         prof_ms += ms; prof_cnt += cnt
         ctx.profile_enable(0)
         ctx.profile_select(None)
-    # exchange 3, outside the timed region: (read, pos, type) rows of every part
-    hinges_per_part, work_reads, exact_annos = [], 0, 0
-    for job, ctx in zip(jobs, ctxs):
-        rows = job.step(fetch_hinges=True)
-        hinges_per_part.append(int(rows.shape[0]))
-        c = ctx.counters()
-        work_reads += int(c[0]); exact_annos += int(c[1])
+
+    # ---- results, outside the timed region: exchange 3 (the (read, pos, type) rows of every part from every rank, on every
+    # rank) and the per-rank counters --------------------------------------------------------------------------------
+    lists = [t.cpu().numpy() for t in batch.hinge_lists()]
+    work_reads = sum(int(ctx.counters()[0]) for ctx in ctxs)
+    exact_annos = sum(int(ctx.counters()[1]) for ctx in ctxs)
+    table_sums = batch.table_checksums()                    # every rank must hold the same mask tables after exchange 2
+    all_sums = host_all_gather(table_sums)
+    got = []                                                # [part][rank] -> {"hinges", "digest"}
+    for p in range(R):
+        rows = lists[p]
+        per_rank = []
+        for r in range(world):
+            lo = batch.id_base(p, r)
+            sel = (rows[:, 0] >= lo) & (rows[:, 0] < lo + S)
+            loc = rows[sel].astype(np.int64)
+            loc[:, 0] -= lo
+            per_rank.append({"hinges": int(len(loc)), "digest": benchsets.digest(loc)})
+        assert sum(e["hinges"] for e in per_rank) == len(rows)
+        got.append(per_rank)
+    sizes = host_all_gather(part_reads + part_records)      # [rank] -> reads of every part, then records of every part
 
     if use_pg:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        d_ = dev if pg_backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=d_)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        t = torch.tensor([n_ovl], dtype=torch.int64, device=dev)
+        t = torch.tensor([n_ovl], dtype=torch.int64, device=d_)
         dist.all_reduce(t)
         total_ovl = int(t.item())
     else:
@@ -328,10 +331,13 @@ def main():
         avg_ms = prof_ms / max(prof_cnt, 1)              # mean launch time over the launches of all R parts
         n_reads = sum(part_reads)
         if kname not in KERNEL_BYTES_PER_OVERLAP:
-            alg_bytes = achieved = None                   # sparse kernel: touches only the work-list reads
+            alg_bytes = achieved = phys_bytes = None      # sparse kernel: touches only the work-list reads
         else:
             alg_bytes = (KERNEL_BYTES_PER_OVERLAP[kname] * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads) / R   # mean per launch
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            # what the kernel has to move: the 16|16 span copy (4 B per overlap, packed by the ingest), the per-read tables and,
+            # for the mask / annotate kernel, the coverage bins it stores
+            phys_bytes = (4 * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads + (4 * sum(part_bins) if kname == "k_mask_annotate" else 0)) / R
         traffic, traffic_src = pmc_traffic(kname)
         resident = sum(part_ovl) * (8 + 8 + 4 + 4) + sum(part_bins) * 4
         roofline = {
@@ -346,6 +352,13 @@ def main():
             "avg_launch_ms": avg_ms,
             "launches_timed": prof_cnt,
             "algorithmic_bytes_per_launch": alg_bytes,
+            "physical_bytes_per_launch": phys_bytes,
+            "achieved_physical": (phys_bytes / (avg_ms * 1e-3) / 1e9) if phys_bytes else None,
+            "frac_physical": (phys_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if phys_bytes else None,
+            "waste_ratio": (traffic / phys_bytes) if (traffic and phys_bytes) else None,
+            "physical_note": "`frac` credits SURVEY 8(d)'s 8 B per overlap (the int32 span pair); the kernel reads the ingest's 16|16 copy (4 B per "
+                             "overlap) and, unlike 8(d)'s accounting, writes the coverage bins: physical = 4 B x overlaps + per-read tables + bins; "
+                             "waste_ratio = counter traffic / physical",
             "coverage_bins_bytes_per_launch": 4 * sum(part_bins) / R if kname == "k_mask_annotate" else None,
             "coverage_bins_note": "k_mask_annotate also stores the cutoff-0 coverage bins (.coverage.txt payload, ~4 B x (rlen/40 + 2) per read); "
                                   "they are NOT counted in `achieved`",
@@ -356,25 +369,36 @@ def main():
                            "pass read %.0f MB (16|16 span copy) each and K2 writes %.0f MB of bins; %.2f GB pass through between two visits of the same part "
                            "(Infinity Cache: 256 MiB)" % (R, resident / 1e9, 4 * n_ovl / R / 1e6, 4 * sum(part_bins) / R / 1e6, (R - 1) * (2 * 4 * n_ovl / R + 4 * sum(part_bins) / R) / 1e9),
             "path_bytes_per_overlap": PATH_BYTES_PER_OVERLAP,
-            "path_achieved_GBs": PATH_BYTES_PER_OVERLAP * n_ovl / (ms_per_step * 1e-3) / 1e9,
+            "path_credit_GBs": PATH_BYTES_PER_OVERLAP * n_ovl / (ms_per_step * 1e-3) / 1e9,
+            "path_credit_note": "SURVEY 8(d)'s 40 B per overlap x overlaps / step time: a figure of merit for the whole path, NOT achieved bandwidth "
+                                "(the design reads ~16 B per overlap)",
         }
-        # ---- results are checked, not just printed -----------------------------------------------------------
-        expect_path = os.path.join(ROOT, "tests", "golden", "bench_expect.json")
-        expect = json.load(open(expect_path)).get(args.workload, {}) if os.path.exists(expect_path) else {}
-        checks = {}
-        if world == 1:
-            want = [expect.get(str(base.seed + 17 * p)) for p in range(R)]
-            checks["hinges_expected_per_part"] = want
-            checks["hinges_match_committed_oracle_counts"] = all(w is None or w == h for w, h in zip(want, hinges_per_part)) and any(w is not None for w in want)
-            assert all(w is None or w == h for w, h in zip(want, hinges_per_part)), "hinge counts %s differ from the oracle's %s" % (hinges_per_part, want)
+        # ---- results are checked, not just printed: at EVERY N, every part of every rank against the CPU oracle's hinge count
+        # and row digest (tests/golden/bench_expect.json, tools/make_bench_expect.py) ----------------------------------
+        expect_path = os.environ.get("HINGE_BENCH_EXPECT") or os.path.join(ROOT, "tests", "golden", "bench_expect.json")
+        expect = json.load(open(expect_path)).get(args.workload, {}).get("worlds", {}).get(str(world), {}) if os.path.exists(expect_path) else {}
+        checks = {"hinges_per_part_and_rank": [[e["hinges"] for e in pr] for pr in got], "parts_checked": 0,
+                  "mask_tables_identical_on_all_ranks": all(s_ == all_sums[0] for s_ in all_sums)}
+        assert checks["mask_tables_identical_on_all_ranks"], "exchange 2 left different mask tables on different ranks: %s" % (all_sums,)
+        for p in range(R):
+            want = expect.get(str(p))
+            if want is None:
+                continue
+            have_sizes = ([sizes[r][p] for r in range(world)], [sizes[r][R + p] for r in range(world)])
+            assert (want["reads"], want["records"]) == have_sizes, "part %d: the generated read sets %s are not the ones the expectations were made for %s" % (p, have_sizes, (want["reads"], want["records"]))
+            assert want["ranks"] == got[p], "part %d: hinges (count, digest) per rank %s differ from the CPU oracle's %s" % (p, got[p], want["ranks"])
+            checks["parts_checked"] += 1
+        checks["hinges_and_digests_match_cpu_oracle"] = checks["parts_checked"] > 0
+        assert checks["parts_checked"] > 0 or R > 4 or args.workload != "cfg2_ecoli160", "no committed expectation for N = %d" % world
         e2e = cpu = None
         if world == 1 and not args.no_e2e:
             e2e, cpu, oracle_hinges = end_to_end(first_data, args.workload)
-            checks["hinges_part0_vs_live_oracle_run"] = [hinges_per_part[0], oracle_hinges]
-            assert hinges_per_part[0] == oracle_hinges, "resident pass found %d hinges on part 0, the oracle's .hinges.txt has %d" % (hinges_per_part[0], oracle_hinges)
+            checks["hinges_part0_vs_live_oracle_run"] = [got[0][0]["hinges"], oracle_hinges]
+            assert got[0][0]["hinges"] == oracle_hinges, "resident pass found %d hinges on part 0, the oracle's .hinges.txt has %d" % (got[0][0]["hinges"], oracle_hinges)
             assert e2e["byte_identical"], "executables differ from the oracle: %s" % e2e["files_differing"]
             if args.no_cpu_baseline:
                 cpu = None
+        collectives = batch.collectives
         out = {
             "metric": "overlaps/sec through filter+hinge-detect, E. coli 160x",
             "value": value,
@@ -389,16 +413,21 @@ def main():
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: synthetic restatement of E. coli P6-C4 160x (G=4.6 Mb, lognormal reads mean 8.5 kb, 7 x 5 kb repeat copies); "
-                            "a step = one whole filter + hinge-detect pass over each of %d distinct such read sets per GPU (seeds %s), all resident in HBM"
-                            % (args.workload, R, [base.seed + 17 * p for p in range(R)]),
+                "workload": ("%s: synthetic restatement of E. coli P6-C4 160x (G=4.6 Mb, lognormal reads mean 8.5 kb, 7 x 5 kb repeat copies); "
+                             "a step = one whole filter + hinge-detect pass over each of %d distinct such read sets per GPU, all resident in HBM"
+                             % (args.workload, R)) +
+                            ("" if world == 1 else "; N > 1: teams of two ranks share a 2-block data set of twice the genome (same reads and overlaps per GPU; "
+                                                   "half of every pile-up's B reads are on the team mate: hinge_amd/benchsets.py)"),
                 "parts_per_step": R,
                 "reads_per_gpu": n_reads,
                 "overlaps_per_gpu": int(n_ovl),
                 "total_overlaps": int(total_ovl),
-                "parallelism": "shard-by-block x%d, merged-las semantics; per part one 16 KiB all-reduce (coverage histogram) + one all-gather (masks, 8 B per read)" % world,
+                "parallelism": "shard-by-block x%d, merged-las semantics; per STEP %s" % (
+                    world, ("one all-reduce (the %d coverage histograms, %d KiB) + %d all-gather(s) (masks, 8 B per read)"
+                            % (R, R * 16, len(batch.groups))) if collectives else "no collective (one rank)"),
+                "collectives_per_step": (1 + len(batch.groups)) if collectives else 0,
+                "process_group": (pg_backend + (" (test rig: all ranks on one device)" if one_device else "")) if use_pg else None,
                 "kernels_in_step": "k_cov_stats, k_median_hist, k_mask_annotate (+ coverage bins), k_hinge_count, k_hinge_call per part; none outside",
-                "hinges_found_per_part": hinges_per_part,
                 "reads_in_hinge_pass": work_reads,
                 "annotations_on_exact_path": exact_annos,
                 "generate_s": t_gen,

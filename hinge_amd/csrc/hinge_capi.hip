@@ -288,6 +288,9 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     ctx->max_rlen = 0;
     for (int i = 0; i < n_reads; i++) ctx->max_rlen = std::max(ctx->max_rlen, rlen[i]);
     ctx->h_rlen.assign(rlen, rlen + n_reads);
+    // the coverage-output layout (slot offsets, buffer size) was made from the OLD read lengths: forget it
+    ctx->cov_key[0] = ctx->cov_key[1] = ctx->cov_key[2] = ctx->cov_key[3] = -1;
+    ctx->cov_valid = false;
     size_t n = (size_t)n_reads;
     if ((rc = ensure(ctx, ctx->mask_own, sizeof(int2) * n))) return rc;
     if ((rc = ensure(ctx, ctx->mean_own, sizeof(int) * n))) return rc;
@@ -771,6 +774,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         else for (int h = std::min(gp, K2_MAX_HEADS); h >= 1; h--) if (gp % h == 0) { n_heads = h; break; }
         const int g = std::max(1, n4 + (n2 + 1) / 2 + gp);
         K2Heads bases;
+        unsigned next_base[K2_MAX_HEADS];   // the host mirror of the device counters moves on only once the launch is known to be queued
         {
             if (!ctx->k2_heads.p) {
                 int rc = ensure(ctx, ctx->k2_heads, sizeof(unsigned) * 32 * K2_MAX_HEADS);
@@ -779,12 +783,12 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
             }
             const int gp_run = g - n4 - (n2 + 1) / 2;   // (g >= 1: an empty part still launches one workgroup)
             for (int h = 0; h < K2_MAX_HEADS; h++) {
-                bases.base[h] = ctx->k2_head_base[h];
+                bases.base[h] = next_base[h] = ctx->k2_head_base[h];
                 if (h >= n_heads) continue;
                 // one draw per wavefront of the head's workgroups + one per item of the head
                 const unsigned wgs_h = (unsigned)(gp_run / n_heads + (h < gp_run % n_heads));
                 const unsigned items_h = (unsigned)(n1 / n_heads + (h < n1 % n_heads));
-                ctx->k2_head_base[h] += wgs_h * WAVES_PER_BLOCK + items_h;
+                next_base[h] += wgs_h * WAVES_PER_BLOCK + items_h;
             }
         }
         {   // the kernel's constants (parameters, output pointers): a 200-byte block in device memory, uploaded when it changes
@@ -818,6 +822,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
                                (const int*)&sc(ctx)->min_cov, slot, cov_out, (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin,
                                (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, (unsigned*)ctx->k2_heads.p, n_heads, bases);
         CK(hipGetLastError());
+        for (int h = 0; h < K2_MAX_HEADS; h++) ctx->k2_head_base[h] = next_base[h];
         _ps.stop();
         // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is
         // skipped when the part's facts rule all three out

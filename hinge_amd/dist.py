@@ -54,6 +54,47 @@ class BlockTable:
         return max(self.size(k) for k in range(self.n_blocks))
 
 
+def _needs_host_staging(device: torch.device, group=None) -> bool:
+    """gloo moves host memory: with device tensors (several test processes sharing ONE GPU, where RCCL refuses to form a
+    communicator) every collective goes through a host copy.  Never the case on the product path (backend "nccl" = RCCL)."""
+    return dist.is_initialized() and device.type == "cuda" and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t: torch.Tensor, group, staged: bool, async_op: bool = False):
+    if staged:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def _all_gather_in_place(table: torch.Tensor, lo: int, hi: int, group, staged: bool, async_op: bool = False):
+    """Every rank has filled rows [lo, hi) of `table` (equal chunks, rank r's at r * (hi - lo)); afterwards all rows are
+    everywhere: ONE all_gather_into_tensor on the table itself."""
+    if staged:
+        h = torch.empty(table.shape, dtype=table.dtype)
+        dist.all_gather_into_tensor(h, table[lo:hi].cpu(), group=group)
+        table.copy_(h)
+        return None
+    return dist.all_gather_into_tensor(table, table[lo:hi], group=group, async_op=async_op)
+
+
+def _host_all_gather(vals: Sequence[int], device: torch.device, group=None, force: bool = True) -> List[List[int]]:
+    """A few host integers per rank -> the same list of per-rank rows on every rank (a host round trip: set-up and status
+    only, never inside the per-step kernel chain)."""
+    vals = [int(v) for v in vals]
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return [vals]
+    world = dist.get_world_size(group)
+    dev = torch.device("cpu") if _needs_host_staging(device, group) else device
+    t = torch.tensor(vals, dtype=torch.int64, device=dev)
+    out = torch.empty(world * len(vals), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, t, group=group)
+    flat = out.cpu().tolist()
+    return [[int(x) for x in flat[k * len(vals):(k + 1) * len(vals)]] for k in range(world)]
+
+
 class Exchange:
     """The collectives of the path on equal-sized padded shards (one block per rank)."""
 
@@ -67,6 +108,7 @@ class Exchange:
         self.S = blocks.max_size
         # HINGE_FORCE_COLLECTIVES=1 runs the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
         self.force = dist.is_initialized() and os.environ.get("HINGE_FORCE_COLLECTIVES", "0") == "1"
+        self.staged = _needs_host_staging(device, group)
         self._buffers = {}
 
     @property
@@ -84,8 +126,8 @@ class Exchange:
         lo, hi = self.my_range
         if all(self.blocks.size(k) == self.S for k in range(self.world)):
             # in place: rank r's rows sit at r * S
-            return dist.all_gather_into_tensor(table, table[lo:hi], group=self.group, async_op=async_op) if async_op else \
-                dist.all_gather_into_tensor(table, table[lo:hi], group=self.group)
+            w = _all_gather_in_place(table, lo, hi, self.group, self.staged, async_op)
+            return w if async_op else None
         key = (table.dtype, tuple(table.shape[1:]), table.device)
         buf = self._buffers.get(key)
         if buf is None:
@@ -98,7 +140,12 @@ class Exchange:
             self._buffers[key] = buf
         send, recv, src, dst = buf
         send[: hi - lo].copy_(table[lo:hi])
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        if self.staged:
+            h = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(h, send.cpu(), group=self.group)
+            recv.copy_(h)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
         if src.numel():
             table.index_copy_(0, dst, recv.index_select(0, src))
         return None
@@ -106,7 +153,7 @@ class Exchange:
     def all_reduce_sum(self, t: torch.Tensor, async_op: bool = False):
         if self.world == 1 and not self.force:
             return None
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return _all_reduce_sum(t, self.group, self.staged, async_op)
 
     def all_gather_scalar(self, v: int) -> List[int]:
         return [r[0] for r in self.all_gather_ints([v])]
@@ -117,8 +164,9 @@ class Exchange:
         vals = [int(v) for v in vals]
         if self.world == 1 and not self.force:
             return [vals]
-        t = torch.tensor(vals, dtype=torch.int64, device=self.device)
-        out = torch.empty(self.world * len(vals), dtype=torch.int64, device=self.device)
+        dev = torch.device("cpu") if self.staged else self.device
+        t = torch.tensor(vals, dtype=torch.int64, device=dev)
+        out = torch.empty(self.world * len(vals), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(out, t, group=self.group)
         flat = out.cpu().tolist()
         return [[int(x) for x in flat[k * len(vals):(k + 1) * len(vals)]] for k in range(self.world)]
@@ -133,7 +181,12 @@ class Exchange:
         send = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
         send[:count] = rows[:count]
         recv = torch.empty((self.world * cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        if self.staged:
+            h = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(h, send.cpu(), group=self.group)
+            recv.copy_(h)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
         return torch.cat([recv[k * cap: k * cap + counts[k]] for k in range(self.world)], dim=0)
 
     def barrier(self):
@@ -268,6 +321,219 @@ def step_pipelined(jobs: Sequence["ShardedFilter"]) -> None:
         j.b.hinges()
 
 
+class PartBatch:
+    """The R .las parts a rank holds resident (R independent sharded jobs over the same ranks, "merged" semantics each), run as
+    ONE chain with the exchanges of all parts **batched**: per step one all-reduce (the R coverage histograms, R x 16 KiB, one
+    contiguous tensor) and one all-gather per gather group (the masks of the group's parts, 8 B per read) - 2 collectives with
+    `gather_groups` = 1 instead of the 2 R of a part-by-part chain.  Every collective is a latency-bound RCCL launch (and, at
+    N = 8, a ring over xGMI links), so their NUMBER is what costs.
+
+    Id space.  For the in-place all-gather a rank's rows must be contiguous, so the parts of one gather group share one
+    table: group g with J parts has world x J x S rows, part j of rank r owns rows [(r J + j) S, (r J + j + 1) S).  S = the
+    largest block over all ranks and parts; ids behind a block's reads are padding (length 0, no overlaps).  A part's B ids
+    are ids of its own table: `global_ids(p, owner_rank, local)` maps (rank that holds the B read's block, index inside the
+    block) to them.
+
+    With gather_groups = 2 the first group's all-gather runs under the second group's mask/annotate kernels and the second
+    one under the first group's hinge kernels (asynchronous enqueue, stream-side waits)."""
+
+    def __init__(self, n_parts: int, block_size: int, device: torch.device, group=None, gather_groups: int = 1):
+        self.R, self.S, self.device, self.group = int(n_parts), int(block_size), device, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.force = dist.is_initialized() and os.environ.get("HINGE_FORCE_COLLECTIVES", "0") == "1"
+        self.collectives = self.world > 1 or self.force
+        self.staged = _needs_host_staging(device, group)
+        G = max(1, min(int(gather_groups), self.R))
+        cut = [round(k * self.R / G) for k in range(G + 1)]
+        self.groups = [list(range(cut[k], cut[k + 1])) for k in range(G)]
+        self.slot = {}                       # part -> (group index, index inside the group, parts in the group)
+        for gi, g in enumerate(self.groups):
+            for j, p in enumerate(g):
+                self.slot[p] = (gi, j, len(g))
+        self.masks = [torch.zeros((self.world * len(g) * self.S, 2), dtype=torch.int32, device=device) for g in self.groups]
+        self.means = [torch.full((self.world * len(g) * self.S,), MEAN_SENTINEL, dtype=torch.int32, device=device) for g in self.groups]
+        self.hist = torch.zeros((self.R, 4096 + 2), dtype=torch.int32, device=device)
+        self.backends: List[Optional[object]] = [None] * self.R
+        self._corrupt = os.environ.get("HINGE_TEST_CORRUPT_GATHER", "0") == "1"
+
+    # ---- id space ---------------------------------------------------------------------------------------------
+    def n_ids(self, p: int) -> int:
+        gi, j, J = self.slot[p]
+        return self.world * J * self.S
+
+    def id_base(self, p: int, rank: Optional[int] = None) -> int:
+        gi, j, J = self.slot[p]
+        return ((self.rank if rank is None else rank) * J + j) * self.S
+
+    def global_ids(self, p: int, owner_rank, local):
+        gi, j, J = self.slot[p]
+        return (np.asarray(owner_rank, dtype=np.int64) * J + j) * self.S + np.asarray(local, dtype=np.int64)
+
+    def mask_table(self, p: int) -> torch.Tensor:
+        return self.masks[self.slot[p][0]]
+
+    def set_backend(self, p: int, backend) -> None:
+        gi = self.slot[p][0]
+        backend.attach(self.means[gi], self.masks[gi])
+        self.backends[p] = backend
+
+    def max_pileup(self) -> int:
+        local = max(b.max_pileup() for b in self.backends)
+        return max(r[0] for r in self._gather_ints([local]))
+
+    # ---- collectives ------------------------------------------------------------------------------------------
+    def _gather_ints(self, vals: Sequence[int]) -> List[List[int]]:
+        return _host_all_gather(vals, self.device, self.group, force=self.collectives)
+
+    def _gather_group(self, gi: int):
+        J = len(self.groups[gi])
+        lo = self.rank * J * self.S
+        return _all_gather_in_place(self.masks[gi], lo, lo + J * self.S, self.group, self.staged, async_op=True)
+
+    # ---- one pass over all parts ------------------------------------------------------------------------------
+    def step(self) -> None:
+        """No host synchronisation and no status exchange inside (call status() after a chain of steps)."""
+        B = self.backends
+        if not self.collectives:              # one rank: part after part, the median straight from the mean coverages
+            for p, b in enumerate(B):
+                lo = self.id_base(p)
+                b.begin()
+                b.stats()
+                b.median(lo, lo + self.S - 1)
+                b.mask_annotate()
+                b.hinges()
+            return
+        for p, b in enumerate(B):
+            lo = self.id_base(p)
+            b.begin()
+            b.stats()
+            b.median_hist(lo, lo + self.S - 1, out=self.hist[p])
+        w = _all_reduce_sum(self.hist, self.group, self.staged, async_op=True)          # exchange 1, all parts at once
+        if w is not None:
+            w.wait()
+        pending = []
+        for gi, g in enumerate(self.groups):
+            for p in g:
+                B[p].median_from_hist(self.hist[p])
+                B[p].mask_annotate()
+            pending.append(self._gather_group(gi))                                      # exchange 2, one per group
+        for gi, g in enumerate(self.groups):
+            if pending[gi] is not None:
+                pending[gi].wait()
+            if self._corrupt:                 # test hook: a broken exchange 2 must not go unnoticed (tests/test_dist_gpu.py)
+                J = len(g)
+                own = slice(self.rank * J * self.S, (self.rank + 1) * J * self.S)
+                keep = self.masks[gi][own].clone()
+                self.masks[gi].zero_()
+                self.masks[gi][own] = keep
+            for p in g:
+                B[p].hinges()
+
+    def settle(self, max_rounds: int = 4) -> None:
+        """Whole steps until no rank reports a full device buffer (HINGE_E_CAPACITY anywhere: every rank regrows, every rank
+        reruns - the buffers' sizes depend on the exchanged masks, so they are only known after a real step).  Callers that
+        time chains of step() run this once first."""
+        for _ in range(max_rounds):
+            self.step()
+            codes = [b.status_code() for b in self.backends]
+            rows = self._gather_ints(codes)
+            flat = [c for r in rows for c in r]
+            if all(c == 0 for c in flat):
+                return
+            if any(c not in (0, -3) for c in flat):
+                self._raise(codes, rows)
+            for b in self.backends:
+                b.regrow()
+        raise RuntimeError("sharded filter: device buffers still too small after %d rounds" % max_rounds)
+
+    def _raise(self, codes, rows):
+        for b, c in zip(self.backends, codes):
+            if c != 0:
+                b.raise_status(rows)
+        raise RuntimeError("sharded filter: another rank failed (status codes per rank and part: %s)" % (rows,))
+
+    def table_checksums(self) -> List[int]:
+        """One position-weighted checksum per mask table: equal on every rank after exchange 2."""
+        out = []
+        for m in self.masks:
+            v = m.reshape(-1).to(torch.int64)
+            w = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521) + 1
+            out.append(int((v * w).sum().item()))
+        return out
+
+    def status(self) -> None:
+        """After a chain of steps: every rank learns every rank's status codes; raises on all ranks if any pass failed."""
+        codes = [b.status_code() for b in self.backends]
+        rows = self._gather_ints(codes)
+        if any(c != 0 for r in rows for c in r):
+            self._raise(codes, rows)
+
+    def hinge_lists(self, drop_global_last: bool = True) -> List[torch.Tensor]:
+        """Exchange 3, all parts at once: per part the (read, pos, type) rows of every rank in rank order, on every rank.
+        `.hinges.txt` stops before the last A read of a merged .las (`i < r_end`, filter.cpp:1091): the last rank drops it."""
+        mine = [b.hinge_rows(drop_global_last and self.rank == self.world - 1) for b in self.backends]
+        if not self.collectives:
+            return [rows[:n] for rows, n in mine]
+        counts = self._gather_ints([n for _, n in mine])                                 # [rank][part]
+        cap = max(1, max(sum(r) for r in counts))
+        send = torch.zeros((cap, 3), dtype=torch.int32, device=self.device)
+        at = 0
+        for rows, n in mine:
+            send[at:at + n] = rows[:n]
+            at += n
+        recv = torch.empty((self.world * cap, 3), dtype=torch.int32, device=self.device)
+        if self.staged:
+            h = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(h, send.cpu(), group=self.group)
+            recv.copy_(h)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        out = []
+        for p in range(self.R):
+            parts = []
+            for r in range(self.world):
+                s0 = r * cap + sum(counts[r][:p])
+                parts.append(recv[s0:s0 + counts[r][p]])
+            out.append(torch.cat(parts, dim=0))
+        return out
+
+
+def resident_batch(parts, params, device: torch.device, gather_groups: int = 1, pad: int = 0, group=None):
+    """A rank's resident parts -> (PartBatch, contexts): what an N-GPU run sets up once before its passes (bench.py, the GPU
+    tests).  parts: objects with rlen, row_ptr (0-based over the own block), a_span, b_span, b_owner, b_local (B read =
+    (rank that holds its block, index inside the block)), comp, last_a - hinge_amd/benchsets.RankPart.  Every block gets the
+    same number of read ids (the largest block's over all ranks and parts, + pad); a collective call on every rank."""
+    from . import capi
+    S = max(max(r) for r in _host_all_gather([rp.n_reads for rp in parts], device, group)) + int(pad)
+    batch = PartBatch(len(parts), S, device, group=group, gather_groups=gather_groups)
+    ctxs = []
+    for p, rp in enumerate(parts):
+        n_ids, lo = batch.n_ids(p), batch.id_base(p)
+        hi = lo + rp.n_reads                   # real reads of this rank's block: [lo, hi); ids [hi, lo + S) are padding
+        rlen_t = torch.zeros(n_ids, dtype=torch.int32, device=device)
+        rlen_t[lo:hi] = torch.from_numpy(np.ascontiguousarray(rp.rlen, dtype=np.int32)).to(device)
+        if batch.collectives:
+            _all_reduce_sum(rlen_t, group, batch.staged)
+        row_ptr = np.zeros(n_ids + 1, np.int64)
+        row_ptr[lo:hi + 1] = rp.row_ptr
+        row_ptr[hi + 1:] = rp.row_ptr[-1]
+        b_flag = batch.global_ids(p, rp.b_owner, rp.b_local).astype(np.uint32) | (np.asarray(rp.comp, dtype=np.uint32) << np.uint32(31))
+        # what the ingest hands over besides the columns (hinge_amd/host/host_common.h LasPart::load does the same per record)
+        span16, max_pile, in_range = capi.pack_spans(rp.row_ptr, rp.a_span, rp.rlen)
+        tens = (torch.from_numpy(row_ptr).to(device), torch.from_numpy(np.ascontiguousarray(rp.a_span, dtype=np.int32)).to(device),
+                torch.from_numpy(np.ascontiguousarray(rp.b_span, dtype=np.int32)).to(device), torch.from_numpy(b_flag.view(np.int32)).to(device),
+                None if span16 is None else torch.from_numpy(span16.view(np.int32)).to(device))
+        ctx = capi.Context(device.index or 0)
+        backend = HipBackend(ctx, params, rlen_t.cpu().numpy(), None, lo, lo + S - 1, tens[0], tens[1], tens[2], tens[3], span16=tens[4],
+                             facts=(max_pile, in_range), last_a=lo + rp.last_a, coverage_out=True)
+        batch.set_backend(p, backend)
+        ctxs.append(ctx)
+    if batch.max_pileup() >= 4096:
+        raise ValueError("PartBatch uses the histogram form of exchange 1: every mean coverage must be below 4096")
+    return batch, ctxs
+
+
 class HipBackend:
     """Per-block compute through libhinge_hip (HIP kernels); tensors are torch CUDA tensors."""
 
@@ -298,7 +564,9 @@ class HipBackend:
         return self.ctx.pileup_facts()[0]
 
     def status_code(self) -> int:
+        """0, or the HINGE_E_* of this rank's pass.  The error is cached: check() may clear the device status."""
         from .capi import HingeError
+        self._last_error = None
         try:
             self.ctx.check()
             return 0
@@ -307,7 +575,8 @@ class HipBackend:
             return ex.code
 
     def raise_status(self, codes):
-        if getattr(self, "_last_error", None) is not None and self.status_code() != 0:
+        """Raise this rank's own error when it has one (from the cache, without asking the device again), else say which did."""
+        if getattr(self, "_last_error", None) is not None:
             raise self._last_error
         raise RuntimeError("sharded filter: another rank failed (status codes per rank: %s)" % (codes,))
 
@@ -334,11 +603,15 @@ class HipBackend:
     def median_fetch(self, lo: int, hi: int) -> int:
         return int(self.ctx.filter_median(self.p, lo, hi, fetch=True).cov_est)
 
-    def median_hist(self, lo: int, hi: int) -> torch.Tensor:
-        if self._hist is None:
-            self._hist = torch.zeros(4096 + 2, dtype=torch.int32, device=self.mean_cov.device)
-        self.ctx.filter_median_hist(self.p, lo, hi, self._hist)
-        return self._hist
+    def median_hist(self, lo: int, hi: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out: a contiguous int32[4096 + 2] device row to fill instead of this backend's own (PartBatch: one row per part of
+        ONE tensor, so that a single all-reduce serves all of them)."""
+        if out is None:
+            if self._hist is None:
+                self._hist = torch.zeros(4096 + 2, dtype=torch.int32, device=self.mean_cov.device)
+            out = self._hist
+        self.ctx.filter_median_hist(self.p, lo, hi, out)
+        return out
 
     def median_from_hist(self, hist: torch.Tensor):
         self.ctx.filter_median_from_hist(self.p, hist)

@@ -79,14 +79,7 @@ int main(int argc, char* argv[]) {
     // A rank = one host thread + one hinge_ctx.  The parts of a --mlas run go to the ranks in waves of n_ranks consecutive parts;
     // what the reference's sequential loop carries from part to part is exchanged between the ranks of a wave (see run_wave):
     // the running MIN_COV (a prefix maximum over the parts) and the mask table (a part sees the masks of the parts before it).
-    int n_ranks = 1;
-    {
-        const char* e = getenv("HINGE_RANKS");
-        const int ndev = hinge_device_count();
-        n_ranks = e ? atoi(e) : ndev;
-        n_ranks = std::max(1, std::min(n_ranks, (int)las_list.size()));
-        if (!reads_to_keep.empty() || fa_and_paf) n_ranks = 1;   // --restrictreads grows its read set from part to part: sequential
-    }
+    const int n_ranks = rank_count(las_list.size(), !reads_to_keep.empty() || fa_and_paf);   // --restrictreads grows its read set from part to part: sequential
     PartLoader loader;
     loader.pairs = !reads_to_keep.empty();   // the neighbours of the listed reads need the per-record B column
     loader.paf = fa_and_paf;
@@ -96,7 +89,7 @@ int main(int argc, char* argv[]) {
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
     std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
     ctxs[0] = gpu.ctx;
-    {
+    if (n_ranks > 1) {
         const int ndev = std::max(1, hinge_device_count());
         for (int r = 1; r < n_ranks; r++)
             if (hinge_ctx_create(r % ndev, &ctxs[(size_t)r]) != HINGE_OK) { console.error("cannot create a context on device %d", r % ndev); return 2; }

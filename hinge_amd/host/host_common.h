@@ -973,6 +973,15 @@ struct CtxInit {
     int join() { if (t.joinable()) t.join(); return rc; }
     ~CtxInit() { if (t.joinable()) t.join(); }
 };
+// Ranks (host thread + context) of a run: one per visible GPU for a --mlas set, HINGE_RANKS overrides.  A single part - the
+// common case - never asks: hipGetDeviceCount() waits for the runtime start-up that CtxInit runs in the background, and the
+// ingest of the first part is meant to run UNDER that start-up, not behind it.
+static inline int rank_count(size_t n_parts, bool sequential_only) {
+    if (n_parts <= 1 || sequential_only) return 1;
+    const char* e = getenv("HINGE_RANKS");
+    const int n = e ? atoi(e) : hinge_device_count();
+    return std::max(1, std::min(n, (int)n_parts));
+}
 // the first part is loaded before the context is joined; later parts when their turn comes
 struct PartLoader {
     std::unique_ptr<LasPart> first;

@@ -227,13 +227,7 @@ int main(int argc, char* argv[]) {
     // contained ("Should not happen", hinging.cpp:590-600) is inactive for the parts after it.  The front halves therefore work on
     // the activity at the start of the wave and are consumed in part order; should a part deactivate a read, the front halves of
     // the wave's later parts are simply run again (on the then current activity), one after the other.
-    int n_ranks = 1;
-    {
-        const char* e = getenv("HINGE_RANKS");
-        n_ranks = e ? atoi(e) : hinge_device_count();
-        n_ranks = std::max(1, std::min(n_ranks, (int)las_list.size()));
-        if (fa_and_paf) n_ranks = 1;
-    }
+    const int n_ranks = rank_count(las_list.size(), fa_and_paf);
     PartLoader loader;
     loader.paf = fa_and_paf;
     if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
@@ -241,7 +235,7 @@ int main(int argc, char* argv[]) {
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
     std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
     ctxs[0] = gpu.ctx;
-    {
+    if (n_ranks > 1) {
         const int ndev = std::max(1, hinge_device_count());
         for (int r = 1; r < n_ranks; r++)
             if (hinge_ctx_create(r % ndev, &ctxs[(size_t)r]) != HINGE_OK) { console.error("cannot create a context on device %d", r % ndev); return 2; }

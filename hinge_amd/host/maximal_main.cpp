@@ -88,13 +88,7 @@ int main(int argc, char* argv[]) {
     // own part; whether a read is examined at all depends on its INITIAL activity), so the parts of a wave run side by side,
     // each on its own GPU.  What the reference does sequentially - a read is dropped only if one of its containers is still
     // active at that moment - stays one host pass over the candidate rows in part order (exchange 4 of the sharded path).
-    int n_ranks = 1;
-    {
-        const char* e = getenv("HINGE_RANKS");
-        n_ranks = e ? atoi(e) : hinge_device_count();
-        n_ranks = std::max(1, std::min(n_ranks, (int)las_list.size()));
-        if (fa_and_paf) n_ranks = 1;
-    }
+    const int n_ranks = rank_count(las_list.size(), fa_and_paf);
     PartLoader loader;
     loader.paf = fa_and_paf;
     if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
@@ -102,7 +96,7 @@ int main(int argc, char* argv[]) {
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
     std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
     ctxs[0] = gpu.ctx;
-    {
+    if (n_ranks > 1) {
         const int ndev = std::max(1, hinge_device_count());
         for (int r = 1; r < n_ranks; r++)
             if (hinge_ctx_create(r % ndev, &ctxs[(size_t)r]) != HINGE_OK) { console.error("cannot create a context on device %d", r % ndev); return 2; }

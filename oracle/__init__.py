@@ -20,6 +20,8 @@ def oracle_lib():
     lib.oracle_filter.argtypes = [c.c_char_p, c.c_char_p, c.c_int, c.c_char_p, c.c_char_p, c.c_char_p]
     lib.oracle_maximal.argtypes = [c.c_char_p, c.c_char_p, c.c_int, c.c_char_p, c.c_char_p]
     lib.oracle_layout.argtypes = [c.c_char_p, c.c_char_p, c.c_int, c.c_char_p, c.c_char_p, c.c_char_p]
+    lib.oracle_probe_means.argtypes = [c.POINTER(c.c_int), c.c_long, c.POINTER(c.c_int)]
+    lib.oracle_probe_means.restype = c.c_long
     _common(lib, "oracle")
     return lib
 

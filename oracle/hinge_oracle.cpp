@@ -26,6 +26,11 @@ using namespace oracle;
 
 namespace {
 
+// probe for tools/make_bench_expect.py: what the LAST part of the last oracle_filter() call fed into its median
+// (filter.cpp:642-664: one mean coverage per read of >= 5000 bp, in read order) and the median it took (before `ec`)
+std::vector<int> g_probe_means;
+int g_probe_cov_est = 0;
+
 struct FilterParams {
     int LENGTH_THRESHOLD, N_ITER, ALN_THRESHOLD, MIN_COV, CUT_OFF, THETA, THETA2, N_PROC, EST_COV;
     int reso = 40;
@@ -290,9 +295,11 @@ int oracle_filter(const char* name_db, const char* las_base, int mlas, const cha
             read_coverage.push_back(mean_read_cov);
         }
         if (read_coverage.empty() || num_slot == 0) { rc = -3; break; }   // reference: UB / SIGFPE
+        g_probe_means = read_coverage;
         size_t median_id = read_coverage.size() / 2;
         if (median_id > 0) std::nth_element(read_coverage.begin(), read_coverage.begin() + median_id, read_coverage.end());
         int cov_est = read_coverage[median_id];
+        g_probe_cov_est = cov_est;
         if (P.EST_COV != 0) cov_est = P.EST_COV;
         if (MIN_COV < cov_est / 3) MIN_COV = cov_est / 3;
 
@@ -1008,6 +1015,14 @@ extern "C" int oracle_layout(const char* name_db, const char* las_base, int mlas
 // array-level entry points (unit parity with the reference library and with the HIP kernels)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+
+// probe (see g_probe_means): returns the number of means; writes min(n, cap) of them; *cov_est = the natural median
+long oracle_probe_means(int* out, long cap, int* cov_est) {
+    long n = (long)g_probe_means.size();
+    for (long i = 0; i < n && i < cap; i++) out[i] = g_probe_means[i];
+    if (cov_est) *cov_est = g_probe_cov_est;
+    return n;
+}
 
 // profileCoverage on one pile-up; returns K (number of bins); writes min(K, cap) counts.
 int oracle_profile_coverage(int n, const int* ab, const int* ae, int reso, int cutoff, int* cov_out, int cap) {

@@ -73,7 +73,7 @@ class TableBackend:
     def median_fetch(self, lo, hi):
         return self._median(lo, hi)
 
-    def median_hist(self, lo, hi):
+    def median_hist(self, lo, hi, out=None):
         v = self.mean_cov[lo:hi + 1].numpy()
         v = v[v != MEAN_SENTINEL]
         h = np.zeros(4096 + 2, np.int32)
@@ -81,6 +81,9 @@ class TableBackend:
         h[:4096] = np.bincount(v[ok], minlength=4096)
         h[4096] = len(v)
         h[4097] = int((~ok).any())
+        if out is not None:
+            out.copy_(torch.from_numpy(h))
+            return out
         return torch.from_numpy(h)
 
     def median_from_hist(self, hist):
@@ -198,6 +201,80 @@ def test_step_pipelined_keeps_jobs_apart():
     for p in procs:
         p.join(120)
     assert all(p.exitcode == 0 for p in procs) and len(ret) == world
+
+
+def _batch_worker(rank, world, port, R, G, S, tables, ret):
+    """dist.PartBatch: R parts per rank, exchanges batched (one all-reduce + G all-gathers per step)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hinge_amd.dist import PartBatch
+        batch = PartBatch(R, S, torch.device("cpu"), gather_groups=G)
+        assert len(batch.groups) == G and sorted(p for g in batch.groups for p in g) == list(range(R))
+        bes = []
+        for p in range(R):
+            gi = batch.slot[p][0]
+            mean_g, mask_g, expect = tables[gi]
+            lo = batch.id_base(p)
+            assert batch.n_ids(p) == len(mean_g) and batch.global_ids(p, rank, 0) == lo
+            # hinge rows of this part: one per rank, on the block's first read, and one on its last read (dropped on the last rank)
+            rows = np.array([[batch.id_base(p, r), 100 + p, -1] for r in range(world)] + [[batch.id_base(p, r) + S - 1, 7, 1] for r in range(world)], np.int32)
+            be = TableBackend(lo, lo + S, mean_g, mask_g, rows, expect[p], mask_g)
+            batch.set_backend(p, be)
+            bes.append(be)
+        batch.settle()
+        for be in bes:
+            assert be.checked == ["min_cov", "masks", "status"], be.checked
+        for gi in range(G):
+            assert np.array_equal(batch.masks[gi].numpy(), tables[gi][1])
+        sums = batch.table_checksums()
+        lists = batch.hinge_lists()
+        for p in range(R):
+            got = lists[p].numpy()
+            want = [[batch.id_base(p, r), 100 + p, -1] for r in range(world)] + [[batch.id_base(p, r) + S - 1, 7, 1] for r in range(world - 1)] + \
+                   [[batch.id_base(p, r) + S - 1, TableBackend.FAKE_POS, 1] for r in range(world - 1)]     # TableBackend plants one more
+            assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want)), (p, got)
+            # rank order
+            assert list(got[:, 0]) == sorted(got[:, 0])
+        ret[rank] = sums
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R,G", [(4, 1), (4, 2), (3, 2)])
+def test_part_batch_batches_the_exchanges(R, G):
+    import torch.multiprocessing as mp
+    world, S = 2, 150
+    rng = np.random.default_rng(11 + R + G)
+    cut = [round(k * R / G) for k in range(G + 1)]
+    tables = []
+    for gi in range(G):
+        J = cut[gi + 1] - cut[gi]
+        n = world * J * S
+        mean_g = rng.integers(20, 400, n).astype(np.int32)
+        for r in range(world):               # every part its own coverage level, so that a mixed-up histogram row shows
+            for j in range(J):
+                lo = (r * J + j) * S
+                mean_g[lo:lo + S] += 300 * (cut[gi] + j)
+                mean_g[lo + S - 5:lo + S] = MEAN_SENTINEL        # padding ids behind the block's reads
+        mask_g = np.stack([rng.integers(0, 100, n), rng.integers(100, 9000, n)], axis=1).astype(np.int32) + 1000 * gi
+        expect = {}
+        for j in range(J):
+            ids = np.concatenate([np.arange((r * J + j) * S, (r * J + j + 1) * S) for r in range(world)])
+            v = np.sort(mean_g[ids][mean_g[ids] != MEAN_SENTINEL])
+            expect[cut[gi] + j] = max(5, int(v[len(v) // 2]) // 3)
+        tables.append((mean_g, mask_g, expect))
+    port = 29500 + (os.getpid() % 400) + 31 + R + 3 * G
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, R, G, S, tables, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs) and len(ret) == world
+    assert ret[0] == ret[1], "mask-table checksums differ between the ranks"
 
 
 @pytest.mark.parametrize("mode,median,equal_blocks", [("merged", "hist", False), ("merged", "gather", False), ("merged", "hist", True),

@@ -1,0 +1,259 @@
+"""The multi-process product path on a real GPU: dist.ShardedFilter / dist.PartBatch over dist.HipBackend (HIP kernels through
+the C ABI) with REAL exchanges between ranks, compared with the CPU oracle's files.
+
+A 1-GPU box cannot form an RCCL communicator of several ranks (one device per rank), so
+  * the multi-rank cases run one process per rank on the SAME device with the gloo transport (dist.py stages the device tensors
+    through host memory for it): every kernel, every table, every id mapping and every exchange's DATA FLOW is the product's;
+  * the RCCL calls themselves (in-place all_gather_into_tensor, all_reduce, asynchronous handles, stream-side waits) run with
+    one rank and HINGE_FORCE_COLLECTIVES=1.
+B reads cross blocks in all of them (DBsplit data sets), so hinge calling only gets the oracle's answers if exchange 2 delivered
+the other ranks' masks and exchange 1 the global median.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import run_in, write_ini
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pairs(path):
+    rows = []
+    for line in open(path):
+        tok = line.split()
+        for j in range(1, len(tok) - 1, 2):
+            rows.append((int(tok[0]), int(tok[j]), int(tok[j + 1])))
+    return np.array(rows, np.int32).reshape(-1, 3)
+
+
+def _table(path):
+    return np.loadtxt(path, dtype=np.int64).reshape(-1, 3)
+
+
+def _sharded_filter_worker(rank, world, port, backend, wd, first, mode, median, force, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if force:
+        os.environ["HINGE_FORCE_COLLECTIVES"] = "1"
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hinge_amd import capi, formats
+        from hinge_amd.config import IniFile, filter_params
+        from hinge_amd.dist import BlockTable, Exchange, HipBackend, ShardedFilter
+        rlen = formats.read_db_index(os.path.join(wd, "G"))["rlen"]
+        lo, hi = first[rank], first[rank + 1]
+        name = os.path.join(wd, "G.%d.las" % (rank + 1)) if world > 1 else os.path.join(wd, "G.las")
+        recs = formats.read_las(name)                                   # this rank's block only
+        pile = formats.pileups_from_las(recs, rlen)
+        assert int(recs.rec["aread"][0]) >= lo and int(recs.rec["aread"][-1]) < hi
+        b = pile.b_flag & np.uint32(0x7FFFFFFF)
+        if world > 1:
+            assert ((b < lo) | (b >= hi)).mean() > 0.3, "the data set has no B reads outside the rank's block"
+        P = filter_params(IniFile(os.path.join(wd, "nominal.ini")), False)
+        ctx = capi.Context(0)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        be = HipBackend(ctx, P, rlen, None, lo, hi - 1, t(pile.row_ptr), t(pile.a_span), t(pile.b_span), t(pile.b_flag.view(np.int32)),
+                        last_a=int(recs.rec["aread"][-1]))
+        job = ShardedFilter(be, Exchange(BlockTable(first), dev), mode=mode, median=median)
+        assert job.x.force == bool(force)
+        rows = job.step(fetch_hinges=True).cpu().numpy()
+
+        # ---- against the oracle's files ----
+        want_mask = _table(os.path.join(wd, "G.mas"))[:, 1:].astype(np.int32)
+        got_mask = job.mask.cpu().numpy()
+        visible = want_mask.copy()
+        if mode == "mlas":
+            visible[hi:] = 0                                            # later parts are not masked yet when part p runs
+        assert np.array_equal(got_mask, visible), "mask table after exchange 2"
+        mask, cmask, flags = ctx.get_masks()
+        assert np.array_equal(mask, want_mask[lo:hi])
+        assert np.array_equal(cmask, _table(os.path.join(wd, "G.cmas"))[lo:hi, 1:])
+        off, pos, typ, ish = ctx.get_annotations()
+        if mode == "merged" or rank == 0:                               # --mlas closes .repeat.txt after the first part (filter.cpp:1086)
+            lines = open(os.path.join(wd, "G.repeat.txt")).read().splitlines()
+            for k, i in enumerate(range(lo, hi)):
+                tok = [int(v) for v in lines[i].split()]
+                assert tok[0] == i
+                s, e = off[k], off[k + 1]
+                assert tok[1:] == [v for q in range(s, e) for v in (int(pos[q]), int(typ[q]))], "annotations of read %d" % i
+        want_rows = _pairs(os.path.join(wd, "G.hinges.txt"))
+        assert np.array_equal(rows, want_rows), "the global hinge list (exchange 3): %d rows, the oracle has %d" % (len(rows), len(want_rows))
+        ret[rank] = int(len(rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world, args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=fn, args=(r, world) + args + (ret,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert len(ret) == world
+    return dict(ret)
+
+
+def _dataset(tmp_path, oracle_lib, mlas, n_blocks=3):
+    import dataclasses
+    from hinge_amd import synth
+    d = synth.generate(dataclasses.replace(synth.CONFIGS["tiny_mlas"], n_blocks=n_blocks))
+    wd = str(tmp_path / "data")
+    synth.write_dataset(d, wd, "G")
+    write_ini(os.path.join(wd, "nominal.ini"))
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G" if mlas else b"G.las", int(mlas), b"G", b"nominal.ini", b"") == 0
+    return wd, d
+
+
+@pytest.mark.parametrize("mode,median", [("merged", "hist"), ("merged", "gather"), ("mlas", "gather")])
+def test_sharded_filter_hip_three_ranks(oracle_lib, tmp_path, mode, median):
+    """Three ranks (processes), one block each, B reads everywhere: masks, annotations and the gathered hinge list equal the
+    oracle's .mas / .cmas / .repeat.txt / .hinges.txt of ONE run over all blocks (merged .las, or the --mlas loop)."""
+    wd, d = _dataset(tmp_path, oracle_lib, mode == "mlas")
+    port = 30100 + (os.getpid() % 1500) + {"hist": 0, "gather": 3}[median] + (5 if mode == "mlas" else 0)
+    ret = _spawn(_sharded_filter_worker, 3, (port, "gloo", wd, list(d.block_first), mode, median, False))
+    assert len(set(ret.values())) == 1 and ret[0] > 0
+
+
+@pytest.mark.parametrize("median", ["hist", "gather"])
+def test_sharded_filter_hip_rccl_forced(oracle_lib, tmp_path, median):
+    """One rank, the collectives forced: the same checks with every exchange going through RCCL."""
+    wd, d = _dataset(tmp_path, oracle_lib, False, n_blocks=1)
+    port = 31700 + (os.getpid() % 1500) + (1 if median == "gather" else 0)
+    ret = _spawn(_sharded_filter_worker, 1, (port, "nccl", wd, [0, d.n_reads], "merged", median, True))
+    assert ret[0] > 0
+
+
+# ---- PartBatch: several parts per rank, exchanges batched (what bench.py runs) ---------------------------------------------
+BATCH_INI = ("[filter]\nlength_threshold = 1000;\naln_threshold = 1000;\nmin_cov = 5;\ncut_off = 300;\ntheta = 300;\n"
+             "[layout]\nhinge_slack = 1000\nmin_connected_component_size = 8\n")
+
+
+def _batch_worker(rank, world, port, backend, workload, R, G, force, want, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if force:
+        os.environ["HINGE_FORCE_COLLECTIVES"] = "1"
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hinge_amd import benchsets, synth
+        from hinge_amd.config import default_filter_params
+        from hinge_amd.dist import resident_batch
+        base = synth.CONFIGS[workload]
+        parts = [benchsets.rank_part(base, world, rank, p) for p in range(R)]
+        batch, ctxs = resident_batch(parts, default_filter_params(), dev, gather_groups=G, pad=3)
+        assert batch.collectives
+        batch.settle()
+        batch.step()                                                    # a second pass over warm buffers gives the same answer
+        batch.status()
+        lists = [t.cpu().numpy() for t in batch.hinge_lists()]
+        got = []
+        for p in range(R):
+            per_rank = []
+            for r in range(world):
+                lo = batch.id_base(p, r)
+                loc = lists[p][(lists[p][:, 0] >= lo) & (lists[p][:, 0] < lo + batch.S)].astype(np.int64)
+                loc[:, 0] -= lo
+                per_rank.append({"hinges": int(len(loc)), "digest": benchsets.digest(loc)})
+            got.append(per_rank)
+        assert got == want, "hinges per part and rank:\n%s\nthe CPU oracle's:\n%s" % (got, want)
+        ret[rank] = batch.table_checksums()
+    finally:
+        dist.destroy_process_group()
+
+
+def _oracle_expectation(oracle_lib, workload, world, R):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_bench_expect as mbe
+    from hinge_amd import benchsets, synth
+    base = synth.CONFIGS[workload]
+    quiet = lambda *a: None
+    want = []
+    for p in range(R):
+        if world == 1:
+            d = synth.generate(benchsets.part_spec(base, 1, 0, p)[0])
+            rows, _, _ = mbe.run_oracle(oracle_lib, d, BATCH_INI)
+            want.append([mbe.entry(rows, 0, d.n_reads)])
+        else:
+            team = mbe.team_runs(oracle_lib, base, world // 2, p, BATCH_INI, quiet)
+            want.append(mbe.world_entries(oracle_lib, team, world, BATCH_INI, 5, quiet)["ranks"])
+    assert sum(e["hinges"] for pr in want for e in pr) > 100
+    return want
+
+
+@pytest.mark.parametrize("world,G", [(2, 1), (2, 2), (4, 1)])
+def test_part_batch_hip_ranks_share_one_gpu(oracle_lib, world, G):
+    """bench.py's N > 1 path in small: teams of two ranks, 3 parts per rank, one all-reduce + G all-gathers per step; every
+    part of every rank gives the oracle's hinges (count + row digest), and all ranks end with the same mask tables."""
+    R = 3
+    want = _oracle_expectation(oracle_lib, "chimera", world, R)
+    port = 33300 + (os.getpid() % 1500) + 10 * world + G
+    ret = _spawn(_batch_worker, world, (port, "gloo", "chimera", R, G, False, want))
+    assert all(v == ret[0] for v in ret.values()), "mask tables differ between ranks"
+
+
+def test_part_batch_hip_rccl_forced(oracle_lib):
+    R = 3
+    want = _oracle_expectation(oracle_lib, "chimera", 1, R)
+    for G in (1, 2):
+        _spawn(_batch_worker, 1, (34900 + (os.getpid() % 1500) + G, "nccl", "chimera", R, G, True, want))
+
+
+# ---- bench.py itself with two ranks, and with a deliberately broken exchange 2 ---------------------------------------------
+def _run_bench(extra_env, workload="chimera", nproc=2):
+    env = dict(os.environ)
+    env.update({"HINGE_BENCH_BACKEND": "gloo", "HINGE_BENCH_ONE_DEVICE": "1", "HINGE_BENCH_EXPECT": extra_env.pop("expect")})
+    env.update(extra_env)
+    port = 36500 + (os.getpid() % 1500) + (7 if extra_env else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--workload", workload, "--parts", "2"]
+    return subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+
+
+def test_bench_two_ranks_asserts_results(oracle_lib, tmp_path):
+    """bench.py --gpus 2 (test rig: both ranks on device 0, gloo) on a small workload: passes against the oracle's expectations
+    and FAILS when exchange 2 is corrupted (other ranks' mask rows zeroed after the all-gather)."""
+    import json
+    want = _oracle_expectation(oracle_lib, "chimera", 2, 2)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from hinge_amd import benchsets, synth
+    exp = {"chimera": {"worlds": {"2": {}}}}
+    for p in range(2):
+        d = synth.generate(benchsets.part_spec(synth.CONFIGS["chimera"], 2, 0, p)[0])
+        reads = [d.block_first[k + 1] - d.block_first[k] for k in range(2)]
+        records = [int(np.sum((d.aread >= d.block_first[k]) & (d.aread < d.block_first[k + 1]))) for k in range(2)]
+        exp["chimera"]["worlds"]["2"][str(p)] = {"ranks": want[p], "reads": reads, "records": records}
+    path = str(tmp_path / "expect.json")
+    json.dump(exp, open(path, "w"))
+    r = _run_bench({"expect": path})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["checks"]["parts_checked"] == 2 and line["checks"]["hinges_and_digests_match_cpu_oracle"]
+    assert line["config"]["collectives_per_step"] == 2
+    bad = _run_bench({"expect": path, "HINGE_TEST_CORRUPT_GATHER": "1"})
+    assert bad.returncode != 0 and b"differ from the CPU oracle" in bad.stderr, bad.stderr.decode()[-2000:]

@@ -4,6 +4,8 @@
 #include <dlfcn.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
 static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define T(what, call) do { double t0 = now(); auto r = (call); double t1 = now(); printf("%-44s %8.1f ms  (rc %d)\n", what, t1 - t0, (int)r); } while (0)
 __global__ void k_touch(int* p) { p[0] = 1; }
@@ -12,6 +14,7 @@ int main(int argc, char** argv) {
     if (argc > 1) { double t0 = now(); void* h = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL); printf("%-44s %8.1f ms  (%s)\n", "dlopen(libhinge_hip.so)", now() - t0, h ? "ok" : dlerror()); }
     int n = 0;
     T("hipInit(0)", hipInit(0));
+    if (getenv("PROBE_INIT_ONLY")) { printf("%-44s %8.1f ms\n", "total", now() - t00); fflush(stdout); _exit(0); }
     T("hipGetDeviceCount", hipGetDeviceCount(&n));
     T("hipSetDevice(0)", hipSetDevice(0));
     int cu = 0;
@@ -27,7 +30,14 @@ int main(int argc, char** argv) {
     T("hipStreamCreate", hipStreamCreate(&s));
     { double t0 = now(); hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, s, p); hipStreamSynchronize(s); printf("%-44s %8.1f ms\n", "first kernel launch + sync", now() - t0); }
     int* big = nullptr;
-    T("hipMalloc(600 MB)", hipMalloc(&big, (size_t)600 << 20));
+    const char* mb = getenv("PROBE_ALLOC_MB");
+    const size_t big_mb = mb ? (size_t)atol(mb) : 600;
+    if (big_mb) { T("hipMalloc(PROBE_ALLOC_MB, default 600)", hipMalloc(&big, big_mb << 20)); }
+    if (big_mb && getenv("PROBE_TOUCH")) { T("hipMemset(all of it)", hipMemset(big, 1, big_mb << 20)); T("sync", hipDeviceSynchronize()); }
+    if (getenv("PROBE_FREE")) { T("hipFree(big)", hipFree(big)); T("hipFree(p)", hipFree(p)); T("hipStreamDestroy", hipStreamDestroy(s)); }
+    if (getenv("PROBE_RESET")) { T("hipDeviceReset", hipDeviceReset()); }
     printf("%-44s %8.1f ms   (%d CUs, %d devices)\n", "total", now() - t00, cu, n);
+    fflush(stdout);
+    if (getenv("PROBE_FAST_EXIT")) _exit(0);   // what the executables do: no runtime teardown of its own, the kernel's only
     return 0;
 }
