@@ -382,14 +382,14 @@ def main():
         assert checks["mask_tables_identical_on_all_ranks"], "exchange 2 left different mask tables on different ranks: %s" % (all_sums,)
         for p in range(R):
             want = expect.get(str(p))
-            if want is None:
+            if want is None or os.environ.get("HINGE_BENCH_NO_ASSERT") == "1":     # (NO_ASSERT: ablation builds produce garbage on purpose)
                 continue
             have_sizes = ([sizes[r][p] for r in range(world)], [sizes[r][R + p] for r in range(world)])
             assert (want["reads"], want["records"]) == have_sizes, "part %d: the generated read sets %s are not the ones the expectations were made for %s" % (p, have_sizes, (want["reads"], want["records"]))
             assert want["ranks"] == got[p], "part %d: hinges (count, digest) per rank %s differ from the CPU oracle's %s" % (p, got[p], want["ranks"])
             checks["parts_checked"] += 1
         checks["hinges_and_digests_match_cpu_oracle"] = checks["parts_checked"] > 0
-        assert checks["parts_checked"] > 0 or R > 4 or args.workload != "cfg2_ecoli160", "no committed expectation for N = %d" % world
+        assert checks["parts_checked"] > 0 or R > 4 or args.workload != "cfg2_ecoli160" or os.environ.get("HINGE_BENCH_NO_ASSERT") == "1", "no committed expectation for N = %d" % world
         e2e = cpu = None
         if world == 1 and not args.no_e2e:
             e2e, cpu, oracle_hinges = end_to_end(first_data, args.workload)

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("hinge_clear_masks", C.c_int, [_VP]),
     ("hinge_filter_stats", C.c_int, [_VP, C.POINTER(FilterParams)]),
     ("hinge_filter_median", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, C.POINTER(CovEstimate)]),
+    ("hinge_filter_stats_median", C.c_int, [_VP, C.POINTER(FilterParams), _VP, C.POINTER(CovEstimate)]),
     ("hinge_filter_median_hist", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, _VP]),
     ("hinge_filter_median_from_hist", C.c_int, [_VP, C.POINTER(FilterParams), _VP]),
     ("hinge_set_read_restriction", C.c_int, [_VP, _VP]),
@@ -295,6 +296,14 @@ class Context:
         est = CovEstimate()
         self._ck(self.lib.hinge_filter_median(self.h, C.byref(p), lo, hi, C.byref(est) if fetch else None))
         return est if fetch else None
+
+    def filter_stats_median(self, p: FilterParams, hist_dev=None, fetch: bool = False) -> Optional[CovEstimate]:
+        """K1 + the median of the part's own reads in one launch.  hist_dev (device int32[4096 + 2]): sharded form, the part's
+        histogram goes there instead (all-reduce it, then filter_median_from_hist)."""
+        est = CovEstimate()
+        self._ck(self.lib.hinge_filter_stats_median(self.h, C.byref(p), _VP(_ptr(hist_dev)) if hist_dev is not None else None,
+                                                    C.byref(est) if (fetch and hist_dev is None) else None))
+        return est if (fetch and hist_dev is None) else None
 
     def filter_median_hist(self, p: FilterParams, lo: int, hi: int, hist_dev):
         """Local histogram of the mean coverages of reads lo..hi into hist_dev (device int32[4096 + 2])."""

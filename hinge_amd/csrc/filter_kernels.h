@@ -398,7 +398,11 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
         case 5: if (s_ts) atomicAdd(&totals[1], s_ts); break;
         default: break;
     }
-    __threadfence();
+    // What this block publishes went out as device-scope atomics, which are performed at the device's coherence point: waiting
+    // for their acknowledgement orders them before the ticket.  NOT __threadfence(): a release fence at device scope writes
+    // back and invalidates the XCD's whole L2 (~1 us, serialised per XCD): 64 blocks doing that cost this kernel 2.5 of its
+    // 19 us, and 2 048 workgroups doing it inside k_cov_stats (a fused variant, round 3) took that sweep from 32 to 281 us.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {   // ONE returning atomic publishes this block and tells the last one everything it needs:
                       // bits 0-39 valid values, 40-51 blocks done, 52-63 blocks that saw an out-of-range value

@@ -597,6 +597,27 @@ int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     return launch_stats(ctx, p);   // a pass always starts here: the kernel clears the pass scalars
 }
 
+static int fetch_estimate(hinge_ctx* ctx, hinge_cov_estimate* out) {
+    Scalars h;
+    CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    out->cov_est = h.est[0];
+    out->n_long = h.est[1];
+    out->total_cov = (int64_t)h.totals[0];
+    out->num_slot = (int64_t)h.totals[1];
+    if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part: the reference is undefined here (filter.cpp:660-666)");
+    return HINGE_OK;
+}
+
+int hinge_filter_stats_median(hinge_ctx* ctx, const hinge_filter_params* p, uint32_t* hist_dev, hinge_cov_estimate* out) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
+    CK(hipSetDevice(ctx->device));
+    if ((rc = launch_stats(ctx, p))) return rc;
+    return hist_dev ? hinge_filter_median_hist(ctx, p, ctx->r_begin, ctx->r_end, hist_dev) : hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, out);
+}
+
 int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out) {
     int rc = check_params(ctx, p);
     if (rc) return rc;
@@ -612,16 +633,7 @@ int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo
                            (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals, (unsigned*)nullptr);
     }
     CK(hipGetLastError());
-    if (out) {
-        Scalars h;
-        CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
-        CK(hipStreamSynchronize(ctx->stream));
-        out->cov_est = h.est[0];
-        out->n_long = h.est[1];
-        out->total_cov = (int64_t)h.totals[0];
-        out->num_slot = (int64_t)h.totals[1];
-        if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part: the reference is undefined here (filter.cpp:660-666)");
-    }
+    if (out) return fetch_estimate(ctx, out);
     return HINGE_OK;
 }
 

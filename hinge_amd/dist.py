@@ -397,18 +397,14 @@ class PartBatch:
         B = self.backends
         if not self.collectives:              # one rank: part after part, the median straight from the mean coverages
             for p, b in enumerate(B):
-                lo = self.id_base(p)
                 b.begin()
-                b.stats()
-                b.median(lo, lo + self.S - 1)
+                b.stats_median()
                 b.mask_annotate()
                 b.hinges()
             return
         for p, b in enumerate(B):
-            lo = self.id_base(p)
             b.begin()
-            b.stats()
-            b.median_hist(lo, lo + self.S - 1, out=self.hist[p])
+            b.stats_median(out=self.hist[p])
         w = _all_reduce_sum(self.hist, self.group, self.staged, async_op=True)          # exchange 1, all parts at once
         if w is not None:
             w.wait()
@@ -596,6 +592,11 @@ class HipBackend:
 
     def stats(self):
         self.ctx.filter_stats(self.p)
+
+    def stats_median(self, out: Optional[torch.Tensor] = None):
+        """The statistics sweep and the median of this block's own reads in ONE launch: MIN_COV updated on the device (out None),
+        or the block's histogram written to `out` (int32[4096 + 2] device row) for the all-reduce over ranks."""
+        self.ctx.filter_stats_median(self.p, out)
 
     def median(self, lo: int, hi: int):
         self.ctx.filter_median(self.p, lo, hi, fetch=False)

@@ -174,8 +174,7 @@ int main(int argc, char* argv[]) {
             for (int i : reads_to_keep) if (i >= 0 && i < n_read) keep[(size_t)i] = 1;
             PART_CHECK(o, cx, hinge_set_read_restriction(cx, keep.data()));
         }
-        PART_CHECK(o, cx, hinge_filter_stats(cx, &P));
-        PART_CHECK(o, cx, hinge_filter_median(cx, &P, las.r_begin, las.r_end, &o.est));
+        PART_CHECK(o, cx, hinge_filter_stats_median(cx, &P, nullptr, &o.est));   // K1 + the part's own median (filter.cpp:642-678), one launch
     };
     // phase B: the mask / annotation pass under the MIN_COV this part sees; its mask rows come back to the host
     auto phase_b = [&](hinge_ctx* cx, int min_cov_seen, PartOut& o) {

@@ -113,6 +113,11 @@ int hinge_filter_stats(hinge_ctx* ctx, const hinge_filter_params* p);
  * filter.cpp:671-678 done on the device scalar. If `out` is non-NULL the estimate is copied back
  * (synchronises).                                                                                 */
 int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out);
+/* hinge_filter_stats followed by the median of the part's OWN reads [r_begin, r_end] (filter.cpp:642-678), no host round trip in
+ * between.  hist_dev == NULL: as hinge_filter_median (MIN_COV updated on the device; `out` non-NULL copies the estimate back and
+ * synchronises).  hist_dev = device uint32[4096 + 2]: as hinge_filter_median_hist, the part's histogram for an all-reduce over
+ * ranks and hinge_filter_median_from_hist (`out` ignored).                                                                        */
+int hinge_filter_stats_median(hinge_ctx* ctx, const hinge_filter_params* p, uint32_t* hist_dev, hinge_cov_estimate* out);
 /* Sharded runs (one context per GPU, reads split by block): the global median without gathering 4 bytes per read.
  * median_hist() histograms the mean coverages of this rank's reads lo..hi into hist_dev[4096 + 2] (device memory:
  * bins, number of values, 1 if a value fell outside [0, 4096)); the caller sums hist_dev over ranks (one 16 KiB

@@ -95,6 +95,13 @@ class TableBackend:
     def set_min_cov(self, v):
         self.min_cov = v
 
+    def stats_median(self, out=None):
+        self.stats()
+        if out is None:
+            self.median(self.lo, self.hi - 1)
+        else:
+            self.median_hist(self.lo, self.hi - 1, out=out)
+
     def mask_annotate(self):
         assert self.min_cov == self.expect_min_cov, (self.min_cov, self.expect_min_cov)
         self.mask[self.lo:self.hi] = torch.from_numpy(self.mask_all[self.lo:self.hi])

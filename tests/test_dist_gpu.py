@@ -256,4 +256,4 @@ def test_bench_two_ranks_asserts_results(oracle_lib, tmp_path):
     assert line["n_gpus"] == 2 and line["checks"]["parts_checked"] == 2 and line["checks"]["hinges_and_digests_match_cpu_oracle"]
     assert line["config"]["collectives_per_step"] == 2
     bad = _run_bench({"expect": path, "HINGE_TEST_CORRUPT_GATHER": "1"})
-    assert bad.returncode != 0 and b"differ from the CPU oracle" in bad.stderr, bad.stderr.decode()[-2000:]
+    assert bad.returncode != 0 and (b"differ from the CPU oracle" in bad.stderr or b"different mask tables on different ranks" in bad.stderr), bad.stderr.decode()[-2000:]

@@ -94,6 +94,42 @@ def test_context_reuse_with_more_reads(datasets, oracle_lib, tmp_path):
     ctx.close()
 
 
+def test_context_reuse_across_read_sets_with_coverage_out(oracle_lib, tmp_path):
+    """One context, K2 storing the coverage bins, read sets with the SAME number of reads and the same part range but different
+    lengths (and pile-ups): every run must lay its bin output out for ITS lengths (the layout used to be cached under
+    (r_begin, r_end, reso, cut_off) only and hinge_set_reads did not invalidate it: short -> long wrote past the slots)."""
+    import dataclasses
+    from hinge_amd import capi, synth
+    base = synth.CONFIGS["tiny"]
+    da = synth.generate(dataclasses.replace(base, len_min=3000, len_max=6000, seed=71))
+    n = da.n_reads
+    db = None
+    for cov in range(80, 200, 10):      # longer reads: the same genome needs fewer of them, so raise the coverage until there are n
+        cand = synth.generate(dataclasses.replace(base, len_min=9000, len_max=14000, coverage=cov, seed=72))
+        if cand.n_reads >= n:
+            db = cand
+            break
+    assert db is not None
+    if db.n_reads > n:      # drop the surplus reads (and their overlaps) from the end of the id range
+        keep = (db.aread < n) & (db.bread < n)
+        db = dataclasses.replace(db, rlen=db.rlen[:n], aread=db.aread[keep], bread=db.bread[keep], comp=db.comp[keep], ab=db.ab[keep], ae=db.ae[keep],
+                                 bb=db.bb[keep], be=db.be[keep], block_first=[0, n])
+    assert db.n_reads == n and int(db.rlen.sum()) > 1.5 * int(da.rlen.sum())
+    ctx = capi.Context(0)
+    for tag, d in (("a", da), ("b", db), ("a2", da)):
+        wd_o, wd_h = str(tmp_path / (tag + "_o")), str(tmp_path / (tag + "_h"))
+        for wd in (wd_o, wd_h):
+            synth.write_dataset(d, wd, "G")
+            write_ini(os.path.join(wd, "nominal.ini"))
+        assert _oracle_filter(oracle_lib, wd_o, False) == 0
+        assert _hip_filter(wd_h, False, ctx=ctx, packed=True) == 0
+        first = open(os.path.join(wd_o, "G.mas")).readline().split()[0]
+        last = open(os.path.join(wd_o, "G.mas")).read().splitlines()[-1].split()[0]
+        assert (int(first), int(last)) == (0, n - 1), "the read sets must span the same part range"
+        _compare(wd_o, wd_h)
+    ctx.close()
+
+
 @pytest.mark.parametrize("extra", ["ec = 60\n", "coverage = false\n", "hinge_min_support = 3\nhinge_unbridged = 2\nhinge_min_pileup = 3\n",
                                    "no_hinge_region = 200\nrepeat_annotation_gap_threshold = 100\n"])
 def test_filter_ini_variants(datasets, oracle_lib, tmp_path, extra):
@@ -230,6 +266,118 @@ def test_filter_fallback_reads(datasets, oracle_lib, tmp_path, mode):
     assert run_in(wd_h, stages.run_filter, "G", "G.las", "G", "nominal.ini", False, 0, True, False, ctx) == 0
     assert ctx.fallback_reads() == 1
     _compare(wd_o, wd_h)
+
+
+def _mean_pileups(rng, kind, n_reads):
+    """Pile-ups whose per-read mean coverage lands where `kind` wants it.  A read of length L whose n overlaps all span
+    [0, L] has K = L / 40 + 2 bins and the sum n (K - 1): mean = n (K - 1) / K, i.e. n - 1 for n < K."""
+    rlen = rng.integers(5200, 9000, size=n_reads).astype(np.int32)
+    if kind == "clustered":
+        cnt = rng.integers(141, 181, size=n_reads)
+    elif kind == "wide":
+        cnt = rng.integers(1, 700, size=n_reads)
+    elif kind == "out_of_range":
+        cnt = rng.integers(100, 200, size=n_reads)
+        cnt[rng.integers(0, n_reads, 3)] = 4300                # means of ~4280: outside the histogram
+    elif kind == "short_reads":
+        cnt = rng.integers(100, 300, size=n_reads)
+        rlen[rng.random(n_reads) < 0.7] = 4000                 # < 5000 bp: not in the median
+    elif kind == "single":
+        cnt = rng.integers(50, 90, size=n_reads)
+        rlen[:] = 3000
+        rlen[n_reads // 3] = 7000
+    elif kind == "none":
+        cnt = rng.integers(50, 90, size=n_reads)
+        rlen[:] = 3000
+    else:   # "negative": some pile-ups made of reversed spans (absurd input the kernels must still count like the reference)
+        cnt = rng.integers(100, 200, size=n_reads)
+    row_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    a_of = np.repeat(np.arange(n_reads), cnt)
+    a_span = np.stack([np.zeros(len(a_of), np.int32), rlen[a_of]], axis=1).astype(np.int32)
+    jitter = rng.integers(0, 400, size=len(a_of)).astype(np.int32)
+    a_span[:, 0] += jitter
+    if kind == "negative":
+        bad = np.isin(a_of, rng.integers(0, n_reads, 40))
+        a_span[bad] = a_span[bad][:, ::-1]
+    return rlen, row_ptr, np.ascontiguousarray(a_span)
+
+
+@pytest.mark.parametrize("kind", ["clustered", "wide", "out_of_range", "negative", "short_reads", "single", "none"])
+@pytest.mark.parametrize("packed", [False, True])
+def test_stats_median_in_one_launch(oracle_lib, kind, packed):
+    """hinge_filter_stats_median (the statistics sweep + the median of the part's own reads, no host round trip): per-read means,
+    median and MIN_COV equal the oracle's profileCoverage sums through filter.cpp:642-678; the histogram form (sharded runs)
+    hands out exactly the histogram of those means; the scratch is clean for the next launch (three launches, two read sets,
+    one context)."""
+    import ctypes
+    import torch
+    from hinge_amd import capi
+    from hinge_amd.config import default_filter_params
+    if packed and kind == "negative":
+        pytest.skip("reversed spans are still inside their reads: same route as the others")
+    P = default_filter_params()
+    ctx = capi.Context(0)
+    ip = ctypes.POINTER(ctypes.c_int)
+    sentinel = np.iinfo(np.int32).min
+    for launch, (seed, n_reads) in enumerate([(5, 30_000), (6, 9_000), (5, 30_000)]):
+        rng = np.random.default_rng(seed)
+        rlen, row_ptr, a_span = _mean_pileups(rng, kind, n_reads)
+        n = len(a_span)
+        # expected means from the oracle's profileCoverage (cutoff 0), then filter.cpp:642-664
+        want_mean = np.full(n_reads, sentinel, np.int64)
+        check = rng.choice(n_reads, size=min(n_reads, 400), replace=False)     # the oracle call per read is slow: a sample + the closed form
+        K = np.where(np.diff(row_ptr) > 0, 0, 0)
+        ab, ae = a_span[:, 0].astype(np.int64), a_span[:, 1].astype(np.int64)
+        binof = lambda v: np.where(v < 0, 0, v // 40 + 1)
+        tot = np.add.reduceat(binof(ae) - binof(ab), row_ptr[:-1])
+        mx = np.maximum.reduceat(np.maximum(ab, ae), row_ptr[:-1])
+        K = binof(mx) + 1
+        mean_closed = np.where(tot >= 0, tot // np.maximum(K, 1), -((-tot) // np.maximum(K, 1)))          # C division
+        cov = np.zeros(4096, np.int32)
+        for i in check:
+            s, e = int(row_ptr[i]), int(row_ptr[i + 1])
+            a0, a1 = np.ascontiguousarray(a_span[s:e, 0]), np.ascontiguousarray(a_span[s:e, 1])
+            k = oracle_lib.oracle_profile_coverage(e - s, a0.ctypes.data_as(ip), a1.ctypes.data_as(ip), 40, 0, cov.ctypes.data_as(ip), 4096)
+            assert k == K[i] and int(cov[:k].sum()) == tot[i], "closed form of the coverage sum, read %d" % i
+        want_mean[rlen >= 5000] = mean_closed[rlen >= 5000]
+        vals = np.sort(want_mean[want_mean != sentinel])
+        b_span = np.zeros((n, 2), np.int32)
+        b_flag = np.zeros(n, np.uint32)
+        ctx.set_reads(rlen, None)
+        if packed:
+            span16, max_pile, in_range = capi.pack_spans(row_ptr, a_span, rlen)
+            assert span16 is not None
+            ctx.set_pileups_packed(0, n_reads - 1, row_ptr, a_span, b_span, b_flag, span16, max_pile, in_range)
+        else:
+            ctx.set_pileups(0, n_reads - 1, row_ptr, a_span, b_span, b_flag)
+        mean_dev = torch.full((n_reads,), 7, dtype=torch.int32, device="cuda")
+        ctx.attach_mean_cov(mean_dev)
+        ctx.set_min_cov(5)
+        if len(vals) == 0:
+            with pytest.raises(capi.HingeError) as ei:
+                ctx.filter_stats_median(P, fetch=True)
+            assert ei.value.code == -4
+            continue
+        if launch == 1:     # the histogram form
+            hist = torch.full((4096 + 2,), -1, dtype=torch.int32, device="cuda")
+            ctx.filter_stats_median(P, hist_dev=hist)
+            ctx.synchronize()
+            h = hist.cpu().numpy()
+            ok = (vals >= 0) & (vals < 4096)
+            assert np.array_equal(h[:4096], np.bincount(vals[ok], minlength=4096)) and h[4096] == len(vals) and (h[4097] != 0) == bool((~ok).any())
+            assert ctx.get_min_cov() == 5, "the histogram form leaves MIN_COV to hinge_filter_median_from_hist"
+            if ok.all():
+                ctx.filter_median_from_hist(P, hist)
+                assert ctx.get_min_cov() == max(5, int(vals[len(vals) // 2]) // 3)
+        else:
+            est = ctx.filter_stats_median(P, fetch=True)
+            assert est.cov_est == int(vals[len(vals) // 2]) and est.n_long == len(vals)
+            assert est.total_cov == int(tot[rlen >= 5000].sum()) and est.num_slot == int(K[rlen >= 5000].sum())
+            c = int(vals[len(vals) // 2])
+            assert ctx.get_min_cov() == max(5, int(c / 3))
+        assert np.array_equal(mean_dev.cpu().numpy().astype(np.int64), want_mean)
+        ctx.attach_mean_cov(None)
+    ctx.close()
 
 
 @pytest.mark.parametrize("kind", ["clustered", "wide", "out_of_range", "negative", "sentinels", "single"])
