@@ -60,6 +60,7 @@ SYMBOLS = [
     ("hinge_filter_stats_median", C.c_int, [_VP, C.POINTER(FilterParams), _VP, C.POINTER(CovEstimate)]),
     ("hinge_filter_median_hist", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, _VP]),
     ("hinge_filter_median_from_hist", C.c_int, [_VP, C.POINTER(FilterParams), _VP]),
+    ("hinge_filter_median_from_hist_batch", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams), _VP, C.c_int64]),
     ("hinge_set_read_restriction", C.c_int, [_VP, _VP]),
     ("hinge_filter_set_min_cov", C.c_int, [_VP, C.c_int32]),
     ("hinge_filter_get_min_cov", C.c_int, [_VP, C.POINTER(C.c_int32)]),
@@ -461,6 +462,15 @@ class Context:
         ms = C.c_float()
         self._ck(self.lib.hinge_timer_stop_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+
+def median_from_hist_batch(ctxs, p: FilterParams, hist_dev, row_stride: int) -> None:
+    """hinge_filter_median_from_hist for several contexts (one device, one stream) in one launch: context k takes row k of hist_dev."""
+    lib = load_library()
+    arr = (_VP * len(ctxs))(*[c.h for c in ctxs])
+    rc = lib.hinge_filter_median_from_hist_batch(arr, len(ctxs), C.byref(p), _VP(_ptr(hist_dev)), int(row_stride))
+    if rc != HINGE_OK:
+        raise HingeError(rc, lib.hinge_last_error(ctxs[0].h).decode())
 
 
 def span16_pad() -> int:

@@ -522,6 +522,49 @@ __global__ __launch_bounds__(256) void k_median_from_hist(const unsigned* __rest
     }
 }
 
+// The same for several parts at once (a rank's resident parts after ONE all-reduce over all their histograms): block b
+// finishes the median of part b.  One launch instead of one per part.
+constexpr int MED_BATCH_MAX = 16;
+struct MedianBatch {
+    int* est[MED_BATCH_MAX];
+    int* min_cov[MED_BATCH_MAX];
+    int* status[MED_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void k_median_from_hist_batch(const unsigned* __restrict__ hist_in, long long row_stride, int est_cov_override,
+                                                                MedianBatch B) {
+    __shared__ unsigned hist[MED_BINS];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const unsigned* __restrict__ h = hist_in + (long long)b * row_stride;
+    for (int k = tid; k < MED_BINS; k += blockDim.x) hist[k] = h[k];
+    const unsigned nvalid = h[MED_BINS], bad = h[MED_BINS + 1];
+    __syncthreads();
+    if (nvalid == 0) {
+        if (tid == 0) { B.est[b][0] = 0; B.est[b][1] = 0; atomicOr(B.status[b], ST_NO_LONG_READ); }
+        return;
+    }
+    if (bad) {
+        if (tid == 0) atomicOr(B.status[b], ST_MEDIAN_RANGE);
+        return;
+    }
+    if (tid < WAVE) {
+        const int r = (int)(nvalid / 2);
+        int carry = 0, found = -1;
+        for (int base = 0; base < MED_BINS && found < 0; base += WAVE) {
+            const int incl = wave_incl_scan((int)hist[base + tid]) + carry;
+            const unsigned long long hit = __ballot(incl > r);
+            if (hit) found = base + __ffsll((long long)hit) - 1;
+            carry = wave_last(incl);
+        }
+        if (tid == 0) {
+            int cov_est = found;
+            B.est[b][0] = cov_est;
+            B.est[b][1] = (int)nvalid;
+            if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
+            atomicMax(B.min_cov[b], cov_est / 3);                     // filter.cpp:677-678
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Facts about a part's pile-ups that stay true for every pass over it (run once by hinge_set_pileups):
 // facts[0] = largest pile-up, facts[1] = 1 if some coordinate lies outside [0, rlen].  With them the host

@@ -666,6 +666,29 @@ int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, 
     return HINGE_OK;
 }
 
+int hinge_filter_median_from_hist_batch(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p, const uint32_t* hist_dev, int64_t row_stride) {
+    if (!ctxs || n <= 0 || n > MED_BATCH_MAX || !hist_dev || row_stride < MED_BINS + 2) return HINGE_E_ARG;
+    for (int k = 0; k < n; k++)
+        if (!ctxs[k] || ctxs[k]->device != ctxs[0]->device || ctxs[k]->stream != ctxs[0]->stream)
+            return fail(ctxs[0], HINGE_E_ARG, "median_from_hist_batch: the contexts must share one device and one stream");
+    hinge_ctx* ctx = ctxs[0];
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    CK(hipSetDevice(ctx->device));
+    MedianBatch B;
+    memset(&B, 0, sizeof(B));
+    for (int k = 0; k < n; k++) {
+        if ((rc = flush_min_cov(ctxs[k]))) return rc;
+        B.est[k] = sc(ctxs[k])->est;
+        B.min_cov[k] = &sc(ctxs[k])->min_cov;
+        B.status[k] = &sc(ctxs[k])->status;
+    }
+    ProfScope _ps(ctx, KID_MEDIAN);
+    hipLaunchKernelGGL(k_median_from_hist_batch, dim3(n), dim3(256), 0, ctx->stream, (const unsigned*)hist_dev, (long long)row_stride, p->est_cov, B);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
 int hinge_set_read_restriction(hinge_ctx* ctx, const uint8_t* keep) {
     if (!ctx || ctx->n_reads <= 0) return fail(ctx, HINGE_E_ARG, "hinge_set_read_restriction: call hinge_set_reads first");
     CK(hipSetDevice(ctx->device));

@@ -386,10 +386,11 @@ class PartBatch:
     def _gather_ints(self, vals: Sequence[int]) -> List[List[int]]:
         return _host_all_gather(vals, self.device, self.group, force=self.collectives)
 
-    def _gather_group(self, gi: int):
+    def _gather_group(self, gi: int, async_op: bool = True):
         J = len(self.groups[gi])
         lo = self.rank * J * self.S
-        return _all_gather_in_place(self.masks[gi], lo, lo + J * self.S, self.group, self.staged, async_op=True)
+        w = _all_gather_in_place(self.masks[gi], lo, lo + J * self.S, self.group, self.staged, async_op=async_op)
+        return w if async_op else None
 
     # ---- one pass over all parts ------------------------------------------------------------------------------
     def step(self) -> None:
@@ -405,15 +406,21 @@ class PartBatch:
         for p, b in enumerate(B):
             b.begin()
             b.stats_median(out=self.hist[p])
-        w = _all_reduce_sum(self.hist, self.group, self.staged, async_op=True)          # exchange 1, all parts at once
-        if w is not None:
-            w.wait()
+        # exchange 1, all parts at once.  Not asynchronous: nothing can run under it, and a synchronous collective is enqueued
+        # on the calling stream's order without the event hand-over between streams an asynchronous handle costs
+        _all_reduce_sum(self.hist, self.group, self.staged, async_op=False)
+        batched = hasattr(B[0], "median_from_hist_batch")
+        if batched:
+            B[0].median_from_hist_batch(B, self.hist)                                   # one launch for all parts
         pending = []
+        last = len(self.groups) - 1
         for gi, g in enumerate(self.groups):
             for p in g:
-                B[p].median_from_hist(self.hist[p])
+                if not batched:
+                    B[p].median_from_hist(self.hist[p])
                 B[p].mask_annotate()
-            pending.append(self._gather_group(gi))                                      # exchange 2, one per group
+            # exchange 2, one per group; asynchronous only where the next group's kernels can run under it
+            pending.append(self._gather_group(gi, async_op=gi != last))
         for gi, g in enumerate(self.groups):
             if pending[gi] is not None:
                 pending[gi].wait()
@@ -616,6 +623,11 @@ class HipBackend:
 
     def median_from_hist(self, hist: torch.Tensor):
         self.ctx.filter_median_from_hist(self.p, hist)
+
+    def median_from_hist_batch(self, backends, hist: torch.Tensor):
+        """All of a rank's parts at once: backend k takes row k of hist ([R, 4096 + 2], contiguous)."""
+        from . import capi
+        capi.median_from_hist_batch([b.ctx for b in backends], self.p, hist, int(hist.stride(0)))
 
     def set_min_cov(self, v: int):
         self.ctx.set_min_cov(v)

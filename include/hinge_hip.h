@@ -126,6 +126,10 @@ int hinge_filter_stats_median(hinge_ctx* ctx, const hinge_filter_params* p, uint
  * hinge_filter_median.                                                                                          */
 int hinge_filter_median_hist(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, uint32_t* hist_dev);
 int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, const uint32_t* hist_dev);
+/* median_from_hist for the n resident parts of a rank in ONE launch (after one all-reduce over all their histograms): part k's
+ * histogram is hist_dev + k * row_stride (uint32 words, row_stride >= 4096 + 2), its context ctxs[k].  The contexts share one
+ * device and one stream; n <= 16.                                                                                              */
+int hinge_filter_median_from_hist_batch(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p, const uint32_t* hist_dev, int64_t row_stride);
 /* --restrictreads (filter.cpp:680-694,767-773): keep[n_reads], 0 = the read's coverage and QV masks are emptied
  * (maxend = maxstart, QV.second = QV.first) before the mask is formed; NULL = no restriction.  The caller builds the
  * set (the listed reads plus every B read they overlap).                                                             */
