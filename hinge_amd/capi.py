@@ -90,6 +90,7 @@ SYMBOLS = [
     ("hinge_profile_kernels", C.c_int, []),
     ("hinge_profile_kernel_name", C.c_char_p, [C.c_int]),
     ("hinge_resolve_containment", C.c_int, [C.c_int32, _VP, C.c_int64, _VP, _VP]),
+    ("hinge_sort_order_desc", C.c_int, [C.c_int32, _VP, C.c_int32, _VP]),
     ("hinge_profile_report", C.c_int, [_VP, _VP, _VP]),
     ("hinge_timer_start", C.c_int, [_VP]),
     ("hinge_timer_stop_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -493,6 +494,16 @@ def pack_spans(row_ptr: np.ndarray, a_span: np.ndarray, rlen: np.ndarray):
         span16 = np.zeros(n + span16_pad(), np.uint32)
         span16[:n] = a_span[:, 0].astype(np.uint32) | (a_span[:, 1].astype(np.uint32) << np.uint32(16))
     return span16, min(max_pile, 0x7FFFFFFF), in_range
+
+
+def sort_order_desc(keys: np.ndarray, n_sorts: int = 1) -> np.ndarray:
+    """hinge_sort_order_desc: the order std::sort(compare_overlap), run n_sorts times, leaves elements with these keys in."""
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    perm = np.zeros(max(len(keys), 1), np.int32)
+    rc = load_library().hinge_sort_order_desc(len(keys), _ptr(keys), int(n_sorts), _ptr(perm))
+    if rc != 0:
+        raise HingeError(rc, "hinge_sort_order_desc")
+    return perm[:len(keys)]
 
 
 MT_BCOVERA = 3   # match type "B covers A" (LAInterface.h:30-33)

@@ -655,9 +655,8 @@ def pick_best_pairs(row_ptr: np.ndarray, a_span: np.ndarray, b_span: np.ndarray,
     """The overlaps `hinge maximal` classifies for the reads [lo, hi) of a block: for every (A, B) pair of an active A
     read the longest overlap, and the second longest with use_two_matches (maximal.cpp:790-805; longest = std::sort by
     compare_overlap, i.e. descending aepos - abpos + bepos - bbpos).  Returns (sel, a_of): indices into the pile-up
-    arrays, grouped by ascending A.  A pair with more than 16 overlaps is refused: libstdc++'s std::sort is an
-    insertion sort (stable) only up to 16 elements, and the tie order beyond that is not restated here (the
-    `get_maximal_reads` executable replays it)."""
+    arrays, grouped by ascending A; inside a group of A by ascending B (the `get_maximal_reads` executable walks the pairs
+    in the reference's hash-map order instead, which only .contained.txt's "last container" column depends on)."""
     s, e = int(row_ptr[lo]), int(row_ptr[hi])
     idx = np.arange(s, e, dtype=np.int64)
     a_of = (np.searchsorted(row_ptr, idx, side="right") - 1).astype(np.int32)
@@ -666,14 +665,22 @@ def pick_best_pairs(row_ptr: np.ndarray, a_span: np.ndarray, b_span: np.ndarray,
     b = (b_flag[idx] & np.uint32(0x7FFFFFFF)).astype(np.int64)
     length = (a_span[idx, 1].astype(np.int64) - a_span[idx, 0] + b_span[idx, 1] - b_span[idx, 0])
     order = np.lexsort((-length, b, a_of))            # stable: equal lengths keep file order
-    idx, a_of, b = idx[order], a_of[order], b[order]
+    idx, a_of, b, length = idx[order], a_of[order], b[order], length[order]
     key = a_of.astype(np.int64) * (int(b.max()) + 1 if len(b) else 1) + b
     first = np.ones(len(key), bool)
     first[1:] = key[1:] != key[:-1]
     start = np.nonzero(first)[0]
     sizes = np.diff(np.append(start, len(key)))
     if len(sizes) and sizes.max() > 16:
-        raise NotImplementedError("more than 16 overlaps between one pair of reads")
+        # libstdc++'s std::sort is an insertion sort - stable, what the lexsort above gives - only up to 16 elements; a larger
+        # pair vector is put in the order the reference's two std::sort calls in a row leave it in (hinge_sort_order_desc runs
+        # the same std::sort on the same sequence: the vector in record order)
+        from . import capi
+        for g in np.nonzero(sizes > 16)[0]:
+            s0, n = int(start[g]), int(sizes[g])
+            rec = np.argsort(idx[s0:s0 + n], kind="stable")                  # the pair's overlaps in record order
+            rec_idx, rec_len = idx[s0:s0 + n][rec], length[s0:s0 + n][rec]
+            idx[s0:s0 + n] = rec_idx[capi.sort_order_desc(rec_len, n_sorts=2)]
     rank_in_group = np.arange(len(key)) - np.repeat(start, sizes)
     take = rank_in_group < (2 if use_two_matches else 1)
     return idx[take], a_of[take]

@@ -129,6 +129,9 @@ int main(int argc, char* argv[]) {
         int _rc = (call);                                                                                         \
         if (_rc != HINGE_OK) PART_FAIL(o, _rc == HINGE_E_UNDEFINED ? 1 : 2, "%s failed (%d): %s", #call, _rc, hinge_last_error(cx)); \
     } while (0)
+    // timed = a single part on the main thread: its .coverage.txt is then written by `cov_writer` and its trace points uploaded
+    // by a helper thread WHILE the host threads group the pairs (the GPU is idle in between; 150 of the stage's 700 ms)
+    std::thread cov_writer;
     auto part_work = [&](hinge_ctx* cx, size_t part, PartOut& o, bool timed) {
         int lrc = 0;
         std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
@@ -144,12 +147,15 @@ int main(int argc, char* argv[]) {
         const size_t nr = (size_t)(r_end - r_begin + 1);
         PART_CHECK(o, cx, hinge_set_pileups_packed(cx, r_begin, r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(), las.b_flag.data(),
                                                    nullptr, las.max_pile, las.spans_in_range ? 1 : 0, 0));   // no coverage passes here: no span copy
-        {
+        int trace_rc = HINGE_OK;
+        auto upload_traces = [&] {
             static const uint8_t no_trace[1] = {0};   // PAF: no trace points, ProcessAlignment(trim = false)
-            PART_CHECK(o, cx, hinge_set_trim(cx, las.is_paf ? 0 : 1));
-            PART_CHECK(o, cx, hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0));
-        }
-        if (timed) tm.mark("set_pileups + set_traces (H2D)");
+            trace_rc = hinge_set_trim(cx, las.is_paf ? 0 : 1);
+            if (trace_rc == HINGE_OK)
+                trace_rc = hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0);
+        };
+        if (!timed) { upload_traces(); PART_CHECK(o, cx, trace_rc); }
+        if (timed) tm.mark("set_pileups (H2D)");
         // .coverage.txt is truncated and rewritten with the same content (maximal.cpp:517,659-685)
         {
             o.nb.resize(nr);
@@ -160,6 +166,12 @@ int main(int argc, char* argv[]) {
             PART_CHECK(o, cx, hinge_filter_coverage_bins(cx, r_begin, r_end, reso, 0, o.nb.data(), o.cov.data(), tot));
         }
         if (timed) tm.mark("coverage bins");
+        std::thread trace_upload;
+        if (timed) {   // from here to the classification the main thread makes no library call: the upload has the context to itself
+            cov_writer = std::thread([&o, f_cov, r_begin, reso] { write_coverage_txt(f_cov, r_begin, o.nb, o.cov, reso); });
+            trace_upload = std::thread(upload_traces);
+        }
+        struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } trace_guard{trace_upload};
         // pairs of every read that is active when its turn comes (activity only changes at a read's own turn).
         // Every read's grouping is independent: chunks of 64 reads go to host threads, each chunk emits its selected
         // overlaps (best one or two per (A,B) pair, in the map's iteration order) into its own buffer; the buffers
@@ -202,7 +214,10 @@ int main(int argc, char* argv[]) {
                 std::vector<int64_t>().swap(chunk_sel[(size_t)c]);
             }
         });
-        if (timed) tm.mark("pick_pairs");
+        if (timed) tm.mark("pick_pairs || traces H2D || coverage.txt");
+        if (trace_upload.joinable()) trace_upload.join();
+        PART_CHECK(o, cx, trace_rc);
+        if (timed) tm.mark("traces H2D (rest)");
         // Nearly every overlap is selected (one or two per (A, B) pair), so the whole part is classified in storage order -
         // coalesced, nothing to upload - and the selected ones are picked out of the result.
         {
@@ -249,16 +264,17 @@ int main(int argc, char* argv[]) {
         for (size_t k = 0; k < nw; k++) {
             PartOut& o = outs[k];
             console.info("name of las: %s", las_list[w0 + k].c_str());
+            if (o.code != 0 && cov_writer.joinable()) cov_writer.join();
             if (o.code == -1) { fprintf(stderr, "%s\n", o.error.c_str()); quit(1); }
             if (o.code != 0) { console.error("%s", o.error.c_str()); return o.code; }
             const int r_begin = o.r_begin, r_end = o.r_end;
             const size_t nr = (size_t)(r_end - r_begin + 1);
-            write_coverage_txt(f_cov, r_begin, o.nb, o.cov, reso);
-            tm.mark("coverage.txt");
+            if (!cov_writer.joinable()) { write_coverage_txt(f_cov, r_begin, o.nb, o.cov, reso); tm.mark("coverage.txt"); }
             // sequential containment resolution, maximal.cpp:780-858
             std::vector<int32_t> containing((size_t)n_read);
             if (hinge_resolve_containment(n_read, active.data(), (int64_t)(o.pairs.size() / 2), o.pairs.data(), containing.data()) != HINGE_OK) {
                 console.error("containment resolution: malformed candidate list");
+                if (cov_writer.joinable()) cov_writer.join();
                 return 2;
             }
             for (int i = r_begin; i <= r_end; i++)
@@ -267,6 +283,7 @@ int main(int argc, char* argv[]) {
             for (int i = r_begin; i <= r_end; i++)
                 if (active[(size_t)i]) { n_active++; fprintf(f_max, "%d\n", i); }
             tm.mark("containment + max txt");
+            if (cov_writer.joinable()) { cov_writer.join(); tm.mark("coverage.txt (rest)"); }
             console.info("classified %lld overlaps; removed contained reads, active reads: %d / %zu", (long long)o.n_classified, n_active, nr);
         }
     }

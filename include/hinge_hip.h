@@ -203,6 +203,11 @@ int hinge_trim_classify_part_full(hinge_ctx* ctx, int32_t aln_threshold, int32_t
  * whose mask is at least length_threshold long, out = the maximal-read mask.  containing[n_reads] (may be NULL): the
  * container printed for a removed read, -1 for the others.  With shards, every rank resolves the all-gathered pairs.  */
 int hinge_resolve_containment(int32_t n_reads, uint8_t* active, int64_t n_pairs, const int32_t* pairs, int32_t* containing);
+/* Host side, no device work: perm[] = where `std::sort(v.begin(), v.end(), compare_overlap)` - run n_sorts times in a row, as
+ * maximal.cpp:790-805 does twice and hinging.cpp:560-570 once - leaves the elements of a pair's overlap vector whose keys
+ * (aepos - abpos + bepos - bbpos, LAInterface.cpp:4884-4889) are key[0..n): descending keys, equal keys where libstdc++'s
+ * introsort puts them (up to 16 elements it is an insertion sort, i.e. stable; beyond that it is not).                       */
+int hinge_sort_order_desc(int32_t n, const int64_t* key, int32_t n_sorts, int32_t* perm);
 /* LOverlap::GetMatchingPosition (LAInterface.cpp:4498-4546) for nq (overlap, position on A) queries.        */
 int hinge_matching_position(hinge_ctx* ctx, int64_t nq, const int64_t* q_ovl, const int32_t* q_pos, int32_t* out);
 

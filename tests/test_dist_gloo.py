@@ -418,3 +418,46 @@ def test_resolve_containment_order_semantics():
         capi.resolve_containment(np.ones(3, np.uint8), np.array([[1, 0], [0, 1]], np.int32))     # not grouped by ascending a
     with pytest.raises(capi.HingeError):
         capi.resolve_containment(np.ones(3, np.uint8), np.array([[0, 3]], np.int32))             # id out of range
+
+
+def test_pick_best_pairs_replays_std_sort_beyond_16(oracle_lib):
+    """A pair of reads with more than 16 overlaps: std::sort is no longer an insertion sort there, so which of several equally
+    long overlaps come first (and get classified) is libstdc++'s introsort's business; dist.pick_best_pairs follows it through
+    hinge_sort_order_desc, checked against the oracle's pinned std::sort replay run twice in a row (maximal.cpp:790-805)."""
+    import ctypes
+    from hinge_amd import capi, dist
+    ip = ctypes.POINTER(ctypes.c_int)
+    rng = np.random.default_rng(1)
+
+    def oracle_twice(keys):
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        p1 = np.zeros(len(k), np.int32)
+        oracle_lib.oracle_sort_perm(len(k), k.ctypes.data_as(ip), 0, p1.ctypes.data_as(ip))
+        k2 = np.ascontiguousarray(k[p1])
+        p2 = np.zeros(len(k), np.int32)
+        oracle_lib.oracle_sort_perm(len(k), k2.ctypes.data_as(ip), 0, p2.ctypes.data_as(ip))
+        return p1, p1[p2]
+
+    for n in (5, 16, 17, 40, 300, 5000):
+        k = rng.integers(0, 6, n).astype(np.int64) * 100
+        once, twice = oracle_twice(k)
+        assert np.array_equal(capi.sort_order_desc(k, 1), once) and np.array_equal(capi.sort_order_desc(k, 2), twice), n
+    differ = 0
+    for trial in range(20):
+        sizes = [40, 5, 2, 100]
+        row_ptr = np.array([0, 45, 45, 147, 147], np.int64)               # read 0: pairs with B = 2 (40) and B = 3 (5); read 2: B = 0 (2), B = 1 (100)
+        b_flag = np.concatenate([np.full(40, 2), np.full(5, 3), np.full(2, 0), np.full(100, 1)]).astype(np.uint32)
+        ab = rng.integers(0, 5, 147).astype(np.int32) * 100
+        a_span = np.stack([ab, ab + rng.integers(1, 4, 147).astype(np.int32) * 1000], 1).astype(np.int32)
+        sel, a_of = dist.pick_best_pairs(row_ptr, a_span, a_span.copy(), b_flag, 0, 4, np.ones(4, np.uint8), True)
+        assert list(a_of) == [0, 0, 0, 0, 2, 2, 2, 2]
+        L = (a_span[:, 1] - a_span[:, 0]).astype(np.int64) * 2
+        want = []
+        for s0, n in ((0, 40), (40, 5), (45, 2), (47, 100)):
+            _, twice = oracle_twice(L[s0:s0 + n])
+            want += [s0 + int(twice[0]), s0 + int(twice[1])]
+        want = want[:4] + want[4:]            # groups of one A come in ascending B
+        assert list(sel) == want, (trial, list(sel), want)
+        stable = [s0 + int(np.argsort(-L[s0:s0 + n], kind="stable")[1]) for s0, n in ((0, 40), (47, 100))]
+        differ += [want[1], want[7]] != stable
+    assert differ > 0, "no case in which the introsort order differs from a stable sort"

@@ -19,7 +19,16 @@ V = [("init_only", {"PROBE_INIT_ONLY": "1"}),
      ("alloc4000_touch", {"PROBE_FAST_EXIT": "1", "PROBE_ALLOC_MB": "4000", "PROBE_TOUCH": "1"}),
      ("alloc4000_touch_free", {"PROBE_FAST_EXIT": "1", "PROBE_ALLOC_MB": "4000", "PROBE_TOUCH": "1", "PROBE_FREE": "1"}),
      ("alloc600_reset", {"PROBE_FAST_EXIT": "1", "PROBE_RESET": "1"}),
-     ("alloc600_normal_exit", {})]
+     ("alloc600_normal_exit", {}),
+     ("one_queue", {"PROBE_FAST_EXIT": "1", "GPU_MAX_HW_QUEUES": "1"}),
+     ("sdma_off", {"PROBE_FAST_EXIT": "1", "HSA_ENABLE_SDMA": "0"}),
+     ("one_queue_sdma_off", {"PROBE_FAST_EXIT": "1", "GPU_MAX_HW_QUEUES": "1", "HSA_ENABLE_SDMA": "0"}),
+     ("no_interrupt", {"PROBE_FAST_EXIT": "1", "HSA_ENABLE_INTERRUPT": "0"}),
+     ("scratch_small", {"PROBE_FAST_EXIT": "1", "HSA_SCRATCH_SINGLE_LIMIT": "0", "HSA_NO_SCRATCH_RECLAIM": "1"}),
+     ("cu_mask_half", {"PROBE_FAST_EXIT": "1", "HSA_CU_MASK": "0:0-127"})]
+import sys
+if len(sys.argv) > 1:
+    V = [v for v in V if v[0] in sys.argv[1:]]
 for name, env in V:
     rows = []
     for _ in range(5):
