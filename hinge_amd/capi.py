@@ -61,6 +61,8 @@ SYMBOLS = [
     ("hinge_filter_median_hist", C.c_int, [_VP, C.POINTER(FilterParams), C.c_int32, C.c_int32, _VP]),
     ("hinge_filter_median_from_hist", C.c_int, [_VP, C.POINTER(FilterParams), _VP]),
     ("hinge_filter_median_from_hist_batch", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams), _VP, C.c_int64]),
+    ("hinge_filter_median_batch", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams), _VP, C.c_int64]),
+    ("hinge_filter_hinges_batch_async", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams)]),
     ("hinge_set_read_restriction", C.c_int, [_VP, _VP]),
     ("hinge_filter_set_min_cov", C.c_int, [_VP, C.c_int32]),
     ("hinge_filter_get_min_cov", C.c_int, [_VP, C.POINTER(C.c_int32)]),
@@ -472,6 +474,24 @@ def median_from_hist_batch(ctxs, p: FilterParams, hist_dev, row_stride: int) -> 
     rc = lib.hinge_filter_median_from_hist_batch(arr, len(ctxs), C.byref(p), _VP(_ptr(hist_dev)), int(row_stride))
     if rc != HINGE_OK:
         raise HingeError(rc, lib.hinge_last_error(ctxs[0].h).decode())
+
+
+def _batch_call(fn_name: str, ctxs, *args) -> None:
+    lib = load_library()
+    arr = (_VP * len(ctxs))(*[c.h for c in ctxs])
+    rc = getattr(lib, fn_name)(arr, len(ctxs), *args)
+    if rc != HINGE_OK:
+        raise HingeError(rc, lib.hinge_last_error(ctxs[0].h).decode())
+
+
+def median_batch(ctxs, p: FilterParams, hist_dev=None, row_stride: int = 0) -> None:
+    """hinge_filter_median_batch: every context's own-range median in one launch (hist_dev: the histogram form, row k for context k)."""
+    _batch_call("hinge_filter_median_batch", ctxs, C.byref(p), _VP(_ptr(hist_dev)) if hist_dev is not None else None, int(row_stride))
+
+
+def hinges_batch_async(ctxs, p: FilterParams) -> None:
+    """hinge_filter_hinges_batch_async: hinge calling of several resident parts, one launch per kernel."""
+    _batch_call("hinge_filter_hinges_batch_async", ctxs, C.byref(p))
 
 
 def span16_pad() -> int:

@@ -326,12 +326,29 @@ constexpr int MED_REPLICAS = 8;
 constexpr int MED_HDR = MED_REPLICAS * MED_BINS;
 constexpr int MED_WORDS = MED_HDR + 32;
 constexpr int MED_MAX_BLOCKS = 64;
+constexpr int MED_BATCH_MAX = 16;
 
-__global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override,
-                                                     unsigned* __restrict__ med, int* __restrict__ est, int* __restrict__ min_cov,
-                                                     int* __restrict__ status, const unsigned long long* __restrict__ wave_totals,
-                                                     int n_wave_totals, unsigned long long* __restrict__ totals,
-                                                     unsigned* __restrict__ hist_out /*nullptr, or [MED_BINS + 2]: histogram, valid, out of range*/) {
+// One part's arguments; a launch takes up to MED_BATCH_MAX parts (round 3: the kernel is a 16-us chain of dependent round trips
+// whatever the part's size, so the resident parts of a GPU go through it together - workgroup b works for part b % n).
+struct MedianPart {
+    const int* mean_cov; int lo, hi;
+    unsigned* med; int* est; int* min_cov; int* status;
+    const unsigned long long* wave_totals; int n_wave_totals; unsigned long long* totals;
+    unsigned* hist_out;   // nullptr, or [MED_BINS + 2]: histogram, valid, out of range
+};
+struct MedianHistBatch {
+    MedianPart part[MED_BATCH_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_median_hist(MedianHistBatch B, int est_cov_override) {
+    const unsigned n_parts = (unsigned)B.n;
+    const MedianPart& A = B.part[blockIdx.x % n_parts];
+    const unsigned bx = blockIdx.x / n_parts, gx = gridDim.x / n_parts;
+    if (bx >= gx) return;
+    const int* __restrict__ mean_cov = A.mean_cov; const int lo = A.lo, hi = A.hi;
+    unsigned* __restrict__ med = A.med; int* __restrict__ est = A.est; int* __restrict__ min_cov = A.min_cov; int* __restrict__ status = A.status;
+    const unsigned long long* __restrict__ wave_totals = A.wave_totals; const int n_wave_totals = A.n_wave_totals;
+    unsigned long long* __restrict__ totals = A.totals; unsigned* __restrict__ hist_out = A.hist_out;
     __shared__ unsigned hist[MED_BINS];
     __shared__ unsigned s_valid, s_oor, s_last, s_lo, s_hi, s_general;
     __shared__ unsigned long long s_tc, s_ts, s_ticket;
@@ -347,11 +364,11 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
     unsigned long long tc = 0, ts = 0;
     {
         constexpr int U = 8;   // independent loads in flight per thread: one memory round trip per 8 values
-        const int stride = gridDim.x * blockDim.x;
+        const int stride = (int)(gx * blockDim.x);
         // total_cov / num_slot of the part (only logged by the reference, filter.cpp:666,672): every block sums a slice of
         // k_cov_stats' per-wave partials; loaded together with the first batch of values
-        for (int w = blockIdx.x * blockDim.x + tid; w < n_wave_totals; w += stride) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
-        for (int i0 = lo + blockIdx.x * blockDim.x + tid; i0 <= hi; i0 += U * stride) {
+        for (int w = (int)(bx * blockDim.x) + tid; w < n_wave_totals; w += stride) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
+        for (int i0 = lo + (int)(bx * blockDim.x) + tid; i0 <= hi; i0 += U * stride) {
             int vv[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
 #ifdef HINGE_TIMING
     const unsigned long long tq1 = wall_clock64();
 #endif
-    unsigned* my_hist = med + (size_t)(blockIdx.x % MED_REPLICAS) * MED_BINS;
+    unsigned* my_hist = med + (size_t)(bx % MED_REPLICAS) * MED_BINS;
     for (unsigned b = s_lo + tid; b <= s_hi; b += blockDim.x)
         if (hist[b]) atomicAdd(&my_hist[b], hist[b]);
     switch (tid) {   // fire-and-forget
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256) void k_median_hist(const int* __restrict__ mea
         const unsigned long long mine = (unsigned long long)s_valid + (1ull << 40) + (s_oor ? (1ull << 52) : 0ull);
         const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long*>(&med[MED_HDR]), mine);
         s_ticket = t + mine;
-        s_last = (((t >> 40) & 0xfffull) == gridDim.x - 1);
+        s_last = (((t >> 40) & 0xfffull) == gx - 1);
     }
     __syncthreads();
 #ifdef HINGE_TIMING
@@ -524,7 +541,6 @@ __global__ __launch_bounds__(256) void k_median_from_hist(const unsigned* __rest
 
 // The same for several parts at once (a rank's resident parts after ONE all-reduce over all their histograms): block b
 // finishes the median of part b.  One launch instead of one per part.
-constexpr int MED_BATCH_MAX = 16;
 struct MedianBatch {
     int* est[MED_BATCH_MAX];
     int* min_cov[MED_BATCH_MAX];

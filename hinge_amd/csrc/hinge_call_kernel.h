@@ -40,6 +40,26 @@ struct alignas(16) HeavyItem {   // everything k_hinge_call needs, so that it st
 };
 __device__ __forceinline__ int slice_len(int n) { return ((n + 4 * WAVE - 1) / (4 * WAVE)) * WAVE; }
 
+// Everything the two hinge kernels read or write for ONE resident part.  A launch takes up to HINGE_BATCH_MAX of them (round 3):
+// both kernels are chains of dependent look-ups over 1-2 % of the reads - ~19 us each however small the part - so the parts a
+// GPU holds resident go through them in ONE launch each (workgroup b works for part b % n) and the chain is paid once.
+struct HingePart {
+    const int64_t* row_ptr; const int2* a_span; const int2* b_span; const unsigned* b_flag; const int2* mask;
+    const int2* anno_buf; const unsigned* anno_off; const int* anno_cnt;
+    const WorkItem* work_list; const unsigned* counters;
+    unsigned char* hinge_flag;
+    HeavyItem* heavy; unsigned* heavy_count; unsigned* heavy_count_big; unsigned heavy_cap;
+    int2* exact_queue; unsigned* exact_count; unsigned exact_cap;
+    int* status; unsigned* work_next; unsigned* work_next_big;
+    unsigned* dbg;
+    int force_exact;
+};
+constexpr int HINGE_BATCH_MAX = 8;
+struct HingeBatch {
+    HingePart part[HINGE_BATCH_MAX];
+    int n;
+};
+
 template <int CAP>
 struct HingeCallLdsT {
     WaveSortLdsT<CAP> ws;
@@ -66,20 +86,24 @@ struct HingeCallLdsT {
 // (support <= SUP: no hinge;  first-branch count > UNB: unbridged whatever the order, filter.cpp:920-931).
 // Undecided annotations get hinge_flag = 2 and their read goes to the heavy list for k_hinge_call.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
-                                                       const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
-                                                       const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
-                                                       const unsigned* __restrict__ anno_off, const int* __restrict__ anno_cnt,
-                                                       const WorkItem* __restrict__ work_list, const unsigned* __restrict__ counters,
-                                                       unsigned char* __restrict__ hinge_flag, HeavyItem* __restrict__ heavy,
-                                                       unsigned* __restrict__ heavy_count, unsigned* __restrict__ heavy_count_big, unsigned heavy_cap,
-                                                       int force_exact, unsigned* __restrict__ dbg) {
+__global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B) {
+    const unsigned n_parts = (unsigned)B.n;
+    const HingePart& A = B.part[blockIdx.x % n_parts];              // (uniform: scalar loads from the kernel arguments)
+    const unsigned bx = blockIdx.x / n_parts, gx = gridDim.x / n_parts;
+    const int64_t* __restrict__ row_ptr = A.row_ptr; const int2* __restrict__ a_span = A.a_span; const int2* __restrict__ b_span = A.b_span;
+    const unsigned* __restrict__ b_flag = A.b_flag; const int2* __restrict__ mask = A.mask; const int2* __restrict__ anno_buf = A.anno_buf;
+    const WorkItem* __restrict__ work_list = A.work_list; const unsigned* __restrict__ counters = A.counters;
+    unsigned char* __restrict__ hinge_flag = A.hinge_flag; HeavyItem* __restrict__ heavy = A.heavy;
+    unsigned* __restrict__ heavy_count = A.heavy_count; unsigned* __restrict__ heavy_count_big = A.heavy_count_big;
+    const unsigned heavy_cap = A.heavy_cap; const int force_exact = A.force_exact; unsigned* __restrict__ dbg = A.dbg;
+    (void)row_ptr;
     __shared__ int s_sup[PRE_MAXA][WAVES_PER_BLOCK], s_near[PRE_MAXA][WAVES_PER_BLOCK];
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned nwork = counters[1];
-    for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {   // one workgroup per work-list read
+    if (bx >= gx) return;   // (a grid that is not a multiple of the parts: the surplus workgroups have no share)
+    for (unsigned w = bx; w < nwork; w += gx) {   // one workgroup per work-list read
 #ifdef HINGE_TIMING
         const unsigned long long tc0 = wall_clock64();
 #endif
@@ -191,15 +215,17 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, const int64_
 // PO_CAP_SMALL instance (72 KiB of LDS: two workgroups per CU) over the items whose pile-up fits it - they are appended from
 // the front of `heavy` - and the PO_CAP instance (one workgroup per CU) over the rest, appended from the back (`from_back`).
 template <int CAP>
-__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, const int64_t* __restrict__ row_ptr, const int2* __restrict__ a_span,
-                                                      const int2* __restrict__ b_span, const unsigned* __restrict__ b_flag,
-                                                      const int2* __restrict__ mask, const int2* __restrict__ anno_buf,
-                                                      const unsigned* __restrict__ anno_off,
-                                                      const HeavyItem* __restrict__ heavy, const unsigned* __restrict__ heavy_count,
-                                                      unsigned char* __restrict__ hinge_flag, int2* __restrict__ exact_queue,
-                                                      unsigned* __restrict__ exact_count, unsigned exact_cap, int force_exact,
-                                                      int* __restrict__ status, unsigned* __restrict__ work_next,
-                                                      unsigned* __restrict__ dbg, int from_back, unsigned heavy_cap) {
+__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B, int from_back) {
+    const HingePart& A = B.part[blockIdx.x % (unsigned)B.n];
+    const int64_t* __restrict__ row_ptr = A.row_ptr; const int2* __restrict__ a_span = A.a_span; const int2* __restrict__ b_span = A.b_span;
+    const unsigned* __restrict__ b_flag = A.b_flag; const int2* __restrict__ mask = A.mask; const int2* __restrict__ anno_buf = A.anno_buf;
+    const unsigned* __restrict__ anno_off = A.anno_off; const HeavyItem* __restrict__ heavy = A.heavy;
+    const unsigned* __restrict__ heavy_count = from_back ? A.heavy_count_big : A.heavy_count;
+    unsigned char* __restrict__ hinge_flag = A.hinge_flag; int2* __restrict__ exact_queue = A.exact_queue;
+    unsigned* __restrict__ exact_count = A.exact_count; const unsigned exact_cap = A.exact_cap; const int force_exact = A.force_exact;
+    int* __restrict__ status = A.status; unsigned* __restrict__ work_next = from_back ? A.work_next_big : A.work_next;
+    unsigned* __restrict__ dbg = A.dbg; const unsigned heavy_cap = A.heavy_cap;
+    (void)row_ptr; (void)anno_off; (void)anno_buf;
     constexpr int SF_BINS = 2 * CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
     __shared__ HingeCallLdsT<CAP> S;
     const int tid = threadIdx.x;

@@ -618,21 +618,40 @@ int hinge_filter_stats_median(hinge_ctx* ctx, const hinge_filter_params* p, uint
     return hist_dev ? hinge_filter_median_hist(ctx, p, ctx->r_begin, ctx->r_end, hist_dev) : hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, out);
 }
 
+static MedianPart median_part_of(hinge_ctx* ctx, int32_t lo, int32_t hi, uint32_t* hist_dev) {
+    MedianPart a;
+    memset(&a, 0, sizeof(a));
+    a.mean_cov = (const int*)ctx->mean_cov; a.lo = lo; a.hi = hi;
+    a.med = (unsigned*)ctx->med.p; a.est = sc(ctx)->est; a.min_cov = &sc(ctx)->min_cov; a.status = &sc(ctx)->status;
+    a.wave_totals = (const unsigned long long*)ctx->wave_totals.p; a.n_wave_totals = ctx->n_wave_totals; a.totals = sc(ctx)->totals;
+    a.hist_out = (unsigned*)hist_dev;
+    return a;
+}
+// k_median_hist over n parts (contexts on one device and one stream), each over its own [lo, hi]; hist_dev[k] as in median_hist
+static int launch_median_batch(hinge_ctx** ctxs, int n, const hinge_filter_params* p, const int32_t* lo, const int32_t* hi, uint32_t* const* hist_dev) {
+    hinge_ctx* ctx = ctxs[0];
+    MedianHistBatch B;
+    memset(&B, 0, sizeof(B));
+    B.n = n;
+    int blocks = 1;
+    for (int k = 0; k < n; k++) {
+        int rc = flush_min_cov(ctxs[k]);
+        if (rc) return rc;
+        B.part[k] = median_part_of(ctxs[k], lo[k], hi[k], hist_dev ? hist_dev[k] : nullptr);
+        blocks = std::max(blocks, std::min((hi[k] - lo[k] + 1 + 1023) / 1024, MED_MAX_BLOCKS));
+    }
+    ProfScope _ps(ctx, KID_MEDIAN);
+    hipLaunchKernelGGL(k_median_hist, dim3(blocks * n), dim3(256), 0, ctx->stream, B, p->est_cov);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
 int hinge_filter_median(hinge_ctx* ctx, const hinge_filter_params* p, int32_t lo, int32_t hi, hinge_cov_estimate* out) {
     int rc = check_params(ctx, p);
     if (rc) return rc;
     if (lo < 0 || hi >= ctx->n_reads || hi < lo) return fail(ctx, HINGE_E_ARG, "median range");
     CK(hipSetDevice(ctx->device));
-    if ((rc = flush_min_cov(ctx))) return rc;
-    {
-        ProfScope _ps(ctx, KID_MEDIAN);
-        const int n = hi - lo + 1;
-        const int grid = std::max(1, std::min((n + 1023) / 1024, MED_MAX_BLOCKS));
-        hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
-                           (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status,
-                           (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals, (unsigned*)nullptr);
-    }
-    CK(hipGetLastError());
+    if ((rc = launch_median_batch(&ctx, 1, p, &lo, &hi, nullptr))) return rc;
     if (out) return fetch_estimate(ctx, out);
     return HINGE_OK;
 }
@@ -643,14 +662,22 @@ int hinge_filter_median_hist(hinge_ctx* ctx, const hinge_filter_params* p, int32
     if (rc) return rc;
     if (lo < 0 || hi >= ctx->n_reads || hi < lo || !hist_dev) return fail(ctx, HINGE_E_ARG, "median_hist: bad arguments");
     CK(hipSetDevice(ctx->device));
-    ProfScope _ps(ctx, KID_MEDIAN);
-    const int n = hi - lo + 1;
-    const int grid = std::max(1, std::min((n + 1023) / 1024, MED_MAX_BLOCKS));
-    hipLaunchKernelGGL(k_median_hist, dim3(grid), dim3(256), 0, ctx->stream, (const int*)ctx->mean_cov, lo, hi, p->est_cov,
-                       (unsigned*)ctx->med.p, sc(ctx)->est, &sc(ctx)->min_cov, &sc(ctx)->status,
-                       (const unsigned long long*)ctx->wave_totals.p, ctx->n_wave_totals, sc(ctx)->totals, (unsigned*)hist_dev);
-    CK(hipGetLastError());
-    return HINGE_OK;
+    return launch_median_batch(&ctx, 1, p, &lo, &hi, &hist_dev);
+}
+
+int hinge_filter_median_batch(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p, uint32_t* hist_dev, int64_t row_stride) {
+    if (!ctxs || n <= 0 || n > MED_BATCH_MAX || (hist_dev && row_stride < MED_BINS + 2)) return HINGE_E_ARG;
+    for (int k = 0; k < n; k++)
+        if (!ctxs[k] || ctxs[k]->device != ctxs[0]->device || ctxs[k]->stream != ctxs[0]->stream || ctxs[k]->r_end < ctxs[k]->r_begin)
+            return fail(ctxs[0], HINGE_E_ARG, "median_batch: the contexts must share one device and one stream and have pile-ups set");
+    hinge_ctx* ctx = ctxs[0];
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    CK(hipSetDevice(ctx->device));
+    int32_t lo[MED_BATCH_MAX], hi[MED_BATCH_MAX];
+    uint32_t* hd[MED_BATCH_MAX];
+    for (int k = 0; k < n; k++) { lo[k] = ctxs[k]->r_begin; hi[k] = ctxs[k]->r_end; hd[k] = hist_dev ? hist_dev + (int64_t)k * row_stride : nullptr; }
+    return launch_median_batch(ctxs, n, p, lo, hi, hist_dev ? hd : nullptr);
 }
 
 int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, const uint32_t* hist_dev) {
@@ -898,41 +925,60 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     return fail(ctx, HINGE_E_CAPACITY, "annotation buffer kept overflowing");
 }
 
-static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
+static HingePart hinge_part_of(hinge_ctx* ctx) {
+    HingePart a;
+    memset(&a, 0, sizeof(a));
+    a.row_ptr = (const int64_t*)ctx->row_ptr.p; a.a_span = (const int2*)ctx->a_span.p; a.b_span = (const int2*)ctx->b_span.p;
+    a.b_flag = (const unsigned*)ctx->b_flag.p; a.mask = (const int2*)ctx->mask;
+    a.anno_buf = (const int2*)ctx->anno_buf.p; a.anno_off = (const unsigned*)ctx->anno_off.p; a.anno_cnt = (const int*)ctx->anno_cnt.p;
+    a.work_list = (const WorkItem*)ctx->work_list.p; a.counters = (const unsigned*)sc(ctx)->counters;
+    a.hinge_flag = (unsigned char*)ctx->hinge_flag.p;
+    a.heavy = (HeavyItem*)ctx->heavy_list.p; a.heavy_count = &sc(ctx)->heavy_count; a.heavy_count_big = &sc(ctx)->heavy_count_big; a.heavy_cap = ctx->anno_cap;
+    a.exact_queue = (int2*)ctx->exact_queue.p; a.exact_count = &sc(ctx)->exact_count; a.exact_cap = ctx->exact_cap;
+    a.status = &sc(ctx)->status; a.work_next = &sc(ctx)->work_next; a.work_next_big = &sc(ctx)->work_next_big;
+    a.dbg = ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr;
+    a.force_exact = ctx->force_exact;
+    return a;
+}
+
+// The hinge kernels over n resident parts (contexts on one device and one stream) in one launch each; n = 1 is the single part.
+static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_params* p) {
+    hinge_ctx* ctx = ctxs[0];
+    HingeBatch B;
+    memset(&B, 0, sizeof(B));
+    B.n = n;
+    bool any_big = false;
+    for (int k = 0; k < n; k++) {
+        B.part[k] = hinge_part_of(ctxs[k]);
+        any_big = any_big || ctxs[k]->max_pile > (unsigned)PO_CAP_SMALL;
+    }
+    const int g_count = std::max(n, (ctx->n_cu * 8 / n) * n);
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
-    hipLaunchKernelGGL(k_hinge_count, dim3(ctx->n_cu * 8), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
-                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
-                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int*)ctx->anno_cnt.p,
-                       (const WorkItem*)ctx->work_list.p, (const unsigned*)sc(ctx)->counters, (unsigned char*)ctx->hinge_flag.p,
-                       (HeavyItem*)ctx->heavy_list.p, &sc(ctx)->heavy_count, &sc(ctx)->heavy_count_big, ctx->anno_cap, ctx->force_exact,
-                       ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr); }
+    hipLaunchKernelGGL(k_hinge_count, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
     CK(hipGetLastError());
     // Undecided annotations: pile-ups of up to PO_CAP_SMALL overlaps go through the 72 KiB instance, two workgroups per CU (one
-    // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if the part has
+    // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if a part has
     // such a pile-up (k_pileup_facts).
-#define LAUNCH_HINGE_CALL(CAP, GRID, COUNT, NEXT, BACK)                                                                                 \
-    hipLaunchKernelGGL(k_hinge_call<CAP>, dim3(GRID), dim3(BLOCK), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,           \
-                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,    \
-                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const HeavyItem*)ctx->heavy_list.p,              \
-                       (const unsigned*)(COUNT), (unsigned char*)ctx->hinge_flag.p, (int2*)ctx->exact_queue.p, &sc(ctx)->exact_count,     \
-                       ctx->exact_cap, ctx->force_exact, &sc(ctx)->status, (NEXT), ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr,  \
-                       (BACK), ctx->anno_cap)
     { ProfScope _ps(ctx, KID_HINGE_CALL);
-    LAUNCH_HINGE_CALL(PO_CAP_SMALL, 2 * ctx->n_cu, &sc(ctx)->heavy_count, &sc(ctx)->work_next, 0);
-    if (ctx->max_pile > (unsigned)PO_CAP_SMALL) LAUNCH_HINGE_CALL(PO_CAP, ctx->n_cu, &sc(ctx)->heavy_count_big, &sc(ctx)->work_next_big, 1); }
-#undef LAUNCH_HINGE_CALL
+    hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0);
+    if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1); }
     CK(hipGetLastError());
-    // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1)
-    if (ctx->max_pile <= (unsigned)PO_CAP && ctx->force_exact != 1) return HINGE_OK;
-    ProfScope _ps2(ctx, KID_HINGE_EXACT);
-    hipLaunchKernelGGL(k_hinge_exact, dim3(64), dim3(64), 0, ctx->stream, to_dev(p), (const int64_t*)ctx->row_ptr.p,
-                       (const int2*)ctx->a_span.p, (const int2*)ctx->b_span.p, (const unsigned*)ctx->b_flag.p, (const int2*)ctx->mask,
-                       (const int2*)ctx->anno_buf.p, (const unsigned*)ctx->anno_off.p, (const int2*)ctx->exact_queue.p,
-                       (const unsigned*)&sc(ctx)->exact_count, ctx->exact_cap, (int*)ctx->arena.p, &sc(ctx)->arena_used, ctx->arena_cap,
-                       (unsigned char*)ctx->hinge_flag.p, &sc(ctx)->status);
-    CK(hipGetLastError());
+    // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1): per part
+    for (int k = 0; k < n; k++) {
+        hinge_ctx* c = ctxs[k];
+        if (c->max_pile <= (unsigned)PO_CAP && c->force_exact != 1) continue;
+        ProfScope _ps2(ctx, KID_HINGE_EXACT);
+        hipLaunchKernelGGL(k_hinge_exact, dim3(64), dim3(64), 0, ctx->stream, to_dev(p), (const int64_t*)c->row_ptr.p,
+                           (const int2*)c->a_span.p, (const int2*)c->b_span.p, (const unsigned*)c->b_flag.p, (const int2*)c->mask,
+                           (const int2*)c->anno_buf.p, (const unsigned*)c->anno_off.p, (const int2*)c->exact_queue.p,
+                           (const unsigned*)&sc(c)->exact_count, c->exact_cap, (int*)c->arena.p, &sc(c)->arena_used, c->arena_cap,
+                           (unsigned char*)c->hinge_flag.p, &sc(c)->status);
+        CK(hipGetLastError());
+    }
     return HINGE_OK;
 }
+
+static int launch_hinges(hinge_ctx* ctx, const hinge_filter_params* p) { return launch_hinges_batch(&ctx, 1, p); }
 
 // checks the capacity flags of the last hinge pass; grows what overflowed. 1 = rerun needed.
 static int hinges_settle(hinge_ctx* ctx, int* rerun) {
@@ -1149,6 +1195,21 @@ int hinge_filter_hinges_async(hinge_ctx* ctx, const hinge_filter_params* p) {
     int rc = check_params(ctx, p);
     if (rc) return rc;
     return launch_hinges(ctx, p);
+}
+static int same_device_and_stream(hinge_ctx** ctxs, int32_t n, int max_n, const char* who) {
+    if (!ctxs || n <= 0 || n > max_n) return HINGE_E_ARG;
+    for (int k = 0; k < n; k++)
+        if (!ctxs[k] || ctxs[k]->device != ctxs[0]->device || ctxs[k]->stream != ctxs[0]->stream)
+            return fail(ctxs[0], HINGE_E_ARG, (std::string(who) + ": the contexts must share one device and one stream").c_str());
+    return HINGE_OK;
+}
+int hinge_filter_hinges_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p) {
+    int rc = same_device_and_stream(ctxs, n, HINGE_BATCH_MAX, "hinge_filter_hinges_batch_async");
+    if (rc) return rc;
+    hinge_ctx* ctx = ctxs[0];
+    if ((rc = check_params(ctx, p))) return rc;
+    CK(hipSetDevice(ctx->device));
+    return launch_hinges_batch(ctxs, n, p);
 }
 int hinge_filter_check(hinge_ctx* ctx) {
     if (!ctx) return HINGE_E_ARG;

@@ -396,20 +396,37 @@ class PartBatch:
     def step(self) -> None:
         """No host synchronisation and no status exchange inside (call status() after a chain of steps)."""
         B = self.backends
-        if not self.collectives:              # one rank: part after part, the median straight from the mean coverages
-            for p, b in enumerate(B):
+        batched = hasattr(B[0], "hinges_batch")       # the product backend: the latency-bound kernels take all parts per launch
+        if not self.collectives:              # one rank: no exchange; the parts only share their launches
+            for b in B:
                 b.begin()
-                b.stats_median()
+                b.stats()
+            if batched:
+                B[0].median_batch(B)
+            else:
+                for p, b in enumerate(B):
+                    lo = self.id_base(p)
+                    b.median(lo, lo + self.S - 1)
+            for b in B:
                 b.mask_annotate()
-                b.hinges()
+            if batched:
+                B[0].hinges_batch(B)
+            else:
+                for b in B:
+                    b.hinges()
             return
-        for p, b in enumerate(B):
+        for b in B:
             b.begin()
-            b.stats_median(out=self.hist[p])
+            b.stats()
+        if batched:
+            B[0].median_batch(B, hist=self.hist)
+        else:
+            for p, b in enumerate(B):
+                lo = self.id_base(p)
+                b.median_hist(lo, lo + self.S - 1, out=self.hist[p])
         # exchange 1, all parts at once.  Not asynchronous: nothing can run under it, and a synchronous collective is enqueued
         # on the calling stream's order without the event hand-over between streams an asynchronous handle costs
         _all_reduce_sum(self.hist, self.group, self.staged, async_op=False)
-        batched = hasattr(B[0], "median_from_hist_batch")
         if batched:
             B[0].median_from_hist_batch(B, self.hist)                                   # one launch for all parts
         pending = []
@@ -430,8 +447,11 @@ class PartBatch:
                 keep = self.masks[gi][own].clone()
                 self.masks[gi].zero_()
                 self.masks[gi][own] = keep
-            for p in g:
-                B[p].hinges()
+            if batched:
+                B[g[0]].hinges_batch([B[p] for p in g])
+            else:
+                for p in g:
+                    B[p].hinges()
 
     def settle(self, max_rounds: int = 4) -> None:
         """Whole steps until no rank reports a full device buffer (HINGE_E_CAPACITY anywhere: every rank regrows, every rank
@@ -623,6 +643,15 @@ class HipBackend:
 
     def median_from_hist(self, hist: torch.Tensor):
         self.ctx.filter_median_from_hist(self.p, hist)
+
+    def median_batch(self, backends, hist: Optional[torch.Tensor] = None):
+        """Every part's median over its own reads in one launch; hist ([R, 4096 + 2], contiguous): the histogram form."""
+        from . import capi
+        capi.median_batch([b.ctx for b in backends], self.p, hist, 0 if hist is None else int(hist.stride(0)))
+
+    def hinges_batch(self, backends):
+        from . import capi
+        capi.hinges_batch_async([b.ctx for b in backends], self.p)
 
     def median_from_hist_batch(self, backends, hist: torch.Tensor):
         """All of a rank's parts at once: backend k takes row k of hist ([R, 4096 + 2], contiguous)."""

@@ -130,6 +130,11 @@ int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, 
  * histogram is hist_dev + k * row_stride (uint32 words, row_stride >= 4096 + 2), its context ctxs[k].  The contexts share one
  * device and one stream; n <= 16.                                                                                              */
 int hinge_filter_median_from_hist_batch(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p, const uint32_t* hist_dev, int64_t row_stride);
+/* The median of each of n resident parts over its OWN reads [r_begin, r_end] in ONE launch (the kernel is a chain of dependent
+ * round trips, ~16 us whatever the part's size: paid once for all parts).  hist_dev == NULL: as hinge_filter_median without
+ * `out` for every part.  hist_dev != NULL: as hinge_filter_median_hist, part k's histogram at hist_dev + k * row_stride.
+ * The contexts share one device and one stream; n <= 16.                                                                    */
+int hinge_filter_median_batch(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p, uint32_t* hist_dev, int64_t row_stride);
 /* --restrictreads (filter.cpp:680-694,767-773): keep[n_reads], 0 = the read's coverage and QV masks are emptied
  * (maxend = maxstart, QV.second = QV.first) before the mask is formed; NULL = no restriction.  The caller builds the
  * set (the listed reads plus every B read they overlap).                                                             */
@@ -233,6 +238,9 @@ int hinge_select_edges(hinge_ctx* ctx, int32_t n_reads, const uint8_t* read_acti
  * itself asynchronous); check reports the HINGE_E_* flags raised since then.                       */
 int hinge_filter_mask_annotate_async(hinge_ctx* ctx, const hinge_filter_params* p);
 int hinge_filter_hinges_async(hinge_ctx* ctx, const hinge_filter_params* p);
+/* hinge_filter_hinges_async for n resident parts (contexts on one device and one stream, n <= 8) in one launch per kernel:
+ * hinge calling touches 1-2 % of the reads through chains of dependent look-ups, ~19 us per kernel however small the part.   */
+int hinge_filter_hinges_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p);
 int hinge_filter_check(hinge_ctx* ctx);
 
 /* Per-kernel timing with HIP events recorded around every launch on the context's stream.

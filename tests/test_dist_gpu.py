@@ -224,6 +224,45 @@ def test_part_batch_hip_rccl_forced(oracle_lib):
         _spawn(_batch_worker, 1, (34900 + (os.getpid() % 1500) + G, "nccl", "chimera", R, G, True, want))
 
 
+def test_part_batch_mixed_parts_share_launches(oracle_lib):
+    """One rank, no collectives: four very different resident parts (a 450x data set whose pile-ups need the large instance of
+    k_hinge_call, heavy ties, chimeric reads, a small one) go through ONE median launch and ONE launch per hinge kernel; every
+    part gives its own oracle answer, pass after pass."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_bench_expect as mbe
+    from hinge_amd import benchsets, synth
+    from hinge_amd.config import default_filter_params
+    from hinge_amd.dist import resident_batch
+    names = ["deep", "ties", "chimera", "tiny"]
+    parts, want = [], []
+    for name in names:
+        d = synth.generate(synth.CONFIGS[name])
+        parts.append(benchsets.rank_part(synth.CONFIGS[name], 1, 0, 0, data=d))
+        rows, _, _ = mbe.run_oracle(oracle_lib, d, BATCH_INI)
+        want.append(mbe.entry(rows, 0, d.n_reads))
+    assert all(w["hinges"] > 0 for w in want)
+    dev = torch.device("cuda", 0)
+    batch, ctxs = resident_batch(parts, default_filter_params(), dev, pad=5)
+    assert not batch.collectives
+    assert ctxs[0].pileup_facts()[0] > 2048, "the deep part should need the large k_hinge_call instance"
+    for c in ctxs:                                   # the synchronous entry points size every part's buffers once
+        c.filter_stats_median(default_filter_params(), fetch=True)
+        c.filter_mask_annotate(default_filter_params())
+        c.filter_hinges(default_filter_params())
+    for rep in range(3):
+        batch.step()
+        batch.status()
+        lists = [t.cpu().numpy() for t in batch.hinge_lists()]
+        for p in range(len(names)):
+            loc = lists[p].astype(np.int64)
+            loc[:, 0] -= batch.id_base(p)
+            got = {"hinges": int(len(loc)), "digest": benchsets.digest(loc)}
+            assert got == want[p], (rep, names[p], got, want[p])
+        used = [c.heavy_items() for c in ctxs]
+    assert used[0][1] > 0, "no annotation of the deep part reached the large instance: %s" % (used,)
+
+
 # ---- bench.py itself with two ranks, and with a deliberately broken exchange 2 ---------------------------------------------
 def _run_bench(extra_env, workload="chimera", nproc=2):
     env = dict(os.environ)

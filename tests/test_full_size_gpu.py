@@ -36,3 +36,17 @@ def test_other_baseline_configs_through_the_executables(oracle_lib, name, genome
     spec = dataclasses.replace(synth.CONFIGS[name], genome_len=genome if os.environ.get("HINGE_SMALL") == "1" else full)
     res = fuzz_pipeline.run_case(0, spec, "", "", oracle_lib, "")
     assert res.startswith("ok"), res
+
+
+@pytest.mark.skipif(os.environ.get("HINGE_FULL_SIZE") != "1", reason="several minutes of single-thread oracle: HINGE_FULL_SIZE=1 (run once per round, log under profiles/)")
+@pytest.mark.parametrize("name", ["cfg3_nctc", "cfg4_yeast"])
+def test_configs_3_and_4_at_their_full_size(oracle_lib, name):
+    """BASELINE configs 3 (NCTC-like: 5 Mb at 100x, 40 repeat families, chimeric reads) and 4 (yeast-like: 12 Mb at 80x, 8 DB
+    blocks, --mlas over one rank per visible GPU) at their OWN size through all three executables, 20 output files against the
+    oracle byte for byte."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_pipeline
+    from hinge_amd import synth
+    res = fuzz_pipeline.run_case(0, synth.CONFIGS[name], "", "", oracle_lib, "")
+    assert res.startswith("ok"), res
+    print(name, res)
