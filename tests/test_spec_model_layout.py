@@ -20,7 +20,8 @@ def _layout_primitives(lib):
         tr = np.ascontiguousarray(trace, dtype=np.uint16)
         out = np.zeros(10, np.int32)
         lib.oracle_process_alignment(hdr.ctypes.data_as(ip), tr.ctypes.data_as(u16p), len(tr), aln_threshold, theta, theta2, out.ctypes.data_as(ip))
-        return {"eff_ab": int(out[0]), "eff_ae": int(out[1]), "type": int(out[4]), "active": bool(out[5]), "weight": int(out[6])}
+        return {"eff_ab": int(out[0]), "eff_ae": int(out[1]), "eff_bb": int(out[2]), "eff_be": int(out[3]), "type": int(out[4]), "active": bool(out[5]),
+                "weight": int(out[6]), "length": int(out[7])}
 
     def matching_position(raw, comp, trace, pos):
         tr = np.ascontiguousarray(trace, dtype=np.uint16)
@@ -30,7 +31,7 @@ def _layout_primitives(lib):
 
 
 @pytest.mark.parametrize("name,mlas,layout_ini", [("tiny", False, ""), ("tiny_mlas", True, ""), ("ties", False, ""), ("chimera", False, ""),
-                                                   ("long_repeat", False, "min_connected_component_size = 3\nmatching_hinge_slack = 400\n"),
+                                                   ("long_repeat", False, "min_connected_component_size = 3\nmatching_hinge_slack = 400\nhinge_slack = 200\nhinge_tolerance = 300\n"),
                                                    ("tspace200", False, "kill_hinge_overlap = 100\nkill_hinge_internal = 10\nuse_two_matches = 0\n")])
 def test_layout_hinge_bookkeeping_agrees_with_the_oracle(datasets, oracle_lib, tmp_path, name, mlas, layout_ini):
     from hinge_amd import formats
@@ -58,7 +59,8 @@ def test_layout_hinge_bookkeeping_agrees_with_the_oracle(datasets, oracle_lib, t
          "kill_hinge_overlap": ini.get_int("layout", "kill_hinge_overlap", 300), "kill_hinge_internal": ini.get_int("layout", "kill_hinge_internal", 40),
          "matching_hinge_slack": ini.get_int("layout", "matching_hinge_slack", 200),
          "min_connected_component_size": ini.get_int("layout", "min_connected_component_size", 8),
-         "use_two_matches": bool(ini.get_int("layout", "use_two_matches", 1))}
+         "use_two_matches": bool(ini.get_int("layout", "use_two_matches", 1)),
+         "hinge_tolerance": ini.get_int("layout", "hinge_tolerance", 150), "hinge_slack": ini.get_int("layout", "hinge_slack", 1000)}
     names = [os.path.join(wd, "G.%d.las" % (k + 1)) for k in range(d.spec.n_blocks)] if mlas else [os.path.join(wd, "G.las")]
     parts = [_part(formats.read_las(p), d.rlen) for p in names]
     got = spec_model_layout.layout_hinges(n, eff, maximal, repeats, hinges, parts, P, *_layout_primitives(oracle_lib))
@@ -68,4 +70,4 @@ def test_layout_hinge_bookkeeping_agrees_with_the_oracle(datasets, oracle_lib, t
         assert lines == want, "%s: %d lines, the oracle has %d; first difference at line %s" % (
             suffix, len(lines), len(want), next((k for k, (x, y) in enumerate(zip(lines, want)) if x != y), min(len(lines), len(want))))
         nonempty += len(want) > 0
-    assert len(got[".hgraph"]) > 0 and nonempty >= 3
+    assert len(got[".hgraph"]) > 0 and len(got[".edges.hinges"]) > 0 and nonempty >= 5
