@@ -46,7 +46,7 @@ __device__ __forceinline__ int slice_len(int n) { return ((n + 4 * WAVE - 1) / (
 struct HingePart {
     const int64_t* row_ptr; const int2* a_span; const int2* b_span; const unsigned* b_flag; const int2* mask;
     const int2* anno_buf; const unsigned* anno_off; const int* anno_cnt;
-    const WorkItem* work_list; const unsigned* counters;
+    const WorkItem* work_list; unsigned work_cap; const unsigned* counters;
     unsigned char* hinge_flag;
     HeavyItem* heavy; unsigned* heavy_count; unsigned* heavy_count_big; unsigned heavy_cap;
     int2* exact_queue; unsigned* exact_count; unsigned exact_cap;
@@ -101,13 +101,17 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned nwork = counters[1];
     if (bx >= gx) return;   // (a grid that is not a multiple of the parts: the surplus workgroups have no share)
+    // The kernel is a chain of dependent memory round trips (~2 us each) per read, so every link counts: the first work item is
+    // fetched together with the number of items (the list has work_cap slots: the read is legal whether or not the slot is in use)
+    WorkItem wi_first;
+    if (bx < A.work_cap) wi_first = work_list[bx];
+    const unsigned nwork = counters[1];
     for (unsigned w = bx; w < nwork; w += gx) {   // one workgroup per work-list read
 #ifdef HINGE_TIMING
         const unsigned long long tc0 = wall_clock64();
 #endif
-        const WorkItem wi = work_list[w];
+        const WorkItem wi = w == bx ? wi_first : work_list[w];
         const int i = wi.read;
         const int64_t s = wi.row, e = wi.row + wi.n;
         const int2 mk = make_int2(wi.mask_lo, wi.mask_hi);
@@ -128,10 +132,15 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
                 int2 av[GATHER_LOADS], bs[GATHER_LOADS], mb[GATHER_LOADS];
                 unsigned bf[GATHER_LOADS];
                 bool nearw[GATHER_LOADS];
+                // (the B-side fields are loaded with the spans, needed or not: 12 more bytes per overlap of a work-list read - 1-2 % of
+                // the part - buy one dependent round trip less per batch)
 #pragma unroll
                 for (int u = 0; u < GATHER_LOADS; u++) {
                     const int64_t k = k0 + u * WAVE + lane;
-                    av[u] = k < k_hi ? a_span[k] : make_int2(0, 0);
+                    const bool in = k < k_hi;
+                    av[u] = in ? a_span[k] : make_int2(0, 0);
+                    bf[u] = in ? b_flag[k] : 0u;
+                    bs[u] = in ? b_span[k] : make_int2(0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < GATHER_LOADS; u++) {
@@ -144,8 +153,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
                         nr = nr || ((c > apos[a] - P.tol) && (c < apos[a] + P.tol));
                     }
                     nearw[u] = nr && k < k_hi;
-                    bf[u] = nearw[u] ? b_flag[k] : 0u;
-                    bs[u] = nearw[u] ? b_span[k] : make_int2(0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < GATHER_LOADS; u++) mb[u] = nearw[u] ? mask[bf[u] & 0x7fffffffu] : make_int2(0, 0);
@@ -273,9 +280,12 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                     unsigned bf[GATHER_LOADS];
                     bool nearw[GATHER_LOADS];
 #pragma unroll
-                    for (int u = 0; u < GATHER_LOADS; u++) {
+                    for (int u = 0; u < GATHER_LOADS; u++) {   // (B-side fields with the spans, needed or not: one round trip less)
                         const int64_t k = k0 + u * WAVE + lane;
-                        av[u] = k < k_hi ? a_span[k] : make_int2(0, 0);
+                        const bool in = k < k_hi;
+                        av[u] = in ? a_span[k] : make_int2(0, 0);
+                        bf[u] = in ? b_flag[k] : 0u;
+                        bs[u] = in ? b_span[k] : make_int2(0, 0);
                     }
                     if (k0 == k_lo) {   // the sort-free evaluation's bins are cleared while the first loads are in flight
                         int4* z23 = reinterpret_cast<int4*>(bin23);
@@ -288,8 +298,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                         const int64_t k = k0 + u * WAVE + lane;
                         const int c = type == -1 ? av[u].y : av[u].x;
                         nearw[u] = k < k_hi && (c > pos - P.tol) && (c < pos + P.tol);
-                        bf[u] = nearw[u] ? b_flag[k] : 0u;
-                        bs[u] = nearw[u] ? b_span[k] : make_int2(0, 0);
                     }
 #pragma unroll
                     for (int u = 0; u < GATHER_LOADS; u++) mb[u] = nearw[u] ? mask[bf[u] & 0x7fffffffu] : make_int2(0, 0);

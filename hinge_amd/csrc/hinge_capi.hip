@@ -931,7 +931,7 @@ static HingePart hinge_part_of(hinge_ctx* ctx) {
     a.row_ptr = (const int64_t*)ctx->row_ptr.p; a.a_span = (const int2*)ctx->a_span.p; a.b_span = (const int2*)ctx->b_span.p;
     a.b_flag = (const unsigned*)ctx->b_flag.p; a.mask = (const int2*)ctx->mask;
     a.anno_buf = (const int2*)ctx->anno_buf.p; a.anno_off = (const unsigned*)ctx->anno_off.p; a.anno_cnt = (const int*)ctx->anno_cnt.p;
-    a.work_list = (const WorkItem*)ctx->work_list.p; a.counters = (const unsigned*)sc(ctx)->counters;
+    a.work_list = (const WorkItem*)ctx->work_list.p; a.work_cap = (unsigned)ctx->n_reads; a.counters = (const unsigned*)sc(ctx)->counters;
     a.hinge_flag = (unsigned char*)ctx->hinge_flag.p;
     a.heavy = (HeavyItem*)ctx->heavy_list.p; a.heavy_count = &sc(ctx)->heavy_count; a.heavy_count_big = &sc(ctx)->heavy_count_big; a.heavy_cap = ctx->anno_cap;
     a.exact_queue = (int2*)ctx->exact_queue.p; a.exact_count = &sc(ctx)->exact_count; a.exact_cap = ctx->exact_cap;
