@@ -93,6 +93,7 @@ SYMBOLS = [
     ("hinge_profile_kernel_name", C.c_char_p, [C.c_int]),
     ("hinge_resolve_containment", C.c_int, [C.c_int32, _VP, C.c_int64, _VP, _VP]),
     ("hinge_sort_order_desc", C.c_int, [C.c_int32, _VP, C.c_int32, _VP]),
+    ("hinge_pick_pairs", C.c_int64, [C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
     ("hinge_profile_report", C.c_int, [_VP, _VP, _VP]),
     ("hinge_timer_start", C.c_int, [_VP]),
     ("hinge_timer_stop_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -514,6 +515,28 @@ def pack_spans(row_ptr: np.ndarray, a_span: np.ndarray, rlen: np.ndarray):
         span16 = np.zeros(n + span16_pad(), np.uint32)
         span16[:n] = a_span[:, 0].astype(np.uint32) | (a_span[:, 1].astype(np.uint32) << np.uint32(16))
     return span16, min(max_pile, 0x7FFFFFFF), in_range
+
+
+def pick_pairs(row_ptr, a_span, b_span, b_flag, lo: int, hi: int, accept_a=None, accept_b=None, self_before=None,
+               two_matches: bool = True, n_sorts: int = 2):
+    """hinge_pick_pairs: (sel, a_of) - the overlaps the reference classifies for the reads [lo, hi), in its own order."""
+    lib = load_library()
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    a_span = np.ascontiguousarray(a_span, dtype=np.int32)
+    b_span = np.ascontiguousarray(b_span, dtype=np.int32)
+    b_flag = np.ascontiguousarray(b_flag, dtype=np.uint32)
+    n = len(row_ptr) - 1
+    u8 = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.uint8)
+    accept_a, accept_b = u8(accept_a), u8(accept_b)
+    sb = None if self_before is None else np.ascontiguousarray(self_before, dtype=np.int32)
+    args = (n, _ptr(row_ptr), _ptr(a_span), _ptr(b_span), _ptr(b_flag), _ptr(sb), _ptr(accept_a), _ptr(accept_b), int(lo), int(hi), 1 if two_matches else 0, int(n_sorts))
+    cnt = lib.hinge_pick_pairs(*args, None, None, 0)
+    if cnt < 0:
+        raise HingeError(int(cnt), "hinge_pick_pairs: malformed pile-up arrays")
+    sel = np.zeros(max(cnt, 1), np.int64)
+    a_of = np.zeros(max(cnt, 1), np.int32)
+    lib.hinge_pick_pairs(*args, _ptr(sel), _ptr(a_of), cnt)
+    return sel[:cnt], a_of[:cnt]
 
 
 def sort_order_desc(keys: np.ndarray, n_sorts: int = 1) -> np.ndarray:

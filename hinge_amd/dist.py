@@ -680,39 +680,19 @@ class HipBackend:
 
 # ---- hinge maximal ---------------------------------------------------------------------------------------------
 def pick_best_pairs(row_ptr: np.ndarray, a_span: np.ndarray, b_span: np.ndarray, b_flag: np.ndarray, lo: int, hi: int,
-                    active: np.ndarray, use_two_matches: bool = True) -> Tuple[np.ndarray, np.ndarray]:
-    """The overlaps `hinge maximal` classifies for the reads [lo, hi) of a block: for every (A, B) pair of an active A
-    read the longest overlap, and the second longest with use_two_matches (maximal.cpp:790-805; longest = std::sort by
-    compare_overlap, i.e. descending aepos - abpos + bepos - bbpos).  Returns (sel, a_of): indices into the pile-up
-    arrays, grouped by ascending A; inside a group of A by ascending B (the `get_maximal_reads` executable walks the pairs
-    in the reference's hash-map order instead, which only .contained.txt's "last container" column depends on)."""
-    s, e = int(row_ptr[lo]), int(row_ptr[hi])
-    idx = np.arange(s, e, dtype=np.int64)
-    a_of = (np.searchsorted(row_ptr, idx, side="right") - 1).astype(np.int32)
-    keep = active[a_of].astype(bool)
-    idx, a_of = idx[keep], a_of[keep]
-    b = (b_flag[idx] & np.uint32(0x7FFFFFFF)).astype(np.int64)
-    length = (a_span[idx, 1].astype(np.int64) - a_span[idx, 0] + b_span[idx, 1] - b_span[idx, 0])
-    order = np.lexsort((-length, b, a_of))            # stable: equal lengths keep file order
-    idx, a_of, b, length = idx[order], a_of[order], b[order], length[order]
-    key = a_of.astype(np.int64) * (int(b.max()) + 1 if len(b) else 1) + b
-    first = np.ones(len(key), bool)
-    first[1:] = key[1:] != key[:-1]
-    start = np.nonzero(first)[0]
-    sizes = np.diff(np.append(start, len(key)))
-    if len(sizes) and sizes.max() > 16:
-        # libstdc++'s std::sort is an insertion sort - stable, what the lexsort above gives - only up to 16 elements; a larger
-        # pair vector is put in the order the reference's two std::sort calls in a row leave it in (hinge_sort_order_desc runs
-        # the same std::sort on the same sequence: the vector in record order)
-        from . import capi
-        for g in np.nonzero(sizes > 16)[0]:
-            s0, n = int(start[g]), int(sizes[g])
-            rec = np.argsort(idx[s0:s0 + n], kind="stable")                  # the pair's overlaps in record order
-            rec_idx, rec_len = idx[s0:s0 + n][rec], length[s0:s0 + n][rec]
-            idx[s0:s0 + n] = rec_idx[capi.sort_order_desc(rec_len, n_sorts=2)]
-    rank_in_group = np.arange(len(key)) - np.repeat(start, sizes)
-    take = rank_in_group < (2 if use_two_matches else 1)
-    return idx[take], a_of[take]
+                    active: np.ndarray, use_two_matches: bool = True, self_before: Optional[np.ndarray] = None,
+                    both_active: bool = False, n_sorts: int = 2) -> Tuple[np.ndarray, np.ndarray]:
+    """The overlaps `hinge maximal` (both_active = False, n_sorts = 2: maximal.cpp:615-654, 780-850) or `hinge layout`
+    (both_active = True, n_sorts = 1: hinging.cpp:478-602) classifies for the reads [lo, hi) of a block: for every (A, B) pair
+    of an active A read the longest overlap, and the second longest with use_two_matches (longest = std::sort by compare_overlap,
+    i.e. descending aepos - abpos + bepos - bbpos, equal lengths where libstdc++'s introsort leaves them).  Returns (sel, a_of):
+    indices into the pile-up arrays; reads ascending, the pairs of a read in the ITERATION ORDER of the reference's
+    std::unordered_map - the order `.contained.txt`'s container column and the tie order of the weight sort in layout depend on
+    (hinge_pick_pairs of the library runs the very container).  self_before: formats.Pileups.self_before."""
+    from . import capi
+    act = np.ascontiguousarray(active, dtype=np.uint8)
+    return capi.pick_pairs(row_ptr, a_span, b_span, b_flag, lo, hi, accept_a=act, accept_b=act if both_active else None,
+                           self_before=self_before, two_matches=use_two_matches, n_sorts=n_sorts)
 
 
 class ShardedMaximal:
@@ -721,18 +701,19 @@ class ShardedMaximal:
     read-id order), then every rank resolves containment over the gathered rows - a sequential pass in read-id order
     (a container of lower id counts with its final state, one of higher id with its initial state), the same for
     one merged .las and for the reference's --mlas loop because a read's pile-up lies in its own block.
-    Returns the maximal-read mask (uint8 [n_reads]).  (.contained.txt also names ONE container per removed read, the last
-    in the reference's hash-map order: that column stays with the `get_maximal_reads` executable.)"""
+    step() returns the maximal-read mask (uint8 [n_reads]); `containing` then holds, for every removed read, the container
+    `.contained.txt` names (the LAST covering B in the reference's hash-map order: the backends pick the pairs in that order)."""
 
     def __init__(self, backend, exchange: Exchange):
         self.b, self.x = backend, exchange
+        self.containing: Optional[np.ndarray] = None
 
     def step(self) -> np.ndarray:
         from . import capi
         rows, count = self.b.candidates()           # int32 [m, 2] on the exchange device, ascending a
         allrows = self.x.gather_lists(rows, count)   # exchange 4
         active = np.ascontiguousarray(self.b.initial_active(), dtype=np.uint8).copy()
-        capi.resolve_containment(active, allrows.cpu().numpy())
+        self.containing = capi.resolve_containment(active, allrows.cpu().numpy())
         return active
 
 
@@ -742,13 +723,15 @@ class HipMaximalBackend:
 
     def __init__(self, ctx, rlen: np.ndarray, eff: np.ndarray, r_begin: int, r_end: int, row_ptr: np.ndarray, a_span: np.ndarray,
                  b_span: np.ndarray, b_flag: np.ndarray, trace: np.ndarray, trace_off: np.ndarray, tlen: np.ndarray, tbytes: int,
-                 length_threshold: int, aln_threshold: int, theta: int, theta2: int, use_two_matches: bool, device: torch.device):
+                 length_threshold: int, aln_threshold: int, theta: int, theta2: int, use_two_matches: bool, device: torch.device,
+                 self_before: Optional[np.ndarray] = None):
         self.ctx = ctx
         self.lo, self.hi = r_begin, r_end + 1
         self.arr = (row_ptr, a_span, b_span, b_flag)
         self.thr = (int(aln_threshold), int(theta), int(theta2))
         self.use_two = bool(use_two_matches)
         self.device = device
+        self.self_before = self_before
         eff = np.ascontiguousarray(eff, dtype=np.int32).reshape(-1, 2)
         self.active0 = ((eff[:, 1] - eff[:, 0]) >= length_threshold).astype(np.uint8)   # maximal.cpp:560-563
         ctx.set_reads(rlen, None)
@@ -763,7 +746,7 @@ class HipMaximalBackend:
     def candidates(self):
         from . import capi
         row_ptr, a_span, b_span, b_flag = self.arr
-        sel, a_of = pick_best_pairs(row_ptr, a_span, b_span, b_flag, self.lo, self.hi, self.active0, self.use_two)
+        sel, a_of = pick_best_pairs(row_ptr, a_span, b_span, b_flag, self.lo, self.hi, self.active0, self.use_two, self_before=self.self_before)
         types = self.ctx.trim_classify_types(sel, a_of, *self.thr)
         hit = types == capi.MT_BCOVERA
         rows = np.stack([a_of[hit], (b_flag[sel[hit]] & np.uint32(0x7FFFFFFF)).astype(np.int32)], axis=1).astype(np.int32)

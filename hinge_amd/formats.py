@@ -288,6 +288,7 @@ class Pileups:
     las_index: np.ndarray   # int64 [n] index of the record in the .las file
     self_a: np.ndarray      # int32 [m] A id of the removed self-overlaps
     self_span: np.ndarray   # int32 [m, 4] abpos, aepos, bbpos', bepos'
+    self_before: np.ndarray = None   # int32 [n_reads]: -1, or the kept overlaps of the read in front of its first A == B record (_self_before)
 
     @property
     def n_ovl(self) -> int:
@@ -323,7 +324,23 @@ def pileups_from_las(recs: LasRecords, rlen: np.ndarray) -> Pileups:
         las_index=np.nonzero(keep)[0].astype(np.int64),
         self_a=r["aread"][is_self].astype(np.int32),
         self_span=self_span,
+        self_before=_self_before(r["aread"], is_self, n_reads),
     )
+
+
+def _self_before(aread: np.ndarray, is_self: np.ndarray, n_reads: int) -> np.ndarray:
+    """For every read: -1 if it has no A == B record, else how many of its OTHER records precede the first one in the file
+    (the key A takes part in the insertion order of the reference's (A, B) hash map: include/hinge_hip.h hinge_pick_pairs)."""
+    out = np.full(n_reads, -1, np.int32)
+    idx = np.nonzero(is_self)[0]
+    if len(idx):
+        kept_before = np.cumsum(~is_self) - (~is_self)          # kept records in front of record j
+        row_first = np.searchsorted(aread, aread[idx], side="left")
+        first_of_read = np.ones(len(idx), bool)
+        first_of_read[1:] = aread[idx][1:] != aread[idx][:-1]
+        sel = idx[first_of_read]
+        out[aread[sel]] = (kept_before[sel] - kept_before[row_first[first_of_read]]).astype(np.int32)
+    return out
 
 
 # ---- FASTA + PAF (the reference's second input mode: filter.cpp:289-291,499-503) -----------------------------

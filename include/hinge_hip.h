@@ -213,6 +213,18 @@ int hinge_resolve_containment(int32_t n_reads, uint8_t* active, int64_t n_pairs,
  * (aepos - abpos + bepos - bbpos, LAInterface.cpp:4884-4889) are key[0..n): descending keys, equal keys where libstdc++'s
  * introsort puts them (up to 16 elements it is an insertion sort, i.e. stable; beyond that it is not).                       */
 int hinge_sort_order_desc(int32_t n, const int64_t* key, int32_t n_sorts, int32_t* perm);
+/* Host side, no device work: the overlaps `hinge maximal` (maximal.cpp:615-654, 780-850) / `hinge layout` (hinging.cpp:478-602)
+ * hand to ProcessAlignment for the reads [lo, hi), in the reference's order: reads ascending; per read its (A, B) pairs in the
+ * ITERATION ORDER of the reference's std::unordered_map<int, std::vector<LOverlap*>> (same container, same insertion sequence);
+ * per pair the first one or two (two_matches) elements after std::sort(compare_overlap) was run n_sorts times (2 / 1).
+ * Arrays as in hinge_set_pileups (host pointers, row_ptr over all n_reads); self_before[a] (may be NULL) = -1, or the number of
+ * read a's kept overlaps that lie in front of its first A == B record in the .las (that record's key takes part in the map's
+ * insertion order); accept_a / accept_b (may be NULL): reads whose pairs are walked / B reads that are inserted at all
+ * (layout: both = the active reads; maximal: accept_a = the initially active reads).  Returns the number of picks (writes
+ * min(that, cap) of them to sel[] = overlap indices and a_of[]; sel == NULL only counts), or a negative HINGE_E_*.            */
+int64_t hinge_pick_pairs(int32_t n_reads, const int64_t* row_ptr, const int32_t* a_span, const int32_t* b_span, const uint32_t* b_flag,
+                         const int32_t* self_before, const uint8_t* accept_a, const uint8_t* accept_b, int32_t lo, int32_t hi,
+                         int32_t two_matches, int32_t n_sorts, int64_t* sel, int32_t* a_of, int64_t cap);
 /* LOverlap::GetMatchingPosition (LAInterface.cpp:4498-4546) for nq (overlap, position on A) queries.        */
 int hinge_matching_position(hinge_ctx* ctx, int64_t nq, const int64_t* q_ovl, const int32_t* q_pos, int32_t* out);
 

@@ -339,7 +339,7 @@ class OracleMaximalBackend:
         import ctypes
         from hinge_amd.dist import pick_best_pairs
         self.active0 = ((eff[:, 1] - eff[:, 0]) >= length_threshold).astype(np.uint8)
-        sel, a_of = pick_best_pairs(pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag, lo, hi, self.active0, use_two)
+        sel, a_of = pick_best_pairs(pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag, lo, hi, self.active0, use_two, self_before=pile.self_before)
         ip, u16p = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint16)
         toff = recs.trace_off[:-1][pile.las_index]
         tlen = recs.rec["tlen"][pile.las_index]
@@ -363,7 +363,7 @@ class OracleMaximalBackend:
         return t, int(t.shape[0])
 
 
-def _maximal_worker(rank, world, port, wd, first, rlen, want_active, ret):
+def _maximal_worker(rank, world, port, wd, first, rlen, want_active, want_contained, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -380,6 +380,8 @@ def _maximal_worker(rank, world, port, wd, first, rlen, want_active, ret):
         job = ShardedMaximal(be, Exchange(BlockTable(first), torch.device("cpu")))
         active = job.step()
         assert np.array_equal(active, want_active), "maximal-read mask"
+        got = ["%d\t%d" % (i, c) for i, c in enumerate(job.containing) if c >= 0]
+        assert got == want_contained, ".contained.txt (the container named is the last covering B in the reference's hash-map order)"
         ret[rank] = int(active.sum())
     finally:
         dist.destroy_process_group()
@@ -403,7 +405,9 @@ def test_sharded_maximal_mask(oracle_lib, tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_maximal_worker, args=(2, port, wd, list(d.block_first), d.rlen, want, ret), nprocs=2, join=True)
+    want_contained = open(os.path.join(wd, "G.contained.txt")).read().split("\n")[:-1]
+    assert len(want_contained) > 10
+    mp.spawn(_maximal_worker, args=(2, port, wd, list(d.block_first), d.rlen, want, want_contained, ret), nprocs=2, join=True)
     assert dict(ret) == {0: int(want.sum()), 1: int(want.sum())}
 
 
@@ -442,9 +446,16 @@ def test_pick_best_pairs_replays_std_sort_beyond_16(oracle_lib):
         k = rng.integers(0, 6, n).astype(np.int64) * 100
         once, twice = oracle_twice(k)
         assert np.array_equal(capi.sort_order_desc(k, 1), once) and np.array_equal(capi.sort_order_desc(k, 2), twice), n
+    oracle_lib.oracle_umap_order.argtypes = [ctypes.c_int, ip, ip]
+
+    def umap_order(keys):
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        out = np.zeros(len(k), np.int32)
+        n = oracle_lib.oracle_umap_order(len(k), k.ctypes.data_as(ip), out.ctypes.data_as(ip))
+        return out[:n].tolist()
+
     differ = 0
     for trial in range(20):
-        sizes = [40, 5, 2, 100]
         row_ptr = np.array([0, 45, 45, 147, 147], np.int64)               # read 0: pairs with B = 2 (40) and B = 3 (5); read 2: B = 0 (2), B = 1 (100)
         b_flag = np.concatenate([np.full(40, 2), np.full(5, 3), np.full(2, 0), np.full(100, 1)]).astype(np.uint32)
         ab = rng.integers(0, 5, 147).astype(np.int32) * 100
@@ -452,12 +463,14 @@ def test_pick_best_pairs_replays_std_sort_beyond_16(oracle_lib):
         sel, a_of = dist.pick_best_pairs(row_ptr, a_span, a_span.copy(), b_flag, 0, 4, np.ones(4, np.uint8), True)
         assert list(a_of) == [0, 0, 0, 0, 2, 2, 2, 2]
         L = (a_span[:, 1] - a_span[:, 0]).astype(np.int64) * 2
+        group = {(0, 2): (0, 40), (0, 3): (40, 5), (2, 0): (45, 2), (2, 1): (47, 100)}
         want = []
-        for s0, n in ((0, 40), (40, 5), (45, 2), (47, 100)):
-            _, twice = oracle_twice(L[s0:s0 + n])
-            want += [s0 + int(twice[0]), s0 + int(twice[1])]
-        want = want[:4] + want[4:]            # groups of one A come in ascending B
+        for a, keys in ((0, [2, 3]), (2, [0, 1])):
+            for bid in umap_order(keys):                                   # the pairs of a read in the hash map's iteration order
+                s0, n = group[(a, bid)]
+                _, twice = oracle_twice(L[s0:s0 + n])
+                want += [s0 + int(twice[0]), s0 + int(twice[1])]
         assert list(sel) == want, (trial, list(sel), want)
-        stable = [s0 + int(np.argsort(-L[s0:s0 + n], kind="stable")[1]) for s0, n in ((0, 40), (47, 100))]
-        differ += [want[1], want[7]] != stable
+        stable = sorted(s0 + int(np.argsort(-L[s0:s0 + n], kind="stable")[1]) for s0, n in ((0, 40), (47, 100)))
+        differ += not set(stable) <= set(want)
     assert differ > 0, "no case in which the introsort order differs from a stable sort"
