@@ -752,3 +752,93 @@ class HipMaximalBackend:
         rows = np.stack([a_of[hit], (b_flag[sel[hit]] & np.uint32(0x7FFFFFFF)).astype(np.int32)], axis=1).astype(np.int32)
         t = torch.from_numpy(np.ascontiguousarray(rows.reshape(-1, 2))).to(self.device)
         return t, int(t.shape[0])
+
+
+# ---- hinge layout ----------------------------------------------------------------------------------------------
+class ShardedLayout:
+    """One rank's share of a sharded `hinge layout` ("layout's selection shards by A again; edges are gathered to
+    rank 0").  Reads shard by DB block as in the other stages; hinge_amd/layout.py holds the steps, this class the exchanges:
+
+      exchange 5  the classified matches of every block (72 bytes each, a few thousand per block) -> every rank: the hinge
+                  bookkeeping of hinging.cpp:1262-1675 is global and sequential, and small - every rank runs it on the same rows
+      exchange 6  GetMatchingPosition of the block's hinges through its matches (32 bytes per query) -> every rank
+      exchange 7  the edges each rank selected for its own reads (k_select_edges) -> rank 0, which prints them in read order
+
+    step() returns the output files as {suffix: lines} (on every rank; only rank 0 needs them).  `backend`: per-block compute
+    (HipLayoutBackend: k_trim_classify, k_matching_position, k_select_edges through the C ABI)."""
+
+    def __init__(self, backend, exchange: Exchange, params, eff: np.ndarray, maximal: np.ndarray, repeats, hinges):
+        self.b, self.x, self.P = backend, exchange, params
+        self.eff = np.asarray(eff, dtype=np.int64).reshape(-1, 2)
+        self.maximal, self.repeats, self.hinges = maximal, repeats, hinges
+
+    def _gather(self, rows: np.ndarray) -> np.ndarray:
+        t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(self.x.device)
+        return self.x.gather_lists(t, int(t.shape[0])).cpu().numpy()
+
+    def step(self):
+        from . import layout as L
+        x, P = self.x, self.P
+        n = x.blocks.n_reads
+        lo, hi = x.my_range
+        active, garbage = L.initial_activity(self.eff, self.maximal, P)
+        mine, contained = self.b.matches(lo, hi, active, P)
+        rows = self._gather(mine)                                                           # exchange 5
+        gone = self._gather(np.array(contained, np.int32).reshape(-1, 1)).reshape(-1)       # "[contained] Should not happen" (:590-600)
+        active[gone] = 0
+        rows, off_fwd, off_bwd = L.weight_order(rows, n)
+        q, q_ovl, q_pos = L.hinge_queries(rows, off_fwd, off_bwd, lo, hi, active, self.hinges)
+        if len(q):
+            q[:, L.Q_POSB] = self.b.matching_positions(q_ovl, q_pos)
+        queries = self._gather(q)                                                           # exchange 6
+        book = L.bookkeeping(n, active, rows, off_fwd, off_bwd, queries, self.repeats, self.hinges, P)
+        # selection of this block's own reads: the other reads' lists are left out (their walks belong to their ranks)
+        own = np.zeros(n, bool)
+        own[lo:hi] = True
+        cnt_f = np.where(own, np.diff(off_fwd), 0)
+        cnt_b = np.where(own, np.diff(off_bwd), 0)
+        keep = np.concatenate([np.arange(off_fwd[i], off_fwd[i + 1]) for i in range(lo, hi)] + [np.arange(off_bwd[i], off_bwd[i + 1]) for i in range(lo, hi)]
+                              or [np.zeros(0, np.int64)]).astype(np.int64)
+        sub = rows[keep]
+        sf = np.concatenate([[0], np.cumsum(cnt_f)]).astype(np.int64)
+        sb = (np.concatenate([[0], np.cumsum(cnt_b)]) + int(cnt_f.sum())).astype(np.int64)
+        rec, h_off, h_rec, k_off, k_rec = L.selection_tables(n, sub, self.hinges, book["h_active"], book["new_killed"])
+        chosen, hpos, poison = self.b.select(active, sf, sb, rec, h_off, h_rec, k_off, k_rec, P.hinge_tolerance, P.hinge_slack)
+        # exchange 7: per own read and direction (read, direction, row picked in the GLOBAL row array or -1, hinge_pos), then the poison hits
+        picks = np.array([(i, d, int(keep[chosen[d][i]]) if chosen[d][i] >= 0 else -1, int(hpos[d][i])) for i in range(lo, hi) for d in (0, 1)],
+                         np.int32).reshape(-1, 4)
+        hits = np.array([(int(keep[j]), int(poison[j])) for j in np.nonzero(poison)[0]], np.int32).reshape(-1, 2)
+        picks, hits = self._gather(picks), self._gather(hits)
+        chosen_all = np.full((2, n), -1, np.int64)
+        hpos_all = np.full((2, n), -1, np.int64)
+        chosen_all[picks[:, 1], picks[:, 0]] = picks[:, 2]
+        hpos_all[picks[:, 1], picks[:, 0]] = picks[:, 3]
+        poison_all = np.zeros(len(rows), np.int64)
+        poison_all[hits[:, 0]] = hits[:, 1]
+        return L.print_files(n, active, self.eff, rows, off_fwd, off_bwd, chosen_all, hpos_all, poison_all, self.hinges, book, garbage)
+
+
+class HipLayoutBackend:
+    """Per-block compute of `hinge layout` through libhinge_hip: the block's pile-ups and trace points resident on this rank's
+    GPU; ProcessAlignment (k_trim_classify), GetMatchingPosition (k_matching_position) and the selection (k_select_edges)."""
+
+    def __init__(self, ctx, rlen: np.ndarray, eff: np.ndarray, pile, trace: np.ndarray, trace_off: np.ndarray, tlen: np.ndarray, tbytes: int):
+        self.ctx, self.pile = ctx, pile
+        ctx.set_reads(rlen, None)
+        nz = np.nonzero(np.diff(pile.row_ptr))[0]            # the block's A range: first and last read with an overlap
+        r_begin, r_end = (int(nz[0]), int(nz[-1])) if len(nz) else (0, 0)
+        ctx.set_pileups(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+        ctx.set_trim(True)
+        ctx.set_traces(trace, trace_off, tlen, tbytes)
+        ctx.set_eff_reads(np.ascontiguousarray(eff, dtype=np.int32).reshape(-1, 2))
+
+    def matches(self, lo: int, hi: int, active: np.ndarray, P):
+        from . import layout as L
+        classify = lambda sel, a_of: self.ctx.trim_classify(sel, a_of, P.aln_threshold, P.theta, P.theta2)
+        return L.block_matches(classify, self.pile, lo, hi, active, P)
+
+    def matching_positions(self, q_ovl: np.ndarray, q_pos: np.ndarray) -> np.ndarray:
+        return self.ctx.matching_position(q_ovl, q_pos)
+
+    def select(self, active, off_fwd, off_bwd, rec, h_off, h_rec, k_off, k_rec, tolerance: int, slack: int):
+        return self.ctx.select_edges(active, off_fwd, off_bwd, rec, h_off, h_rec, k_off, k_rec, tolerance, slack)

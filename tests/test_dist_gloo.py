@@ -474,3 +474,123 @@ def test_pick_best_pairs_replays_std_sort_beyond_16(oracle_lib):
         stable = sorted(s0 + int(np.argsort(-L[s0:s0 + n], kind="stable")[1]) for s0, n in ((0, 40), (47, 100)))
         differ += not set(stable) <= set(want)
     assert differ > 0, "no case in which the introsort order differs from a stable sort"
+
+
+# ---- sharded `hinge layout`: exchanges 5-7 around the host steps of hinge_amd/layout.py -----------------------------------------
+LAYOUT_FILES = [".garbage.txt", ".killed.hinges", ".hgraph", ".hinge.list", ".edges.hinges", ".edges.hinges2", ".edges.skipped", ".deadends.txt"]
+
+
+class OracleLayoutBackend:
+    """Stands in for HipLayoutBackend on CPU: ProcessAlignment and GetMatchingPosition overlap by overlap through the CPU oracle
+    (both pinned to the reference's compiled code), the selection through the statement-level restatement of
+    hinging.cpp:1911-2148 that tests/test_select_gpu.py holds k_select_edges against."""
+
+    def __init__(self, oracle_lib, pile, recs, eff):
+        self.lib, self.pile, self.recs, self.eff = oracle_lib, pile, recs, eff
+        self.toff = recs.trace_off[:-1][pile.las_index]
+        self.tlen = recs.rec["tlen"][pile.las_index]
+
+    def _trace(self, k):
+        return self.recs.trace[self.toff[k]:self.toff[k] + self.tlen[k]].astype(np.uint16)
+
+    def matches(self, lo, hi, active, P):
+        import ctypes
+        from hinge_amd import layout as L
+        ip, u16p = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint16)
+        pile, eff = self.pile, self.eff
+
+        def classify(sel, a_of):
+            out = np.zeros((len(sel), 10), np.int32)
+            for n, (k, a) in enumerate(zip(sel, a_of)):
+                b = int(pile.b_flag[k] & 0x7FFFFFFF)
+                hdr = np.array([pile.a_span[k, 0], pile.a_span[k, 1], pile.b_span[k, 0], pile.b_span[k, 1], int(pile.b_flag[k] >> 31),
+                                eff[a][0], eff[a][1], eff[b][0], eff[b][1]], np.int32)
+                tr = self._trace(k)
+                self.lib.oracle_process_alignment(hdr.ctypes.data_as(ip), tr.ctypes.data_as(u16p), len(tr), P.aln_threshold, P.theta, P.theta2,
+                                                  out[n].ctypes.data_as(ip))
+            return out
+        return L.block_matches(classify, pile, lo, hi, active, P)
+
+    def matching_positions(self, q_ovl, q_pos):
+        import ctypes
+        u16p = ctypes.POINTER(ctypes.c_uint16)
+        pile = self.pile
+        out = np.zeros(len(q_ovl), np.int32)
+        for n, (k, pos) in enumerate(zip(q_ovl, q_pos)):
+            tr = self._trace(k)
+            out[n] = self.lib.oracle_matching_position(int(pile.a_span[k, 0]), int(pile.a_span[k, 1]), int(pile.b_span[k, 0]), int(pile.b_span[k, 1]),
+                                                       int(pile.b_flag[k] >> 31), tr.ctypes.data_as(u16p), len(tr), int(pos))
+        return out
+
+    def select(self, active, off_fwd, off_bwd, rec, h_off, h_rec, k_off, k_rec, tol, slack):
+        from test_select_gpu import reference_selection
+        n = len(active)
+        names = ("b", "comp", "type", "active", "weight", "eff_bb", "eff_be", "bb", "be")
+        mk = lambda j: dict(zip(names, (int(v) for v in rec[j])), gid=int(j))
+        fwd = [[mk(j) for j in range(int(off_fwd[i]), int(off_fwd[i + 1]))] for i in range(n)]
+        bwd = [[mk(j) for j in range(int(off_bwd[i]), int(off_bwd[i + 1]))] for i in range(n)]
+        hinges = [[tuple(int(v) for v in h_rec[q]) for q in range(int(h_off[i]), int(h_off[i + 1]))] for i in range(n)]
+        killed = [[tuple(int(v) for v in k_rec[q]) for q in range(int(k_off[i]), int(k_off[i + 1]))] for i in range(n)]
+        chosen, hp, skipped = reference_selection(active, fwd, bwd, hinges, killed, tol, slack)
+        poison = np.zeros(max(len(rec), 1), np.int32)
+        for g in skipped:
+            poison[g] += 1
+        return chosen, hp, poison[:len(rec)]
+
+
+def _layout_inputs(wd, n_read):
+    from hinge_amd import layout as L
+    from hinge_amd.config import IniFile
+    eff = np.zeros((n_read, 2), np.int64)
+    for line in open(os.path.join(wd, "G.mas")):
+        i, s, e = (int(t) for t in line.split())
+        eff[i] = (s, e)
+    maximal = np.zeros(n_read, bool)
+    for line in open(os.path.join(wd, "G.max")):
+        maximal[int(line)] = True
+    P = L.LayoutParams.from_ini(IniFile(os.path.join(wd, "nominal.ini")))
+    return eff, maximal, L.read_pairs_file(os.path.join(wd, "G.repeat.txt"), n_read), L.read_pairs_file(os.path.join(wd, "G.hinges.txt"), n_read), P
+
+
+def _layout_worker(rank, world, port, wd, first, rlen, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from hinge_amd import formats
+        from hinge_amd.dist import BlockTable, Exchange, ShardedLayout
+        n = len(rlen)
+        eff, maximal, repeats, hinges, P = _layout_inputs(wd, n)
+        recs = formats.read_las(os.path.join(wd, "G.%d.las" % (rank + 1)))          # this rank's block only
+        pile = formats.pileups_from_las(recs, rlen)
+        be = OracleLayoutBackend(oracle.oracle_lib(), pile, recs, eff.tolist())
+        job = ShardedLayout(be, Exchange(BlockTable(first), torch.device("cpu")), P, eff, maximal, repeats, hinges)
+        files = job.step()
+        bad = [f for f in LAYOUT_FILES if files[f] != open(os.path.join(wd, "G" + f)).read().split("\n")[:-1]]
+        assert not bad, "rank %d: %s differ from the oracle's" % (rank, bad)
+        ret[rank] = len(files[".edges.hinges"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_layout_files(oracle_lib, tmp_path):
+    """world 2: each rank classifies the active x active pairs of its own block, the matches and matching positions are gathered,
+    every rank runs the hinge bookkeeping, selects the edges of its own reads; the eight files equal the oracle's --mlas run."""
+    import dataclasses
+    from hinge_amd import synth
+    from conftest import write_ini
+    d = synth.generate(dataclasses.replace(synth.CONFIGS["tiny_mlas"], n_blocks=2))
+    wd = str(tmp_path / "data")
+    synth.write_dataset(d, wd, "G")
+    write_ini(os.path.join(wd, "nominal.ini"))
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G", 1, b"G", b"nominal.ini", b"") == 0
+    assert run_in(wd, oracle_lib.oracle_maximal, b"G", b"G", 1, b"G", b"nominal.ini") == 0
+    assert run_in(wd, oracle_lib.oracle_layout, b"G", b"G", 1, b"G", b"G", b"nominal.ini") == 0
+    n_edges = len(open(os.path.join(wd, "G.edges.hinges")).read().split("\n")) - 1
+    assert n_edges > 50 and os.path.getsize(os.path.join(wd, "G.hgraph")) > 0
+    port = 32900 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_layout_worker, args=(2, port, wd, list(d.block_first), d.rlen, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: n_edges, 1: n_edges}

@@ -142,6 +142,71 @@ def test_sharded_filter_hip_rccl_forced(oracle_lib, tmp_path, median):
     assert ret[0] > 0
 
 
+# ---- sharded `hinge layout` -------------------------------------------------------------------------------------------------
+LAYOUT_FILES = [".garbage.txt", ".killed.hinges", ".hgraph", ".hinge.list", ".edges.hinges", ".edges.hinges2", ".edges.skipped", ".deadends.txt"]
+
+
+def _layout_worker(rank, world, port, wd, first, mlas, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hinge_amd import capi, formats
+        from hinge_amd import layout as L
+        from hinge_amd.config import IniFile
+        from hinge_amd.dist import BlockTable, Exchange, HipLayoutBackend, ShardedLayout
+        rlen = formats.read_db_index(os.path.join(wd, "G"))["rlen"]
+        n = len(rlen)
+        eff = np.zeros((n, 2), np.int64)
+        for line in open(os.path.join(wd, "G.mas")):
+            i, s, e = (int(t) for t in line.split())
+            eff[i] = (s, e)
+        maximal = np.zeros(n, bool)
+        for line in open(os.path.join(wd, "G.max")):
+            maximal[int(line)] = True
+        P = L.LayoutParams.from_ini(IniFile(os.path.join(wd, "nominal.ini")))
+        repeats = L.read_pairs_file(os.path.join(wd, "G.repeat.txt"), n)
+        hinges = L.read_pairs_file(os.path.join(wd, "G.hinges.txt"), n)
+        recs = formats.read_las(os.path.join(wd, "G.%d.las" % (rank + 1)) if mlas else os.path.join(wd, "G.las"))
+        pile = formats.pileups_from_las(recs, rlen)
+        tb = 1 if recs.tspace <= formats.TRACE_XOVR else 2
+        be = HipLayoutBackend(capi.Context(0), rlen, eff, pile, recs.trace, recs.trace_off[:-1][pile.las_index], recs.rec["tlen"][pile.las_index], tb)
+        job = ShardedLayout(be, Exchange(BlockTable(first), dev), P, eff, maximal, repeats, hinges)
+        files = job.step()
+        bad = [f for f in LAYOUT_FILES if files[f] != open(os.path.join(wd, "G" + f)).read().split("\n")[:-1]]
+        assert not bad, "rank %d: %s differ from the oracle's" % (rank, bad)
+        ret[rank] = len(files[".edges.hinges"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("tiny_mlas", 3), ("tiny_mlas", 1), ("ties", 1), ("chimera", 1), ("tspace200", 1), ("edges", 1)])
+def test_sharded_layout_hip(oracle_lib, tmp_path, name, world):
+    """`hinge layout` as dist.ShardedLayout over HipLayoutBackend (k_trim_classify, k_matching_position, k_select_edges): three
+    ranks with one block each (exchanges 5-7 for real), and single-block runs on data sets with heavy ties, chimeric reads,
+    two-byte traces and A == B records; eight output files equal the oracle's."""
+    import dataclasses
+    from hinge_amd import synth
+    d = synth.generate(dataclasses.replace(synth.CONFIGS[name], n_blocks=world if world > 1 else 1))
+    wd = str(tmp_path / "data")
+    synth.write_dataset(d, wd, "G")
+    write_ini(os.path.join(wd, "nominal.ini"))
+    mlas = world > 1
+    las = b"G" if mlas else b"G.las"
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", las, int(mlas), b"G", b"nominal.ini", b"") == 0
+    assert run_in(wd, oracle_lib.oracle_maximal, b"G", las, int(mlas), b"G", b"nominal.ini") == 0
+    assert run_in(wd, oracle_lib.oracle_layout, b"G", las, int(mlas), b"G", b"G", b"nominal.ini") == 0
+    n_edges = len(open(os.path.join(wd, "G.edges.hinges")).read().split("\n")) - 1
+    assert n_edges > 20
+    first = list(d.block_first) if mlas else [0, d.n_reads]
+    ret = _spawn(_layout_worker, world, (35300 + (os.getpid() % 1500) + 7 * world + len(name), wd, first, mlas))
+    assert all(v == n_edges for v in ret.values())
+
+
 # ---- PartBatch: several parts per rank, exchanges batched (what bench.py runs) ---------------------------------------------
 BATCH_INI = ("[filter]\nlength_threshold = 1000;\naln_threshold = 1000;\nmin_cov = 5;\ncut_off = 300;\ntheta = 300;\n"
              "[layout]\nhinge_slack = 1000\nmin_connected_component_size = 8\n")
