@@ -407,7 +407,8 @@ class PartBatch:
                 for p, b in enumerate(B):
                     lo = self.id_base(p)
                     b.median(lo, lo + self.S - 1)
-            for b in B:
+            # (last part first: its span copy is what the statistics sweeps left in the 256 MiB Infinity Cache; -1.5 us per launch)
+            for b in (reversed(B) if os.environ.get("HINGE_K2_REVERSE", "1") == "1" else B):
                 b.mask_annotate()
             if batched:
                 B[0].hinges_batch(B)
