@@ -111,7 +111,8 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
 #ifdef HINGE_TIMING
         const unsigned long long tc0 = wall_clock64();
 #endif
-        const WorkItem wi = w == bx ? wi_first : work_list[w];
+        const WorkItem wi = wi_first;
+        if (w + gx < nwork) wi_first = work_list[w + gx];   // the next item travels while this one is worked on
         const int i = wi.read;
         const int64_t s = wi.row, e = wi.row + wi.n;
         const int2 mk = make_int2(wi.mask_lo, wi.mask_hi);
@@ -200,9 +201,10 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
                     it.base[0] = b1; it.base[1] = b2; it.base[2] = b3;
                     it.sup = psup; it.near_end = pnear; it.pad = 0;
                     it.n = (int)(e - s); it.row = s; it.mask_lo = mk.x; it.mask_hi = mk.y;
-                    {
-                        const int2 an = anno_buf[off + a0 + tid];
-                        it.pos = an.x; it.type = an.y;
+                    {   // (the annotation is in registers already - indexed by a lane-varying tid, so by selects - not a dependent re-load)
+                        static_assert(PRE_MAXA == 4, "select chain below");
+                        it.pos = tid == 0 ? apos[0] : tid == 1 ? apos[1] : tid == 2 ? apos[2] : apos[3];
+                        it.type = tid == 0 ? atype[0] : tid == 1 ? atype[1] : tid == 2 ? atype[2] : atype[3];
                     }
                     it.slot = off + a0 + tid;
                     // pile-ups that fit the half-size instance of k_hinge_call from the front, the others from the back

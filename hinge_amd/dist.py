@@ -645,19 +645,25 @@ class HipBackend:
     def median_from_hist(self, hist: torch.Tensor):
         self.ctx.filter_median_from_hist(self.p, hist)
 
+    MEDIAN_BATCH_MAX, HINGE_BATCH_MAX = 16, 8      # parts per launch the library takes (MED_BATCH_MAX, HINGE_BATCH_MAX)
+
     def median_batch(self, backends, hist: Optional[torch.Tensor] = None):
-        """Every part's median over its own reads in one launch; hist ([R, 4096 + 2], contiguous): the histogram form."""
+        """Every part's median over its own reads in one launch (per 16 parts); hist ([R, 4096 + 2], contiguous): the histogram form."""
         from . import capi
-        capi.median_batch([b.ctx for b in backends], self.p, hist, 0 if hist is None else int(hist.stride(0)))
+        for k in range(0, len(backends), self.MEDIAN_BATCH_MAX):
+            chunk = backends[k:k + self.MEDIAN_BATCH_MAX]
+            capi.median_batch([b.ctx for b in chunk], self.p, None if hist is None else hist[k:], 0 if hist is None else int(hist.stride(0)))
 
     def hinges_batch(self, backends):
         from . import capi
-        capi.hinges_batch_async([b.ctx for b in backends], self.p)
+        for k in range(0, len(backends), self.HINGE_BATCH_MAX):
+            capi.hinges_batch_async([b.ctx for b in backends[k:k + self.HINGE_BATCH_MAX]], self.p)
 
     def median_from_hist_batch(self, backends, hist: torch.Tensor):
-        """All of a rank's parts at once: backend k takes row k of hist ([R, 4096 + 2], contiguous)."""
+        """All of a rank's parts at once (per 16): backend k takes row k of hist ([R, 4096 + 2], contiguous)."""
         from . import capi
-        capi.median_from_hist_batch([b.ctx for b in backends], self.p, hist, int(hist.stride(0)))
+        for k in range(0, len(backends), self.MEDIAN_BATCH_MAX):
+            capi.median_from_hist_batch([b.ctx for b in backends[k:k + self.MEDIAN_BATCH_MAX]], self.p, hist[k:], int(hist.stride(0)))
 
     def set_min_cov(self, v: int):
         self.ctx.set_min_cov(v)
