@@ -165,3 +165,98 @@ def run_filter(db_name: str, las_base: str, prefix: str, config: str, mlas: bool
         if own_ctx:
             ctx.close()
     return rc
+
+
+def _read_mas(path: str, n_read: int) -> np.ndarray:
+    eff = np.zeros((n_read, 2), np.int64)
+    for line in open(path):
+        tok = line.split()
+        if len(tok) >= 3:
+            eff[int(tok[0])] = (int(tok[1]), int(tok[2]))
+    return eff
+
+
+def run_maximal(db_name: str, las_base: str, prefix: str, config: str, mlas: bool = False, device: int = 0) -> int:
+    """`hinge maximal --db DB --las LAS [--mlas] -x PREFIX --config INI`: writes PREFIX.max and PREFIX.contained.txt
+    (maximal.cpp:517-531, 780-878; the `.coverage.txt` rewrite of :659-685 is left to `hinge filter`'s file).  One process, one
+    GPU, part after part: the single-rank case of dist.ShardedMaximal."""
+    import torch
+    from . import capi
+    from .dist import BlockTable, Exchange, HipMaximalBackend, ShardedMaximal
+    try:
+        rlen = formats.read_db_index(db_name)["rlen"]
+    except OSError:
+        return 1
+    n = len(rlen)
+    names = las_list(las_base, mlas)
+    ini = IniFile(config)
+    if not names or ini.error < 0:
+        return 1
+    g = ini.get_int
+    eff = _read_mas(prefix + ".mas", n)
+    ctx = Context(device)
+    active = None
+    contained_lines, max_lines = [], []
+    try:
+        for name in names:
+            recs = formats.read_las(name)
+            if recs.novl == 0:
+                return 1
+            pile = formats.pileups_from_las(recs, rlen)
+            r_begin, r_end = int(recs.rec["aread"][0]), int(recs.rec["aread"][-1])
+            tb = 1 if recs.tspace <= formats.TRACE_XOVR else 2
+            be = HipMaximalBackend(ctx, rlen, eff, r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag, recs.trace,
+                                   recs.trace_off[:-1][pile.las_index], recs.rec["tlen"][pile.las_index], tb,
+                                   g("filter", "length_threshold", -1), g("filter", "aln_threshold", -1), g("filter", "theta", -1), g("filter", "theta2", 0),
+                                   bool(g("layout", "use_two_matches", 1)), torch.device("cuda", device), self_before=pile.self_before)   # (maximal.cpp:471 reads it from [layout])
+            if active is not None:      # the sequential --mlas loop: a read removed by an earlier part stays removed
+                be.active0 = (be.active0.astype(bool) & active.astype(bool)).astype(np.uint8)
+            job = ShardedMaximal(be, Exchange(BlockTable([0, n]), torch.device("cuda", device)))
+            active = job.step()
+            contained_lines += ["%d\t%d" % (i, c) for i, c in enumerate(job.containing) if c >= 0]
+            max_lines += ["%d" % i for i in range(r_begin, r_end + 1) if active[i]]
+    finally:
+        ctx.close()
+    open(prefix + ".contained.txt", "w").write("".join(l + "\n" for l in contained_lines))
+    open(prefix + ".max", "w").write("".join(l + "\n" for l in max_lines))
+    return 0
+
+
+def run_layout(db_name: str, las_name: str, prefix: str, out: str, config: str, device: int = 0) -> int:
+    """`hinge layout --db DB --las LAS -x PREFIX --config INI -o OUT` for one merged .las: writes OUT.edges.hinges, .edges.hinges2,
+    .edges.skipped, .deadends.txt, .hinge.list, .killed.hinges, .hgraph and PREFIX.garbage.txt (hinging.cpp:616-2148; the debug dumps
+    and the pure-greedy .edges.greedy / .1 / .2 of :1724-1860 are the C++ executable's).  The single-rank case of dist.ShardedLayout."""
+    import torch
+    from . import layout as L
+    from .dist import BlockTable, Exchange, HipLayoutBackend, ShardedLayout
+    try:
+        rlen = formats.read_db_index(db_name)["rlen"]
+    except OSError:
+        return 1
+    n = len(rlen)
+    ini = IniFile(config)
+    if ini.error < 0:
+        return 1
+    P = L.LayoutParams.from_ini(ini)
+    eff = _read_mas(prefix + ".mas", n)
+    maximal = np.zeros(n, bool)
+    for line in open(prefix + ".max"):
+        if line.strip():
+            maximal[int(line)] = True
+    repeats = L.read_pairs_file(prefix + ".repeat.txt", n)
+    hinges = L.read_pairs_file(prefix + ".hinges.txt", n)
+    recs = formats.read_las(las_name if las_name.endswith(".las") else las_name + ".las")
+    if recs.novl == 0:
+        return 1
+    pile = formats.pileups_from_las(recs, rlen)
+    tb = 1 if recs.tspace <= formats.TRACE_XOVR else 2
+    ctx = Context(device)
+    try:
+        be = HipLayoutBackend(ctx, rlen, eff, pile, recs.trace, recs.trace_off[:-1][pile.las_index], recs.rec["tlen"][pile.las_index], tb)
+        files = ShardedLayout(be, Exchange(BlockTable([0, n]), torch.device("cuda", device)), P, eff, maximal, repeats, hinges).step()
+    finally:
+        ctx.close()
+    for suffix, lines in files.items():
+        base = prefix if suffix in (".garbage.txt", ".killed.hinges") else out      # hinging.cpp:659, 1201 write these two under --prefix
+        open(base + suffix, "w").write("".join(l + "\n" for l in lines))
+    return 0
