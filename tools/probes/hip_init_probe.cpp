@@ -38,6 +38,19 @@ int main(int argc, char** argv) {
     if (getenv("PROBE_RESET")) { T("hipDeviceReset", hipDeviceReset()); }
     printf("%-44s %8.1f ms   (%d CUs, %d devices)\n", "total", now() - t00, cu, n);
     fflush(stdout);
+    if (getenv("PROBE_EARLY_SHUTDOWN")) {   // give the device back BEFORE the (simulated) text output: does the next process start on a quiet GPU?
+        typedef int (*shut_t)(void);
+        shut_t shut = (shut_t)dlsym(RTLD_DEFAULT, "hsa_shut_down");
+        double t0 = now();
+        int rc = -1, rounds = 0;
+        if (getenv("PROBE_RESET_FIRST")) (void)hipDeviceReset();
+        while (shut && rounds < 8) { rc = shut(); rounds++; if (rc != 0) break; }   // (reference counted: until it says "not initialised")
+        printf("%-44s %8.1f ms  (%d calls, last rc %d)\n", "hsa_shut_down", now() - t0, rounds, rc);
+        fflush(stdout);
+        usleep(1000 * atoi(getenv("PROBE_EARLY_SHUTDOWN")));
+        _exit(0);
+    }
+    if (getenv("PROBE_SLEEP_MS")) usleep(1000 * atoi(getenv("PROBE_SLEEP_MS")));
     if (getenv("PROBE_FAST_EXIT")) _exit(0);   // what the executables do: no runtime teardown of its own, the kernel's only
     return 0;
 }

@@ -25,7 +25,10 @@ V = [("init_only", {"PROBE_INIT_ONLY": "1"}),
      ("one_queue_sdma_off", {"PROBE_FAST_EXIT": "1", "GPU_MAX_HW_QUEUES": "1", "HSA_ENABLE_SDMA": "0"}),
      ("no_interrupt", {"PROBE_FAST_EXIT": "1", "HSA_ENABLE_INTERRUPT": "0"}),
      ("scratch_small", {"PROBE_FAST_EXIT": "1", "HSA_SCRATCH_SINGLE_LIMIT": "0", "HSA_NO_SCRATCH_RECLAIM": "1"}),
-     ("cu_mask_half", {"PROBE_FAST_EXIT": "1", "HSA_CU_MASK": "0:0-127"})]
+     ("cu_mask_half", {"PROBE_FAST_EXIT": "1", "HSA_CU_MASK": "0:0-127"}),
+     ("sleep150_then_exit", {"PROBE_FAST_EXIT": "1", "PROBE_SLEEP_MS": "150"}),
+     ("shutdown_then_150ms", {"PROBE_EARLY_SHUTDOWN": "150"}),
+     ("reset_shutdown_then_150ms", {"PROBE_EARLY_SHUTDOWN": "150", "PROBE_RESET_FIRST": "1"})]
 import sys
 if len(sys.argv) > 1:
     V = [v for v in V if v[0] in sys.argv[1:]]
