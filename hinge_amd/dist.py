@@ -293,7 +293,10 @@ def step_pipelined(jobs: Sequence["ShardedFilter"]) -> None:
     (a stream-side wait, no host block with RCCL) only where its output is read, so exchange 1 of job j runs under the stats sweep
     of job j + 1 and exchange 2 under the next job's mask/annotate kernel; only the last one of each kind is exposed.
     Same kernels, same collectives, same results as [j.step(False, False) for j in jobs] (tests/test_dist_gloo.py).
-    Jobs in "mlas" mode or with the all-gather form of exchange 1 (host decisions in between) are run one after the other."""
+    Jobs in "mlas" mode or with the all-gather form of exchange 1 (host decisions in between) are run one after the other.
+    No status is read inside: a device buffer that overflows in this chain is only seen by the next ctx.check().  Callers run one
+    synchronous pass first (ShardedFilter.step(check=True), or the staged synchronous entry points as bench.py does) so that the
+    buffers are sized before the unchecked chain; PartBatch.settle() is that warm-up for the batched form."""
     if not jobs:
         return
     x0 = jobs[0].x
