@@ -76,6 +76,9 @@ struct hinge_ctx {
     int k2_order_bp = 1024;                   // bucket width of the longest-first order of the one-slot reads (HINGE_K2_ORDER_BP)
     int k2_occ_lds = -1, k2_occ = 0;          // occupancy calculator: workgroups per CU at that many bytes of dynamic LDS
     std::vector<int> k2_list;                 // host copy of bucket_list (the upload is asynchronous)
+    std::vector<int> k2_c1;                   // the one-slot reads in storage order (for the XCD-contiguous deal, see launch_mask_annotate)
+    int k2_deal = 1;                          // 1: deal every XCD a contiguous eighth of the one-slot reads, in storage order (HINGE_K2_DEAL=0: longest first, round 2's order)
+    int k2_deal_heads = -1, k2_deal_rot = -1; // what the list on the device was dealt for
     int n_class[3] = {0, 0, 0};               // bucket_list = [reads needing 1 (longest first) | 2 | 4 LDS slots of a K2 workgroup] of the current part
     unsigned k2_head_base[K2_MAX_HEADS] = {}; // value of every item counter of k_mask_annotate_q20 (DevBuf k2_heads) before its next launch
     DevBuf k2c;                  // K2Const of k_mask_annotate_q20 in device memory
@@ -235,6 +238,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_NO_SPAN16")) ctx->no_span16 = atoi(g);
     if (const char* g = getenv("HINGE_K2_WGS")) ctx->k2_wgs = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_K2_ORDER_BP")) ctx->k2_order_bp = std::max(1, atoi(g));
+    if (const char* g = getenv("HINGE_K2_DEAL")) ctx->k2_deal = atoi(g);
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -383,6 +387,12 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
             if (l <= len1) lst[(size_t)at[(size_t)(std::max(l, 0) / ob)]++] = i; else if (l <= len2) lst[(size_t)p2++] = i; else lst[(size_t)p4++] = i;
         }
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
+        ctx->k2_deal_heads = ctx->k2_deal_rot = -1;
+        ctx->k2_c1.clear();
+        if (ctx->k2_deal) {
+            ctx->k2_c1.reserve((size_t)n1);
+            for (int i = r_begin; i <= r_end; i++) if (ctx->h_rlen[(size_t)i] <= len1) ctx->k2_c1.push_back(i);
+        }
         if ((rc = ensure(ctx, ctx->bucket_list, sizeof(int) * (size_t)std::max(nr, 1)))) return rc;
         if (nr > 0) CK(hipMemcpyAsync(ctx->bucket_list.p, lst.data(), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, ctx->stream));
         const bool pack_ok = ctx->max_rlen < 65536 && n_ovl > 0 && !ctx->no_span16;
@@ -835,6 +845,20 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         if (gp >= 2 * K2_MAX_HEADS) { n_heads = K2_MAX_HEADS; gp -= gp % K2_MAX_HEADS; }
         else for (int h = std::min(gp, K2_MAX_HEADS); h >= 1; h--) if (gp % h == 0) { n_heads = h; break; }
         const int g = std::max(1, n4 + (n2 + 1) / 2 + gp);
+        // XCD-contiguous deal (HINGE_K2_DEAL=1): workgroups go round-robin to the 8 XCDs, each with its own L2; head h is served by
+        // the workgroups g4 + g2 + h, + n_heads, ... - all on XCD (g4 + g2 + h) % 8 when n_heads is a multiple of 8 - and takes the
+        // list positions h, h + n_heads, ...  So the LIST is arranged such that the positions of one XCD's heads hold one contiguous
+        // eighth of the reads in storage order: that L2 then sees one eighth of the span copy and of the per-read tables, and the
+        // rows it fetches next to each other in memory are worked on next to each other in time.
+        if (ctx->k2_deal && n1 > 0 && n_heads % 8 == 0 && (ctx->k2_deal_heads != n_heads || ctx->k2_deal_rot != (n4 + (n2 + 1) / 2) % 8)) {
+            const int rot = (n4 + (n2 + 1) / 2) % 8;
+            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at[8];
+            for (int pz = 0; pz < n1; pz++) cnt[((pz % n_heads) + rot) % 8]++;
+            for (int x = 0, run = 0; x < 8; x++) { at[x] = run; run += cnt[x]; }
+            for (int pz = 0; pz < n1; pz++) ctx->k2_list[(size_t)pz] = ctx->k2_c1[(size_t)at[((pz % n_heads) + rot) % 8]++];
+            CK(hipMemcpyAsync(ctx->bucket_list.p, ctx->k2_list.data(), sizeof(int) * (size_t)n1, hipMemcpyHostToDevice, ctx->stream));
+            ctx->k2_deal_heads = n_heads; ctx->k2_deal_rot = rot;
+        }
         K2Heads bases;
         unsigned next_base[K2_MAX_HEADS];   // the host mirror of the device counters moves on only once the launch is known to be queued
         {
