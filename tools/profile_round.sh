@@ -11,10 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e"
 PMCB="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e"      # counter passes serialise the kernels: few steps
 (cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err)
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- $BENCH > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG --output-format csv -- $PMCB > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o $TAG --output-format csv -- $PMCB > $OUT/pmc_sq.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- $BENCH > $OUT/trace.log 2>&1
+timeout 420 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
+timeout 420 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG --output-format csv -- $PMCB > $OUT/pmc_write.log 2>&1
+timeout 420 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o $TAG --output-format csv -- $PMCB > $OUT/pmc_sq.log 2>&1
 cd $R
 python tools/pmc_summary.py $(find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv") | sed '1s/mean_value/mean_value_KB/' > $OUT/${TAG}_rocprofv3_pmc_summary.csv
 python tools/pmc_summary.py $(find $OUT/pmc_sq -name "*counter_collection.csv") > $OUT/${TAG}_rocprofv3_sq_summary.csv
