@@ -130,6 +130,24 @@ def test_context_reuse_across_read_sets_with_coverage_out(oracle_lib, tmp_path):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,wgs,deal", [("chimera", 8, 1), ("tiny_mlas", 16, 1), ("long_reads", 16, 1), ("edges", 24, 1), ("chimera", 16, 0)])
+def test_filter_k2_read_deal(datasets, oracle_lib, tmp_path, monkeypatch, name, wgs, deal):
+    """k_mask_annotate_q20's drawn reads dealt XCD-contiguously in storage order (on when the persistent workgroups are a
+    multiple of the 8 XCDs: forced here on small data through HINGE_K2_WGS) and in round 2's longest-first order: same files."""
+    from hinge_amd import capi
+    monkeypatch.setenv("HINGE_K2_WGS", str(wgs))
+    monkeypatch.setenv("HINGE_K2_DEAL", str(deal))
+    src, _ = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    mlas = name == "tiny_mlas"
+    assert _oracle_filter(oracle_lib, wd_o, mlas) == 0
+    ctx = capi.Context(0)
+    assert _hip_filter(wd_h, mlas, ctx=ctx, packed=True) == 0
+    _compare(wd_o, wd_h)
+    ctx.close()
+
+
 @pytest.mark.parametrize("extra", ["ec = 60\n", "coverage = false\n", "hinge_min_support = 3\nhinge_unbridged = 2\nhinge_min_pileup = 3\n",
                                    "no_hinge_region = 200\nrepeat_annotation_gap_threshold = 100\n"])
 def test_filter_ini_variants(datasets, oracle_lib, tmp_path, extra):

@@ -81,7 +81,10 @@ def random_paths(rng, spec):
     if rng.random() < 0.3:
         env["HINGE_THREADS"] = str(int(rng.choice([1, 3, 16])))
     if rng.random() < 0.3:
-        env["HINGE_K2_WGS"] = str(int(rng.choice([1, 2, 5])))   # few persistent workgroups: every wavefront of k_mask_annotate_q20 takes several reads
+        env["HINGE_K2_WGS"] = str(int(rng.choice([1, 2, 5, 8, 16])))   # few persistent workgroups: every wavefront of k_mask_annotate_q20 takes several reads
+                                                                          # (8, 16: a multiple of the 8 XCDs, so the XCD-contiguous deal of the reads is on)
+    if rng.random() < 0.2:
+        env["HINGE_K2_DEAL"] = "0"                   # round 2's longest-first order of the drawn reads
     paf = spec.n_blocks == 1 and rng.random() < 0.2
     return env, paf
 
