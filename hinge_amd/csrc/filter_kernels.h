@@ -240,7 +240,9 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
         }
         if (lane == 0) {
             const int K = nbins_of<RESO>((int)(e - s), mx, reso);
-            nbins0[i] = q20_ok ? K : -1;   // bins of the plain profile for k_mask_annotate_q20, -1 = not a read for that kernel
+            // bins of the plain profile for k_mask_annotate_q20, -1 = not a read for that kernel (a coordinate outside the read, or
+            // 65536+ overlaps: its 16-bit counts would overflow)
+            nbins0[i] = (q20_ok && e - s < 65536) ? K : -1;
             if (rl >= 5000) {
                 const long long m = tot / (long long)max(1, K);   // C division, filter.cpp:654
                 mean_cov[i] = (int)m;
@@ -1009,20 +1011,24 @@ __device__ unsigned long long* g_k2_trace = nullptr;
 
 // (eight wavefronts per SIMD: with the scalar and the vector unit both ~60 % busy the kernel is latency-sensitive again - 84.7 us at
 // six (77 VGPRs, the compiler's choice), 79.7 at seven, 78.3 at eight with a one-VGPR scratch spill and 52 SGPR spills)
-template <bool PACKED>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off, int mulpath_thr /*min(MIN_RA, MAX_RA) when the
-                                                             division-free annotation test applies, else -1*/,
-                                                             int nhr /*NO_HINGE_REGION*/, int use_cov /*the coverage mask takes part in the mask*/,
+// COVOUT: the .coverage.txt bins are written too (a template parameter, like the flags below that became launch conditions: a
+// run-time flag of this kernel is a lane mask or a scalar that lives - spilled - across the whole read loop).
+// CUT20: cut_off / 20 when it is the shipped 300 (the pads, the profile accessors' offsets and the bounds below are then immediates), else -1.
+template <bool PACKED, bool COVOUT, int CUT20>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off_arg, int mulpath_thr /*min(MIN_RA, MAX_RA) >= 0: the
+                                                             division-free annotation test applies (a launch condition)*/,
+                                                             int nhr /*NO_HINGE_REGION*/, int cov_mask_off /*INT_MIN if the coverage mask takes part in the mask, else 1 << 29*/,
                                                              const int* __restrict__ read_list, int n1, int n2, int n4,
                                                              const int64_t* __restrict__ row_ptr,
                                                              const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
                                                              const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints,
-                                                             int* __restrict__ cov_out /*nullptr, or the coverage-bin output*/,
+                                                             int* __restrict__ cov_out /*COVOUT: the coverage-bin output*/,
                                                              const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
                                                              int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count,
                                                              unsigned* __restrict__ heads, int n_heads, K2Heads bases) {
     extern __shared__ int lds[];
-    constexpr int HOT = 4;
+    constexpr int HOT = 4;    // words per lane the slot has room for behind the profile (candidate list of the last phase)
+    constexpr int HOTW = 2;   // of which hot words: W0 = begins in bin 0 | ends in bin qe - 1 << 16, W1 = begins in bin 1 | ends in bin qe << 16
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // A workgroup has four LDS slots of slot_ints words.  read_list = [n1 reads that fit one slot, longest first | n2 reads that
@@ -1057,7 +1063,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (lane == 0) grab = atomicAdd(head_ptr, 1u);   // (its latency is covered by the set-up below)
     }
     constexpr int reso = 40;
-    const int SH = cut_off / 20;
+    const int SH = CUT20 >= 0 ? CUT20 : cut_off_arg / 20;
+    const int cut_off = CUT20 >= 0 ? CUT20 * 20 : cut_off_arg;
     // Zero words in front of the prefix array and copies of the totals behind it make PB[q < 0] = 0 and P[q > last] = P[last]
     // plain loads: the profile accessors below need no clamps and issue their LDS reads back to back.
     const int PADF = (SH + 2 + 3) & ~3, PADT = (2 * SH + 4 + 3) & ~3;
@@ -1065,9 +1072,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int* Pq = lds + (size_t)wib * slot_ints + PADF;
     int* hot = Pq + qcap + PADT;                   // lane-private words for the four hot bins (see below)
 #pragma unroll
-    for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
-    int* const hot_b = hot + lane;                 // + q * 64        for q in {0, 1}
-    int* const hot_e = hot + 2 * WAVE + lane;      // + (qe - q) * 64 for qe - q in {0, 1}
+    for (int h = 0; h < HOTW; h++) hot[h * WAVE + lane] = 0;
+    int* const hot_l = hot + lane;                 // begins: + q * 64 for q in {0, 1}; ends: + (q - (qe - 1)) * 64 for q in {qe - 1, qe}
     const int MIN_COV = *d_min_cov;
 #ifdef HINGE_ABLATE
     struct { int ablate; } P = {C->P.ablate};
@@ -1088,10 +1094,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const int64_t s = rb.s, e = rb.e;
         const int rl = load_at32(rlen, (unsigned)i << 2);
         const int K0 = load_at32(nbins0, (unsigned)i << 2);   // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
-        const long long cov_at = cov_out ? load_at32(cov_off, (unsigned)(i - cov_base) << 3) : 0;   // (fetched with the row bounds, used after phase 1)
+        const long long cov_at = COVOUT ? load_at32(cov_off, (unsigned)(i - cov_base) << 3) : 0;   // (fetched with the row bounds, used after phase 1)
         const int64_t n64 = e - s;
         const int qe = rl / 20;                       // last bin an event can fall in
-        if (n64 >= 65536 || K0 < 0 || qe >= qcap || rl >= 600000) {   // 16-bit counts would overflow / malformed / too long: general kernel
+        // k_cov_stats says no (16-bit counts would overflow, malformed), or too long for the LDS (then also: bins < 16384 for the keys
+        // of the run search below): general kernel
+        if (K0 < 0 || qe >= qcap) {
             if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
             continue;
         }
@@ -1099,66 +1107,101 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         typedef SpanLoad<PACKED> SL;
         const typename SL::raw* __restrict__ row = a_span + s;
         const int Qn = qe + 1;                        // bins in use
-        bool cleared = false;
         const unsigned last = n > 0 ? (unsigned)(n - 1) : 0u;
-        for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
-            typename SL::raw v[LOADS_IN_FLIGHT];
-            if constexpr (PACKED) {
-                // the 16|16 copy is padded by half a batch, so the loads need neither a clamp nor a branch each: scalar row base
-                // + one lane offset + immediates, the whole batch or its first half
+        // the ends' hot word from the bin itself: hot_l + (qd - (qe - 1)) * 64 (one shift-add per event off a per-read base)
+        // (LDS byte addresses the compiler must take as they are: with the pads' sizes known at compile time it splits every base
+        // into a register and a constant and adds the constant per event)
+        typedef __attribute__((address_space(3))) int lds_int;
+        unsigned pq_a = (unsigned)(uintptr_t)(lds_int*)Pq, hot_b = (unsigned)(uintptr_t)(lds_int*)hot_l;
+        asm("" : "+s"(pq_a));
+        asm("" : "+v"(hot_b));
+        unsigned hot_e = hot_b - (unsigned)((qe - 1) * WAVE * 4);
+        asm("" : "+v"(hot_e));
+        auto event = [&](typename SL::raw raw) {
+            // k_cov_stats vouches for 0 <= abpos, aepos <= rl: the bins need no clamp
+            const int2 w = SL::get(raw);
+            unsigned qb = (unsigned)w.x / 20u, qd = (unsigned)w.y / 20u;
+            // (the tests on the BINS: left to itself the compiler tests the begin's position - an extra mask of the packed word)
+            asm("" : "+v"(qb));
+            asm("" : "+v"(qd));
+            const bool hb = qb < 2u, he = (int)qd > qe - 2;
+            __builtin_amdgcn_sched_barrier(0);   // (the compares first: a select right behind its compare costs wait states)
+            lds_int* pb = (lds_int*)(uintptr_t)(hb ? hot_b + qb * (WAVE * 4) : pq_a + qb * 4);
+            lds_int* pe = (lds_int*)(uintptr_t)(he ? hot_e + qd * (WAVE * 4) : pq_a + qd * 4);
+            __hip_atomic_fetch_add(pb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(pe, 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto clear_bins = [&]() {   // (under the first batch's loads)
+            int4* z4 = reinterpret_cast<int4*>(Pq);
+            for (int t = lane; t < (Qn + 3) / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
+        };
+        if constexpr (PACKED) {
+            // The 16|16 copy is padded by half a batch, so the loads need neither a clamp nor a branch each: scalar row base + one
+            // lane offset + immediates.  As many loads as the row has 64-overlap batches left, in eight tiers (three uniform
+            // branches): the reads are not visited in storage order, so what a wavefront loads past its row's end is fetched from HBM
+            // for nothing.  A tier knows how many of its batches are FULL: those run without a lane test and without the uniform
+            // "any overlap left?" test - per batch an exec-mask save / restore, two branches and a compare less on the scalar side.
+            static_assert(LOADS_IN_FLIGHT == 8, "load tiers below");
+            int base = 0;
+            do {
                 const typename SL::raw* __restrict__ p = row + (unsigned)(base + lane);
-                // as many loads as the row has batches left, in seven tiers (three uniform branches): the reads are not visited in
-                // storage order, so what a wavefront loads past its row's end is fetched from HBM for nothing - with "the whole batch
-                // or its first half" FETCH_SIZE was twice the rows' bytes
-                static_assert(LOADS_IN_FLIGHT == 8, "load tiers below");
                 const int left = n - base;
-#define HINGE_K2_LOADS(CNT) _Pragma("unroll") for (int u = 0; u < (CNT); u++) v[u] = p[u * WAVE];
+                const int rem = left - lane;       // this lane has an overlap in batch u iff u * 64 < rem
+                typename SL::raw v[LOADS_IN_FLIGHT];
+#define HINGE_K2_TIER(CNT, FULL)                                                         \
+                {                                                                        \
+                    _Pragma("unroll") for (int u = 0; u < (CNT); u++) v[u] = p[u * WAVE]; \
+                    if (base == 0) clear_bins();                                         \
+                    _Pragma("unroll") for (int u = 0; u < (FULL); u++) event(v[u]);      \
+                    _Pragma("unroll") for (int u = (FULL); u < (CNT); u++) if (u * WAVE < rem) event(v[u]); \
+                }
                 if (left > 4 * WAVE) {
-                    if (left > 6 * WAVE) { HINGE_K2_LOADS(8) } else if (left > 5 * WAVE) { HINGE_K2_LOADS(6) } else { HINGE_K2_LOADS(5) }
+                    if (left >= 8 * WAVE) HINGE_K2_TIER(8, 8)
+                    else if (left > 6 * WAVE) HINGE_K2_TIER(8, 6)
+                    else if (left > 5 * WAVE) HINGE_K2_TIER(6, 5)
+                    else HINGE_K2_TIER(5, 4)
                 } else if (left > 2 * WAVE) {
-                    if (left > 3 * WAVE) { HINGE_K2_LOADS(4) } else { HINGE_K2_LOADS(3) }
-                } else if (left > WAVE) { HINGE_K2_LOADS(2) } else if (n > 0) { HINGE_K2_LOADS(1) }
-#undef HINGE_K2_LOADS
-            } else if (n > 0) {   // (the int32 spans may be the caller's buffer: clamped index)
+                    if (left > 3 * WAVE) HINGE_K2_TIER(4, 3) else HINGE_K2_TIER(3, 2)
+                } else if (left > WAVE) HINGE_K2_TIER(2, 1)
+                else if (left > 0) HINGE_K2_TIER(1, 0)
+                else if (base == 0) clear_bins();
+#undef HINGE_K2_TIER
+                base += LOADS_IN_FLIGHT * WAVE;
+            } while (base < n);
+        } else {
+            bool cleared = false;
+            for (int base = 0; base < n || !cleared; base += LOADS_IN_FLIGHT * WAVE) {
+                typename SL::raw v[LOADS_IN_FLIGHT];
+                if (n > 0) {   // (the int32 spans may be the caller's buffer: clamped index)
 #pragma unroll
-                for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
-            }
-            if (!cleared) {   // cleared while the first batch is in flight
-                int4* z4 = reinterpret_cast<int4*>(Pq);
-                for (int t = lane; t < (Qn + 3) / 4; t += WAVE) z4[t] = make_int4(0, 0, 0, 0);
-                cleared = true;
-            }
-            const int rem = n - base - lane;       // this lane has an overlap in batch u iff u * 64 < rem
+                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min((unsigned)(base + u * WAVE + lane), last)];
+                }
+                if (!cleared) { clear_bins(); cleared = true; }
+                const int rem = n - base - lane;
 #pragma unroll
-            for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
-                if (base + u * WAVE >= n) break;   // wave-uniform
-                if (u * WAVE < rem) {
-                    // k_cov_stats vouches for 0 <= abpos, aepos <= rl: the bins need no clamp
-                    const int2 w = SL::get(v[u]);
-                    const unsigned qb = (unsigned)w.x / 20u, qd = (unsigned)w.y / 20u;
-                    const unsigned de = (unsigned)qe - qd;
-                    int* pb = qb < 2u ? hot_b + qb * WAVE : Pq + qb;
-                    int* pe = de < 2u ? hot_e + de * WAVE : Pq + qd;
-                    atomicAdd(pb, 1);
-                    atomicAdd(pe, 0x10000);
+                for (int u = 0; u < LOADS_IN_FLIGHT; u++) {
+                    if (base + u * WAVE >= n) break;   // wave-uniform
+                    if (u * WAVE < rem) event(v[u]);
                 }
             }
         }
         HINGE_K2_STAMP(1);
         HINGE_ABLATE_POINT(9)    // (ablation builds: 9 = stop after the histogram, before the hot-word fold)
         {   // fold the lane-private hot words into their bins (and zero them for the next read)
-            int hv[HOT];
-#pragma unroll
-            for (int h = 0; h < HOT; h++) { hv[h] = hot[h * WAVE + lane]; hot[h * WAVE + lane] = 0; }
-            // per-lane counts are < 65536, wave totals too (n < 65536): two per scan
-            const int sb = wave_sum(hv[0] | (hv[1] << 16));                                  // B0 | B1 << 16
-            const int se = wave_sum((int)((unsigned)hv[2] >> 16) | (hv[3] & (int)0xffff0000));   // E0 | E1 << 16
-            // lanes 0-3 add B0 -> bin 0, B1 -> bin 1, E0 -> bin qe, E1 -> bin qe - 1
-            const int pick = (lane & 2) ? se : sb;
-            const int cnt = (lane & 1) ? (int)((unsigned)pick >> 16) : (pick & 0xffff);
-            const int idx = (lane & 2) ? qe - (lane & 1) : (lane & 1);
-            const int val = (lane & 2) ? cnt << 16 : cnt;
-            if (lane < 4 && val != 0) atomicAdd(&Pq[idx], val);   // non-zero only if some event had that bin
+            const int h0 = hot[lane], h1 = hot[WAVE + lane];
+            hot[lane] = 0; hot[WAVE + lane] = 0;
+            // per-lane counts are < 65536, wave totals too (n < 65536): the two halves of a word never meet
+            const int t0 = wave_incl_scan(h0);   // last lane: begins in bin 0 | ends in bin qe - 1 << 16
+            const int t1 = wave_incl_scan(h1);   // last lane: begins in bin 1 | ends in bin qe << 16
+            // The last lane adds all four where it holds them (no broadcast, no lane masks to keep across the loop).  Plain ds_add
+            // instructions: from atomicAdd on a uniform address the compiler builds a wave-aggregated atomic (mbcnt, bcnt, multiply).
+            // A zero count adds zero; with qe = 0 the third add goes to the zero pad in front of the bins, with zero.
+            if (lane == WAVE - 1) {
+                const unsigned a0 = (unsigned)(size_t)(__attribute__((address_space(3))) int*)Pq;
+                const unsigned a1 = a0 + (unsigned)(qe * 4);
+                asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %0, %3 offset:4\n\tds_add_u32 %1, %4\n\tds_add_u32 %1, %5 offset:4"
+                             :: "v"(a0), "v"(a1 - 4u), "v"(t0 & 0xffff), "v"(t1 & 0xffff), "v"(t0 & (int)0xffff0000), "v"(t1 & (int)0xffff0000) : "memory");
+            }
         }
         HINGE_ABLATE_POINT(1)
         // The cutoff profile is zero from its last bin on (every event consumed: begins - ends = 0), and a zero bin that
@@ -1168,17 +1211,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 
         // ---- inclusive prefixes of begins|ends, 8 consecutive bins per lane (512 per step: one step for reads of up to 10 kb) -----
         int carry = 0;
-        int* __restrict__ const cov_dst = cov_out ? cov_out + cov_at : (int*)nullptr;
+        int* __restrict__ const cov_dst = COVOUT ? cov_out + cov_at : (int*)nullptr;
         // Which 64-bin words of the plain profile can hold an annotation at all: an annotation needs |cov0[k+1] - cov0[k]| above
         // min(MIN_RA, MAX_RA), and that difference is simply the begins minus the ends of the two 20-bp bins 2k, 2k+1 - the raw
         // counts this loop holds before it sums them.  A typical read has no such bin between its ends' pile-ups.
-        unsigned long long flag_words = mulpath_thr >= 0 ? 0ull : ~0ull;
+        unsigned long long flag_words = 0ull;
         // ... and only between the bounds every annotation window respects: 40 j >= mask.first + NHR >= NHR, j <= K0 - 3, and with
         // the coverage mask 40 j <= mask.second - NHR <= rl - cut_off - NHR (a bin of the cutoff profile is positive only while an
         // overlap still has cut_off bases to go, so the mask ends at rl - cut_off at the latest).  The pile-ups of begins at the
         // read's start and of ends at its end - which exceed the threshold in every read - lie outside them.
         const int jlo_b = max(nhr, 0) / reso;
-        const int jhi_b = use_cov ? min(K0 - 3, rl - cut_off - nhr < 0 ? -1 : (rl - cut_off - nhr) / reso) : K0 - 3;
+        const int jhi_b = min(K0 - 3, max(rl - cut_off - nhr < 0 ? -1 : (rl - cut_off - nhr) / reso, cov_mask_off));
         // as one unsigned range test per lane: a lane's four 40-bp bins are hb + 4 lane .. + 3 (hb = first 40-bp bin of the step),
         // some of them inside [jlo_b, jhi_b] iff 4 lane - (b_lo - hb) <= b_span (no bin at all: b_lo beyond every lane)
         const bool no_bins = jhi_b - jlo_b + 1 <= 0;
@@ -1189,11 +1232,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 #endif
         for (int base = 0; base < Qn; base += 8 * WAVE) {
             const int t = base + 8 * lane;
-            int4 v = t < Qn ? *reinterpret_cast<const int4*>(Pq + t) : make_int4(0, 0, 0, 0);
-            int4 w = t + 4 < Qn ? *reinterpret_cast<const int4*>(Pq + t + 4) : make_int4(0, 0, 0, 0);
+            // (lanes past the last bin read the zero pad in front of the bins: an address select instead of an exec-mask save /
+            // restore and four register clears per load)
+            int4 v = *reinterpret_cast<const int4*>(t < Qn ? Pq + t : Pq - PADF);
+            int4 w = *reinterpret_cast<const int4*>(t + 4 < Qn ? Pq + t + 4 : Pq - PADF);
             v.y += v.x;                                        // (= begins|ends of this lane's first 40-bp bin, both halves below 65536)
             w.y += w.x;
-            if (mulpath_thr >= 0) {
+            {
                 // |begins - ends| > thr  <=>  (unsigned)(begins - ends + thr) > 2 thr (thr < 2^28, the host sees to it)
                 const int s1 = v.z + v.w, s3 = w.z + w.w;
                 auto excess = [&](int pair) { return (unsigned)((pair & 0xffff) - (int)((unsigned)pair >> 16) + mulpath_thr); };
@@ -1221,7 +1266,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             w.x += excl; w.y += excl; w.z += excl; w.w += excl;
             if (t < Qn) *reinterpret_cast<int4*>(Pq + t) = v;
             if (t + 4 < Qn) *reinterpret_cast<int4*>(Pq + t + 4) = w;
-            if (cov_dst) {
+            if constexpr (COVOUT) {
                 // the .coverage.txt bins straight from the registers of the scan: cov0[k] = PB[2k-1] - PE[2k-1], and this lane holds
                 // the prefixes of bins t .. t+7, i.e. 2k-1 = t+1, t+3, t+5, t+7 (k = t/2 + 1 .. t/2 + 4): one 16-byte store (4-byte
                 // aligned; a read's area has room for the up to three values it writes past the read's last bin).  Stored here - not
@@ -1235,13 +1280,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             }
             carry += wave_last(incl);
         }
-        if (cov_dst && lane == 0) {
+        if (COVOUT && lane == 0) {
             if (K0 > 0) cov_dst[0] = 0;                      // cov0[0]: nothing is consumed before position 0
             store_at32(cov_nbins, in_vgpr((unsigned)(i - cov_base)) << 2, K0);
         }
         {   // copies of the totals behind the scanned bins (the scan ran over [0, round-up-to-4 of Qn))
             const int Qs = (Qn + 3) & ~3;
-            for (int t = lane; t < PADT; t += WAVE) Pq[Qs + t] = carry;
+            if (PADT <= WAVE) { if (lane < PADT) Pq[Qs + lane] = carry; }   // (cut_off <= 600)
+            else for (int t = lane; t < PADT; t += WAVE) Pq[Qs + t] = carry;
         }
         HINGE_K2_STAMP(2);
         auto cov0 = [&](int k) { const int p = Pq[2 * k - 1]; return (p & 0xffff) - (int)((unsigned)p >> 16); };
@@ -1261,26 +1307,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             int zc = 0, pc = 0;                        // carries: z and positivity of the previous word's last bin
             const int* pcb = Pq + 2 * lane - 1 - SH;   // covc(base + lane) = begins below pcb[2 base] - ends below pce[2 base]
             const int* pce = Pq + 2 * lane - 1 + SH;
-#ifdef HINGE_ABLATE
-            if (P.ablate != 7 && P.ablate != 8)
-#endif
-            for (int base = 0; base < KC; base += WAVE, pcb += 2 * WAVE, pce += 2 * WAVE) {
+            // a word that is not all positive (a read's first and last word, hardly another)
+            auto word = [&](int base, bool p, unsigned long long M) {
                 const int j = base + lane;
-                const bool valid = j < KC;
-                // (loaded by every lane: past the last bin that is the pad, the next slot or nothing - LDS reads do not fault)
-                const int cvj = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16);
-                const bool p = valid && cvj > MIN_COV;
-                const unsigned long long M = ballot_of(p);
-                // 64 bins above MIN_COV (the interior of nearly every read) open or continue a run and close none
-                if (M == ~0ull) { pc = 1; continue; }
-                const int z = max(wave_incl_max_scan(valid && !p ? j : 0), zc);
+                const int z = max(wave_incl_max_scan(p ? 0 : j), zc);   // (only valid bins reach here as non-positive ones: see the tail below)
                 const int zprev = shfl_up1(z, zc);
                 const int pprev = shfl_up1(p ? 1 : 0, pc);
                 const int bins = j - zprev - 2;
                 const int key = (bins << 14) | (16383 - j);
-                key_best = max(key_best, (valid && !p && pprev != 0 && bins > 0) ? key : 0);
+                key_best = max(key_best, (!p && pprev != 0 && bins > 0) ? key : 0);
                 zc = wave_last(z);
                 pc = (int)(M >> 63);
+            };
+            int base = 0;
+#ifdef HINGE_ABLATE
+            if (P.ablate == 7 || P.ablate == 8) base = KC;
+#endif
+            // (loaded by every lane: LDS reads do not fault)
+            for (; base + WAVE <= KC; base += WAVE, pcb += 2 * WAVE, pce += 2 * WAVE) {
+                const bool p = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16) > MIN_COV;
+                const unsigned long long M = ballot_of(p);
+                // 64 bins above MIN_COV (the interior of nearly every read) open or continue a run and close none
+                if (M == ~0ull) { pc = 1; continue; }
+                word(base, p, M);
+            }
+            if (base < KC) {   // the last, partial word: the bins from KC on count as positive ones that belong to no run (they close
+                               // none, and a run that is still open at the last valid bin is not counted, as in the reference's loop)
+                const bool valid = base + lane < KC;
+                const bool p = !valid || (*pcb & 0xffff) - (int)((unsigned)*pce >> 16) > MIN_COV;
+                word(base, p, ballot_of(p));
             }
         }
         RunState run{0, 0ull, 0, 0};
@@ -1300,7 +1355,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                                            true, !cand_apart, flag_words));
         if (cand_apart && used > 0) {   // the hot words start every read at zero
 #pragma unroll
-            for (int h = 0; h < HOT; h++) hot[h * WAVE + lane] = 0;
+            for (int h = 0; h < HOTW; h++) hot[h * WAVE + lane] = 0;
         }
         HINGE_K2_STAMP(4);
     }

@@ -822,7 +822,12 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     const int grid = std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
     // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
     // (it takes the bin count and the well-formedness of each pile-up from k_cov_stats<40> of this pass)
-    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0 && ctx->nbins0_reso == 40;
+    // ... and the division-free annotation test of mask_gate_annotate applies: then |gradient| > min(MIN_RA, MAX_RA) is necessary for an
+    // annotation, which is what the fast kernel's scan flags its 64-bin words with (the threshold is added to a count there: < 2^28)
+    const int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
+                                ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
+    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0 && ctx->nbins0_reso == 40 &&
+                     mulpath_thr >= 0 && mulpath_thr < (1 << 28);
     if (q20) {
         // bins + hot words (the read classes of hinge_set_pileups are cut for this much) + the zero / total pads of this cut_off
         const int SH = p->cut_off / 20;
@@ -832,8 +837,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         const size_t lds_all = lds20;
         if (ctx->k2_occ_lds != (int)lds_all) {
             int nb = 0;
-            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true>, BLOCK, lds_all));
-            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false>, BLOCK, lds_all));
+            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true, true, 15>, BLOCK, lds_all));
+            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false, true, 15>, BLOCK, lds_all));
             ctx->k2_occ = std::max(nb, 1);
             ctx->k2_occ_lds = (int)lds_all;
         }
@@ -891,22 +896,18 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
             }
         }
         int* cov_out = ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr;
-        // the division-free annotation test of mask_gate_annotate applies: then |gradient| > min(MIN_RA, MAX_RA) is necessary
-        int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
-                                    ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
-        if (mulpath_thr >= (1 << 28)) mulpath_thr = -1;   // (the kernel's range test adds it to a count: every word is looked at instead)
-        if (ctx->use_span16)
-            hipLaunchKernelGGL(k_mask_annotate_q20<true>, dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
-                               p->no_hinge_region, (p->use_coverage_mask != 0) ? 1 : 0, (const int*)ctx->bucket_list.p, n1, n2, n4,
-                               (const int64_t*)ctx->row_ptr.p, (const unsigned*)ctx->span16.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, cov_out, (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin,
-                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, (unsigned*)ctx->k2_heads.p, n_heads, bases);
-        else
-            hipLaunchKernelGGL(k_mask_annotate_q20<false>, dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, mulpath_thr,
-                               p->no_hinge_region, (p->use_coverage_mask != 0) ? 1 : 0, (const int*)ctx->bucket_list.p, n1, n2, n4,
-                               (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p,
-                               (const int*)&sc(ctx)->min_cov, slot, cov_out, (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin,
-                               (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count, (unsigned*)ctx->k2_heads.p, n_heads, bases);
+        const int cov_mask_off = p->use_coverage_mask != 0 ? INT_MIN : (1 << 29);
+#define LAUNCH_K2C(PACKED, COVOUT, CUT20, SPANS)                                                                                                            \
+        hipLaunchKernelGGL((k_mask_annotate_q20<PACKED, COVOUT, CUT20>), dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off,        \
+                           mulpath_thr, p->no_hinge_region, cov_mask_off, (const int*)ctx->bucket_list.p, n1, n2, n4, (const int64_t*)ctx->row_ptr.p, SPANS, \
+                           (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, (const int*)&sc(ctx)->min_cov, slot, cov_out,                                 \
+                           (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count,      \
+                           (unsigned*)ctx->k2_heads.p, n_heads, bases)
+#define LAUNCH_K2(PACKED, COVOUT, SPANS) do { if (p->cut_off == 300) LAUNCH_K2C(PACKED, COVOUT, 15, SPANS); else LAUNCH_K2C(PACKED, COVOUT, -1, SPANS); } while (0)
+        if (ctx->use_span16) { if (cov_out) LAUNCH_K2(true, true, (const unsigned*)ctx->span16.p); else LAUNCH_K2(true, false, (const unsigned*)ctx->span16.p); }
+        else { if (cov_out) LAUNCH_K2(false, true, (const int2*)ctx->a_span.p); else LAUNCH_K2(false, false, (const int2*)ctx->a_span.p); }
+#undef LAUNCH_K2
+#undef LAUNCH_K2C
         CK(hipGetLastError());
         for (int h = 0; h < K2_MAX_HEADS; h++) ctx->k2_head_base[h] = next_base[h];
         _ps.stop();
