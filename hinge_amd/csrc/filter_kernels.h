@@ -996,6 +996,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
 struct K2Const {
     FilterDev P;
     AnnoOut o;
+    int* fallback_list;         // reads handed back to the general kernel (hardly ever: the pointers are looked up when one is)
+    unsigned* fallback_count;
 };
 constexpr int K2_MAX_HEADS = 64;
 struct K2Heads { unsigned base[K2_MAX_HEADS]; };   // value of every item counter before this launch
@@ -1024,7 +1026,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                              const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints,
                                                              int* __restrict__ cov_out /*COVOUT: the coverage-bin output*/,
                                                              const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
-                                                             int* __restrict__ fallback_list, unsigned* __restrict__ fallback_count,
                                                              unsigned* __restrict__ heads, int n_heads, K2Heads bases) {
     extern __shared__ int lds[];
     constexpr int HOT = 4;    // words per lane the slot has room for behind the profile (candidate list of the last phase)
@@ -1084,7 +1085,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     for (int t = lane; t < PADF; t += WAVE) Pq[t - PADF] = 0;
     auto drawn = [&]() { return head + n_heads * (int)((unsigned)__builtin_amdgcn_readfirstlane((int)grab) - head_base); };
     if (dyn) item = drawn();
-
     for (; (unsigned)item < (unsigned)item_end; item = dyn ? drawn() : item_end) {   // `continue` leaves a read
         if (dyn && lane == 0) grab = atomicAdd(head_ptr, 1u);   // the item after this one
         HINGE_K2_STAMP(0);
@@ -1095,12 +1095,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const int rl = load_at32(rlen, (unsigned)i << 2);
         const int K0 = load_at32(nbins0, (unsigned)i << 2);   // k_cov_stats: bins of the plain profile, or -1 if a coordinate leaves [0, rl]
         const long long cov_at = COVOUT ? load_at32(cov_off, (unsigned)(i - cov_base) << 3) : 0;   // (fetched with the row bounds, used after phase 1)
+        // (all five look-ups in flight together: left alone the compiler moves the row bounds behind the hand-back test below - a
+        // third dependent round trip per read, 69.1 -> 70.3 us)
+        asm volatile("" :: "s"(rb.s), "s"(rb.e), "s"(cov_at));
         const int64_t n64 = e - s;
         const int qe = rl / 20;                       // last bin an event can fall in
         // k_cov_stats says no (16-bit counts would overflow, malformed), or too long for the LDS (then also: bins < 16384 for the keys
         // of the run search below): general kernel
         if (K0 < 0 || qe >= qcap) {
-            if (lane == 0) fallback_list[atomicAdd(fallback_count, 1u)] = i;
+            if (lane == 0) { int* const fl = C->fallback_list; fl[atomicAdd(C->fallback_count, 1u)] = i; }
             continue;
         }
         const int n = (int)n64;

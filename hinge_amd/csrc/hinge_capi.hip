@@ -887,6 +887,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
             memset(&hc, 0, sizeof(hc));
             hc.P = to_dev(p);
             hc.o = anno_out(ctx);
+            hc.fallback_list = (int*)ctx->fallback_list.p;
+            hc.fallback_count = &sc(ctx)->fallback_count;
             int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
             if (rc) return rc;
             if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
@@ -901,8 +903,7 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         hipLaunchKernelGGL((k_mask_annotate_q20<PACKED, COVOUT, CUT20>), dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off,        \
                            mulpath_thr, p->no_hinge_region, cov_mask_off, (const int*)ctx->bucket_list.p, n1, n2, n4, (const int64_t*)ctx->row_ptr.p, SPANS, \
                            (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, (const int*)&sc(ctx)->min_cov, slot, cov_out,                                 \
-                           (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (int*)ctx->fallback_list.p, &sc(ctx)->fallback_count,      \
-                           (unsigned*)ctx->k2_heads.p, n_heads, bases)
+                           (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (unsigned*)ctx->k2_heads.p, n_heads, bases)
 #define LAUNCH_K2(PACKED, COVOUT, SPANS) do { if (p->cut_off == 300) LAUNCH_K2C(PACKED, COVOUT, 15, SPANS); else LAUNCH_K2C(PACKED, COVOUT, -1, SPANS); } while (0)
         if (ctx->use_span16) { if (cov_out) LAUNCH_K2(true, true, (const unsigned*)ctx->span16.p); else LAUNCH_K2(true, false, (const unsigned*)ctx->span16.p); }
         else { if (cov_out) LAUNCH_K2(false, true, (const int2*)ctx->a_span.p); else LAUNCH_K2(false, false, (const int2*)ctx->a_span.p); }
