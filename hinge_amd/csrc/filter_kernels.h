@@ -683,6 +683,18 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
                                                    const long long row, const int n_pile, const bool cov_done = false,
                                                    const bool cand_in_profile = true /*cand[] overwrites what z() reads*/,
                                                    const unsigned long long flag_words = ~0ull /*bit w clear: no bin of [64 w, 64 w + 63] can be an annotation*/) {
+    // What every read needs of the parameters and output pointers, looked up TOGETHER: where P and o are in device memory
+    // (k_mask_annotate_q20) each look-up at its point of use is a scalar-load round trip of its own in the read's dependency
+    // chain - six of them, one behind the other, before this.
+    const int del_telo = P.del_telo, use_qv = P.use_qv, use_cov = P.use_cov;
+    const int2* const qv_maskp = o.qv_mask;
+    const unsigned char* const keepp = o.keep;
+    int2* const maskp = o.mask;
+    int2* const cmaskp = o.cmask;
+    unsigned char* const rflagsp = o.rflags;
+    unsigned* const anno_offp = o.anno_off;
+    int* const anno_cntp = o.anno_cnt;
+    asm volatile("" :: "s"(del_telo), "s"(use_qv), "s"(use_cov), "s"(qv_maskp), "s"(keepp), "s"(maskp), "s"(cmaskp), "s"(rflagsp), "s"(anno_offp), "s"(anno_cntp));
     if (o.cov_out && !cov_done) {   // before anything reuses the profile's LDS (cand)
         int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
         for (int j = lane; j < K0; j += WAVE) dst[j] = z(j);
@@ -696,7 +708,7 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
         msc = maxstart / reso;              // = z + 1
     }
     unsigned char fl = 0;
-    if (P.del_telo && lane == 0) {   // filter.cpp:731-760 on cutoff_cov + MIN_COV = max(cov, MIN_COV)
+    if (del_telo && lane == 0) {   // filter.cpp:731-760 on cutoff_cov + MIN_COV = max(cov, MIN_COV)
         int sc = 0, ec = 0;
         if (mec - msc + 1 > 20) {
             for (int d = 0; d < 10; d++) { sc += max(c(msc + d), MIN_COV); ec += max(c(mec - d), MIN_COV); }
@@ -711,16 +723,16 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
     const unsigned iv = in_vgpr((unsigned)i);   // the read's index for the lane-0 stores below (vector-side address arithmetic)
     int2 mk;
     {
-        int2 q = o.qv_mask ? load_at32(o.qv_mask, (unsigned)i << 3) : make_int2(0, 0);
-        if (o.keep && !load_at32(o.keep, (unsigned)i)) { maxend = maxstart; q.y = q.x; }   // filter.cpp:767-773
-        if (P.use_qv && P.use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
-        else if (P.use_cov && !P.use_qv) mk = make_int2(maxstart, maxend);
+        int2 q = qv_maskp ? load_at32(qv_maskp, (unsigned)i << 3) : make_int2(0, 0);
+        if (keepp && !load_at32(keepp, (unsigned)i)) { maxend = maxstart; q.y = q.x; }   // filter.cpp:767-773
+        if (use_qv && use_cov) mk = make_int2(max(maxstart, q.x), min(maxend, q.y));
+        else if (use_cov && !use_qv) mk = make_int2(maxstart, maxend);
         else mk = q;
     }
     if (lane == 0) {
-        store_at32(o.mask, iv << 3, mk);
-        store_at32(o.cmask, iv << 3, make_int2(msc, mec));
-        store_at32(o.rflags, iv, fl);
+        store_at32(maskp, iv << 3, mk);
+        store_at32(cmaskp, iv << 3, make_int2(msc, mec));
+        store_at32(rflagsp, iv, fl);
     }
     HINGE_ABLATE_RETURN_V(2)
     // ---- gate sums over the two NO_HINGE_REGION windows only (filter.cpp:842-865) -----------------
@@ -751,7 +763,7 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
             S = wave_sum(S); E = wave_sum(E);
         }
     };
-    if (cand_in_profile) gate_sums();
+    if (cand_in_profile && flag_words != 0ull) gate_sums();   // (no flagged word: no candidate, no gate)
     HINGE_ABLATE_RETURN_V(3)
     // annotation window in bins: reso*j in [mk.x + nhr, mk.y - nhr], j < K0 - 2
     // (nothing of this - window bounds, parameter loads - when no word can hold an annotation: the usual case in k_mask_annotate_q20)
@@ -791,8 +803,8 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
     HINGE_ABLATE_RETURN_V(4)
     if (ncand == 0) {   // (wave-uniform; most reads: no merge, no gate, no work item)
         if (lane == 0) {
-            store_at32(o.anno_off, iv << 2, 0u);
-            store_at32(o.anno_cnt, iv << 2, 0);
+            store_at32(anno_offp, iv << 2, 0u);
+            store_at32(anno_cntp, iv << 2, 0);
         }
         return 0;
     }
@@ -829,8 +841,8 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
             off = atomicAdd(&o.counters[0], (unsigned)m);
             if (off + (unsigned)m > o.anno_cap) { atomicOr(o.status, ST_ANNO_CAP); m = 0; }
         }
-        store_at32(o.anno_off, iv << 2, off);
-        store_at32(o.anno_cnt, iv << 2, m);
+        store_at32(anno_offp, iv << 2, off);
+        store_at32(anno_cntp, iv << 2, m);
         if (m > 0 && !gate_skip) {
             const unsigned w = atomicAdd(&o.counters[1], 1u);
             WorkItem it;
@@ -1322,6 +1334,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 zc = wave_last(z);
                 pc = (int)(M >> 63);
             };
+            // A word in which no run ends (no non-positive bin behind a positive one: a read's FIRST word, where the coverage rises
+            // once) only moves the carries - a dozen scalar instructions instead of the ~45 of the vector form.
+            auto closes_none = [&](int base, unsigned long long M) {
+                const unsigned long long N = ~M;
+                if (N & ((M << 1) | (unsigned long long)pc)) return false;
+                if (N) zc = base + 63 - __builtin_clzll(N);   // the word's last non-positive bin (bins ascend: it is the largest so far)
+                pc = (int)(M >> 63);
+                return true;
+            };
             int base = 0;
 #ifdef HINGE_ABLATE
             if (P.ablate == 7 || P.ablate == 8) base = KC;
@@ -1332,13 +1353,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 const unsigned long long M = ballot_of(p);
                 // 64 bins above MIN_COV (the interior of nearly every read) open or continue a run and close none
                 if (M == ~0ull) { pc = 1; continue; }
+                if (closes_none(base, M)) continue;
                 word(base, p, M);
             }
             if (base < KC) {   // the last, partial word: the bins from KC on count as positive ones that belong to no run (they close
                                // none, and a run that is still open at the last valid bin is not counted, as in the reference's loop)
                 const bool valid = base + lane < KC;
                 const bool p = !valid || (*pcb & 0xffff) - (int)((unsigned)*pce >> 16) > MIN_COV;
-                word(base, p, ballot_of(p));
+                const unsigned long long M = ballot_of(p);
+                if (!closes_none(base, M)) word(base, p, M);
             }
         }
         RunState run{0, 0ull, 0, 0};
