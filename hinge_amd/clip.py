@@ -1,0 +1,438 @@
+"""`hinge clip` - the first consumer of `hinge layout`'s files: graph construction from `.edges.hinges` /
+`.hinge.list`, dead-end clipping, Z-edge clipping and bubble bursting on the strand-symmetric read graph, `G0` / `G1` written as
+GraphML.
+
+Restated from the BEHAVIOUR of the reference's scripts/pruning_and_clipping.py (its reader :1295-1419 and the three operations
+:197-262, :331-390, :561-622 as its main body applies them, :1436-1480), not from its text: this module has its own graph type
+(the reference drives networkx 1.9 under Python 2), works on (read, strand) pairs instead of "read_strand" strings, and treats a
+clipped path and its mirror image as one operation.  Host code by nature - a few thousand vertices, pointer chasing; the reference
+runs it in the Python interpreter too.
+
+**PARITY UNPINNED, and knowingly order-dependent.**  The reference cannot run in this image (Python 2, networkx 1.9, ujson,
+colormap), so nothing here is compared with its output.  Its results depend on iteration orders this module cannot reproduce:
+it walks `set`s of node-name strings and `successors()` lists in CPython 2's hash-table order.  The operations commute
+whenever the paths they remove do not touch each other, so for those graphs any order gives the reference's graph; where two
+candidate paths overlap (two dead ends into one junction, two Z edges out of one vertex - it keeps its last way out, so the
+one visited first is cut -, a bubble - the branch listed FIRST among a vertex's two successors is the one removed), the
+reference's own outcome is an accident of string hashes.  Here the orders are fixed and documented:
+vertices in order of first appearance in `.edges.hinges`, successors in order of edge insertion.  tests/test_clip.py checks
+the three operations on hand-built graphs, the strand symmetry of every result, and order-independence on the layout output
+of the synthetic data sets (three of four are order-free; `long_repeat` has two competing Z edges).
+
+Not built: the later stages of the script (loop resolution :705-839, random condensation :456-500, strand overlay, Y pruning,
+ground-truth and colour annotation) and the files they write (G2, Gs, G2s, Gc, G2c, G3*).
+
+    python -m hinge_amd.clip G.edges.hinges G.hinge.list <suffix> [nominal.ini]
+"""
+from __future__ import annotations
+
+import configparser
+import os
+import sys
+from typing import Dict, Iterable, Iterator, List, Optional, Set, Tuple
+from xml.sax.saxutils import escape, quoteattr
+
+Node = Tuple[int, int]          # (read id, strand)
+
+
+def mirror(v: Node) -> Node:
+    """The same read end seen from the other strand (pruning_and_clipping.py:191-194)."""
+    return (v[0], 1 - v[1])
+
+
+def node_name(v: Node) -> str:
+    return "%d_%d" % v
+
+
+class StrandGraph:
+    """Directed graph with attribute dictionaries on vertices and edges; adjacency in insertion order (Python dicts)."""
+
+    def __init__(self):
+        self.attr: Dict[Node, dict] = {}
+        self.out: Dict[Node, Dict[Node, dict]] = {}
+        self.inn: Dict[Node, Dict[Node, dict]] = {}
+
+    # ---- construction -------------------------------------------------------------------------------------------------------
+    def add_node(self, v: Node) -> None:
+        if v not in self.attr:
+            self.attr[v] = {}
+            self.out[v] = {}
+            self.inn[v] = {}
+
+    def add_edge(self, u: Node, v: Node, **attr) -> None:
+        """A second add of the same edge updates its attributes in place (what the reference's graph library does)."""
+        self.add_node(u)
+        self.add_node(v)
+        d = self.out[u].get(v)
+        if d is None:
+            d = {}
+            self.out[u][v] = d
+            self.inn[v][u] = d
+        d.update(attr)
+
+    def copy(self) -> "StrandGraph":
+        g = StrandGraph()
+        for v, a in self.attr.items():
+            g.add_node(v)
+            g.attr[v].update(a)
+        for u, nb in self.out.items():
+            for v, a in nb.items():
+                g.add_edge(u, v, **a)
+        return g
+
+    # ---- queries ------------------------------------------------------------------------------------------------------------
+    def __contains__(self, v: Node) -> bool:
+        return v in self.attr
+
+    def __len__(self) -> int:
+        return len(self.attr)
+
+    def nodes(self) -> List[Node]:
+        return list(self.attr)
+
+    def edges(self) -> Iterator[Tuple[Node, Node, dict]]:
+        for u, nb in self.out.items():
+            for v, a in nb.items():
+                yield u, v, a
+
+    def has_edge(self, u: Node, v: Node) -> bool:
+        return u in self.out and v in self.out[u]
+
+    def successors(self, v: Node) -> List[Node]:
+        return list(self.out[v])
+
+    def out_degree(self, v: Node) -> int:
+        return len(self.out[v])
+
+    def in_degree(self, v: Node) -> int:
+        return len(self.inn[v])
+
+    def n_edges(self) -> int:
+        return sum(len(nb) for nb in self.out.values())
+
+    # ---- removal ------------------------------------------------------------------------------------------------------------
+    def remove_edge(self, u: Node, v: Node) -> bool:
+        if not self.has_edge(u, v):
+            return False
+        del self.out[u][v]
+        del self.inn[v][u]
+        return True
+
+    def remove_node(self, v: Node) -> bool:
+        if v not in self.attr:
+            return False
+        for w in list(self.out[v]):
+            del self.inn[w][v]
+        for w in list(self.inn[v]):
+            del self.out[w][v]
+        del self.out[v], self.inn[v], self.attr[v]
+        return True
+
+    def is_strand_symmetric(self) -> bool:
+        """u -> v present iff mirror(v) -> mirror(u) is, every vertex with its mirror image."""
+        return all(mirror(v) in self.attr for v in self.attr) and all(self.has_edge(mirror(v), mirror(u)) for u, v, _ in self.edges())
+
+
+# ---- reading the layout's files -----------------------------------------------------------------------------------------------
+def _bracket(tok: str) -> int:
+    return int(tok.strip("[]"))
+
+
+def read_edges(path: str) -> StrandGraph:
+    """`.edges.hinges` -> graph (pruning_and_clipping.py:1314-1371).  A line `A B len sa sb hinged [..] [..] [..] [..] [..] [..]`
+    (hinging.cpp:188-248) is the edge A_sa -> B_sb AND its mirror image B_(1-sb) -> A_(1-sa), with A's and B's coordinates
+    exchanged on the mirror.  `intersection` = 1 on an edge (and its mirror) that a later line names again."""
+    g = StrandGraph()
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) < 5:
+                continue
+            a, b = (int(t[0]), int(t[3])), (int(t[1]), int(t[4]))
+            seen = 1 if g.has_edge(a, b) else 0
+            ma = (_bracket(t[6]), _bracket(t[7]))
+            mb = (_bracket(t[8]), _bracket(t[9]))
+            ra = (_bracket(t[-4]), _bracket(t[-3]))
+            rb = (_bracket(t[-2]), _bracket(t[-1]))
+            for u, v, (x, y, xr, yr) in ((a, b, (ma, mb, ra, rb)), (mirror(b), mirror(a), (mb, ma, rb, ra))):
+                g.add_edge(u, v, hinge_edge=int(t[5]), intersection=seen, length=int(t[2]), z=0,
+                           read_a_match_start=x[0], read_a_match_end=x[1], read_b_match_start=y[0], read_b_match_end=y[1],
+                           read_a_match_start_raw=xr[0], read_a_match_end_raw=xr[1], read_b_match_start_raw=yr[0], read_b_match_end_raw=yr[1])
+    return g
+
+
+def read_hinges(path: str) -> Tuple[Set[Node], Set[Node]]:
+    """`.hinge.list` (hinging.cpp:1694-1704) -> (in-hinge vertices, out-hinge vertices), pruning_and_clipping.py:1402-1414:
+    a hinge of type 1 makes read_0 an in-hinge and read_1 an out-hinge, type -1 the other way round."""
+    ins: Set[Node] = set()
+    outs: Set[Node] = set()
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) < 3:
+                continue
+            r = int(t[0])
+            if t[2] == "1":
+                ins.add((r, 0)); outs.add((r, 1))
+            elif t[2] == "-1":
+                ins.add((r, 1)); outs.add((r, 0))
+    return ins, outs
+
+
+def annotate_hinges(g: StrandGraph, ins: Set[Node], outs: Set[Node]) -> None:
+    """Vertex attribute `hinge`: 1 in-hinge, -1 out-hinge, else 0; an in-hinge wins (pruning_and_clipping.py:1040-1051)."""
+    for v in g.attr:
+        g.attr[v]["hinge"] = 1 if v in ins else -1 if v in outs else 0
+
+
+def flag_bad_coverage(g: StrandGraph, path: str) -> int:
+    """`<prefix>.cov.flag` (one read id per line): CFLAG on both strands' vertices (pruning_and_clipping.py:1056-1083)."""
+    for v in g.attr:
+        g.attr[v]["CFLAG"] = False
+    n = 0
+    with open(path) as f:
+        for line in f:
+            name = line.strip()
+            if not name:
+                continue
+            r = int(name)
+            if ((r, 0) in g) != ((r, 1) in g):
+                raise ValueError("%s is not symmetrically present in the graph input." % name)
+            if (r, 0) in g:
+                g.attr[(r, 0)]["CFLAG"] = g.attr[(r, 1)]["CFLAG"] = True
+                n += 1
+    return n
+
+
+def mark_skipped(g: StrandGraph, path: str) -> None:
+    """`.edges.skipped`: `skipped` = 1 on the edges of the graph it names, and on their mirror images (:1021-1034)."""
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) < 5:
+                continue
+            a, b = (int(t[0]), int(t[3])), (int(t[1]), int(t[4]))
+            if g.has_edge(a, b):
+                g.out[a][b]["skipped"] = 1
+                g.out[mirror(b)][mirror(a)]["skipped"] = 1
+
+
+# ---- the three operations -------------------------------------------------------------------------------------------------------
+def _chain(h: StrandGraph, first: Node, limit: int) -> Tuple[List[Node], Node]:
+    """Follow the unbranched chain that starts at `first`: vertices with one way in and one way out, at most until the chain
+    (counting what the caller already holds) has `limit` members.  Returns (the chain's vertices, the vertex it ends in front of)."""
+    chain: List[Node] = []
+    cur = first
+    while h.in_degree(cur) == 1 and h.out_degree(cur) == 1 and len(chain) < limit:
+        chain.append(cur)
+        cur = h.successors(cur)[0]
+    return chain, cur
+
+
+def clip_dead_ends(g: StrandGraph, threshold: int, order: Optional[Iterable[Node]] = None) -> StrandGraph:
+    """Remove short dead ends, both strands at once (pruning_and_clipping.py:197-262).  A vertex nothing points to starts a path
+    along vertices with exactly one way in and out; if the path has at most `threshold` vertices and ends in front of a junction
+    (something else also points there) or at a vertex with no way on, the path and its mirror image go.  The mirror images are
+    the dead ENDS of the other strand, so sources are all that is looked at."""
+    h = g.copy()
+    starts = [v for v in (h.nodes() if order is None else order) if v in h and h.in_degree(v) == 0]
+    for st in starts:
+        if st not in h:
+            continue
+        path = [st]
+        cur = st
+        if h.out_degree(st) == 1:
+            more, cur = _chain(h, h.successors(st)[0], threshold + 1)   # (the path is followed two vertices past the threshold at most)
+            path += more
+        if len(path) <= threshold and (h.in_degree(cur) > 1 or h.out_degree(cur) == 0):
+            for v in path:
+                h.remove_node(v)
+                h.remove_node(mirror(v))
+    return h
+
+
+def clip_z_edges(g: StrandGraph, threshold: int, ins: Set[Node] = frozenset(), outs: Set[Node] = frozenset(),
+                 order: Optional[Iterable[Node]] = None) -> Tuple[StrandGraph, StrandGraph]:
+    """Remove short cross links between two well-supported paths (pruning_and_clipping.py:331-390): from a vertex with several
+    ways out (and not an out-hinge), a branch that runs unbranched for fewer than `threshold` edges into a vertex that something
+    else also points to (and that is not an in-hinge) is cut, with its mirror image, while the start still has another way out.
+    Returns (the clipped graph, a copy of the input with `z` = 1 on what was cut)."""
+    h = g.copy()
+    marked = g.copy()
+    starts = [v for v in (h.nodes() if order is None else order) if v in h and h.out_degree(v) > 1 and v not in outs]
+    for st in starts:
+        if st not in h:
+            continue
+        for sec in h.successors(st):
+            if h.out_degree(st) == 1:
+                break
+            if sec not in h:      # (cut as the interior of an earlier branch of this vertex)
+                continue
+            path = [(st, sec)]
+            cur = sec
+            while h.in_degree(cur) == 1 and h.out_degree(cur) == 1:
+                nxt = h.successors(cur)[0]
+                path.append((cur, nxt))
+                cur = nxt
+                if len(path) > threshold + 1:
+                    break
+            if len(path) <= threshold and h.in_degree(cur) > 1 and h.out_degree(st) > 1 and cur not in ins:
+                for u, v in path:
+                    marked.out[u][v]["z"] = 1
+                    marked.out[mirror(v)][mirror(u)]["z"] = 1
+                    if h.remove_edge(u, v):
+                        h.remove_edge(mirror(v), mirror(u))
+                for _, v in path[:-1]:
+                    marked.attr[v]["z"] = 1
+                    marked.attr[mirror(v)]["z"] = 1
+                    if h.remove_node(v):
+                        h.remove_node(mirror(v))
+    return h, marked
+
+
+def burst_bubbles(h: StrandGraph, threshold: int, order: Optional[Iterable[Node]] = None) -> StrandGraph:
+    """Remove one side of short bubbles, in place (pruning_and_clipping.py:561-622): a vertex with exactly two ways out whose two
+    branches run unbranched (at most `threshold` edges each) into the same vertex loses its FIRST branch - edges and interior
+    vertices, with their mirror images.  "First" is the first of the vertex's two successors in this graph's adjacency order
+    (edge insertion order); in the reference it is whichever of the two names CPython 2 hashes first."""
+    starts = [v for v in (h.nodes() if order is None else order) if v in h and h.out_degree(v) == 2]
+    for st in starts:
+        if st not in h or h.out_degree(st) < 2:
+            continue
+        branches = []
+        for sec in h.successors(st)[:2]:
+            path = [(st, sec)]
+            cur = sec
+            while h.in_degree(cur) == 1 and h.out_degree(cur) == 1:
+                nxt = h.successors(cur)[0]
+                path.append((cur, nxt))
+                cur = nxt
+                if len(path) > threshold + 1:
+                    break
+            branches.append((path, cur))
+        (first, end0), (second, end1) = branches
+        if len(first) <= threshold and len(second) <= threshold and end0 == end1:
+            for u, v in first:
+                h.remove_edge(u, v)
+                h.remove_edge(mirror(v), mirror(u))
+            for _, v in first[:-1]:
+                h.remove_node(v)
+                h.remove_node(mirror(v))
+    return h
+
+
+# ---- GraphML ------------------------------------------------------------------------------------------------------------------
+_GRAPHML_TYPE = {bool: "boolean", int: "int", float: "double", str: "string"}
+
+
+def write_graphml(g: StrandGraph, path: str) -> None:
+    """GraphML as graph libraries read it (one <key> per attribute name and domain, typed; vertices named `read_strand`).
+    Vertices, edges and keys are written in this graph's own order - the reference's file has the same content in its graph
+    library's hash order."""
+    keys: Dict[Tuple[str, str], Tuple[str, str]] = {}
+
+    def key_of(domain: str, name: str, value) -> str:
+        k = keys.get((domain, name))
+        if k is None:
+            k = ("d%d" % len(keys), _GRAPHML_TYPE[type(value)])
+            keys[(domain, name)] = k
+        return k[0]
+
+    body: List[str] = []
+    for v, a in g.attr.items():
+        body.append("    <node id=%s>" % quoteattr(node_name(v)) if a else "    <node id=%s />" % quoteattr(node_name(v)))
+        for name, value in a.items():
+            body.append("      <data key=\"%s\">%s</data>" % (key_of("node", name, value), escape(_text(value))))
+        if a:
+            body.append("    </node>")
+    for u, v, a in g.edges():
+        body.append("    <edge source=%s target=%s>" % (quoteattr(node_name(u)), quoteattr(node_name(v))))
+        for name, value in a.items():
+            body.append("      <data key=\"%s\">%s</data>" % (key_of("edge", name, value), escape(_text(value))))
+        body.append("    </edge>")
+    with open(path, "w") as f:
+        f.write("<?xml version='1.0' encoding='utf-8'?>\n")
+        f.write("<graphml xmlns=\"http://graphml.graphdrawing.org/xmlns\" xmlns:xsi=\"http://www.w3.org/2001/XMLSchema-instance\" "
+                "xsi:schemaLocation=\"http://graphml.graphdrawing.org/xmlns http://graphml.graphdrawing.org/xmlns/1.0/graphml.xsd\">\n")
+        for (domain, name), (kid, typ) in keys.items():
+            f.write("  <key id=\"%s\" for=\"%s\" attr.name=%s attr.type=\"%s\" />\n" % (kid, domain, quoteattr(name), typ))
+        f.write("  <graph edgedefault=\"directed\">\n")
+        f.write("\n".join(body))
+        f.write("\n  </graph>\n</graphml>\n")
+
+
+def _text(value) -> str:
+    return str(value)      # (booleans as "True" / "False": what the reference's graph library writes, and reads back)
+
+
+# ---- the command ----------------------------------------------------------------------------------------------------------------
+def layout_prefix(edges_path: str) -> str:
+    """Everything before the FIRST dot of the path as given (pruning_and_clipping.py:1246: directories with dots included)."""
+    return edges_path.split(".")[0]
+
+
+def clip_settings(ini_path: Optional[str]) -> dict:
+    """[layout] del_telomeres / aggressive_pruning / max_plasmid_length (pruning_and_clipping.py:1256-1277; only the first
+    changes anything in the stages built here)."""
+    out = {"del_telomeres": False, "aggressive_pruning": False, "max_plasmid_length": 500000}
+    if ini_path:
+        cp = configparser.ConfigParser()
+        cp.read(ini_path)
+        for name in ("del_telomeres", "aggressive_pruning"):
+            try:
+                out[name] = cp.getint("layout", name) == 1
+            except Exception:
+                pass
+        try:
+            out["max_plasmid_length"] = cp.getint("layout", "max_plasmid_length")
+        except Exception:
+            pass
+    return out
+
+
+def build_graph(edges_path: str, hinges_path: str) -> Tuple[StrandGraph, Set[Node], Set[Node]]:
+    g = read_edges(edges_path)
+    ins, outs = read_hinges(hinges_path)
+    annotate_hinges(g, ins, outs)
+    prefix = layout_prefix(edges_path)
+    if os.path.isfile(prefix + ".cov.flag"):
+        flag_bad_coverage(g, prefix + ".cov.flag")
+    if os.path.isfile(prefix + ".edges.skipped"):
+        mark_skipped(g, prefix + ".edges.skipped")
+    return g, ins, outs
+
+
+def clip(g: StrandGraph, del_telomeres: bool = False) -> Tuple[StrandGraph, StrandGraph]:
+    """(G0, G1) as the reference's main body makes them (pruning_and_clipping.py:1436-1471): dead ends of up to 10 vertices,
+    Z edges of fewer than 6 (the hinge sets play no part: the script passes empty ones), bubbles of up to 10 edges a side,
+    then dead ends of up to 5 once more (20 and 20 with del_telomeres).  G0 = the graph after the first clipping with what
+    the Z clipping cut marked `z` = 1; G1 = the end result."""
+    g0 = clip_dead_ends(g, 10)
+    g1, g0 = clip_z_edges(g0, 6)
+    g1 = burst_bubbles(g1, 20 if del_telomeres else 10)
+    g1 = clip_dead_ends(g1, 20 if del_telomeres else 5)
+    return g0, g1
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) < 3:
+        sys.stderr.write("usage: hinge clip <prefix>.edges.hinges <prefix>.hinge.list <suffix> [nominal.ini]\n")
+        return 1
+    edges_path, hinges_path, suffix = argv[0], argv[1], argv[2]
+    cfg = clip_settings(argv[3] if len(argv) >= 4 else None)
+    if len(argv) >= 5:
+        sys.stderr.write("[clip] ground-truth annotation (5th argument) is not part of this build; ignored\n")
+    g, _, _ = build_graph(edges_path, hinges_path)
+    print("[clip] Graph with %d nodes built" % len(g))
+    g0, g1 = clip(g, cfg["del_telomeres"])
+    print("[clip] Number of nodes remaining: %d" % len(g1))
+    out = layout_prefix(edges_path) + suffix
+    write_graphml(g0, out + ".G0.graphml")
+    write_graphml(g1, out + ".G1.graphml")
+    print("[clip] Done (G0, G1; the later stages of the reference's script - loop resolution, condensation, strand overlay - are not part of this build)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
