@@ -77,6 +77,8 @@ struct hinge_ctx {
     int k2_occ_lds = -1, k2_occ = 0;          // occupancy calculator: workgroups per CU at that many bytes of dynamic LDS
     std::vector<int> k2_list;                 // host copy of bucket_list (the upload is asynchronous)
     std::vector<int> k2_c1;                   // the one-slot reads in storage order (for the XCD-contiguous deal, see launch_mask_annotate)
+    std::vector<unsigned char> k2_heavy;      // per read of the part: its pile-up is far deeper than the part's mean (see hinge_set_pileups)
+    int k2_heavy_mode = 2;                    // HINGE_K2_HEAVY: 2 = the deep pile-ups at even intervals over the first 60 % of an XCD's sequence, 1 = first, 0 = where the storage order puts them
     int k2_deal = 1;                          // 1: deal every XCD a contiguous eighth of the one-slot reads, in storage order (HINGE_K2_DEAL=0: longest first, round 2's order)
     int k2_deal_heads = -1, k2_deal_rot = -1; // what the list on the device was dealt for
     int n_class[3] = {0, 0, 0};               // bucket_list = [reads needing 1 (longest first) | 2 | 4 LDS slots of a K2 workgroup] of the current part
@@ -239,6 +241,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_K2_WGS")) ctx->k2_wgs = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_K2_ORDER_BP")) ctx->k2_order_bp = std::max(1, atoi(g));
     if (const char* g = getenv("HINGE_K2_DEAL")) ctx->k2_deal = atoi(g);
+    if (const char* g = getenv("HINGE_K2_HEAVY")) ctx->k2_heavy_mode = atoi(g);
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -387,6 +390,18 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
             if (l <= len1) lst[(size_t)at[(size_t)(std::max(l, 0) / ob)]++] = i; else if (l <= len2) lst[(size_t)p2++] = i; else lst[(size_t)p4++] = i;
         }
         ctx->n_class[0] = n1; ctx->n_class[1] = n2; ctx->n_class[2] = n4;
+        ctx->k2_heavy.assign((size_t)std::max(nr, 1), 0);
+        if (ctx->k2_heavy_mode && nr > 0) {
+            std::vector<int64_t> rp_copy;
+            const int64_t* rp = row_ptr;
+            if (on_device) {   // (once per part, outside any pass)
+                rp_copy.resize((size_t)nr + 1);
+                CK(hipMemcpy(rp_copy.data(), row_ptr + r_begin, sizeof(int64_t) * ((size_t)nr + 1), hipMemcpyDeviceToHost));
+                rp = rp_copy.data() - r_begin;
+            }
+            const int64_t deep = 2 * ((rp[r_end + 1] - rp[r_begin]) / nr) + 64;   // deep = more than twice the part's mean
+            for (int i = r_begin; i <= r_end; i++) ctx->k2_heavy[(size_t)(i - r_begin)] = rp[i + 1] - rp[i] > deep;
+        }
         ctx->k2_deal_heads = ctx->k2_deal_rot = -1;
         ctx->k2_c1.clear();
         if (ctx->k2_deal) {
@@ -860,7 +875,28 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
             int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at[8];
             for (int pz = 0; pz < n1; pz++) cnt[((pz % n_heads) + rot) % 8]++;
             for (int x = 0, run = 0; x < 8; x++) { at[x] = run; run += cnt[x]; }
-            for (int pz = 0; pz < n1; pz++) ctx->k2_list[(size_t)pz] = ctx->k2_c1[(size_t)at[((pz % n_heads) + rot) % 8]++];
+            std::vector<int> c1(ctx->k2_c1);
+            if (ctx->k2_heavy_mode) {
+                // Where an XCD's DEEP pile-ups go in its sequence.  A read's time is ~1.3 us + 12 ns per overlap (per-read time stamps,
+                // tools/k2_trace.py: 5 us on average, 20-30 us for the 2 000 overlaps of a read inside a repeat), and one that is drawn in
+                // the last third of the launch ends long after everything else: the launch's last 7 us ran at falling occupancy behind
+                // a handful of them.  All of them FIRST is far worse (66 -> 90 us): hundreds of their overlaps begin or end in the same
+                // 20-bp bin, a same-address LDS atomic costs 0.83 ns of the CU's LDS pipe per lane that shares the word
+                // (tools/probes/lds_atomic_probe.cpp), and a CU full of them stalls on it; already over the first 50 % of the
+                // sequence they are too dense (69 us).  At even intervals over the first 60 %: 67.2 -> 64.4 us.
+                auto heavy = [&](int i) { return ctx->k2_heavy[(size_t)(i - ctx->r_begin)] != 0; };
+                for (int x = 0; x < 8; x++) {
+                    std::vector<int> seg(c1.begin() + at[x], c1.begin() + at[x] + cnt[x]), hv, rest;
+                    for (int i : seg) (heavy(i) ? hv : rest).push_back(i);
+                    size_t o = (size_t)at[x], ih = 0, ir = 0;
+                    const size_t span = ctx->k2_heavy_mode == 2 ? (size_t)(0.6 * seg.size()) : hv.size();
+                    for (size_t k = 0; k < seg.size(); k++) {
+                        const bool take_h = ih < hv.size() && (ir >= rest.size() || (k < span && ih * span <= k * hv.size()));
+                        c1[o + k] = take_h ? hv[ih++] : rest[ir++];
+                    }
+                }
+            }
+            for (int pz = 0; pz < n1; pz++) ctx->k2_list[(size_t)pz] = c1[(size_t)at[((pz % n_heads) + rot) % 8]++];
             CK(hipMemcpyAsync(ctx->bucket_list.p, ctx->k2_list.data(), sizeof(int) * (size_t)n1, hipMemcpyHostToDevice, ctx->stream));
             ctx->k2_deal_heads = n_heads; ctx->k2_deal_rot = rot;
         }

@@ -130,13 +130,16 @@ def test_context_reuse_across_read_sets_with_coverage_out(oracle_lib, tmp_path):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,wgs,deal", [("chimera", 8, 1), ("tiny_mlas", 16, 1), ("long_reads", 16, 1), ("edges", 24, 1), ("chimera", 16, 0)])
-def test_filter_k2_read_deal(datasets, oracle_lib, tmp_path, monkeypatch, name, wgs, deal):
+@pytest.mark.parametrize("name,wgs,deal,heavy", [("chimera", 8, 1, 2), ("tiny_mlas", 16, 1, 2), ("long_reads", 16, 1, 2), ("edges", 24, 1, 2), ("chimera", 16, 0, 2),
+                                                 ("deep", 8, 1, 2), ("deep", 16, 1, 1), ("deep", 8, 1, 0), ("long_repeat", 8, 1, 2)])
+def test_filter_k2_read_deal(datasets, oracle_lib, tmp_path, monkeypatch, name, wgs, deal, heavy):
     """k_mask_annotate_q20's drawn reads dealt XCD-contiguously in storage order (on when the persistent workgroups are a
-    multiple of the 8 XCDs: forced here on small data through HINGE_K2_WGS) and in round 2's longest-first order: same files."""
+    multiple of the 8 XCDs: forced here on small data through HINGE_K2_WGS) and in round 2's longest-first order; the deep
+    pile-ups of an XCD's sequence spread over its first 60 % (2, the default), first (1) or left where they are (0): same files."""
     from hinge_amd import capi
     monkeypatch.setenv("HINGE_K2_WGS", str(wgs))
     monkeypatch.setenv("HINGE_K2_DEAL", str(deal))
+    monkeypatch.setenv("HINGE_K2_HEAVY", str(heavy))
     src, _ = datasets(name)
     wd_o = clone_dataset(src, str(tmp_path / "oracle"))
     wd_h = clone_dataset(src, str(tmp_path / "hip"))

@@ -85,6 +85,8 @@ def random_paths(rng, spec):
                                                                           # (8, 16: a multiple of the 8 XCDs, so the XCD-contiguous deal of the reads is on)
     if rng.random() < 0.2:
         env["HINGE_K2_DEAL"] = "0"                   # round 2's longest-first order of the drawn reads
+    if rng.random() < 0.2:
+        env["HINGE_K2_HEAVY"] = str(int(rng.choice([0, 1])))   # the deep pile-ups first / left in storage order (default: spread over the first 60 %)
     paf = spec.n_blocks == 1 and rng.random() < 0.2
     return env, paf
 

@@ -15,6 +15,8 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = [
     ("default", {}),
+    ("heavy=0", {"HINGE_K2_HEAVY": "0"}),
+    ("heavy=1", {"HINGE_K2_HEAVY": "1"}),
     ("wgs=5/cu", {"HINGE_K2_WGS": "1280"}),
     ("wgs=6/cu", {"HINGE_K2_WGS": "1536"}),
     ("order=64", {"HINGE_K2_ORDER_BP": "64"}),
@@ -51,7 +53,7 @@ def main():
     for name, env in VARIANTS:
         if only and name not in only:
             continue
-        for k in ("HINGE_K2_ORDER_BP", "HINGE_K2_WGS", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
+        for k in ("HINGE_K2_ORDER_BP", "HINGE_K2_WGS", "HINGE_K2_HEAVY", "HINGE_K2_DEAL", "HINGE_NO_SPAN16", "HINGE_K2_ABLATE", "HINGE_K1_W8"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctxs = []
