@@ -59,6 +59,7 @@ def main():
     out = np.zeros((n, 5), np.uint64)
     assert lib.hinge_debug_k2_trace_end(out.ctypes.data, n) == 0
     ctx.check(); ctx.close()
+    items = np.nonzero(out[:, 4] > 0)[0]
     t = out[out[:, 4] > 0].astype(np.int64)
     t0 = t[:, 0].min()
     t = (t - t0) * 10e-3          # us (100 MHz)
@@ -77,6 +78,17 @@ def main():
     done = np.sort(t[:, 4])
     for q in (50, 90, 95, 99, 100):
         print("  %3d %% of the reads done at %.1f us" % (q, done[min(len(done) - 1, int(len(done) * q / 100))] if q < 100 else done[-1]))
+    print("the last reads to end (list item: the two- and four-slot reads are the last %d or so items of the list; start, duration, histogram phase, us):" % int((d.rlen > 19000).sum()))
+    for k in np.argsort(t[:, 4])[-12:]:
+        print("    item %6d  start %5.1f  duration %5.1f  histogram %5.1f  end %5.1f" % (items[k], t[k, 0], dur[k], t[k, 1] - t[k, 0], t[k, 4]))
+    # when each of the 64 item counters ("heads": list positions h, h + 64, ...) runs dry, and each XCD's group of eight
+    n1 = int((d.rlen <= 19000).sum())
+    one = items < n1
+    head_end = np.array([t[one & (items % 64 == h), 4].max() for h in range(64)])
+    print("last read of a head ends at: min %.1f, median %.1f, max %.1f us; by group of eight heads (h %% 8): %s" % (
+        head_end.min(), np.median(head_end), head_end.max(), " ".join("%.1f" % head_end[g::8].max() for g in range(8))))
+    head_sum = np.array([dur[one & (items % 64 == h)].sum() for h in range(64)])
+    print("sum of a head's read times: min %.0f, max %.0f us (/128 wavefronts: %.1f .. %.1f us)" % (head_sum.min(), head_sum.max(), head_sum.min() / 128, head_sum.max() / 128))
     started = np.sort(t[:, 0])
     print("  first start of the last 10 %% of reads: %.1f us; reads started in the first 2 us: %d" % (started[int(len(started) * 0.9)], int((started < 2).sum())))
 
