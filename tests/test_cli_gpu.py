@@ -54,6 +54,14 @@ def test_cli_pipeline_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas,
     bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
     assert not bad, "differs from the oracle: %s" % bad
     assert os.path.getsize(os.path.join(wd_h, "G.edges.hinges")) > 0 and os.path.getsize(os.path.join(wd_h, "G.max")) > 0
+    if not mlas and not extra_filter:
+        # ... and `hinge clip` on top of the pipeline's files (hinge_amd/clip.py, parity unpinned: here only that the dispatcher runs
+        # it where the reference runs its script, and that identical layout files give identical graphs)
+        for wd in (wd_o, wd_h):
+            r = subprocess.run([HINGE, "clip", "G.edges.hinges", "G.hinge.list", ".c", "v.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            assert r.returncode == 0, r.stdout.decode()[-2000:]
+        for f in ("G.c.G0.graphml", "G.c.G1.graphml"):
+            assert os.path.getsize(os.path.join(wd_h, f)) > 0 and filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)
 
 
 def test_cli_reads_outside_the_overlap_id_range(datasets, oracle_lib, tmp_path):

@@ -19,6 +19,7 @@ VARIANTS = [
     ("heavy=1", {"HINGE_K2_HEAVY": "1"}),
     ("wgs=5/cu", {"HINGE_K2_WGS": "1280"}),
     ("wgs=6/cu", {"HINGE_K2_WGS": "1536"}),
+    ("wgs=7/cu", {"HINGE_K2_WGS": "1792"}),
     ("order=64", {"HINGE_K2_ORDER_BP": "64"}),
     ("order=4096", {"HINGE_K2_ORDER_BP": "4096"}),
     ("order=none", {"HINGE_K2_ORDER_BP": "1000000"}),
