@@ -63,6 +63,11 @@ SYMBOLS = [
     ("hinge_filter_median_from_hist_batch", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams), _VP, C.c_int64]),
     ("hinge_filter_median_batch", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams), _VP, C.c_int64]),
     ("hinge_filter_hinges_batch_async", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams)]),
+    ("hinge_filter_sweep_batch_async", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams), _VP, C.c_int64]),
+    ("hinge_filter_finish_batch_async", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(FilterParams)]),
+    ("hinge_filter_sweep", C.c_int, [_VP, C.POINTER(FilterParams), C.POINTER(CovEstimate)]),
+    ("hinge_filter_spec_stats", C.c_int, [_VP, _VP]),
+    ("hinge_debug_spec", C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
     ("hinge_set_read_restriction", C.c_int, [_VP, _VP]),
     ("hinge_filter_set_min_cov", C.c_int, [_VP, C.c_int32]),
     ("hinge_filter_get_min_cov", C.c_int, [_VP, C.POINTER(C.c_int32)]),
@@ -331,6 +336,21 @@ class Context:
     def filter_hinges(self, p: FilterParams):
         self._ck(self.lib.hinge_filter_hinges(self.h, C.byref(p)))
 
+    def filter_sweep(self, p: FilterParams, fetch: bool = True) -> Optional[CovEstimate]:
+        """The one-sweep pass of one part, synchronously (statistics, median, masks, annotations)."""
+        est = CovEstimate()
+        self._ck(self.lib.hinge_filter_sweep(self.h, C.byref(p), C.byref(est) if fetch else None))
+        return est if fetch else None
+
+    def spec_stats(self):
+        """(passes verified, exact != predicted, outside the band, guard-band reads of the last pass, predicted, exact MIN_COV)"""
+        out = (C.c_int64 * 6)()
+        self._ck(self.lib.hinge_filter_spec_stats(self.h, out))
+        return tuple(int(v) for v in out)
+
+    def debug_spec(self, band: int = -1, sample: int = 0, bias: int = 0):
+        self._ck(self.lib.hinge_debug_spec(self.h, int(band), int(sample), int(bias)))
+
     def filter_run(self, p: FilterParams):
         self._ck(self.lib.hinge_filter_run(self.h, C.byref(p)))
 
@@ -488,6 +508,16 @@ def _batch_call(fn_name: str, ctxs, *args) -> None:
 def median_batch(ctxs, p: FilterParams, hist_dev=None, row_stride: int = 0) -> None:
     """hinge_filter_median_batch: every context's own-range median in one launch (hist_dev: the histogram form, row k for context k)."""
     _batch_call("hinge_filter_median_batch", ctxs, C.byref(p), _VP(_ptr(hist_dev)) if hist_dev is not None else None, int(row_stride))
+
+
+def sweep_batch_async(ctxs, p: FilterParams, hist_dev=None, row_stride: int = 0) -> None:
+    """hinge_filter_sweep_batch_async: the one-sweep pass's prediction + sweep + verifying median of several resident parts."""
+    _batch_call("hinge_filter_sweep_batch_async", ctxs, C.byref(p), _VP(_ptr(hist_dev)) if hist_dev is not None else None, int(row_stride))
+
+
+def finish_batch_async(ctxs, p: FilterParams) -> None:
+    """hinge_filter_finish_batch_async: the guard-band reads with the exact MIN_COV."""
+    _batch_call("hinge_filter_finish_batch_async", ctxs, C.byref(p))
 
 
 def hinges_batch_async(ctxs, p: FilterParams) -> None:

@@ -34,6 +34,40 @@ constexpr int ST_QUEUE_CAP = 4;    // exact queue full
 constexpr int ST_ARENA_CAP = 8;    // exact-path scratch arena full
 constexpr int ST_NO_LONG_READ = 16;
 constexpr int ST_MEDIAN_RANGE = 32;   // sharded median: a mean coverage outside [0, MED_BINS), the histogram exchange cannot be used
+constexpr int ST_REDO_CAP = 64;       // one-sweep pass: the guard-band list is full (cannot happen: it has room for every read)
+
+// ---- the one-sweep pass (round 4) -----------------------------------------------------------------------------------
+// filter.cpp needs the whole part's median coverage (a GLOBAL BARRIER, filter.cpp:642-678) before it can cut a single mask:
+// MIN_COV = max(MIN_COV, cov_est / 3).  Rounds 1-3 therefore swept every pile-up twice (k_cov_stats for the means, then K2).
+// Now K2 runs FIRST, with a MIN_COV predicted from a sample of the part (k_spec_predict), and produces the exact per-read
+// coverage sums as a by-product of its prefix scan.  It is exact for every MIN_COV in [pred - band, pred + band]:
+//   * a read for which some MIN_COV-dependent predicate (a bin of the cutoff profile above MIN_COV, filter.cpp:703; an
+//     annotation threshold (cov + MIN_COV) / F, filter.cpp:803) is NOT constant over that band emits nothing and goes on the
+//     guard-band list (about 1 % of the reads of an E. coli 160x part at band 1);
+//   * the exact median then runs as VERIFICATION (k_median_hist on the sums of this same sweep), and the listed reads are
+//     run with the exact MIN_COV (k_mask_annotate in MODE_FINAL); if the exact value falls outside the band (not seen with
+//     4096 sample reads) spec_state = 1 and that launch takes every read of the part instead, after the verification reset
+//     the annotation allocator.
+// Nothing is taken from an earlier pass over the same data: prediction, sweep and verification are one pass.
+constexpr int MODE_CLASSIC = 0;   // MIN_COV is exact (k_cov_stats + median ran before)
+constexpr int MODE_SPEC = 1;      // first sweep of a one-sweep pass: per-read sums out, guard band, deferral
+constexpr int MODE_FINAL = 2;     // after the verification: the guard-band list (or everything) with the exact MIN_COV
+struct SpecVerify {               // per part; spec_min_cov == nullptr: a classic pass, nothing to verify
+    const int* spec_min_cov;      // MIN_COV the sweep ran with
+    int band;
+    int* spec_state;              // out: 0 = the exact MIN_COV lies inside the band, 1 = outside (everything is redone)
+    unsigned* counters;           // annotation allocator, work-list length: reset when everything is redone
+    unsigned* stats;              // cumulative: [0] passes verified, [1] exact != predicted, [2] outside the band
+};
+__device__ __forceinline__ void spec_verify(const SpecVerify& v, int exact) {
+    if (!v.spec_min_cov) return;
+    const int pred = *v.spec_min_cov;
+    const int miss = (exact < pred - v.band || exact > pred + v.band) ? 1 : 0;
+    *v.spec_state = miss;
+    atomicAdd(&v.stats[0], 1u);
+    if (exact != pred) atomicAdd(&v.stats[1], 1u);
+    if (miss) { atomicAdd(&v.stats[2], 1u); v.counters[0] = 0u; v.counters[1] = 0u; }
+}
 
 #ifdef HINGE_ABLATE
 #define HINGE_ABLATE_POINT(k) if (P.ablate == (k)) continue;
@@ -262,20 +296,21 @@ __global__ __launch_bounds__(BLOCK) void k_cov_stats(int r_begin, int r_end, con
 
 // General median (any int32 values): one workgroup, 4-pass 8-bit radix select.  Run by the last block of
 // k_median_hist when some mean coverage falls outside [0, MED_BINS).
-__device__ void median_radix_select(const int* __restrict__ mean_cov, int lo, int hi, int est_cov_override, int* __restrict__ est,
-                                    int* __restrict__ min_cov, int* __restrict__ status) {
+template <typename VF>
+__device__ void median_radix_select(VF value_of, int lo, int hi, int est_cov_override, int* __restrict__ est,
+                                    int* __restrict__ min_cov, int* __restrict__ status, const SpecVerify& spec) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_rank, s_nvalid;
     const int tid = threadIdx.x;
     if (tid == 0) s_nvalid = 0;
     __syncthreads();
     unsigned cnt = 0;
-    for (int i = lo + tid; i <= hi; i += blockDim.x) cnt += (mean_cov[i] != MEAN_SENTINEL);
+    for (int i = lo + tid; i <= hi; i += blockDim.x) cnt += (value_of(i) != MEAN_SENTINEL);
     atomicAdd(&s_nvalid, cnt);
     __syncthreads();
     const unsigned nvalid = s_nvalid;
     if (nvalid == 0) {
-        if (tid == 0) { est[0] = 0; est[1] = 0; atomicOr(status, ST_NO_LONG_READ); }
+        if (tid == 0) { est[0] = 0; est[1] = 0; atomicOr(status, ST_NO_LONG_READ); spec_verify(spec, *min_cov); }
         return;
     }
     if (tid == 0) { s_prefix = 0; s_rank = nvalid / 2; }
@@ -286,7 +321,7 @@ __device__ void median_radix_select(const int* __restrict__ mean_cov, int lo, in
         const unsigned prefix = s_prefix;
         const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
         for (int i = lo + tid; i <= hi; i += blockDim.x) {
-            const int v = mean_cov[i];
+            const int v = value_of(i);
             if (v == MEAN_SENTINEL) continue;
             const unsigned u = (unsigned)v ^ 0x80000000u;   // order-preserving map to unsigned
             if ((u & himask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1u);
@@ -309,6 +344,7 @@ __device__ void median_radix_select(const int* __restrict__ mean_cov, int lo, in
         est[1] = (int)nvalid;
         if (est_cov_override != 0) cov_est = est_cov_override;
         if (*min_cov < cov_est / 3) *min_cov = cov_est / 3;
+        spec_verify(spec, *min_cov);
     }
 }
 
@@ -337,7 +373,18 @@ struct MedianPart {
     unsigned* med; int* est; int* min_cov; int* status;
     const unsigned long long* wave_totals; int n_wave_totals; unsigned long long* totals;
     unsigned* hist_out;   // nullptr, or [MED_BINS + 2]: histogram, valid, out of range
+    // one-sweep pass (cov_tot != nullptr): the means do not exist yet.  Read i has nbins0[i] bins and the coverage sum cov_tot[i]
+    // (stored by k_mask_annotate_q20<SPEC>); nbins0[i] < 0: a read the general kernel took, which stored mean_out[i] itself and
+    // accounted for its sums in wave_totals.  This kernel then also writes the means (mean_out = mean_cov).
+    const int* cov_tot; const int* nbins0; const int* rlen; int* mean_out;
+    SpecVerify spec;
 };
+// mean coverage of read i of a one-sweep pass (filter.cpp:642-656: C division of the sum by max(1, bins), reads >= 5000 bp only)
+__device__ __forceinline__ int fused_mean(int K, int tot, int rl, int stored) {
+    if (K < 0) return stored;
+    if (rl < 5000) return MEAN_SENTINEL;
+    return tot / max(1, K);
+}
 struct MedianHistBatch {
     MedianPart part[MED_BATCH_MAX];
     int n;
@@ -351,6 +398,8 @@ __global__ __launch_bounds__(256) void k_median_hist(MedianHistBatch B, int est_
     unsigned* __restrict__ med = A.med; int* __restrict__ est = A.est; int* __restrict__ min_cov = A.min_cov; int* __restrict__ status = A.status;
     const unsigned long long* __restrict__ wave_totals = A.wave_totals; const int n_wave_totals = A.n_wave_totals;
     unsigned long long* __restrict__ totals = A.totals; unsigned* __restrict__ hist_out = A.hist_out;
+    const int* __restrict__ cov_tot = A.cov_tot; const int* __restrict__ nb0 = A.nbins0; const int* __restrict__ rlen = A.rlen;
+    const bool fused = cov_tot != nullptr;
     __shared__ unsigned hist[MED_BINS];
     __shared__ unsigned s_valid, s_oor, s_last, s_lo, s_hi, s_general;
     __shared__ unsigned long long s_tc, s_ts, s_ticket;
@@ -372,10 +421,30 @@ __global__ __launch_bounds__(256) void k_median_hist(MedianHistBatch B, int est_
         for (int w = (int)(bx * blockDim.x) + tid; w < n_wave_totals; w += stride) { tc += wave_totals[2 * w]; ts += wave_totals[2 * w + 1]; }
         for (int i0 = lo + (int)(bx * blockDim.x) + tid; i0 <= hi; i0 += U * stride) {
             int vv[U];
+            if (!fused) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const long long i = (long long)i0 + (long long)u * stride;
-                vv[u] = i <= hi ? mean_cov[i] : MEAN_SENTINEL;
+                for (int u = 0; u < U; u++) {
+                    const long long i = (long long)i0 + (long long)u * stride;
+                    vv[u] = i <= hi ? mean_cov[i] : MEAN_SENTINEL;
+                }
+            } else {
+                int kk[U], tt[U], rr[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {   // (all loads of the batch in flight together)
+                    const long long i = min((long long)i0 + (long long)u * stride, (long long)hi);
+                    kk[u] = nb0[i]; tt[u] = cov_tot[i]; rr[u] = rlen[i]; vv[u] = mean_cov[i];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const long long i = (long long)i0 + (long long)u * stride;
+                    if (i > hi) { vv[u] = MEAN_SENTINEL; continue; }
+                    const int v = fused_mean(kk[u], tt[u], rr[u], vv[u]);
+                    if (kk[u] >= 0) {
+                        A.mean_out[i] = v;
+                        if (v != MEAN_SENTINEL) { tc += (unsigned long long)(long long)tt[u]; ts += (unsigned long long)kk[u]; }
+                    }
+                    vv[u] = v;
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -472,6 +541,7 @@ __global__ __launch_bounds__(256) void k_median_hist(MedianHistBatch B, int est_
         if (nvalid == 0) {
             est[0] = 0; est[1] = 0;
             atomicOr(status, ST_NO_LONG_READ);
+            spec_verify(A.spec, *min_cov);
         } else if (bad) {
             s_general = 1;
         } else {
@@ -496,26 +566,31 @@ __global__ __launch_bounds__(256) void k_median_hist(MedianHistBatch B, int est_
             est[0] = cov_est;
             est[1] = (int)nvalid;
             if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
-            atomicMax(min_cov, cov_est / 3);                          // filter.cpp:677-678: if (MIN_COV < cov_est/3) MIN_COV = cov_est/3
+            const int before = atomicMax(min_cov, cov_est / 3);       // filter.cpp:677-678: if (MIN_COV < cov_est/3) MIN_COV = cov_est/3
+            spec_verify(A.spec, max(before, cov_est / 3));
         }
     }
 #ifdef HINGE_TIMING
 #endif
     __syncthreads();
-    if (s_general == 1) median_radix_select(mean_cov, lo, hi, est_cov_override, est, min_cov, status);
+    if (s_general == 1) {
+        // (the means other workgroups stored in this launch are not visible here: a one-sweep pass derives them again)
+        if (fused) median_radix_select([&](int i) { return fused_mean(nb0[i], cov_tot[i], rlen[i], mean_cov[i]); }, lo, hi, est_cov_override, est, min_cov, status, A.spec);
+        else median_radix_select([&](int i) { return mean_cov[i]; }, lo, hi, est_cov_override, est, min_cov, status, A.spec);
+    }
 }
 
 // Median from a histogram that was summed over ranks (hist[MED_BINS + 2]: bins, valid values, ranks that saw a value
 // outside [0, MED_BINS)).  One workgroup; same walk and MIN_COV update as the tail of k_median_hist.
 __global__ __launch_bounds__(256) void k_median_from_hist(const unsigned* __restrict__ hist_in, int est_cov_override, int* __restrict__ est,
-                                                          int* __restrict__ min_cov, int* __restrict__ status) {
+                                                          int* __restrict__ min_cov, int* __restrict__ status, SpecVerify spec) {
     __shared__ unsigned hist[MED_BINS];
     const int tid = threadIdx.x;
     for (int b = tid; b < MED_BINS; b += blockDim.x) hist[b] = hist_in[b];
     const unsigned nvalid = hist_in[MED_BINS], bad = hist_in[MED_BINS + 1];
     __syncthreads();
     if (nvalid == 0) {
-        if (tid == 0) { est[0] = 0; est[1] = 0; atomicOr(status, ST_NO_LONG_READ); }
+        if (tid == 0) { est[0] = 0; est[1] = 0; atomicOr(status, ST_NO_LONG_READ); spec_verify(spec, *min_cov); }
         return;
     }
     if (bad) {   // needs the values themselves: the caller has to all-gather the means and use k_median_hist
@@ -536,7 +611,8 @@ __global__ __launch_bounds__(256) void k_median_from_hist(const unsigned* __rest
             est[0] = cov_est;
             est[1] = (int)nvalid;
             if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
-            atomicMax(min_cov, cov_est / 3);                          // filter.cpp:677-678
+            const int before = atomicMax(min_cov, cov_est / 3);       // filter.cpp:677-678
+            spec_verify(spec, max(before, cov_est / 3));
         }
     }
 }
@@ -547,6 +623,7 @@ struct MedianBatch {
     int* est[MED_BATCH_MAX];
     int* min_cov[MED_BATCH_MAX];
     int* status[MED_BATCH_MAX];
+    SpecVerify spec[MED_BATCH_MAX];
 };
 __global__ __launch_bounds__(256) void k_median_from_hist_batch(const unsigned* __restrict__ hist_in, long long row_stride, int est_cov_override,
                                                                 MedianBatch B) {
@@ -557,7 +634,7 @@ __global__ __launch_bounds__(256) void k_median_from_hist_batch(const unsigned* 
     const unsigned nvalid = h[MED_BINS], bad = h[MED_BINS + 1];
     __syncthreads();
     if (nvalid == 0) {
-        if (tid == 0) { B.est[b][0] = 0; B.est[b][1] = 0; atomicOr(B.status[b], ST_NO_LONG_READ); }
+        if (tid == 0) { B.est[b][0] = 0; B.est[b][1] = 0; atomicOr(B.status[b], ST_NO_LONG_READ); spec_verify(B.spec[b], *B.min_cov[b]); }
         return;
     }
     if (bad) {
@@ -578,7 +655,121 @@ __global__ __launch_bounds__(256) void k_median_from_hist_batch(const unsigned* 
             B.est[b][0] = cov_est;
             B.est[b][1] = (int)nvalid;
             if (est_cov_override != 0) cov_est = est_cov_override;   // filter.cpp:671
-            atomicMax(B.min_cov[b], cov_est / 3);                     // filter.cpp:677-678
+            const int before = atomicMax(B.min_cov[b], cov_est / 3);  // filter.cpp:677-678
+            spec_verify(B.spec[b], max(before, cov_est / 3));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One-sweep pass, step 1: the MIN_COV the sweep will run with.  ns reads of the part, evenly spaced over its id range, get
+// their exact mean coverage (the closed form of k_cov_stats over their pile-ups: 1/20 of the part's spans at 4096 of 87 k
+// reads); the sample's median stands in for the part's (filter.cpp:660-678).  Two reads per wavefront (32 lanes each, all of a
+// read's loads in flight together), 32 reads per 1024-thread workgroup; the means go out as device-scope atomic stores, the
+// workgroups count themselves on a ticket and the last one histograms the sample and walks to its median - the same
+// publication pattern as k_median_hist.  Workgroup 0 of a part also clears the pass scalars and applies a pending MIN_COV
+// (what k_cov_stats did for the two-sweep pass).  Up to MED_BATCH_MAX parts per launch (workgroup b works for part b % n).
+// A prediction only: whatever it says, the verification after the sweep decides (SpecVerify); `bias` (tests) shifts it.
+// ------------------------------------------------------------------------------------------------
+struct SpecPart {
+    int r_begin, r_end;
+    const int64_t* row_ptr; const int2* a_span; const unsigned* span16; const int* rlen; const int* nbins0;
+    int* pass_scalars; int n_pass_scalars;
+    int* min_cov; int set_min_cov, min_cov_value;
+    int* spec_min_cov;
+    int* sample;                 // [ns] scratch
+    unsigned* ticket;            // one word, zero between launches
+    int bias;
+};
+struct SpecBatch {
+    SpecPart part[MED_BATCH_MAX];
+    int n, ns;
+};
+constexpr int SPEC_BLOCK = 1024;
+constexpr int SPEC_READS_PER_BLOCK = SPEC_BLOCK / 32;
+template <int RESO, bool PACKED>
+__global__ __launch_bounds__(SPEC_BLOCK) void k_spec_predict(SpecBatch B, int reso, int est_cov_override) {
+    const unsigned n_parts = (unsigned)B.n;
+    const SpecPart& A = B.part[blockIdx.x % n_parts];
+    const unsigned bx = blockIdx.x / n_parts, gx = gridDim.x / n_parts;
+    if (bx >= gx) return;
+    const int tid = threadIdx.x;
+    const int cur_min_cov = A.set_min_cov ? A.min_cov_value : *A.min_cov;   // (nobody writes *min_cov in this launch unless set_min_cov)
+    if (bx == 0) {
+        for (int t = tid; t < A.n_pass_scalars; t += SPEC_BLOCK) A.pass_scalars[t] = 0;
+        if (tid == 0 && A.set_min_cov) *A.min_cov = A.min_cov_value;
+    }
+    if (est_cov_override != 0) {   // `ec` in the ini (filter.cpp:671): MIN_COV does not depend on the data
+        if (bx == 0 && tid == 0) *A.spec_min_cov = max(cur_min_cov, est_cov_override / 3) + A.bias;
+        return;
+    }
+    const long long nr = (long long)A.r_end - A.r_begin + 1;
+    const int ns = (int)min((long long)B.ns, max(nr, 0ll));
+    __shared__ unsigned hist[MED_BINS];
+    __shared__ unsigned s_last, s_n;
+    const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const int k = (int)bx * SPEC_READS_PER_BLOCK + wib * 2 + half;   // sample index of this half wavefront
+        int mean = MEAN_SENTINEL;
+        if (k < ns) {
+            const int i = A.r_begin + (int)(((long long)k * nr) / ns);
+            const int64_t s = A.row_ptr[i], e = A.row_ptr[i + 1];
+            const int rl = A.rlen[i], K = A.nbins0[i];
+            typedef SpanLoad<PACKED> SL;
+            const typename SL::raw* __restrict__ row = (PACKED ? (const typename SL::raw*)(const void*)A.span16 : (const typename SL::raw*)(const void*)A.a_span) + s;
+            const long long n = e - s;
+            long long sum = 0;
+            if (rl >= 5000 && K >= 0) {   // (K < 0: 65536+ overlaps or a coordinate outside the read - not sampled)
+                for (long long base = 0; base < n; base += LOADS_IN_FLIGHT * 32) {
+                    typename SL::raw v[LOADS_IN_FLIGHT];
+#pragma unroll
+                    for (int u = 0; u < LOADS_IN_FLIGHT; u++) v[u] = row[min(base + u * 32 + l32, n - 1)];
+#pragma unroll
+                    for (int u = 0; u < LOADS_IN_FLIGHT; u++)
+                        if (base + u * 32 + l32 < n) { const int2 w = SL::get(v[u]); sum += bin_of<RESO>(w.y, reso) - bin_of<RESO>(w.x, reso); }
+                }
+            }
+            // the two halves of the wavefront are summed apart: xor butterflies stay inside 32 lanes
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+            if (rl >= 5000 && K >= 0) mean = (int)(sum / (long long)max(1, K));
+            if (l32 == 0) __hip_atomic_store(&A.sample[k], mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see k_median_hist: the stores above are performed at device scope)
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(A.ticket, 1u) == gx - 1) ? 1u : 0u;
+    for (int b = tid; b < MED_BINS; b += SPEC_BLOCK) hist[b] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    if (!s_last) return;
+    unsigned cnt = 0;
+    for (int k = tid; k < ns; k += SPEC_BLOCK) {
+        const int v = __hip_atomic_load(&A.sample[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == MEAN_SENTINEL) continue;
+        atomicAdd(&hist[min(max(v, 0), MED_BINS - 1)], 1u);
+        cnt++;
+    }
+    if (cnt) atomicAdd(&s_n, cnt);
+    __syncthreads();
+    if (tid < WAVE) {
+        const unsigned nvalid = s_n;
+        int found = 0;
+        if (nvalid) {
+            const int r = (int)(nvalid / 2);
+            int carry = 0;
+            found = -1;
+            for (int base = 0; base < MED_BINS && found < 0; base += WAVE) {
+                const int incl = wave_incl_scan((int)hist[base + tid]) + carry;
+                const unsigned long long hit = __ballot(incl > r);
+                if (hit) found = base + __ffsll((long long)hit) - 1;
+                carry = wave_last(incl);
+            }
+        }
+        if (tid == 0) {
+            *A.spec_min_cov = max(cur_min_cov, found / 3) + A.bias;
+            *A.ticket = 0u;
         }
     }
 }
@@ -677,12 +868,14 @@ __device__ __forceinline__ void run_feed(RunState& r, int base, unsigned long lo
 // packed candidates (pos << 1 | (type == +1)): slot t is written only after z(j) was read for every j <= t.
 // PT / OT: FilterDev / AnnoOut, possibly qualified with the constant address space (k_mask_annotate_q20 passes them in device
 // memory: every field is then a scalar load at its point of use instead of an SGPR that is live - or spilled - across the read loop).
+constexpr int SPEC_DEFERRED = 1 << 30;   // mask_gate_annotate's return value: the read emitted nothing and waits for the exact MIN_COV
 template <typename PT, typename OT, typename ZF, typename CF>
 __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, const int MIN_COV, const int i, const int lane,
                                                    const int K0, const RunState& run, ZF z, CF c, int* cand, const OT& o,
                                                    const long long row, const int n_pile, const bool cov_done = false,
                                                    const bool cand_in_profile = true /*cand[] overwrites what z() reads*/,
-                                                   const unsigned long long flag_words = ~0ull /*bit w clear: no bin of [64 w, 64 w + 63] can be an annotation*/) {
+                                                   const unsigned long long flag_words = ~0ull /*bit w clear: no bin of [64 w, 64 w + 63] can be an annotation*/,
+                                                   const int band = 0 /*MODE_SPEC: MIN_COV is only known to lie in [MIN_COV - band, MIN_COV + band]*/) {
     // What every read needs of the parameters and output pointers, looked up TOGETHER: where P and o are in device memory
     // (k_mask_annotate_q20) each look-up at its point of use is a scalar-load round trip of its own in the read's dependency
     // chain - six of them, one behind the other, before this.
@@ -785,16 +978,21 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
             const int G = g < 0 ? -g : g;
             // an annotation needs |g| > min(lo, hi) on the division-free path: most 64-bin words have none at all
             if (mulpath && !ballot_of(in && G > min(P.min_ra, P.max_ra))) continue;
+            bool near = false;   // the test's outcome is not the same for every MIN_COV of the band
             if (in) {
                 const int x = cv + MIN_COV;
-                if (mulpath && x >= 0 && (unsigned)G < 131072u) {   // thr >= 0 here: the sign of g picks the type, g == 0 never passes
-                    if ((G > P.max_ra) || ((G > P.min_ra) && (G * P.cov_frac > x))) code = ((reso * j) << 1) | (g > 0 ? 1 : 0);
+                if (mulpath && x >= band && (unsigned)G < 131072u) {   // thr >= 0 here: the sign of g picks the type, g == 0 never passes
+                    const int gf = G * P.cov_frac;
+                    if ((G > P.max_ra) || ((G > P.min_ra) && (gf > x))) code = ((reso * j) << 1) | (g > 0 ? 1 : 0);
+                    if (band > 0) near = G <= P.max_ra && G > P.min_ra && ((gf > x - band) != (gf > x + band));
                 } else {
                     const int thr = min(max(x / P.cov_frac, P.min_ra), P.max_ra);
                     if (g > thr) code = ((reso * j) << 1) | 1;
                     else if (g < -thr) code = ((reso * j) << 1) | 0;
+                    near = band > 0;   // (the division path: not analysed, the read waits for the exact MIN_COV)
                 }
             }
+            if (band > 0 && ballot_of(near)) return ncand | SPEC_DEFERRED;   // nothing was emitted: the read goes on the guard-band list
             const unsigned long long bal = ballot_of(code != -1);
             if (code != -1) cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = code;
             ncand += __popcll(bal);
@@ -865,11 +1063,24 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
 // General kernel.  LDS per wave: h0[kcap] (cutoff-0 difference histogram -> coverage), hc[kcap] (cutoff
 // CUT_OFF; reused as the candidate list once the mask is known).  With read_list != nullptr it runs the
 // *list_count reads of that list (the fast kernel's hand-backs) instead of [r_begin, r_end].
+// One-sweep pass (SpecArgs.mode): MODE_SPEC - d_min_cov is the predicted MIN_COV; every read's mean coverage goes to mean_cov
+// (the sums to wave_totals, one slot per wavefront, as k_cov_stats writes them) and a read that is not decided for the whole band
+// goes to redo_list instead of emitting.  MODE_FINAL - d_min_cov is exact; the reads of read_list (the guard-band list), or every
+// read of [r_begin, r_end] when *spec_state says the prediction missed the band; the coverage bins were stored by the first sweep.
+struct SpecArgs {
+    int mode, band;
+    int* mean_cov;
+    unsigned long long* wave_totals;
+    const int* spec_state;
+    int* redo_list;
+    unsigned* redo_count;
+    unsigned redo_cap;
+};
 template <int RESO>
 __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                          const int2* __restrict__ a_span, const int* __restrict__ rlen,
                                                          const int* __restrict__ d_min_cov, int kcap, AnnoOut o,
-                                                         const int* __restrict__ read_list, const unsigned* __restrict__ list_count) {
+                                                         const int* __restrict__ read_list, const unsigned* __restrict__ list_count, SpecArgs sa) {
     extern __shared__ int lds[];
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; lets the per-read control flow go scalar
@@ -879,7 +1090,10 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
     const int nwaves = gridDim.x * WAVES_PER_BLOCK;
     const int MIN_COV = *d_min_cov;
     const int reso = RESO > 0 ? RESO : P.reso;   // compile-time 40 in the shipped configuration: no runtime divisions
+    if (sa.mode == MODE_FINAL && *sa.spec_state != 0) read_list = nullptr;   // the prediction missed the band: everything again
     const int n_items = read_list ? (int)*list_count : r_end - r_begin + 1;
+    const int band = sa.mode == MODE_SPEC ? sa.band : 0;
+    long long blk_cov = 0, blk_slot = 0;   // MODE_SPEC: this wavefront's share of total_cov / num_slot (filter.cpp:666,672)
 
     for (int item = wave; item < n_items; item += nwaves) {
         const int i = read_list ? read_list[item] : r_begin + item;
@@ -963,6 +1177,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         // ---- both prefix scans in one sweep; coverage mask on the cutoff bins (filter.cpp:696-728) ----
         int carry = 0, carry0 = 0;   // running coverage (cutoff / cutoff-0)
         RunState run{0, 0ull, 0, 0};
+        unsigned long long near = 0ull;   // MODE_SPEC: bins whose `c > MIN_COV` is not the same for every MIN_COV of the band
         const int Kmax = max(K0, KC);
         const bool packed = n < 32768;     // cutoff-0 prefix in [0, n], cutoff prefix in [-n, n]: one 16|16 scan does both
         for (int base = 0; base < Kmax; base += WAVE) {
@@ -986,9 +1201,40 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
             const int left = KC - base;
             const unsigned long long V = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
             run_feed(run, base, __ballot(c > MIN_COV) & V, V, reso);   // c[j] > 0 after subtracting MIN_COV
+            if (band > 0) near |= (__ballot(c > MIN_COV - band) ^ __ballot(c > MIN_COV + band)) & V;
         }
-        mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, [&](int j) { return h0[j]; }, [&](int j) { return hc[j]; }, hc, o, (long long)s, n, false,
-                           false /*the candidates go where the cutoff profile was: the gate reads the plain one*/);
+        if (sa.mode == MODE_SPEC) {   // the read's mean coverage, as k_cov_stats has it (filter.cpp:642-656)
+            long long t = 0;
+            for (int j = lane; j < K0; j += WAVE) t += h0[j];
+            t = wave_sum64(t);
+            if (lane == 0) {
+                if (rl >= 5000) {
+                    sa.mean_cov[i] = (int)(t / (long long)max(1, K0));
+                    blk_cov += t;
+                    blk_slot += K0;
+                } else {
+                    sa.mean_cov[i] = MEAN_SENTINEL;
+                }
+            }
+        }
+        int used = 0;
+        if (near == 0ull)
+            used = mask_gate_annotate(P, reso, MIN_COV, i, lane, K0, run, [&](int j) { return h0[j]; }, [&](int j) { return hc[j]; }, hc, o, (long long)s, n,
+                                      sa.mode == MODE_FINAL /*the first sweep stored the bins*/,
+                                      false /*the candidates go where the cutoff profile was: the gate reads the plain one*/, ~0ull, band);
+        else if (o.cov_out) {   // (a deferred read still owes its coverage bins: the final launch does not store them)
+            int* __restrict__ dst = o.cov_out + o.cov_off[i - o.cov_base];
+            for (int j = lane; j < K0; j += WAVE) dst[j] = h0[j];
+            if (lane == 0) o.cov_nbins[i - o.cov_base] = K0;
+        }
+        if ((near != 0ull || (used & SPEC_DEFERRED)) && lane == 0) {
+            const unsigned at = atomicAdd(sa.redo_count, 1u);
+            if (at < sa.redo_cap) sa.redo_list[at] = i; else atomicOr(o.status, ST_REDO_CAP);
+        }
+    }
+    if (sa.mode == MODE_SPEC && lane == 0) {
+        sa.wave_totals[2 * wave] = (unsigned long long)blk_cov;
+        sa.wave_totals[2 * wave + 1] = (unsigned long long)blk_slot;
     }
 }
 
@@ -1010,6 +1256,9 @@ struct K2Const {
     AnnoOut o;
     int* fallback_list;         // reads handed back to the general kernel (hardly ever: the pointers are looked up when one is)
     unsigned* fallback_count;
+    int* redo_list;             // SPEC: the guard-band list (reads that wait for the exact MIN_COV), its length and capacity
+    unsigned* redo_count;
+    unsigned redo_cap;
 };
 constexpr int K2_MAX_HEADS = 64;
 struct K2Heads { unsigned base[K2_MAX_HEADS]; };   // value of every item counter before this launch
@@ -1028,7 +1277,11 @@ __device__ unsigned long long* g_k2_trace = nullptr;
 // COVOUT: the .coverage.txt bins are written too (a template parameter, like the flags below that became launch conditions: a
 // run-time flag of this kernel is a lane mask or a scalar that lives - spilled - across the whole read loop).
 // CUT20: cut_off / 20 when it is the shipped 300 (the pads, the profile accessors' offsets and the bounds below are then immediates), else -1.
-template <bool PACKED, bool COVOUT, int CUT20>
+// SPEC: the first sweep of a one-sweep pass (see MODE_SPEC above): *d_min_cov is the PREDICTED MIN_COV, the read's coverage sum
+// goes to cov_tot (it falls out of the prefix scan: cov0[k] = PB[2k-1] - PE[2k-1] is zero behind the last event, so the sum of the
+// scan's values at the odd indices is the sum over the read's bins), and a read that is not decided for every MIN_COV in
+// [pred - band, pred + band] emits nothing and goes on the guard-band list.
+template <bool PACKED, bool COVOUT, int CUT20, bool SPEC>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off_arg, int mulpath_thr /*min(MIN_RA, MAX_RA) >= 0: the
                                                              division-free annotation test applies (a launch condition)*/,
                                                              int nhr /*NO_HINGE_REGION*/, int cov_mask_off /*INT_MIN if the coverage mask takes part in the mask, else 1 << 29*/,
@@ -1038,7 +1291,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                              const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints,
                                                              int* __restrict__ cov_out /*COVOUT: the coverage-bin output*/,
                                                              const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
-                                                             unsigned* __restrict__ heads, int n_heads, K2Heads bases) {
+                                                             unsigned* __restrict__ heads, int n_heads, K2Heads bases,
+                                                             int* __restrict__ cov_tot /*SPEC*/, int band /*SPEC*/) {
     extern __shared__ int lds[];
     constexpr int HOT = 4;    // words per lane the slot has room for behind the profile (candidate list of the last phase)
     constexpr int HOTW = 2;   // of which hot words: W0 = begins in bin 0 | ends in bin qe - 1 << 16, W1 = begins in bin 1 | ends in bin qe << 16
@@ -1226,6 +1480,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 
         // ---- inclusive prefixes of begins|ends, 8 consecutive bins per lane (512 per step: one step for reads of up to 10 kb) -----
         int carry = 0;
+        int tot_l = 0;   // SPEC: this lane's share of the read's coverage sum
         int* __restrict__ const cov_dst = COVOUT ? cov_out + cov_at : (int*)nullptr;
         // Which 64-bin words of the plain profile can hold an annotation at all: an annotation needs |cov0[k+1] - cov0[k]| above
         // min(MIN_RA, MAX_RA), and that difference is simply the begins minus the ends of the two 20-bp bins 2k, 2k+1 - the raw
@@ -1281,6 +1536,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             w.x += excl; w.y += excl; w.z += excl; w.w += excl;
             if (t < Qn) *reinterpret_cast<int4*>(Pq + t) = v;
             if (t + 4 < Qn) *reinterpret_cast<int4*>(Pq + t + 4) = w;
+            if constexpr (SPEC && !COVOUT) {
+                auto cv = [&](int pre) { return (pre & 0xffff) - (int)((unsigned)pre >> 16); };
+                tot_l += cv(v.y) + cv(v.w) + cv(w.y) + cv(w.w);
+            }
             if constexpr (COVOUT) {
                 // the .coverage.txt bins straight from the registers of the scan: cov0[k] = PB[2k-1] - PE[2k-1], and this lane holds
                 // the prefixes of bins t .. t+7, i.e. 2k-1 = t+1, t+3, t+5, t+7 (k = t/2 + 1 .. t/2 + 4): one 16-byte store (4-byte
@@ -1291,13 +1550,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 const int k1 = (t >> 1) + 1;
                 auto cv = [&](int pre) { return (pre & 0xffff) - (int)((unsigned)pre >> 16); };
                 struct __attribute__((packed, aligned(4))) Bins4 { int a, b, c, d; };
-                if (k1 < K0) *reinterpret_cast<Bins4*>(cov_dst + k1) = Bins4{cv(v.y), cv(v.w), cv(w.y), cv(w.w)};
+                const Bins4 b4{cv(v.y), cv(v.w), cv(w.y), cv(w.w)};
+                if (k1 < K0) *reinterpret_cast<Bins4*>(cov_dst + k1) = b4;
+                if constexpr (SPEC) tot_l += (b4.a + b4.b) + (b4.c + b4.d);   // (lanes past the last event hold begins = ends: zero)
             }
             carry += wave_last(incl);
         }
         if (COVOUT && lane == 0) {
             if (K0 > 0) cov_dst[0] = 0;                      // cov0[0]: nothing is consumed before position 0
             store_at32(cov_nbins, in_vgpr((unsigned)(i - cov_base)) << 2, K0);
+        }
+        if constexpr (SPEC) {   // the last lane of the scan holds the wavefront's sum: it stores it (no broadcast)
+            const int tot = wave_incl_scan(tot_l);
+            if (lane == WAVE - 1) store_at32(cov_tot, in_vgpr((unsigned)i) << 2, tot);
         }
         {   // copies of the totals behind the scanned bins (the scan ran over [0, round-up-to-4 of Qn))
             const int Qs = (Qn + 3) & ~3;
@@ -1318,6 +1583,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         //           beyond 600 kb are handed back above); every lane keeps the largest key it saw, ONE wave maximum at the end.
         // A run still open at the last valid bin is not counted, as in the reference's loop.
         int key_best = 0;
+        bool near_band = false;   // SPEC: some bin's `covc > MIN_COV` depends on where in the band the exact MIN_COV lies
         {
             int zc = 0, pc = 0;                        // carries: z and positivity of the previous word's last bin
             const int* pcb = Pq + 2 * lane - 1 - SH;   // covc(base + lane) = begins below pcb[2 base] - ends below pce[2 base]
@@ -1349,7 +1615,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 #endif
             // (loaded by every lane: LDS reads do not fault)
             for (; base + WAVE <= KC; base += WAVE, pcb += 2 * WAVE, pce += 2 * WAVE) {
-                const bool p = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16) > MIN_COV;
+                const int cvv = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16);
+                if constexpr (SPEC) {
+                    // 64 bins above the band's upper end: positive whatever the exact MIN_COV turns out to be
+                    const unsigned long long MH = ballot_of(cvv > MIN_COV + band);
+                    if (MH == ~0ull) { pc = 1; continue; }
+                    if (ballot_of(cvv > MIN_COV - band) != MH) near_band = true;   // a bin inside the band: the read waits
+                }
+                const bool p = cvv > MIN_COV;
                 const unsigned long long M = ballot_of(p);
                 // 64 bins above MIN_COV (the interior of nearly every read) open or continue a run and close none
                 if (M == ~0ull) { pc = 1; continue; }
@@ -1359,9 +1632,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             if (base < KC) {   // the last, partial word: the bins from KC on count as positive ones that belong to no run (they close
                                // none, and a run that is still open at the last valid bin is not counted, as in the reference's loop)
                 const bool valid = base + lane < KC;
-                const bool p = !valid || (*pcb & 0xffff) - (int)((unsigned)*pce >> 16) > MIN_COV;
+                const int cvv = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16);
+                if constexpr (SPEC) {
+                    if (ballot_of(valid && cvv > MIN_COV - band) != ballot_of(valid && cvv > MIN_COV + band)) near_band = true;
+                }
+                const bool p = !valid || cvv > MIN_COV;
                 const unsigned long long M = ballot_of(p);
                 if (!closes_none(base, M)) word(base, p, M);
+            }
+        }
+        if constexpr (SPEC) {
+            if (near_band) {   // (wave-uniform) nothing emitted: the guard-band list takes the read
+                if (lane == 0) {
+                    const unsigned at = atomicAdd(C->redo_count, 1u);
+                    if (at < C->redo_cap) C->redo_list[at] = i; else atomicOr(C->o.status, ST_REDO_CAP);
+                }
+                continue;
             }
         }
         RunState run{0, 0ull, 0, 0};
@@ -1377,8 +1663,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         asm volatile("" : "+s"(c));   // (hides the pointer from the hoisting passes: the loads below stay inside this phase)
         typedef const K2Const __attribute__((address_space(4))) K2ConstK;   // constant address space: scalar loads
         K2ConstK& kc = *(K2ConstK*)(unsigned long long)c;
-        const int used = __builtin_amdgcn_readfirstlane(mask_gate_annotate(kc.P, reso, MIN_COV, i, lane, K0, run, cov0, covc, cand_apart ? hot : Pq, kc.o, (long long)s, n,
-                                                                           true, !cand_apart, flag_words));
+        int used = __builtin_amdgcn_readfirstlane(mask_gate_annotate(kc.P, reso, MIN_COV, i, lane, K0, run, cov0, covc, cand_apart ? hot : Pq, kc.o, (long long)s, n,
+                                                                     true, !cand_apart, flag_words, SPEC ? band : 0));
+        if constexpr (SPEC) {
+            if (used & SPEC_DEFERRED) {   // an annotation threshold inside the band: the guard-band list takes the read
+                used &= ~SPEC_DEFERRED;
+                if (lane == 0) {
+                    const unsigned at = atomicAdd(C->redo_count, 1u);
+                    if (at < C->redo_cap) C->redo_list[at] = i; else atomicOr(C->o.status, ST_REDO_CAP);
+                }
+            }
+        }
         if (cand_apart && used > 0) {   // the hot words start every read at zero
 #pragma unroll
             for (int h = 0; h < HOTW; h++) hot[h * WAVE + lane] = 0;

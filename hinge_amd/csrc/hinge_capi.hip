@@ -55,6 +55,12 @@ struct hinge_ctx {
     DevBuf arena;
     unsigned long long arena_cap = 0;
     DevBuf scalars;   // see Scalars
+    // one-sweep pass (round 4, see MODE_SPEC in filter_kernels.h)
+    DevBuf cov_tot, redo_list, spec_sample;   // int[n_reads] coverage sums, int[n_reads] guard-band list, int[spec_ns] sample means
+    int spec_band = 1;        // the sweep is exact for every MIN_COV within +- this of the prediction (HINGE_SPEC_BAND)
+    int spec_ns = 4096;       // reads k_spec_predict samples per part (HINGE_SPEC_SAMPLE)
+    int spec_bias = 0;        // tests: added to the prediction (hinge_debug_spec)
+    int pass_mode = 0;        // what the current pass's first sweep was: 0 classic, 1 one-sweep through k_mask_annotate_q20<SPEC>, 2 one-sweep through the general kernel
     DevBuf med;       // median histogram scratch (k_median_hist)
     DevBuf wave_totals;   // k_cov_stats per-wave (total_cov, num_slot) partials
     int n_wave_totals = 0;
@@ -62,6 +68,7 @@ struct hinge_ctx {
     int force_exact = 0;
     int trim = 1;                 // ProcessAlignment's trim flag: 0 for PAF input (no trace points)
     int force_general_mask = 0;
+    int one_sweep = 1;            // HINGE_ONE_SWEEP=0: hinge_filter_sweep_batch_async always runs the two-sweep pass
     bool debug_paths = false;     // HINGE_DEBUG_PATHS: path counters (same-line global atomics, ~12 ns each: off by default)
     bool min_cov_pending = false;   // hinge_filter_set_min_cov is applied by the next launch that needs it
     int min_cov_value = 0;
@@ -108,9 +115,10 @@ struct hinge_ctx {
 };
 
 enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY,
-                KID_PILEUP_FACTS, KID_MATCHING_POSITION, KID_SELECT_EDGES, KID_COUNT };
+                KID_PILEUP_FACTS, KID_MATCHING_POSITION, KID_SELECT_EDGES, KID_SPEC_PREDICT, KID_MASK_FINAL, KID_COUNT };
 static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_hist", "k_mask_annotate", "k_mask_annotate_fallback", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
-                                                     "k_coverage_bins", "k_trim_classify", "k_pileup_facts", "k_matching_position", "k_select_edges"};
+                                                     "k_coverage_bins", "k_trim_classify", "k_pileup_facts", "k_matching_position", "k_select_edges", "k_spec_predict",
+                                                     "k_mask_annotate_final"};
 
 struct ProfScope {
     hinge_ctx* c;
@@ -154,6 +162,8 @@ struct Scalars {
     unsigned heavy_count;               // annotations the count-only sweep could not decide, pile-up <= PO_CAP_SMALL (front of heavy_list)
     unsigned work_next_big;             // the same two for the pile-ups beyond PO_CAP_SMALL (back of heavy_list, PO_CAP instance)
     unsigned heavy_count_big;
+    unsigned redo_count;                // one-sweep pass: length of the guard-band list
+    int spec_state;                     // one-sweep pass: 1 = the exact MIN_COV fell outside the band (SpecVerify)
     int status;
     // ---- persistent across passes ----
     int est[2];                         // cov_est, n_long
@@ -163,6 +173,9 @@ struct Scalars {
     int bins_status;                    // hinge_filter_coverage_bins' own range flag
     int pad2;
     unsigned dbg[16];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds
+    int spec_min_cov;                   // one-sweep pass: the MIN_COV the sweep ran with (k_spec_predict)
+    unsigned spec_ticket;               // k_spec_predict's workgroup counter (zero between launches)
+    unsigned spec_stats[3];             // cumulative: passes verified, exact != predicted, exact outside the band
 };
 static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
 
@@ -244,6 +257,9 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_K2_HEAVY")) ctx->k2_heavy_mode = atoi(g);
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
+    if (const char* g = getenv("HINGE_ONE_SWEEP")) ctx->one_sweep = atoi(g);
+    if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
+    if (const char* g = getenv("HINGE_SPEC_SAMPLE")) ctx->spec_ns = std::max(1, atoi(g));
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
     ctx->med.bytes = sizeof(unsigned) * MED_WORDS;
     (void)hipMemset(ctx->med.p, 0, ctx->med.bytes);
@@ -259,7 +275,8 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
-                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c};
+                     &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c,
+                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -308,6 +325,8 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->work_list, sizeof(WorkItem) * n))) return rc;
     if ((rc = ensure(ctx, ctx->fallback_list, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->cov_tot, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->redo_list, sizeof(int) * n))) return rc;
     // (the own tables may just have been reallocated: re-point unless a caller table is attached)
     if (!ctx->mask_attached) ctx->mask = (int2*)ctx->mask_own.p;
     if (!ctx->mean_attached) ctx->mean_cov = (int*)ctx->mean_own.p;
@@ -611,6 +630,7 @@ static int launch_stats(hinge_ctx* ctx, const hinge_filter_params* p) {
     else LAUNCH_COV_STATS(0, false);
     CK(hipGetLastError());
     ctx->nbins0_reso = p->reso;   // nbins0[] now describes these pile-ups at this reso
+    ctx->pass_mode = 0;           // a two-sweep pass: MIN_COV is exact when K2 starts
     return HINGE_OK;
 }
 
@@ -643,6 +663,15 @@ int hinge_filter_stats_median(hinge_ctx* ctx, const hinge_filter_params* p, uint
     return hist_dev ? hinge_filter_median_hist(ctx, p, ctx->r_begin, ctx->r_end, hist_dev) : hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, out);
 }
 
+static SpecVerify spec_verify_of(hinge_ctx* ctx) {
+    SpecVerify v;
+    memset(&v, 0, sizeof(v));
+    if (ctx->pass_mode != 0) {
+        v.spec_min_cov = &sc(ctx)->spec_min_cov; v.band = ctx->spec_band; v.spec_state = &sc(ctx)->spec_state;
+        v.counters = sc(ctx)->counters; v.stats = sc(ctx)->spec_stats;
+    }
+    return v;
+}
 static MedianPart median_part_of(hinge_ctx* ctx, int32_t lo, int32_t hi, uint32_t* hist_dev) {
     MedianPart a;
     memset(&a, 0, sizeof(a));
@@ -650,6 +679,10 @@ static MedianPart median_part_of(hinge_ctx* ctx, int32_t lo, int32_t hi, uint32_
     a.med = (unsigned*)ctx->med.p; a.est = sc(ctx)->est; a.min_cov = &sc(ctx)->min_cov; a.status = &sc(ctx)->status;
     a.wave_totals = (const unsigned long long*)ctx->wave_totals.p; a.n_wave_totals = ctx->n_wave_totals; a.totals = sc(ctx)->totals;
     a.hist_out = (unsigned*)hist_dev;
+    if (ctx->pass_mode == 1) {   // one-sweep pass through k_mask_annotate_q20<SPEC>: the means are derived here, from the sweep's sums
+        a.cov_tot = (const int*)ctx->cov_tot.p; a.nbins0 = (const int*)ctx->nbins0.p; a.rlen = (const int*)ctx->rlen.p; a.mean_out = ctx->mean_cov;
+    }
+    a.spec = spec_verify_of(ctx);
     return a;
 }
 // k_median_hist over n parts (contexts on one device and one stream), each over its own [lo, hi]; hist_dev[k] as in median_hist
@@ -662,7 +695,10 @@ static int launch_median_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
     for (int k = 0; k < n; k++) {
         int rc = flush_min_cov(ctxs[k]);
         if (rc) return rc;
+        if (ctxs[k]->pass_mode == 1 && (lo[k] < ctxs[k]->r_begin || hi[k] > ctxs[k]->r_end))
+            return fail(ctxs[k], HINGE_E_ARG, "median of a one-sweep pass: the range must lie inside the part's own reads (the means of other reads do not exist)");
         B.part[k] = median_part_of(ctxs[k], lo[k], hi[k], hist_dev ? hist_dev[k] : nullptr);
+        if (hist_dev) memset(&B.part[k].spec, 0, sizeof(SpecVerify));   // the histogram form: verified where the median is finished (k_median_from_hist)
         blocks = std::max(blocks, std::min((hi[k] - lo[k] + 1 + 1023) / 1024, MED_MAX_BLOCKS));
     }
     ProfScope _ps(ctx, KID_MEDIAN);
@@ -713,7 +749,7 @@ int hinge_filter_median_from_hist(hinge_ctx* ctx, const hinge_filter_params* p, 
     if ((rc = flush_min_cov(ctx))) return rc;
     ProfScope _ps(ctx, KID_MEDIAN);
     hipLaunchKernelGGL(k_median_from_hist, dim3(1), dim3(256), 0, ctx->stream, (const unsigned*)hist_dev, p->est_cov, sc(ctx)->est,
-                       &sc(ctx)->min_cov, &sc(ctx)->status);
+                       &sc(ctx)->min_cov, &sc(ctx)->status, spec_verify_of(ctx));
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -734,6 +770,7 @@ int hinge_filter_median_from_hist_batch(hinge_ctx** ctxs, int32_t n, const hinge
         B.est[k] = sc(ctxs[k])->est;
         B.min_cov[k] = &sc(ctxs[k])->min_cov;
         B.status[k] = &sc(ctxs[k])->status;
+        B.spec[k] = spec_verify_of(ctxs[k]);
     }
     ProfScope _ps(ctx, KID_MEDIAN);
     hipLaunchKernelGGL(k_median_from_hist_batch, dim3(n), dim3(256), 0, ctx->stream, (const unsigned*)hist_dev, (long long)row_stride, p->est_cov, B);
@@ -790,10 +827,28 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
     return o;
 }
 
-#define LAUNCH_MASK_ANNOTATE(RESO, GRID, LIST, COUNT)                                                                         \
+#define LAUNCH_MASK_ANNOTATE(RESO, GRID, LIST, COUNT, SA)                                                                     \
     hipLaunchKernelGGL(k_mask_annotate<RESO>, dim3(GRID), dim3(BLOCK), lds, ctx->stream, to_dev(p), ctx->r_begin, ctx->r_end,  \
                        (const int64_t*)ctx->row_ptr.p, (const int2*)ctx->a_span.p, (const int*)ctx->rlen.p,                     \
-                       (const int*)&sc(ctx)->min_cov, kcap, anno_out(ctx), LIST, COUNT)
+                       (const int*)((SA).mode == MODE_SPEC ? &sc(ctx)->spec_min_cov : &sc(ctx)->min_cov), kcap, anno_out(ctx), LIST, COUNT, SA)
+
+// arguments of the general kernel's one-sweep modes (MODE_CLASSIC: all unused); MODE_SPEC launches write one (sum, slots) pair per wavefront
+static int spec_args_of(hinge_ctx* ctx, int mode, int grid, SpecArgs* out) {
+    SpecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = mode; a.band = ctx->spec_band;
+    a.mean_cov = ctx->mean_cov;
+    a.spec_state = &sc(ctx)->spec_state;
+    a.redo_list = (int*)ctx->redo_list.p; a.redo_count = &sc(ctx)->redo_count; a.redo_cap = (unsigned)ctx->n_reads;
+    if (mode == MODE_SPEC) {
+        ctx->n_wave_totals = grid * WAVES_PER_BLOCK;
+        int rc = ensure(ctx, ctx->wave_totals, sizeof(unsigned long long) * 2 * (size_t)ctx->n_wave_totals);
+        if (rc) return rc;
+    }
+    a.wave_totals = (unsigned long long*)ctx->wave_totals.p;
+    *out = a;
+    return HINGE_OK;
+}
 
 // Layout of K2's coverage-bin output: read i of the part gets (rlen + cut_off) / reso + 3 slots, the most bins a profile the
 // kernels accept can have (more raises ST_RANGE).  Host-computable, so no device prefix sum and no second launch.
@@ -817,12 +872,13 @@ static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
     return HINGE_OK;
 }
 
-static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
+static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p, int mode = MODE_CLASSIC) {
     {
         int rc = flush_min_cov(ctx);
         if (rc) return rc;
         if ((rc = prepare_cov_out(ctx, p))) return rc;
     }
+    if (mode == MODE_SPEC) ctx->n_wave_totals = 0;   // (set again below if the general kernel takes part in the sweep)
     const int kcap = kcap_for(ctx, p);
     const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
     if (lds > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
@@ -843,6 +899,20 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
                                 ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
     const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0 && ctx->nbins0_reso == 40 &&
                      mulpath_thr >= 0 && mulpath_thr < (1 << 28);
+    if (mode == MODE_FINAL) {
+        // the guard-band list of a one-sweep pass (about 1 % of the part's reads; every read if the prediction missed the band),
+        // one read per wavefront through the general kernel
+        SpecArgs sa;
+        const int gfin = std::max(64, std::min(grid, std::max(nr / 128, 1)));
+        int rc = spec_args_of(ctx, MODE_FINAL, gfin, &sa);
+        if (rc) return rc;
+        ProfScope _ps(ctx, KID_MASK_FINAL);
+        if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40, gfin, (const int*)ctx->redo_list.p, (const unsigned*)&sc(ctx)->redo_count, sa);
+        else LAUNCH_MASK_ANNOTATE(0, gfin, (const int*)ctx->redo_list.p, (const unsigned*)&sc(ctx)->redo_count, sa);
+        CK(hipGetLastError());
+        return HINGE_OK;
+    }
+    if (mode == MODE_SPEC) ctx->pass_mode = q20 ? 1 : 2;
     if (q20) {
         // bins + hot words (the read classes of hinge_set_pileups are cut for this much) + the zero / total pads of this cut_off
         const int SH = p->cut_off / 20;
@@ -852,8 +922,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         const size_t lds_all = lds20;
         if (ctx->k2_occ_lds != (int)lds_all) {
             int nb = 0;
-            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true, true, 15>, BLOCK, lds_all));
-            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false, true, 15>, BLOCK, lds_all));
+            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true, true, 15, false>, BLOCK, lds_all));
+            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false, true, 15, false>, BLOCK, lds_all));
             ctx->k2_occ = std::max(nb, 1);
             ctx->k2_occ_lds = (int)lds_all;
         }
@@ -925,6 +995,9 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
             hc.o = anno_out(ctx);
             hc.fallback_list = (int*)ctx->fallback_list.p;
             hc.fallback_count = &sc(ctx)->fallback_count;
+            hc.redo_list = (int*)ctx->redo_list.p;
+            hc.redo_count = &sc(ctx)->redo_count;
+            hc.redo_cap = (unsigned)ctx->n_reads;
             int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
             if (rc) return rc;
             if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
@@ -935,16 +1008,19 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         }
         int* cov_out = ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr;
         const int cov_mask_off = p->use_coverage_mask != 0 ? INT_MIN : (1 << 29);
-#define LAUNCH_K2C(PACKED, COVOUT, CUT20, SPANS)                                                                                                            \
-        hipLaunchKernelGGL((k_mask_annotate_q20<PACKED, COVOUT, CUT20>), dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off,        \
+#define LAUNCH_K2S(PACKED, COVOUT, CUT20, SPEC, SPANS)                                                                                                      \
+        hipLaunchKernelGGL((k_mask_annotate_q20<PACKED, COVOUT, CUT20, SPEC>), dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off,  \
                            mulpath_thr, p->no_hinge_region, cov_mask_off, (const int*)ctx->bucket_list.p, n1, n2, n4, (const int64_t*)ctx->row_ptr.p, SPANS, \
-                           (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, (const int*)&sc(ctx)->min_cov, slot, cov_out,                                 \
-                           (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (unsigned*)ctx->k2_heads.p, n_heads, bases)
+                           (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, (const int*)(SPEC ? &sc(ctx)->spec_min_cov : &sc(ctx)->min_cov), slot, cov_out, \
+                           (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (unsigned*)ctx->k2_heads.p, n_heads, bases,                \
+                           (int*)ctx->cov_tot.p, ctx->spec_band)
+#define LAUNCH_K2C(PACKED, COVOUT, CUT20, SPANS) do { if (mode == MODE_SPEC) LAUNCH_K2S(PACKED, COVOUT, CUT20, true, SPANS); else LAUNCH_K2S(PACKED, COVOUT, CUT20, false, SPANS); } while (0)
 #define LAUNCH_K2(PACKED, COVOUT, SPANS) do { if (p->cut_off == 300) LAUNCH_K2C(PACKED, COVOUT, 15, SPANS); else LAUNCH_K2C(PACKED, COVOUT, -1, SPANS); } while (0)
         if (ctx->use_span16) { if (cov_out) LAUNCH_K2(true, true, (const unsigned*)ctx->span16.p); else LAUNCH_K2(true, false, (const unsigned*)ctx->span16.p); }
         else { if (cov_out) LAUNCH_K2(false, true, (const int2*)ctx->a_span.p); else LAUNCH_K2(false, false, (const int2*)ctx->a_span.p); }
 #undef LAUNCH_K2
 #undef LAUNCH_K2C
+#undef LAUNCH_K2S
         CK(hipGetLastError());
         for (int h = 0; h < K2_MAX_HEADS; h++) ctx->k2_head_base[h] = next_base[h];
         _ps.stop();
@@ -952,14 +1028,24 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         // skipped when the part's facts rule all three out
         const bool no_handback = ctx->max_pile < 65536u && ctx->spans_in_range && ctx->max_rlen / 20 < WAVES_PER_BLOCK * k2_slot_ints(ctx) - 4 * WAVE;   // (bins-only slots: conservative)
         if (no_handback) return HINGE_OK;
+        SpecArgs sa;
+        {
+            int rc = spec_args_of(ctx, mode, std::min(grid, 64), &sa);
+            if (rc) return rc;
+        }
         ProfScope _ps2(ctx, KID_MASK_FALLBACK);
-        LAUNCH_MASK_ANNOTATE(40, std::min(grid, 64), (const int*)ctx->fallback_list.p, (const unsigned*)&sc(ctx)->fallback_count);
+        LAUNCH_MASK_ANNOTATE(40, std::min(grid, 64), (const int*)ctx->fallback_list.p, (const unsigned*)&sc(ctx)->fallback_count, sa);
         CK(hipGetLastError());
         return HINGE_OK;
     }
+    SpecArgs sa;
+    {
+        int rc = spec_args_of(ctx, mode, grid, &sa);
+        if (rc) return rc;
+    }
     ProfScope _ps(ctx, KID_MASK_ANNOTATE);
-    if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40, grid, (const int*)nullptr, (const unsigned*)nullptr);
-    else LAUNCH_MASK_ANNOTATE(0, grid, (const int*)nullptr, (const unsigned*)nullptr);
+    if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40, grid, (const int*)nullptr, (const unsigned*)nullptr, sa);
+    else LAUNCH_MASK_ANNOTATE(0, grid, (const int*)nullptr, (const unsigned*)nullptr, sa);
     CK(hipGetLastError());
     return HINGE_OK;
 }
@@ -1084,11 +1170,10 @@ int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p) {
     if (rc) return rc;
     if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
     CK(hipSetDevice(ctx->device));
-    ctx->min_cov_pending = true;   // single part: MIN_COV starts at the ini value (applied by k_cov_stats)
+    ctx->min_cov_pending = true;   // single part: MIN_COV starts at the ini value (applied by the pass's first kernel)
     ctx->min_cov_value = p->min_cov;
-    if ((rc = hinge_filter_stats(ctx, p))) return rc;
-    if ((rc = hinge_filter_median(ctx, p, ctx->r_begin, ctx->r_end, nullptr))) return rc;
-    if ((rc = launch_mask_annotate(ctx, p))) return rc;
+    if ((rc = hinge_filter_sweep_batch_async(&ctx, 1, p, nullptr, 0))) return rc;
+    if ((rc = hinge_filter_finish_batch_async(&ctx, 1, p))) return rc;
     if ((rc = launch_hinges(ctx, p))) return rc;
     return HINGE_OK;
 }
@@ -1100,6 +1185,7 @@ static int check_status(hinge_ctx* ctx) {
     if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part");
     if (h.status & ST_RANGE) return fail(ctx, HINGE_E_RANGE, "overlap coordinate beyond read length + cut_off");
     if (h.status & ST_MEDIAN_RANGE) return fail(ctx, HINGE_E_RANGE, "a mean coverage lies outside [0, 4096): all-gather the means and call hinge_filter_median instead of the histogram exchange");
+    if (h.status & ST_REDO_CAP) return fail(ctx, HINGE_E_CAPACITY, "guard-band list overflow (cannot happen: it has a slot per read)");
     if (h.status & (ST_ANNO_CAP | ST_QUEUE_CAP | ST_ARENA_CAP))
         return fail(ctx, HINGE_E_CAPACITY, "device buffer overflow in hinge_filter_run: use the staged calls (they regrow)");
     return HINGE_OK;
@@ -1276,6 +1362,131 @@ int hinge_filter_hinges_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_fil
 int hinge_filter_check(hinge_ctx* ctx) {
     if (!ctx) return HINGE_E_ARG;
     return check_status(ctx);
+}
+
+// ---- the one-sweep pass (round 4; filter_kernels.h "the one-sweep pass") ------------------------------------------------
+// per-read bin counts / well-formedness of the current pile-ups (nbins0[]): a fact of the pile-ups like the 16|16 span copy,
+// made once per hinge_set_pileups and reso (k_cov_stats is the kernel that knows how)
+static int ensure_pile_bins(hinge_ctx* ctx, const hinge_filter_params* p) {
+    if (ctx->nbins0_reso == p->reso) return HINGE_OK;
+    return launch_stats(ctx, p);
+}
+static int launch_spec_predict(hinge_ctx** ctxs, int n, const hinge_filter_params* p) {
+    hinge_ctx* ctx = ctxs[0];
+    static_assert(SCALARS_RESET_BYTES % sizeof(int) == 0, "reset region is whole ints");
+    for (int packed = 0; packed < 2; packed++) {   // (one launch per span format; a rank's parts normally share one)
+        SpecBatch B;
+        memset(&B, 0, sizeof(B));
+        B.ns = ctx->spec_ns;
+        int max_nr = 1;
+        for (int k = 0; k < n; k++) {
+            hinge_ctx* c = ctxs[k];
+            if ((c->use_span16 ? 1 : 0) != packed) continue;
+            int rc = ensure(c, c->spec_sample, sizeof(int) * (size_t)ctx->spec_ns);
+            if (rc) return rc;
+            SpecPart& a = B.part[B.n++];
+            a.r_begin = c->r_begin; a.r_end = c->r_end;
+            a.row_ptr = (const int64_t*)c->row_ptr.p; a.a_span = (const int2*)c->a_span.p; a.span16 = (const unsigned*)c->span16.p;
+            a.rlen = (const int*)c->rlen.p; a.nbins0 = (const int*)c->nbins0.p;
+            a.pass_scalars = (int*)c->scalars.p; a.n_pass_scalars = (int)(SCALARS_RESET_BYTES / sizeof(int));
+            a.min_cov = &sc(c)->min_cov; a.set_min_cov = c->min_cov_pending ? 1 : 0; a.min_cov_value = c->min_cov_value;
+            c->min_cov_pending = false;
+            a.spec_min_cov = &sc(c)->spec_min_cov; a.sample = (int*)c->spec_sample.p; a.ticket = &sc(c)->spec_ticket; a.bias = c->spec_bias;
+            max_nr = std::max(max_nr, c->r_end - c->r_begin + 1);
+        }
+        if (B.n == 0) continue;
+        const int bpp = (std::min(B.ns, max_nr) + SPEC_READS_PER_BLOCK - 1) / SPEC_READS_PER_BLOCK;
+        ProfScope _ps(ctx, KID_SPEC_PREDICT);
+        if (p->reso == 40) { if (packed) hipLaunchKernelGGL((k_spec_predict<40, true>), dim3(bpp * B.n), dim3(SPEC_BLOCK), 0, ctx->stream, B, p->reso, p->est_cov);
+                             else hipLaunchKernelGGL((k_spec_predict<40, false>), dim3(bpp * B.n), dim3(SPEC_BLOCK), 0, ctx->stream, B, p->reso, p->est_cov); }
+        else { if (packed) hipLaunchKernelGGL((k_spec_predict<0, true>), dim3(bpp * B.n), dim3(SPEC_BLOCK), 0, ctx->stream, B, p->reso, p->est_cov);
+               else hipLaunchKernelGGL((k_spec_predict<0, false>), dim3(bpp * B.n), dim3(SPEC_BLOCK), 0, ctx->stream, B, p->reso, p->est_cov); }
+        CK(hipGetLastError());
+    }
+    return HINGE_OK;
+}
+
+int hinge_filter_sweep_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p, uint32_t* hist_dev, int64_t row_stride) {
+    int rc = same_device_and_stream(ctxs, n, MED_BATCH_MAX, "hinge_filter_sweep_batch_async");
+    if (rc) return rc;
+    hinge_ctx* ctx = ctxs[0];
+    if ((rc = check_params(ctx, p))) return rc;
+    if (hist_dev && row_stride < MED_BINS + 2) return fail(ctx, HINGE_E_ARG, "sweep_batch: a histogram row has MED_BINS + 2 words");
+    for (int k = 0; k < n; k++)
+        if (ctxs[k]->r_end < ctxs[k]->r_begin) return fail(ctxs[k], HINGE_E_ARG, "no pile-ups set");
+    CK(hipSetDevice(ctx->device));
+    int32_t lo[MED_BATCH_MAX], hi[MED_BATCH_MAX];
+    uint32_t* hd[MED_BATCH_MAX];
+    for (int k = 0; k < n; k++) { lo[k] = ctxs[k]->r_begin; hi[k] = ctxs[k]->r_end; hd[k] = hist_dev ? hist_dev + (int64_t)k * row_stride : nullptr; }
+    // the telomere test (filter.cpp:731-760) sums max(cov, MIN_COV): not constant over a band of MIN_COV values - two sweeps
+    const bool one_sweep = ctx->one_sweep != 0 && p->delete_telomere == 0;
+    if (!one_sweep) {
+        for (int k = 0; k < n; k++)
+            if ((rc = launch_stats(ctxs[k], p))) return rc;
+        return launch_median_batch(ctxs, n, p, lo, hi, hist_dev ? hd : nullptr);
+    }
+    for (int k = 0; k < n; k++)
+        if ((rc = ensure_pile_bins(ctxs[k], p))) return rc;
+    if ((rc = launch_spec_predict(ctxs, n, p))) return rc;
+    for (int k = 0; k < n; k++)
+        if ((rc = launch_mask_annotate(ctxs[k], p, MODE_SPEC))) return rc;
+    return launch_median_batch(ctxs, n, p, lo, hi, hist_dev ? hd : nullptr);
+}
+
+int hinge_filter_finish_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p) {
+    int rc = same_device_and_stream(ctxs, n, MED_BATCH_MAX, "hinge_filter_finish_batch_async");
+    if (rc) return rc;
+    hinge_ctx* ctx = ctxs[0];
+    if ((rc = check_params(ctx, p))) return rc;
+    CK(hipSetDevice(ctx->device));
+    for (int k = 0; k < n; k++)
+        if ((rc = launch_mask_annotate(ctxs[k], p, ctxs[k]->pass_mode != 0 ? MODE_FINAL : MODE_CLASSIC))) return rc;
+    return HINGE_OK;
+}
+
+int hinge_filter_sweep(hinge_ctx* ctx, const hinge_filter_params* p, hinge_cov_estimate* out) {
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (ctx->r_end < ctx->r_begin) return fail(ctx, HINGE_E_ARG, "no pile-ups set");
+    CK(hipSetDevice(ctx->device));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        // (the pass's first kernel clears the pass scalars: status, annotation allocator, work list, guard-band list)
+        if ((rc = hinge_filter_sweep_batch_async(&ctx, 1, p, nullptr, 0))) return rc;
+        if ((rc = hinge_filter_finish_batch_async(&ctx, 1, p))) return rc;
+        Scalars h;
+        CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        if (out) { out->cov_est = h.est[0]; out->n_long = h.est[1]; out->total_cov = (int64_t)h.totals[0]; out->num_slot = (int64_t)h.totals[1]; }
+        if (h.status & ST_NO_LONG_READ) return fail(ctx, HINGE_E_UNDEFINED, "no read >= 5000 bp in this part: the reference is undefined here (filter.cpp:660-666)");
+        if (h.status & ST_RANGE) return fail(ctx, HINGE_E_RANGE, "overlap coordinate beyond read length + cut_off");
+        if (h.status & ST_REDO_CAP) return fail(ctx, HINGE_E_CAPACITY, "guard-band list overflow (cannot happen: it has a slot per read)");
+        if (!(h.status & ST_ANNO_CAP)) return HINGE_OK;
+        // the annotation buffer is sized optimistically; grow + rerun the pass on overflow (rare; MIN_COV's update is idempotent)
+        ctx->anno_cap = std::max(ctx->anno_cap * 2, h.counters[0] + 1024);
+        if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+    }
+    return fail(ctx, HINGE_E_CAPACITY, "annotation buffer kept overflowing");
+}
+
+int hinge_filter_spec_stats(hinge_ctx* ctx, int64_t out[6]) {
+    if (!ctx || !out) return HINGE_E_ARG;
+    Scalars h;
+    CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    out[0] = h.spec_stats[0]; out[1] = h.spec_stats[1]; out[2] = h.spec_stats[2];
+    out[3] = ctx->pass_mode != 0 ? (int64_t)h.redo_count : -1;
+    out[4] = h.spec_min_cov; out[5] = h.min_cov;
+    return HINGE_OK;
+}
+
+int hinge_debug_spec(hinge_ctx* ctx, int band, int sample, int bias) {
+    if (!ctx) return HINGE_E_ARG;
+    if (band >= 0) ctx->spec_band = band;
+    if (sample > 0) ctx->spec_ns = sample;
+    ctx->spec_bias = bias;
+    return HINGE_OK;
 }
 
 int hinge_profile_enable(hinge_ctx* ctx, int max_launches) {

@@ -359,6 +359,7 @@ class PartBatch:
         self.hist = torch.zeros((self.R, 4096 + 2), dtype=torch.int32, device=device)
         self.backends: List[Optional[object]] = [None] * self.R
         self._corrupt = os.environ.get("HINGE_TEST_CORRUPT_GATHER", "0") == "1"
+        self.one_sweep = os.environ.get("HINGE_ONE_SWEEP", "1") != "0"     # 0: the two-sweep pass of rounds 1-3 (k_cov_stats first)
 
     # ---- id space ---------------------------------------------------------------------------------------------
     def n_ids(self, p: int) -> int:
@@ -400,6 +401,32 @@ class PartBatch:
         """No host synchronisation and no status exchange inside (call status() after a chain of steps)."""
         B = self.backends
         batched = hasattr(B[0], "hinges_batch")       # the product backend: the latency-bound kernels take all parts per launch
+        if batched and self.one_sweep:
+            # the one-sweep pass (include/hinge_hip.h): per part ONE sweep over the pile-ups with a predicted MIN_COV that also
+            # yields the coverage sums, the exact median as verification (exchange 1 sums its histograms over the ranks), then
+            # the ~1 % guard-band reads with the exact MIN_COV
+            for b in B:
+                b.begin()
+            if not self.collectives:
+                B[0].sweep_batch(B)
+                B[0].finish_batch(B)
+                B[0].hinges_batch(B)
+                return
+            B[0].sweep_batch(B, hist=self.hist)
+            _all_reduce_sum(self.hist, self.group, self.staged, async_op=False)          # exchange 1
+            B[0].median_from_hist_batch(B, self.hist)                                    # ... and the verification
+            pending = []
+            last = len(self.groups) - 1
+            for gi, g in enumerate(self.groups):
+                B[g[0]].finish_batch([B[p] for p in g])
+                pending.append(self._gather_group(gi, async_op=gi != last))              # exchange 2
+            for gi, g in enumerate(self.groups):
+                if pending[gi] is not None:
+                    pending[gi].wait()
+                if self._corrupt:
+                    self._corrupt_foreign_rows(gi)
+                B[g[0]].hinges_batch([B[p] for p in g])
+            return
         if not self.collectives:              # one rank: no exchange; the parts only share their launches
             for b in B:
                 b.begin()
@@ -446,16 +473,19 @@ class PartBatch:
             if pending[gi] is not None:
                 pending[gi].wait()
             if self._corrupt:                 # test hook: a broken exchange 2 must not go unnoticed (tests/test_dist_gpu.py)
-                J = len(g)
-                own = slice(self.rank * J * self.S, (self.rank + 1) * J * self.S)
-                keep = self.masks[gi][own].clone()
-                self.masks[gi].zero_()
-                self.masks[gi][own] = keep
+                self._corrupt_foreign_rows(gi)
             if batched:
                 B[g[0]].hinges_batch([B[p] for p in g])
             else:
                 for p in g:
                     B[p].hinges()
+
+    def _corrupt_foreign_rows(self, gi: int) -> None:
+        J = len(self.groups[gi])
+        own = slice(self.rank * J * self.S, (self.rank + 1) * J * self.S)
+        keep = self.masks[gi][own].clone()
+        self.masks[gi].zero_()
+        self.masks[gi][own] = keep
 
     def settle(self, max_rounds: int = 4) -> None:
         """Whole steps until no rank reports a full device buffer (HINGE_E_CAPACITY anywhere: every rank regrows, every rank
@@ -656,6 +686,18 @@ class HipBackend:
         for k in range(0, len(backends), self.MEDIAN_BATCH_MAX):
             chunk = backends[k:k + self.MEDIAN_BATCH_MAX]
             capi.median_batch([b.ctx for b in chunk], self.p, None if hist is None else hist[k:], 0 if hist is None else int(hist.stride(0)))
+
+    def sweep_batch(self, backends, hist: Optional[torch.Tensor] = None):
+        """One-sweep pass, first half, all parts (per 16): prediction, sweep, verifying median (hist: its histogram form)."""
+        from . import capi
+        for k in range(0, len(backends), self.MEDIAN_BATCH_MAX):
+            capi.sweep_batch_async([b.ctx for b in backends[k:k + self.MEDIAN_BATCH_MAX]], self.p, None if hist is None else hist[k:],
+                                   0 if hist is None else int(hist.stride(0)))
+
+    def finish_batch(self, backends):
+        from . import capi
+        for k in range(0, len(backends), self.MEDIAN_BATCH_MAX):
+            capi.finish_batch_async([b.ctx for b in backends[k:k + self.MEDIAN_BATCH_MAX]], self.p)
 
     def hinges_batch(self, backends):
         from . import capi

@@ -83,8 +83,11 @@ def write_db(
     all_flag: int = 1,
     flags: Optional[np.ndarray] = None,
     write_bases: bool = True,
+    bases: Optional[Sequence[np.ndarray]] = None,
 ) -> None:
     """Write NAME.db, .NAME.idx and (optionally) .NAME.bps for reads of the given lengths.
+    bases: one uint8 array of 0..3 (A C G T) per read - packed four to a byte, first base in the two high bits
+    (Compress_Read, src/lib/DB.c:239-262); without it the .bps is all zeroes (the graph stages never read it).
 
     ``block_first`` = untrimmed first-read index of every block plus the total (DBsplit's
     table); defaults to a single block.  With ``cutoff=0, all_flag=1`` nothing is trimmed.
@@ -125,7 +128,11 @@ def write_db(
     with open(idx, "wb") as f:
         f.write(hdr)
         f.write(rec.tobytes())
-    if write_bases:
+    if write_bases and bases is not None:
+        with open(bps, "wb") as f:
+            for i in range(n):
+                f.write(pack_bases(bases[i]).tobytes())
+    elif write_bases:
         with open(bps, "wb") as f:
             total = int(nbytes.sum())
             chunk = bytes(1 << 20)
@@ -133,6 +140,28 @@ def write_db(
                 w = min(total, len(chunk))
                 f.write(chunk[:w])
                 total -= w
+
+
+def pack_bases(b: np.ndarray) -> np.ndarray:
+    """uint8 0..3 per base -> DAZZ_DB's 2-bit form, (len + 3) // 4 bytes, the tail padded with zeroes."""
+    b = np.asarray(b, dtype=np.uint8)
+    pad = (-len(b)) % 4
+    q = np.concatenate([b, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    return ((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).astype(np.uint8)
+
+
+def read_bases(db_name: str, idx: Optional[dict] = None) -> List[np.ndarray]:
+    """Every (trimmed) read's bases (uint8 0..3) from .NAME.bps."""
+    if idx is None:
+        idx = read_db_index(db_name)
+    _, _, bps, _ = db_paths(db_name)
+    raw = np.fromfile(bps, dtype=np.uint8)
+    out = []
+    for ln, off in zip(idx["rlen"], idx["boff"]):
+        pk = raw[int(off):int(off) + (int(ln) + 3) // 4]
+        un = np.stack([(pk >> 6) & 3, (pk >> 4) & 3, (pk >> 2) & 3, pk & 3], axis=1).reshape(-1)[:int(ln)]
+        out.append(un.astype(np.uint8))
+    return out
 
 
 def read_db_index(db_name: str) -> dict:
@@ -162,6 +191,7 @@ def read_db_index(db_name: str) -> dict:
         "all": all_flag,
         "rlen": rec["rlen"][keep].astype(np.int32),
         "keep": keep,
+        "boff": rec["boff"][keep].astype(np.int64),
     }
 
 

@@ -119,12 +119,12 @@ def run_filter(db_name: str, las_base: str, prefix: str, config: str, mlas: bool
             else:
                 ctx.set_pileups(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
             ctx.coverage_out(packed and write_coverage)
-            if packed:      # the route of the executables: statistics + the part's median in one launch
-                ctx.filter_stats_median(P, fetch=True)
+            if packed:      # the route of the executables: the one-sweep pass (statistics, median, masks, annotations)
+                ctx.filter_sweep(P, fetch=True)
             else:
                 ctx.filter_stats(P)
                 ctx.filter_median(P, r_begin, r_end, fetch=True)
-            ctx.filter_mask_annotate(P)
+                ctx.filter_mask_annotate(P)
             ctx.filter_hinges(P)
             mask, cmask, flags = ctx.get_masks()
             off, pos, typ, ish = ctx.get_annotations()

@@ -150,6 +150,33 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p);
 int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p);
 /* All of the above for one single-GPU part, asynchronously on the stream, no host round trip.    */
 int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p);
+/* ---- the one-sweep pass (round 4) --------------------------------------------------------------------------------------
+ * filter.cpp sweeps every pile-up twice because the coverage mask needs MIN_COV = max(MIN_COV, median coverage / 3), a
+ * whole-part barrier (filter.cpp:642-678) that lies between profileCoverage (filter.cpp:597-598) and the mask loop
+ * (filter.cpp:696-829).  Here ONE sweep does both: sweep_batch() predicts MIN_COV from a sample of each part, runs K2 with it -
+ * exact for every MIN_COV within +-band (default 1) of the prediction; the ~1 % of reads with a coverage bin or an annotation
+ * threshold inside that band emit nothing and are listed - while K2's prefix scan yields the per-read coverage sums, and then
+ * runs the exact median on those sums as VERIFICATION (MIN_COV is updated as by hinge_filter_median).  finish_batch() runs
+ * the listed reads with the exact MIN_COV (all reads if it fell outside the band).  Results are those of
+ * stats + median + mask_annotate, bit for bit.  n <= 16 parts (contexts on one device and one stream), each over its own
+ * reads [r_begin, r_end]; asynchronous; status through hinge_filter_check / the getters.
+ *   hist_dev == NULL: the median is finished on this GPU.  hist_dev != NULL (sharded runs): part k's histogram goes to
+ *   hist_dev + k * row_stride as by hinge_filter_median_hist; the caller all-reduces and calls
+ *   hinge_filter_median_from_hist_batch (which verifies) before finish_batch().
+ * With delete_telomere != 0 (the telomere test sums max(cov, MIN_COV): no band) or HINGE_ONE_SWEEP=0 the two calls run the
+ * two-sweep pass: sweep_batch = stats + median, finish_batch = mask_annotate.                                                */
+int hinge_filter_sweep_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p, uint32_t* hist_dev, int64_t row_stride);
+int hinge_filter_finish_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p);
+/* The same for one part, synchronously: sweep + verification + guard-band reads, the annotation buffer regrown and the pass
+ * repeated when it overflows; `out` (may be NULL) as from hinge_filter_median.  Replaces the sequence
+ * hinge_filter_stats_median + hinge_filter_mask_annotate (profileCoverage .. annotation merge, filter.cpp:597-829).          */
+int hinge_filter_sweep(hinge_ctx* ctx, const hinge_filter_params* p, hinge_cov_estimate* out);
+/* out[0] one-sweep passes verified so far, [1] of which the exact MIN_COV differed from the prediction, [2] of which it fell
+ * outside the band (whole part redone); last pass: [3] reads on the guard-band list (-1: it was a two-sweep pass),
+ * [4] predicted MIN_COV, [5] exact MIN_COV.  Synchronises.                                                                   */
+int hinge_filter_spec_stats(hinge_ctx* ctx, int64_t out[6]);
+/* Tests: band (>= 0; -1 keeps), sample size (> 0; else keeps), bias added to every prediction (forces mispredictions).        */
+int hinge_debug_spec(hinge_ctx* ctx, int band, int sample, int bias);
 
 /* ---- filter results (host buffers; these synchronise) ---------------------------------------- */
 /* mask/cmask: int32[n][2] for reads r_begin..r_end (n = r_end-r_begin+1); flags: bit0 = .cov.flag
