@@ -1077,17 +1077,18 @@ struct SpecArgs {
     unsigned redo_cap;
 };
 template <int RESO>
-__global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
-                                                         const int2* __restrict__ a_span, const int* __restrict__ rlen,
-                                                         const int* __restrict__ d_min_cov, int kcap, AnnoOut o,
-                                                         const int* __restrict__ read_list, const unsigned* __restrict__ list_count, SpecArgs sa) {
+__device__ __forceinline__ void mask_annotate_body(const FilterDev& P, int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+                                                   const int2* __restrict__ a_span, const int* __restrict__ rlen,
+                                                   const int* __restrict__ d_min_cov, int kcap, const AnnoOut& o,
+                                                   const int* __restrict__ read_list, const unsigned* __restrict__ list_count, const SpecArgs& sa,
+                                                   int block_index, int n_blocks) {
     extern __shared__ int lds[];
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction; lets the per-read control flow go scalar
     int* h0 = lds + (size_t)wib * 2 * kcap;
     int* hc = h0 + kcap;
-    const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-    const int nwaves = gridDim.x * WAVES_PER_BLOCK;
+    const int wave = block_index * WAVES_PER_BLOCK + wib;
+    const int nwaves = n_blocks * WAVES_PER_BLOCK;
     const int MIN_COV = *d_min_cov;
     const int reso = RESO > 0 ? RESO : P.reso;   // compile-time 40 in the shipped configuration: no runtime divisions
     if (sa.mode == MODE_FINAL && *sa.spec_state != 0) read_list = nullptr;   // the prediction missed the band: everything again
@@ -1236,6 +1237,35 @@ __global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begi
         sa.wave_totals[2 * wave] = (unsigned long long)blk_cov;
         sa.wave_totals[2 * wave + 1] = (unsigned long long)blk_slot;
     }
+}
+template <int RESO>
+__global__ __launch_bounds__(BLOCK) void k_mask_annotate(FilterDev P, int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+                                                         const int2* __restrict__ a_span, const int* __restrict__ rlen,
+                                                         const int* __restrict__ d_min_cov, int kcap, AnnoOut o,
+                                                         const int* __restrict__ read_list, const unsigned* __restrict__ list_count, SpecArgs sa) {
+    mask_annotate_body<RESO>(P, r_begin, r_end, row_ptr, a_span, rlen, d_min_cov, kcap, o, read_list, list_count, sa, (int)blockIdx.x, (int)gridDim.x);
+}
+// MODE_FINAL for up to MASK_FINAL_BATCH_MAX resident parts in ONE launch (block b works for part b % n): the guard-band lists are
+// ~1 % of a part's reads each, the launch is a chain of a few dependent look-ups whose length does not depend on how many
+// parts share it (four launches: 4 x 17 us; one: 18 us - profiles/r4a vs r4b).
+constexpr int MASK_FINAL_BATCH_MAX = 8;
+struct MaskFinalPart {
+    int r_begin, r_end;
+    const int64_t* row_ptr; const int2* a_span; const int* rlen; const int* d_min_cov;
+    AnnoOut o;
+    const int* read_list; const unsigned* list_count;
+    SpecArgs sa;
+};
+struct MaskFinalBatch { int n; MaskFinalPart part[MASK_FINAL_BATCH_MAX]; };
+template <int RESO>
+__global__ __launch_bounds__(BLOCK) void k_mask_final_batch(FilterDev P, const MaskFinalBatch* __restrict__ B, int kcap) {
+    typedef const MaskFinalBatch __attribute__((address_space(4))) BatchK;   // constant address space: scalar loads
+    BatchK& b = *(BatchK*)(unsigned long long)B;
+    const int n = b.n;
+    const int part = (int)blockIdx.x % n;
+    const MaskFinalPart a = const_cast<const MaskFinalBatch*>(B)->part[part];
+    mask_annotate_body<RESO>(P, a.r_begin, a.r_end, a.row_ptr, a.a_span, a.rlen, a.d_min_cov, kcap, a.o, a.read_list, a.list_count, a.sa,
+                             (int)blockIdx.x / n, (int)gridDim.x / n);
 }
 
 // Fast kernel for reso = 40 and cut_off = 20 * SH >= 0.  Per wave: Pq[qcap] = begin|end counts per 20-bp bin

@@ -56,6 +56,11 @@ struct hinge_ctx {
     unsigned long long arena_cap = 0;
     DevBuf scalars;   // see Scalars
     // one-sweep pass (round 4, see MODE_SPEC in filter_kernels.h)
+    DevBuf final_batch;                       // k_mask_final_batch's arguments (of the batch's first context)
+    MaskFinalBatch final_batch_host;
+    bool final_batch_valid = false;
+    size_t lds_attr_final = 0;
+    int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
     DevBuf cov_tot, redo_list, spec_sample;   // int[n_reads] coverage sums, int[n_reads] guard-band list, int[spec_ns] sample means
     int spec_band = 1;        // the sweep is exact for every MIN_COV within +- this of the prediction (HINGE_SPEC_BAND)
     int spec_ns = 4096;       // reads k_spec_predict samples per part (HINGE_SPEC_SAMPLE)
@@ -258,6 +263,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_DEBUG_FORCE_EXACT")) ctx->force_exact = atoi(g);   // 1: serial exact kernel, 2: exact replay in LDS (tests)
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (const char* g = getenv("HINGE_ONE_SWEEP")) ctx->one_sweep = atoi(g);
+    if (const char* g = getenv("HINGE_FINAL_BATCH")) ctx->final_batched = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
     if (const char* g = getenv("HINGE_SPEC_SAMPLE")) ctx->spec_ns = std::max(1, atoi(g));
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -276,7 +282,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c,
-                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample};
+                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1439,8 +1445,54 @@ int hinge_filter_finish_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_fil
     hinge_ctx* ctx = ctxs[0];
     if ((rc = check_params(ctx, p))) return rc;
     CK(hipSetDevice(ctx->device));
-    for (int k = 0; k < n; k++)
-        if ((rc = launch_mask_annotate(ctxs[k], p, ctxs[k]->pass_mode != 0 ? MODE_FINAL : MODE_CLASSIC))) return rc;
+    bool all_final = true;
+    for (int k = 0; k < n; k++) all_final = all_final && ctxs[k]->pass_mode != 0;
+    if (!all_final || ctx->final_batched == 0) {
+        for (int k = 0; k < n; k++)
+            if ((rc = launch_mask_annotate(ctxs[k], p, ctxs[k]->pass_mode != 0 ? MODE_FINAL : MODE_CLASSIC))) return rc;
+        return HINGE_OK;
+    }
+    // the guard-band lists of all parts in one launch per MASK_FINAL_BATCH_MAX parts (k_mask_final_batch)
+    for (int k0 = 0; k0 < n; k0 += MASK_FINAL_BATCH_MAX) {
+        const int nb = std::min(n - k0, (int)MASK_FINAL_BATCH_MAX);
+        MaskFinalBatch B;
+        memset(&B, 0, sizeof(B));
+        B.n = nb;
+        int kcap = 0, nr_max = 1;
+        for (int k = 0; k < nb; k++) {
+            hinge_ctx* c = ctxs[k0 + k];
+            if ((rc = flush_min_cov(c))) return rc;
+            if ((rc = prepare_cov_out(c, p))) return rc;
+            kcap = std::max(kcap, kcap_for(c, p));
+            nr_max = std::max(nr_max, c->r_end - c->r_begin + 1);
+            MaskFinalPart& a = B.part[k];
+            a.r_begin = c->r_begin; a.r_end = c->r_end;
+            a.row_ptr = (const int64_t*)c->row_ptr.p; a.a_span = (const int2*)c->a_span.p; a.rlen = (const int*)c->rlen.p;
+            a.d_min_cov = &sc(c)->min_cov;
+            a.o = anno_out(c);
+            a.read_list = (const int*)c->redo_list.p; a.list_count = &sc(c)->redo_count;
+            if ((rc = spec_args_of(c, MODE_FINAL, 0, &a.sa))) return rc;
+        }
+        const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
+        if (lds > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
+        if (lds > 48 * 1024 && lds > ctx->lds_attr_final) {
+            CK(hipFuncSetAttribute((const void*)k_mask_final_batch<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipFuncSetAttribute((const void*)k_mask_final_batch<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ctx->lds_attr_final = lds;
+        }
+        if ((rc = ensure(ctx, ctx->final_batch, sizeof(MaskFinalBatch)))) return rc;
+        if (!ctx->final_batch_valid || memcmp(&B, &ctx->final_batch_host, sizeof(B)) != 0) {
+            ctx->final_batch_host = B;
+            CK(hipMemcpyAsync(ctx->final_batch.p, &ctx->final_batch_host, sizeof(B), hipMemcpyHostToDevice, ctx->stream));
+            ctx->final_batch_valid = true;
+        }
+        // (as many workgroups per part as the single launch takes: the lists are ~1 % of the reads, a whole part if the band was missed)
+        const int gper = std::max(64, std::min((nr_max + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, std::max(nr_max / 128, 1)));
+        ProfScope _ps(ctx, KID_MASK_FINAL);
+        if (p->reso == 40) hipLaunchKernelGGL(k_mask_final_batch<40>, dim3(gper * nb), dim3(BLOCK), lds, ctx->stream, to_dev(p), (const MaskFinalBatch*)ctx->final_batch.p, kcap);
+        else hipLaunchKernelGGL(k_mask_final_batch<0>, dim3(gper * nb), dim3(BLOCK), lds, ctx->stream, to_dev(p), (const MaskFinalBatch*)ctx->final_batch.p, kcap);
+        CK(hipGetLastError());
+    }
     return HINGE_OK;
 }
 
