@@ -12,7 +12,7 @@ LIB  = hinge_amd/lib/libhinge_hip.so
 BIN  = hinge_amd/bin
 HOST = hinge_amd/host
 HOSTDEPS = $(wildcard $(HOST)/*.h) include/hinge_hip.h $(LIB)
-PROGS = $(BIN)/Reads_filter $(BIN)/get_maximal_reads $(BIN)/hinging $(BIN)/hinge
+PROGS = $(BIN)/Reads_filter $(BIN)/get_maximal_reads $(BIN)/hinging $(BIN)/consensus $(BIN)/hinge
 
 SYNTHIO = hinge_amd/lib/libhinge_synthio.so
 
@@ -27,6 +27,10 @@ $(BIN)/get_maximal_reads: $(HOST)/maximal_main.cpp $(HOSTDEPS)
 	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
 
 $(BIN)/hinging: $(HOST)/layout_main.cpp $(HOSTDEPS)
+	mkdir -p $(BIN)
+	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(BIN)/consensus: $(HOST)/consensus_main.cpp $(HOSTDEPS)
 	mkdir -p $(BIN)
 	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
 

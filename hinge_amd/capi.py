@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HINGE_LIB") or os.path.join(_HERE, "lib", "libhinge_hip.so")   # HINGE_LIB: another build of the library (tools/ablate_k2.sh)
 
 HINGE_OK = 0
+HINGE_E_ARG, HINGE_E_DEVICE, HINGE_E_CAPACITY, HINGE_E_UNDEFINED, HINGE_E_RANGE = -1, -2, -3, -4, -5
 ERR_NAMES = {-1: "HINGE_E_ARG", -2: "HINGE_E_DEVICE", -3: "HINGE_E_CAPACITY", -4: "HINGE_E_UNDEFINED", -5: "HINGE_E_RANGE"}
 
 
@@ -99,6 +100,11 @@ SYMBOLS = [
     ("hinge_resolve_containment", C.c_int, [C.c_int32, _VP, C.c_int64, _VP, _VP]),
     ("hinge_sort_order_desc", C.c_int, [C.c_int32, _VP, C.c_int32, _VP]),
     ("hinge_pick_pairs", C.c_int64, [C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
+    ("hinge_consensus_set_db", C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int64]),
+    ("hinge_consensus_run", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int64, C.c_int32]),
+    ("hinge_consensus_get_contig", C.c_int, [_VP, C.c_int32, _VP, C.c_int64, C.POINTER(C.c_int64), _VP]),
+    ("hinge_consensus_get_offsets", C.c_int, [_VP, _VP]),
+    ("hinge_consensus_get_indels", C.c_int, [_VP, C.c_int64, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     ("hinge_profile_report", C.c_int, [_VP, _VP, _VP]),
     ("hinge_timer_start", C.c_int, [_VP]),
     ("hinge_timer_stop_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -486,6 +492,67 @@ class Context:
         ms = C.c_float()
         self._ck(self.lib.hinge_timer_stop_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+
+CNS_ALN_DTYPE = np.dtype([("aread", "<i4"), ("bread", "<i4"), ("comp", "<i4"), ("abpos", "<i4"), ("aepos", "<i4"), ("bbpos", "<i4"), ("bepos", "<i4"),
+                          ("tlen", "<i4"), ("trace_off", "<i8")])   # hinge_cns_alignment
+
+
+class CnsStats(C.Structure):
+    _fields_ = [("sum_coverage", C.c_int64)] + [(n, C.c_int32) for n in ("contig_length", "good_bases", "insertions", "deletions", "low_coverage_bases", "consensus_length")]
+
+
+class Consensus:
+    """`hinge consensus` over the C ABI (hinge_consensus_*): the two DBs' bases go to the GPU once, run() takes the alignments
+    (rows of a formats.LasRecords) that vote."""
+
+    def __init__(self, ctx: Context, draft_db: str, read_db: str):
+        from . import formats
+        self.ctx = ctx
+        self.n = []
+        for which, name in enumerate((draft_db, read_db)):
+            idx = formats.read_db_index(name)
+            rlen = np.ascontiguousarray(idx["rlen"], dtype=np.int32)
+            boff = np.ascontiguousarray(idx["boff"], dtype=np.int64)
+            bps = np.fromfile(formats.db_paths(name)[2], dtype=np.uint8)
+            ctx._ck(ctx.lib.hinge_consensus_set_db(ctx.h, which, len(rlen), _ptr(rlen), _ptr(boff), _ptr(bps), bps.size))
+            self.n.append(len(rlen))
+        self.n_aln = 0
+
+    def run(self, las, picks) -> None:
+        picks = np.asarray(picks, dtype=np.int64)
+        tb = 1 if las.tspace <= 125 else 2
+        tr16 = las.trace.astype(np.uint16) if tb == 1 else np.ascontiguousarray(las.trace).view("<u2")
+        a = np.zeros(len(picks), dtype=CNS_ALN_DTYPE)
+        r = las.rec[picks]
+        a["aread"], a["bread"], a["comp"] = r["aread"], r["bread"], r["flags"] & 1
+        a["abpos"], a["aepos"], a["bbpos"], a["bepos"], a["tlen"] = r["abpos"], r["aepos"], r["bbpos"], r["bepos"], r["tlen"]
+        a["trace_off"] = las.trace_off[picks] // tb
+        tr16 = np.ascontiguousarray(tr16)
+        self.n_aln = len(picks)
+        self.ctx._ck(self.ctx.lib.hinge_consensus_run(self.ctx.h, len(picks), _ptr(a), _ptr(tr16), tr16.size, las.tspace))
+
+    def contig(self, c: int):
+        n = C.c_int64(0)
+        st = CnsStats()
+        self.ctx._ck(self.ctx.lib.hinge_consensus_get_contig(self.ctx.h, c, None, 0, C.byref(n), C.byref(st)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        self.ctx._ck(self.ctx.lib.hinge_consensus_get_contig(self.ctx.h, c, _ptr(buf), n.value, C.byref(n), C.byref(st)))
+        return buf[:n.value].tobytes(), st
+
+    def offsets(self) -> np.ndarray:
+        out = np.zeros(max(self.n_aln, 1), dtype=np.int32)
+        if self.n_aln:
+            self.ctx._ck(self.ctx.lib.hinge_consensus_get_offsets(self.ctx.h, _ptr(out)))
+        return out[:self.n_aln]
+
+    def indels(self, k: int) -> np.ndarray:
+        n = C.c_int64(0)
+        self.ctx._ck(self.ctx.lib.hinge_consensus_get_indels(self.ctx.h, k, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        if n.value:
+            self.ctx._ck(self.ctx.lib.hinge_consensus_get_indels(self.ctx.h, k, _ptr(out), n.value, C.byref(n)))
+        return out[:n.value]
 
 
 def median_from_hist_batch(ctxs, p: FilterParams, hist_dev, row_stride: int) -> None:

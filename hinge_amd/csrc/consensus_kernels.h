@@ -1,0 +1,412 @@
+// `hinge consensus` on the GPU: per-contig pile-up vote over base-level realignments.
+// Reference: consensus/consensus.cpp:77-288 and, under it, LAInterface::recoverAlignment (lib/LAInterface.cpp:4125-4244) ->
+// computeTracePTS (:3410-3506) -> iter_np (:3152-3404), LAInterface::getAlignmentTags (:3709-3905), chop_end (consensus.cpp:27-45).
+//
+// Roofline: NOT HBM.  The work is Myers' O(np) wave algorithm between successive trace points - a serial recurrence along each
+// wave (a diagonal needs its neighbour of the SAME wave) - so the unit of parallelism is the trace-point segment (~100 x ~100
+// bases), one LANE per segment, tens of thousands of segments per contig.  Bound by instruction issue and the latency of the
+// lane-private wave arrays; bytes moved are a few hundred per segment.
+//
+// Kernels:
+//   k_cns_realign   one lane per segment: forward waves, the reference's trace-back with re-sliding, the indel list
+//   k_cns_columns   one thread per alignment: column offsets of its segments, chop_end's start / offset / end
+//   k_cns_vote      one lane per segment: replays the columns, votes into the per-position counters (global atomics)
+//   k_cns_call      one thread per contig position: the reference's base calls (0-2 characters), block sums
+//   k_cns_scan      exclusive scan of the block sums;  k_cns_emit  writes the characters at their final offsets
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hinge {
+
+struct CnsSeqs {                   // one DAZZ_DB with bases: 2 bits per base, four per byte, first base in the top bits (DB.c Compress_Read)
+    const unsigned char* bps;
+    const long long* boff;         // per (trimmed) read: first byte
+    const int* rlen;
+};
+struct CnsAln {
+    int a, b, comp;
+    int ab, ae, bb, be;            // as in the .las record: B in the complemented frame when comp
+    int blen;
+    int seg0, nseg;                // its segments
+    int dcap;                      // waves its segments may need: the largest recorded `diffs` of its trace (what the reference sizes its arrays from, LAInterface.cpp:3444-3456)
+};
+struct CnsSeg {
+    int aln;
+    int a0, m;                     // A bases [a0, a0 + m)
+    int b0, n;                     // B bases [b0, b0 + n) (complemented frame when comp)
+    unsigned out_off;              // first slot of its indel list
+    int out_cap;
+};
+constexpr int CNS_ST_WAVES = 1;    // a segment needed more waves than its alignment's recorded diffs allow (the reference overruns its arrays there)
+constexpr int CNS_ST_INDELS = 2;   // ... or more indel slots
+constexpr int CNS_ST_RANGE = 4;    // a coordinate outside its sequence
+
+__device__ __forceinline__ int cns_base(const unsigned char* __restrict__ bps, long long boff, int p) {
+    const unsigned b = bps[boff + (p >> 2)];
+    return (int)((b >> (6 - 2 * (p & 3))) & 3u);
+}
+struct CnsPair {                   // the two sequences of one alignment, addressed as the reference's aseq / bseq
+    const unsigned char* abps; long long aoff;
+    const unsigned char* bbps; long long boff;
+    int comp, blen;
+    __device__ __forceinline__ int A(int x) const { return cns_base(abps, aoff, x); }
+    __device__ __forceinline__ int B(int x) const { return comp ? 3 - cns_base(bbps, boff, blen - 1 - x) : cns_base(bbps, boff, x); }
+};
+
+// ---- wave storage of one lane ---------------------------------------------------------------------------------------------
+// Row D (= -2, -1, 0, 1, ...) holds the diagonals k in [lo0 - ext(D) - 1, hi0 + ext(D) + 1], ext(D) = max(D, 0) / 2, lo0 = min(0, del),
+// hi0 = max(0, del): exactly what iter_np's wave D touches, sentinels included (the reference's rows are tspace + nmax + 3 wide
+// and never read outside this range either - checked with a probe in oracle/consensus_oracle.cpp).  A cell is furthest << 8 | move.
+struct CnsWaves {
+    int* W; int w0, lo0, cap_cells;
+    __device__ __forceinline__ int row_off(int D) const { const int d = D > 0 ? D : 0; return (D + 2) * w0 + 2 * (((d - 1) * (d - 1)) >> 2); }
+    __device__ __forceinline__ int klo(int D) const { return lo0 - (D > 0 ? (D >> 1) : 0) - 1; }
+    __device__ __forceinline__ int* row(int D) const { return W + row_off(D) - klo(D); }   // row(D)[k]
+    __device__ __forceinline__ int v(int D, int k) const { return row(D)[k] >> 8; }
+    __device__ __forceinline__ int h(int D, int k) const { return (int)(signed char)(row(D)[k] & 0xff); }
+    __device__ __forceinline__ void set_v(int D, int k, int val) { int* p = row(D) + k; *p = (int)((unsigned)val << 8) | (*p & 0xff); }
+    __device__ __forceinline__ void set_h(int D, int k, int e) { int* p = row(D) + k; *p = (*p & ~0xff) | (e & 0xff); }
+};
+__host__ __device__ inline long long cns_cells(int dcap, int del_abs) {   // cells of rows -2 .. dcap
+    const long long d = dcap + 1;
+    return (d + 2) * (long long)(del_abs + 3) + 2 * (((d - 1) * (d - 1)) >> 2);
+}
+
+// iter_np (LAInterface.cpp:3152-3404) for the segment A[a0, a0 + M) x B[b0, b0 + N).  Writes the indel list (1-based absolute
+// positions: +B position for a gap in B, -(A position) for a gap in A) to out[0..), returns its length, or -1 / -2 on overflow.
+__device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N, CnsWaves w, int dcap, int* __restrict__ out, int out_cap, int& n_ins) {
+    const int del = M - N;
+    int low = del >= 0 ? 0 : del, hgh = del >= 0 ? del : 0;
+    w.lo0 = low; w.w0 = (del >= 0 ? del : -del) + 3;
+    {
+        int* r2 = w.row(-2); int* r1 = w.row(-1);
+        for (int k = low - 1; k <= hgh + 1; k++) { r2[k] = -512; r1[k] = -512; }
+        r1[0] = -256;
+    }
+    low += 1; hgh -= 1;
+    int D;
+    for (D = 0;; D++) {
+        if (D > dcap) return -1;
+        if ((D & 1) == 0) { low -= 1; hgh += 1; }
+        int* __restrict__ F0 = w.row(D);
+        const int* __restrict__ F1 = w.row(D - 1);
+        const int* __restrict__ F2 = w.row(D - 2);
+        F0[hgh + 1] = -512; F0[low - 1] = -512;
+        auto move = [&](int k, int am, int ap, int mdir, int pdir) {
+            const int ac = (F1[k] >> 8) + 1;
+            int j, hc;
+            if (ac < am) { if (ap < am) { hc = mdir; j = am; } else { hc = pdir; j = ap; } }
+            else { if (ap < ac) { hc = 0; j = ac; } else { hc = pdir; j = ap; } }
+            const int i = M - k;
+            const int lim = N < i ? N : i;
+            // (j >= 0 always: every diagonal of wave D is reachable from (0, 0) - the oracle counts the exceptions: none)
+            while (j < lim && j >= 0 && S.B(b0 + j) == S.A(a0 + j + k)) j++;
+            F0[k] = (int)((unsigned)j << 8) | (hc & 0xff);
+            return j;
+        };
+        int j = -2;
+        for (int k = hgh; k > del; k--) j = move(k, F2[k - 1] >> 8, j + 1, -1, 4);
+        j = -2;
+        for (int k = low; k < del; k++) j = move(k, j, (F2[k + 1] >> 8) + 1, 2, 1);
+        j = move(del, j, (F0[del + 1] >> 8) + 1, 2, 4);
+        if (j >= N) break;
+    }
+    // trace-back with re-sliding (LAInterface.cpp:3285-3352)
+    {
+        w.set_h(0, 0, 3);
+        int c = N, k = del;
+        int e = w.h(D, k);
+        w.set_h(D, k, 3);
+        while (e != 3) {
+            int h = k + e;
+            if (e > 1) h -= 3;
+            else if (e == 0) D -= 1;
+            else D -= 2;
+            if (h < k) {
+                int m = k < 0 ? -k : 0;
+                const int vh = w.v(D, h);
+                if (vh <= c) c = vh - 1;
+                while (c >= m && S.A(a0 + c + k) == S.B(b0 + c)) c -= 1;
+                if (e < 1) {
+                    if (c <= w.v(D + 2, k + 1)) { e = 4; h = k + 1; D = D + 2; }
+                    else if (c == w.v(D + 1, k)) { e = 0; h = k; D = D + 1; }
+                    else w.set_v(D, h, c + 1);
+                } else {
+                    m = (k == del) ? D : D - 2;
+                    if (c <= w.v(m, k + 1)) { e = (k == del) ? 4 : 1; h = k + 1; D = m; }
+                    else if (c == w.v(D - 1, k)) { e = 0; h = k; D = D - 1; }
+                    else w.set_v(D, h, c + 1);
+                }
+            }
+            const int m2 = w.h(D, h);
+            w.set_h(D, h, e);
+            e = m2;
+            k = h;
+        }
+    }
+    // forward along the reversed chain: one entry per indel (LAInterface.cpp:3354-3371)
+    int cnt = 0;
+    n_ins = 0;
+    {
+        const int ap = -a0 - 1, bp = b0 + 1;
+        int k = 0, DD = 0;
+        int e = w.h(DD, k);
+        while (e != 3) {
+            int h = k - e;
+            const int c = w.v(DD, k);
+            if (e > 1) h += 3;
+            else if (e == 0) DD += 1;
+            else DD += 2;
+            if (h != k) {
+                if (cnt >= out_cap) return -2;
+                if (h > k) out[cnt++] = bp + c;
+                else { out[cnt++] = ap - (c + k); n_ins++; }
+            }
+            k = h;
+            e = w.h(DD, h);
+        }
+    }
+    return cnt;
+}
+
+constexpr int CNS_BLOCK = 256;
+
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_realign(CnsSeqs SA, CnsSeqs SB, const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, int n_seg,
+                                                           int* __restrict__ scratch, long long cells_per_lane, int* __restrict__ indels,
+                                                           int* __restrict__ n_indel, int* __restrict__ n_ins_out, int* __restrict__ status) {
+    const long long lane_g = (long long)blockIdx.x * CNS_BLOCK + threadIdx.x;
+    const long long n_lanes = (long long)gridDim.x * CNS_BLOCK;
+    CnsWaves w;
+    w.W = scratch + lane_g * cells_per_lane; w.cap_cells = (int)cells_per_lane; w.w0 = 0; w.lo0 = 0;
+    for (long long s = lane_g; s < n_seg; s += n_lanes) {
+        const CnsSeg g = segs[s];
+        const CnsAln al = alns[g.aln];
+        CnsPair S;
+        S.abps = SA.bps; S.aoff = SA.boff[al.a]; S.bbps = SB.bps; S.boff = SB.boff[al.b]; S.comp = al.comp; S.blen = al.blen;
+        const int del_abs = g.m >= g.n ? g.m - g.n : g.n - g.m;
+        int dcap = al.dcap;
+        if (cns_cells(dcap, del_abs) > cells_per_lane) { atomicOr(status, CNS_ST_WAVES); n_indel[s] = 0; n_ins_out[s] = 0; continue; }
+        int nins = 0;
+        const int cnt = cns_iter_np(S, g.a0, g.m, g.b0, g.n, w, dcap, indels + g.out_off, g.out_cap, nins);
+        if (cnt < 0) { atomicOr(status, cnt == -1 ? CNS_ST_WAVES : CNS_ST_INDELS); n_indel[s] = 0; n_ins_out[s] = 0; continue; }
+        n_indel[s] = cnt;
+        n_ins_out[s] = nins;
+    }
+}
+
+// The columns of a segment, as getAlignmentTags lays them out (LAInterface.cpp:3822-3866): runs of aligned pairs separated by
+// single gap columns.  f(kind, i, j, cnt): kind 0 = cnt aligned pairs starting at A position i, B position j (1-based);
+// 1 = one column with a gap in A (B base j);  2 = one column with a gap in B (A base i).  f returns false to stop.
+template <typename F>
+__device__ __forceinline__ void cns_walk(const CnsSeg& g, const int* __restrict__ ind, int cnt, F f) {
+    int i = g.a0 + 1, j = g.b0 + 1;
+    for (int t = 0; t < cnt; t++) {
+        const int p = ind[t];
+        if (p < 0) {
+            const int run = -p - i;
+            if (run > 0) { if (!f(0, i, j, run)) return; i += run; j += run; }
+            if (!f(1, i, j, 1)) return;
+            j += 1;
+        } else {
+            const int run = p - j;
+            if (run > 0) { if (!f(0, i, j, run)) return; i += run; j += run; }
+            if (!f(2, i, j, 1)) return;
+            i += 1;
+        }
+    }
+    const int run = g.a0 + g.m + 1 - i;
+    if (run > 0) f(0, i, j, run);
+}
+
+struct CnsCols { int start, end, offset; };   // columns [start, end) of the alignment vote; offset = chop_end's return value
+
+// one thread per alignment (an alignment has ~100 segments; the walk to column `chop` touches two or three of them)
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_columns(const CnsAln* __restrict__ alns, int n_aln, const CnsSeg* __restrict__ segs, const int* __restrict__ indels,
+                                                           const int* __restrict__ n_indel, const int* __restrict__ n_ins, int* __restrict__ col_base,
+                                                           CnsCols* __restrict__ cols, int chop) {
+    const int x = blockIdx.x * CNS_BLOCK + threadIdx.x;
+    if (x >= n_aln) return;
+    const CnsAln al = alns[x];
+    int len = 0;
+    for (int s = al.seg0; s < al.seg0 + al.nseg; s++) { col_base[s] = len; len += segs[s].m + n_ins[s]; }
+    CnsCols c;
+    c.start = 0; c.end = len; c.offset = 0;
+    if (len >= chop * 2 + 10) {   // chop_end (consensus.cpp:27-45): the first non-gap column of A at or behind column `chop`
+        int col = 0, abases = 0, start = -1;
+        for (int s = al.seg0; s < al.seg0 + al.nseg && start < 0; s++) {
+            const CnsSeg g = segs[s];
+            cns_walk(g, indels + g.out_off, n_indel[s], [&](int kind, int, int, int cnt) {
+                if (kind == 1) { col += 1; return true; }                 // a gap in A is never the start
+                if (col + cnt > chop) {                                     // the run reaches column `chop` or lies behind it
+                    const int skip = chop > col ? chop - col : 0;
+                    start = col + skip; abases += skip;
+                    return false;
+                }
+                col += cnt; abases += cnt;
+                return true;
+            });
+        }
+        c.start = start; c.offset = abases; c.end = len - chop;
+    }
+    cols[x] = c;
+}
+
+// counters: nine int32 planes over the concatenated contig positions: A C G T '-' of the aligned columns, A C G T of the
+// inserted ones (consensus.cpp:163-212: contig_base_scores, insertion_base_scores; cov_depth and insertion_score are their sums)
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_vote(CnsSeqs SB, const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, int n_seg,
+                                                        const int* __restrict__ indels, const int* __restrict__ n_indel, const int* __restrict__ col_base,
+                                                        const CnsCols* __restrict__ cols, const long long* __restrict__ cbase, int* __restrict__ counts,
+                                                        long long plane) {
+    const int s = blockIdx.x * CNS_BLOCK + threadIdx.x;
+    if (s >= n_seg) return;
+    const CnsSeg g = segs[s];
+    const CnsAln al = alns[g.aln];
+    const CnsCols c = cols[g.aln];
+    const unsigned char* __restrict__ bbps = SB.bps;
+    const long long boff = SB.boff[al.b];
+    auto Bb = [&](int j1) { return al.comp ? 3 - cns_base(bbps, boff, al.blen - j1) : cns_base(bbps, boff, j1 - 1); };   // 1-based position
+    int* __restrict__ cnt0 = counts + cbase[al.a];
+    int col = col_base[s];
+    if (col >= c.end || col + g.m + 2 * g.out_cap < c.start) return;   // (cheap reject; the exact test is per column)
+    cns_walk(g, indels + g.out_off, n_indel[s], [&](int kind, int i, int j, int cnt) {
+        if (kind == 0) {
+            int lo = c.start > col ? c.start - col : 0;
+            int hi = c.end - col < cnt ? c.end - col : cnt;
+            for (int t = lo; t < hi; t++) atomicAdd(cnt0 + (long long)Bb(j + t) * plane + (i - 1 + t), 1);
+            col += cnt;
+        } else {
+            if (col >= c.start && col < c.end) {
+                if (kind == 1) atomicAdd(cnt0 + (long long)(5 + Bb(j)) * plane + (i - 1), 1);
+                else atomicAdd(cnt0 + 4ll * plane + (i - 1), 1);
+            }
+            col += 1;
+        }
+        return col < c.end;
+    });
+}
+
+struct CnsStats { long long sum_cov; int good, insertions, deletions, low_cov, clen, pad; };
+
+// one thread per contig position (consensus.cpp:228-270): packed = count | c0 << 8 | c1 << 16; per-block character counts
+constexpr int CNS_CALL_ITEMS = 8;   // positions per thread in k_cns_call / k_cns_emit (a block covers CNS_BLOCK * CNS_CALL_ITEMS)
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_call(CnsSeqs SA, const int* __restrict__ counts, long long plane, long long n_pos,
+                                                        const int* __restrict__ contig_of_block, const long long* __restrict__ cbase,
+                                                        unsigned* __restrict__ packed, unsigned* __restrict__ block_sum, CnsStats* __restrict__ stats) {
+    // blocks never straddle contigs: block b works on contig contig_of_block[b], positions from its own first position on
+    __shared__ int red[8];
+    __shared__ long long redl;
+    const int cg = contig_of_block[blockIdx.x];
+    // first block of this contig
+    int b0 = blockIdx.x;
+    while (b0 > 0 && contig_of_block[b0 - 1] == cg) b0--;   // (a few hundred steps at most per block; contigs are long)
+    const long long base = cbase[cg], alen = cbase[cg + 1] - base;
+    const long long first = (long long)(blockIdx.x - b0) * CNS_BLOCK * CNS_CALL_ITEMS;
+    const unsigned char* __restrict__ abps = SA.bps;
+    const long long aoff = SA.boff[cg];
+    int chars = 0, good = 0, ins = 0, dels = 0, low = 0;
+    long long sum = 0;
+    for (int u = 0; u < CNS_CALL_ITEMS; u++) {
+        const long long j = first + (long long)u * CNS_BLOCK + threadIdx.x;
+        if (j >= alen) continue;
+        const long long gp = base + j;
+        int sc[5], ib[4];
+#pragma unroll
+        for (int b = 0; b < 5; b++) sc[b] = counts[(long long)b * plane + gp];
+#pragma unroll
+        for (int b = 0; b < 4; b++) ib[b] = counts[(long long)(5 + b) * plane + gp];
+        const int depth = sc[0] + sc[1] + sc[2] + sc[3] + sc[4];
+        const int iscore = ib[0] + ib[1] + ib[2] + ib[3];
+        sum += depth;
+        unsigned pk;
+        if (depth < 3) {
+            low++;
+            pk = 1u | ((unsigned)("acgt"[cns_base(abps, aoff, (int)j)]) << 8);
+        } else {
+            int n = 0; unsigned c0 = 0, c1 = 0;
+            if (iscore > depth / 2) {
+                int mb = 0;
+                for (int b = 1; b < 4; b++) if (ib[b] > ib[mb]) mb = b;
+                c0 = (unsigned)"ACGT"[mb]; n = 1; ins++;
+            }
+            int mb = 0;
+            for (int b = 1; b < 5; b++) if (sc[b] > sc[mb]) mb = b;
+            if (mb < 4) { if (n == 0) c0 = (unsigned)"ACGT"[mb]; else c1 = (unsigned)"ACGT"[mb]; n++; good++; }
+            else dels++;
+            pk = (unsigned)n | (c0 << 8) | (c1 << 16);
+        }
+        packed[gp] = pk;
+        chars += (int)(pk & 0xff);
+    }
+    // block reductions (six small sums): wave shuffles, then the four waves through LDS
+    auto wsum = [&](int v) { for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d); return v; };
+    auto wsuml = [&](long long v) { for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d); return v; };
+    if (threadIdx.x < 8) red[threadIdx.x] = 0;
+    if (threadIdx.x == 0) redl = 0;
+    __syncthreads();
+    const int v0 = wsum(chars), v1 = wsum(good), v2 = wsum(ins), v3 = wsum(dels), v4 = wsum(low);
+    const long long v5 = wsuml(sum);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&red[0], v0); atomicAdd(&red[1], v1); atomicAdd(&red[2], v2); atomicAdd(&red[3], v3); atomicAdd(&red[4], v4);
+        atomicAdd((unsigned long long*)&redl, (unsigned long long)v5);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_sum[blockIdx.x] = (unsigned)red[0];
+        CnsStats* st = stats + cg;
+        atomicAdd(&st->good, red[1]); atomicAdd(&st->insertions, red[2]); atomicAdd(&st->deletions, red[3]); atomicAdd(&st->low_cov, red[4]);
+        atomicAdd(&st->clen, red[1] + red[2]);
+        atomicAdd((unsigned long long*)&st->sum_cov, (unsigned long long)redl);
+    }
+}
+
+// exclusive scan of n values in place, one workgroup of 1024 threads; total to *total
+__global__ __launch_bounds__(1024) void k_cns_scan(unsigned* __restrict__ v, int n, unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, n);
+    unsigned long long s = 0;
+    for (int k = lo; k < hi; k++) s += v[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        unsigned long long t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned long long run = part[threadIdx.x] - s;
+    for (int k = lo; k < hi; k++) { const unsigned x = v[k]; v[k] = (unsigned)run; run += x; }
+    if (threadIdx.x == 1023) *total = part[1023];
+}
+
+// characters to their final places: block b's output starts at block_off[b] (exclusive scan of the block sums)
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_emit(const unsigned* __restrict__ packed, const int* __restrict__ contig_of_block, const long long* __restrict__ cbase,
+                                                        const unsigned* __restrict__ block_off, char* __restrict__ out) {
+    __shared__ unsigned wsum_[4];
+    const int cg = contig_of_block[blockIdx.x];
+    int b0 = blockIdx.x;
+    while (b0 > 0 && contig_of_block[b0 - 1] == cg) b0--;
+    const long long base = cbase[cg], alen = cbase[cg + 1] - base;
+    const long long first = (long long)(blockIdx.x - b0) * CNS_BLOCK * CNS_CALL_ITEMS;
+    unsigned run = block_off[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int u = 0; u < CNS_CALL_ITEMS; u++) {
+        const long long j = first + (long long)u * CNS_BLOCK + threadIdx.x;
+        const unsigned pk = j < alen ? packed[base + j] : 0u;
+        const unsigned n = pk & 0xff;
+        unsigned inc = n;                                   // inclusive scan inside the wavefront
+        for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum_[wv] = inc;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+        for (int q = 0; q < 4; q++) { if (q < wv) before += wsum_[q]; all += wsum_[q]; }
+        const unsigned at = run + before + inc - n;
+        if (n >= 1) out[at] = (char)((pk >> 8) & 0xff);
+        if (n >= 2) out[at + 1] = (char)((pk >> 16) & 0xff);
+        run += all;
+        __syncthreads();
+    }
+}
+
+}  // namespace hinge

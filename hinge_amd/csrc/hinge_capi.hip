@@ -13,6 +13,7 @@
 #include "hinge_call_kernel.h"
 #include "align_kernels.h"
 #include "select_kernel.h"
+#include "consensus_kernels.h"
 
 using namespace hinge;
 
@@ -117,13 +118,15 @@ struct hinge_ctx {
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
     std::vector<int> prof_kid;
+
+    struct CnsState* cns = nullptr;     // `hinge consensus` (consensus_capi.inc)
 };
 
 enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY,
-                KID_PILEUP_FACTS, KID_MATCHING_POSITION, KID_SELECT_EDGES, KID_SPEC_PREDICT, KID_MASK_FINAL, KID_COUNT };
+                KID_PILEUP_FACTS, KID_MATCHING_POSITION, KID_SELECT_EDGES, KID_SPEC_PREDICT, KID_MASK_FINAL, KID_CNS_REALIGN, KID_CNS_COLUMNS, KID_CNS_VOTE, KID_CNS_CALL, KID_COUNT };
 static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_hist", "k_mask_annotate", "k_mask_annotate_fallback", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
                                                      "k_coverage_bins", "k_trim_classify", "k_pileup_facts", "k_matching_position", "k_select_edges", "k_spec_predict",
-                                                     "k_mask_annotate_final"};
+                                                     "k_mask_annotate_final", "k_cns_realign", "k_cns_columns", "k_cns_vote", "k_cns_call"};
 
 struct ProfScope {
     hinge_ctx* c;
@@ -275,9 +278,11 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     return HINGE_OK;
 }
 
+static void cns_release(hinge_ctx* ctx);
 void hinge_ctx_destroy(hinge_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    cns_release(ctx);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
@@ -1592,6 +1597,7 @@ int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms) {
 }  // extern "C"
 
 #include "align_capi.inc"
+#include "consensus_capi.inc"
 
 #ifdef HINGE_K2_TRACE
 // Trace builds only (tools/k2_trace.py): a device buffer of 5 * n_items time stamps for k_mask_annotate_q20.

@@ -388,8 +388,10 @@ template <typename T> inline T rd(const uint8_t* p) { T v; memcpy(&v, p, sizeof(
 struct ReadDB {
     int ureads = 0, treads = 0, cutoff = 0, all = 1;
     std::vector<int32_t> rlen;        // trimmed order = the ids the .las uses
+    std::vector<int64_t> boff;        // trimmed order: first byte of the read's bases in .<root>.bps (`hinge consensus`)
     std::vector<uint8_t> keep;        // per untrimmed read
     std::string dir, root;
+    int nfiles = 0;
 
     static std::string dirname_of(const std::string& p) { size_t s = p.rfind('/'); return s == std::string::npos ? "." : p.substr(0, s); }
     static std::string rootname_of(const std::string& p) {
@@ -404,7 +406,7 @@ struct ReadDB {
         root = rootname_of(name);
         FILE* stub = fopen((dir + "/" + root + ".db").c_str(), "r");
         if (!stub) return -1;
-        int nfiles = 0;
+        nfiles = 0;
         bool ok = fscanf(stub, "files = %9d\n", &nfiles) == 1;
         for (int i = 0; ok && i < nfiles; i++) {
             int last;
@@ -428,11 +430,13 @@ struct ReadDB {
         const int allflag = all ? 0 : 0x800;                 // DB_BEST
         keep.assign(ureads, 1);
         rlen.clear();
+        boff.clear();
         for (int i = 0; i < ureads; i++) {
             const uint8_t* r = idx.p + 112 + (size_t)i * 40;
             const int len = rd<int32_t>(r + 4), flags = rd<int32_t>(r + 32);
             if (trim && !((flags & 0x800) >= allflag && len >= cutoff)) { keep[i] = 0; continue; }
             rlen.push_back(len);
+            boff.push_back(rd<int64_t>(r + 16));
         }
         return 0;
     }

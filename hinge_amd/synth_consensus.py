@@ -47,8 +47,8 @@ class ConsensusData:
     contigs: List[np.ndarray]          # uint8 0..3
     reads: List[np.ndarray]            # uint8 0..3, as stored in the read DB
     rec: np.ndarray                    # formats.LAS_REC_DTYPE, sorted by aread
-    trace: np.ndarray                  # uint8 pairs (diffs, b advance), concatenated
-    trace_off: np.ndarray              # int64 [n + 1]
+    trace: np.ndarray                  # the trace bytes of the file: (diffs, b advance) pairs, uint8 or little-endian uint16
+    trace_off: np.ndarray              # int64 [n + 1], in bytes
 
     @property
     def n_alignments(self) -> int:
@@ -101,6 +101,8 @@ def generate(spec: ConsensusSpec) -> ConsensusData:
     contigs, reads = [], []
     recs, traces = [], []
     n_total = spec.n_contigs + spec.empty_contigs
+    tdt = np.uint8 if spec.tspace <= 125 else np.dtype("<u2")      # trace values: one byte up to tspace 125, two beyond (align.h:64-69)
+    tmax = 255 if spec.tspace <= 125 else 65535
     for c in range(n_total):
         L = int(rng.integers(spec.contig_len[0], spec.contig_len[1] + 1))
         draft = rng.integers(0, 4, size=L, dtype=np.uint8)
@@ -147,9 +149,9 @@ def generate(spec: ConsensusSpec) -> ConsensusData:
             whole = np.concatenate([rng.integers(0, 4, size=fl, dtype=np.uint8), B, rng.integers(0, 4, size=fr, dtype=np.uint8)])
             comp = int(rng.integers(0, 2))
             reads.append(revcomp(whole) if comp else whole)
-            assert all(0 <= d <= 255 and 0 <= b <= 255 for d, b in pairs)
+            assert all(0 <= d <= tmax and 0 <= b <= tmax for d, b in pairs)
             recs.append((2 * len(pairs), sum(d for d, _ in pairs), ab, fl, ae, fl + len(B), comp, c, len(reads) - 1))
-            traces.append(np.asarray(pairs, dtype=np.uint8).reshape(-1))
+            traces.append(np.asarray(pairs, dtype=tdt).reshape(-1))
         for _ in range(spec.duplicate_b):          # a read with two alignments to the same contig
             if len(reads) == first_read_of_contig:
                 break
@@ -171,7 +173,7 @@ def generate(spec: ConsensusSpec) -> ConsensusData:
     for o, i in enumerate(order):
         r = recs[i]
         rec[o] = (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8])
-    tr = [traces[i] for i in order]
+    tr = [traces[i].view(np.uint8) for i in order]                 # as the bytes of the file
     toff = np.concatenate([[0], np.cumsum([len(t) for t in tr])]).astype(np.int64)
     return ConsensusData(spec, contigs, reads, rec, np.concatenate(tr) if tr else np.zeros(0, np.uint8), toff)
 
@@ -192,5 +194,7 @@ CONFIGS = {
     "cns_small": ConsensusSpec(n_contigs=3, contig_len=(12_000, 30_000), coverage=25.0, seed=12, empty_contigs=1),
     "cns_noisy": ConsensusSpec(n_contigs=2, contig_len=(8_000, 12_000), coverage=30.0, p_sub=0.05, p_ins=0.09, p_del=0.05, seed=13),
     "cns_clean": ConsensusSpec(n_contigs=2, contig_len=(6_000, 9_000), coverage=8.0, p_sub=0.0, p_ins=0.0, p_del=0.0, draft_errors_per_kb=3.0, p_carry=1.0, seed=14),
+    "cns_twobyte": ConsensusSpec(n_contigs=2, contig_len=(7_000, 10_000), coverage=14.0, read_len=(900, 3_000), tspace=200, seed=16),
+    "cns_midsize": ConsensusSpec(n_contigs=3, contig_len=(60_000, 90_000), coverage=22.0, read_len=(2_000, 9_000), p_sub=0.04, p_ins=0.07, p_del=0.04, seed=17, low_cov_windows=3),
     "cns_bench": ConsensusSpec(n_contigs=4, contig_len=(900_000, 1_300_000), coverage=30.0, read_len=(3_000, 11_000), seed=15, low_cov_windows=3),
 }

@@ -282,6 +282,42 @@ int hinge_filter_hinges_async(hinge_ctx* ctx, const hinge_filter_params* p);
 int hinge_filter_hinges_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p);
 int hinge_filter_check(hinge_ctx* ctx);
 
+/* ---- hinge consensus (consensus/consensus.cpp:77-288) --------------------------------------------------
+ * The per-contig pile-up vote over base-level realignments.  Replaces, for the alignments the caller selected:
+ *   LAInterface::recoverAlignment -> computeTracePTS -> iter_np   lib/LAInterface.cpp:4125-4244, :3410-3506, :3152-3404
+ *     (Myers' O(np) waves between successive trace points, one GPU lane per ~100 x ~100-base segment, the reference's
+ *     trace-back with re-sliding: the SAME indel list, entry for entry)
+ *   LAInterface::getAlignmentTags + chop_end(100)                  lib/LAInterface.cpp:3709-3905, consensus.cpp:27-45
+ *   the column vote and the base calls                             consensus.cpp:163-283
+ * What stays with the caller (hinge_amd/host/consensus_main.cpp): reading the two DBs and the .las, the per-contig
+ * std::sort(compare_overlap_aln) (hinge_sort_order_desc gives libstdc++'s order) and remove_multialign's count
+ * (consensus.cpp:126-150), the FASTA / stdout text.                                                                         */
+typedef struct hinge_cns_alignment {
+    int32_t aread, bread;                 /* contig in the draft DB, read in the read DB (trimmed ids, as in the .las)          */
+    int32_t comp;                         /* flags & 1                                                                          */
+    int32_t abpos, aepos, bbpos, bepos;   /* as in the .las record: B in the complemented frame when comp (NOT flipped)         */
+    int32_t tlen;                         /* trace values of this alignment: (diffs, B advance) pairs, 16 bit each              */
+    int64_t trace_off;                    /* its first value in the trace array                                                  */
+} hinge_cns_alignment;
+typedef struct hinge_cns_stats {          /* what consensus.cpp:272-278 prints per contig                                        */
+    int64_t sum_coverage;
+    int32_t contig_length, good_bases, insertions, deletions, low_coverage_bases, consensus_length;
+} hinge_cns_stats;
+/* which: 0 = draft DB (the A reads), 1 = read DB.  rlen[n], boff[n] (byte offset of read i in bps), bps = the .bps file's bytes
+ * (2 bits per base, first base in a byte's top bits: DB.c Compress_Read).  Host buffers; copied.                               */
+int hinge_consensus_set_db(hinge_ctx* ctx, int32_t which, int32_t n, const int32_t* rlen, const int64_t* boff, const uint8_t* bps, int64_t bps_bytes);
+/* Realign, vote and call: every alignment given takes part (in any order).  trace: 16-bit values (byte traces widened, as
+ * Decompress_TraceTo16 does).  HINGE_E_RANGE when a segment needs more edit operations than the largest `diffs` its
+ * alignment's trace records - where the reference overruns the arrays it sized from that number (LAInterface.cpp:3444-3466). */
+int hinge_consensus_run(hinge_ctx* ctx, int64_t n_aln, const hinge_cns_alignment* alns, const uint16_t* trace, int64_t n_trace, int32_t tspace);
+/* The consensus string of one contig (no header, no newline; lower case = coverage below 3, consensus.cpp:232-238).
+ * out may be NULL to ask for *len only.                                                                                        */
+int hinge_consensus_get_contig(hinge_ctx* ctx, int32_t contig, char* out, int64_t cap, int64_t* len, hinge_cns_stats* stats);
+/* chop_end's return value per alignment, in the order given to run() (consensus.cpp:176-177 prints them).                     */
+int hinge_consensus_get_offsets(hinge_ctx* ctx, int32_t* offsets);
+/* Tests: the recovered indel list of one alignment (LAlignment::trace after recoverAlignment).                                */
+int hinge_consensus_get_indels(hinge_ctx* ctx, int64_t aln, int32_t* out, int64_t cap, int64_t* n);
+
 /* Per-kernel timing with HIP events recorded around every launch on the context's stream.
  * enable(max_launches > 0) starts a fresh recording; report() synchronises and returns total ms and
  * launch count per kernel id in [0, hinge_profile_kernels()).  select() restricts the events to the

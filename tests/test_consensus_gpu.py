@@ -1,0 +1,69 @@
+"""`hinge consensus` on the GPU (hinge_amd/bin/consensus over hinge_consensus_*) against the reference's OWN program
+(oracle/_ref/consensus, which travels to the GPU box) and its golden digests: FASTA and stdout byte for byte; the recovered
+indel lists against the oracle's, alignment by alignment."""
+import ctypes
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import consensus_common as cc
+
+pytestmark = pytest.mark.gpu
+NAMES = sorted(cc.GOLDEN)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_consensus_matches_the_reference_program(tmp_path, name):
+    wd = str(tmp_path)
+    cc.make(name, wd)
+    fasta, out = cc.run_product(wd)
+    g = cc.GOLDEN[name]
+    ref = cc.run_reference(wd)
+    if ref is not None:
+        assert ref[0] == fasta, "FASTA differs from the reference program's"
+        assert ref[1] == out, "stdout differs from the reference program's"
+    assert cc.sha(fasta) == g["fasta_sha256"]
+    assert cc.sha(out) == g["stdout_sha256"]
+
+
+def test_indel_lists_match_the_oracle(oracle_lib, tmp_path):
+    """recoverAlignment's result per alignment (LAInterface.cpp:4125-4244): the same entries in the same order."""
+    from hinge_amd import capi, formats
+    wd = str(tmp_path)
+    d = cc.make("cns_noisy", wd)
+    cc.run_oracle(oracle_lib, wd, dump="ora.dump")
+    raw = open(os.path.join(wd, "ora.dump"), "rb").read()
+    want = {}
+    p = 0
+    while p < len(raw):
+        contig, pos, off, n = struct.unpack_from("<4i", raw, p)
+        p += 16
+        want[pos] = (off, np.frombuffer(raw, dtype=np.int32, count=n, offset=p).copy())
+        p += 4 * n
+    ctx = capi.Context(0)
+    cns = capi.Consensus(ctx, os.path.join(wd, "draft"), os.path.join(wd, "reads"))
+    las = formats.read_las(os.path.join(wd, "draft.reads.las"))
+    picks = sorted(want)
+    cns.run(las, picks)
+    offs = cns.offsets()
+    for k, pos in enumerate(picks):
+        got = cns.indels(k)
+        assert np.array_equal(got, want[pos][1]), "alignment %d: indel list differs" % pos
+        assert offs[k] == want[pos][0]
+
+
+def test_inconsistent_diffs_are_refused(tmp_path):
+    """A trace whose recorded diffs are too small for its bases: the reference overruns the arrays it sized from them
+    (LAInterface.cpp:3444-3466); the library returns HINGE_E_RANGE."""
+    from hinge_amd import capi, formats
+    wd = str(tmp_path)
+    cc.make("cns_noisy", wd)
+    ctx = capi.Context(0)
+    cns = capi.Consensus(ctx, os.path.join(wd, "draft"), os.path.join(wd, "reads"))
+    las = formats.read_las(os.path.join(wd, "draft.reads.las"))
+    las.trace[0::2] = 0          # every segment claims to be error-free
+    with pytest.raises(capi.HingeError) as e:
+        cns.run(las, list(range(len(las.rec))))
+    assert e.value.code == capi.HINGE_E_RANGE
