@@ -59,41 +59,37 @@ def revcomp(b: np.ndarray) -> np.ndarray:
     return (3 - b[::-1]).astype(np.uint8)
 
 
-def _make_read(rng, draft: np.ndarray, planted: dict, ab: int, ae: int, spec: ConsensusSpec):
-    """One read over draft[ab:ae): returns (aligned B bases, per-segment (diffs, b advance) list)."""
+def _make_read(rng, draft: np.ndarray, planted, ab: int, ae: int, spec: ConsensusSpec):
+    """One read over draft[ab:ae): returns (aligned B bases, per-segment (diffs, b advance) list).  planted = (kind[L], base[L]):
+    kind 0 none, 1 the truth has `base` in front of this draft base, 2 the draft base is one too many, 3 it should be `base`.
+    Vectorised over the stretch: per draft position up to three bases come out (planted insertion, noise insertion, the
+    position's own base unless deleted), in that order."""
     ts = spec.tspace
-    out = []
-    pairs = []
-    ops = 0
-    seg_b0 = 0
-    p = ab
-    while p < ae:
-        # planted difference between draft and truth at this draft position
-        kind = planted.get(p)
-        carried = kind is not None and rng.random() < spec.p_carry
-        if carried and kind[0] == "ins":          # the truth has a base the draft lacks, in front of draft[p]
-            out.append(kind[1]); ops += 1
-        r = rng.random()
-        if r < spec.p_ins:                        # noise insertion in front of draft[p]
-            out.append(int(rng.integers(0, 4))); ops += 1
-        if carried and kind[0] == "del":          # the draft has a base too much
-            ops += 1
-        elif carried and kind[0] == "sub":
-            out.append(kind[1]); ops += 1
-        else:
-            r = rng.random()
-            if r < spec.p_del:
-                ops += 1
-            elif r < spec.p_del + spec.p_sub:
-                out.append(int((draft[p] + rng.integers(1, 4)) % 4)); ops += 1
-            else:
-                out.append(int(draft[p]))
-        p += 1
-        if p % ts == 0 or p == ae:
-            pairs.append((ops, len(out) - seg_b0))
-            ops = 0
-            seg_b0 = len(out)
-    return np.asarray(out, dtype=np.uint8), pairs
+    n = ae - ab
+    P = np.arange(ab, ae)
+    pk, pb = planted[0][ab:ae], planted[1][ab:ae]
+    carried = (pk > 0) & (rng.random(n) < spec.p_carry)
+    c_ins, c_del, c_sub = carried & (pk == 1), carried & (pk == 2), carried & (pk == 3)
+    n_ins = rng.random(n) < spec.p_ins
+    other = ~(c_del | c_sub)
+    r2 = rng.random(n)
+    n_del = other & (r2 < spec.p_del)
+    n_sub = other & ~n_del & (r2 < spec.p_del + spec.p_sub)
+    E = np.zeros((n, 3), dtype=np.uint8)
+    M = np.zeros((n, 3), dtype=bool)
+    E[:, 0] = pb; M[:, 0] = c_ins
+    E[:, 1] = rng.integers(0, 4, size=n); M[:, 1] = n_ins
+    main = draft[ab:ae].copy()
+    main[n_sub] = (main[n_sub] + rng.integers(1, 4, size=int(n_sub.sum()))) % 4
+    main[c_sub] = pb[c_sub]
+    E[:, 2] = main; M[:, 2] = ~(c_del | n_del)
+    out = E[M]
+    ops = c_ins.astype(np.int64) + n_ins + c_del + c_sub + n_del + n_sub
+    seg = P // ts - ab // ts
+    nseg = int(seg[-1]) + 1
+    d = np.bincount(seg, weights=ops, minlength=nseg).astype(np.int64)
+    b = np.bincount(seg, weights=M.sum(axis=1), minlength=nseg).astype(np.int64)
+    return out, list(zip(d.tolist(), b.tolist()))
 
 
 def generate(spec: ConsensusSpec) -> ConsensusData:
@@ -109,10 +105,11 @@ def generate(spec: ConsensusSpec) -> ConsensusData:
         contigs.append(draft)
         if c >= spec.n_contigs:
             continue
-        planted = {}
+        planted = (np.zeros(L, np.uint8), np.zeros(L, np.uint8))
         for pos in rng.choice(np.arange(200, L - 200), size=max(1, int(L / 1000 * spec.draft_errors_per_kb)), replace=False):
-            k = ("ins", "del", "sub")[int(rng.integers(0, 3))]
-            planted[int(pos)] = (k, int(rng.integers(0, 4)) if k == "ins" else int((draft[pos] + rng.integers(1, 4)) % 4))
+            k = int(rng.integers(1, 4))
+            planted[0][pos] = k
+            planted[1][pos] = int(rng.integers(0, 4)) if k == 1 else int((draft[pos] + rng.integers(1, 4)) % 4)
         lows = []
         for _ in range(spec.low_cov_windows):
             s = int(rng.integers(500, max(501, L - 1500)))

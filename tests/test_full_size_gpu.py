@@ -38,15 +38,37 @@ def test_other_baseline_configs_through_the_executables(oracle_lib, name, genome
     assert res.startswith("ok"), res
 
 
-@pytest.mark.skipif(os.environ.get("HINGE_FULL_SIZE") != "1", reason="several minutes of single-thread oracle: HINGE_FULL_SIZE=1 (run once per round, log under profiles/)")
-@pytest.mark.parametrize("name", ["cfg3_nctc", "cfg4_yeast"])
-def test_configs_3_and_4_at_their_full_size(oracle_lib, name):
-    """BASELINE configs 3 (NCTC-like: 5 Mb at 100x, 40 repeat families, chimeric reads) and 4 (yeast-like: 12 Mb at 80x, 8 DB
-    blocks, --mlas over one rank per visible GPU) at their OWN size through all three executables, 20 output files against the
-    oracle byte for byte."""
+@pytest.mark.parametrize("name", ["cfg3_nctc", "cfg4_yeast", "cfg2_ecoli160"])
+def test_configs_at_their_full_size_against_committed_digests(name, tmp_path):
+    """BASELINE configs 3 (NCTC-like: 5 Mb at 100x, 40 repeat families, chimeric reads: 62 500 reads, 18.7 M overlaps, 14 657
+    hinges), 4 (yeast-like: 12 Mb at 80x, 8 DB blocks, --mlas over one rank per visible GPU: 120 000 reads, 18.8 M overlaps) and
+    2 (E. coli 160x: 86 588 reads, 26.2 M overlaps) at their OWN size through all three executables; the 20 output files against
+    the sha256 digests of the CPU oracle's files, made once in the build container (tests/golden/make_full_size_digests.py ->
+    tests/golden/full_size_digests.json: 96-190 s of single-thread oracle per configuration that the GPU box does not spend).
+    The generated input is digested too, so a drifting generator is reported as such."""
+    import hashlib
+    import conftest
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import fuzz_pipeline
+    import make_full_size_digests as mk
     from hinge_amd import synth
-    res = fuzz_pipeline.run_case(0, synth.CONFIGS[name], "", "", oracle_lib, "")
-    assert res.startswith("ok"), res
-    print(name, res)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digests.json")))[name]
+    spec = synth.CONFIGS[name]
+    d = synth.generate(spec)
+    assert (int(d.n_reads), int(d.novl)) == (want["reads"], want["records"])
+    assert mk.input_digest(d) == want["input_sha256"], "the generator no longer produces the data set the digests were made on"
+    wd = str(tmp_path)
+    synth.write_dataset(d, wd, "G", write_bases=False)
+    del d
+    conftest.write_ini(os.path.join(wd, "v.ini"))
+    mlas = spec.n_blocks > 1
+    hinge = os.path.join(ROOT, "hinge_amd", "bin", "hinge")
+    for sub, extra in (("filter", []), ("maximal", []), ("layout", ["-o", "G"])):
+        argv = [hinge, sub, "--db", "G", "--las", "G" if mlas else "G.las"] + (["--mlas"] if mlas else []) + ["-x", "G", "--config", "v.ini"] + extra
+        r = subprocess.run(argv, cwd=wd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        assert r.returncode == 0, (sub, r.stderr.decode()[-1500:])
+    bad = [f for f in fuzz_pipeline.FILES if mk.sha(os.path.join(wd, f)) != want["sha256"][f]]
+    assert not bad, "differs from the oracle's digests in %s" % bad
+    hinges = sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd, "G.hinges.txt")))
+    assert hinges == want["hinges"]

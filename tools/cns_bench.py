@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""`hinge consensus` at bench size (hinge_amd/synth_consensus.py "cns_bench": 4 contigs of ~1.1 Mb at 30x = E. coli-sized: 18.8 k
+alignments, 1.33 M trace-point segments, 134 M aligned bases): the reference's own program (oracle/_ref/consensus) where it
+exists - else the oracle restatement - against the GPU executable (wall clock, three runs) and the kernels on resident data
+(HIP events around every launch, hinge_profile_*).  Prints one JSON line; the FASTA must be byte-identical or it fails.
+
+    python tools/cns_bench.py [--config cns_bench] [--steps 5] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cns_bench")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--keep", default="")
+    args = ap.parse_args()
+    import numpy as np
+    import consensus_common as cc
+    from hinge_amd import capi, formats
+    wd = args.keep or tempfile.mkdtemp(prefix="hinge_cns_")
+    os.makedirs(wd, exist_ok=True)
+    t0 = time.time()
+    d = cc.make(args.config, wd)
+    gen_s = time.time() - t0
+    las = formats.read_las(os.path.join(wd, "draft.reads.las"))
+    tb = 1 if las.tspace <= 125 else 2
+    n_seg = int((las.rec["tlen"] // 2).sum())
+    aligned = int((las.rec["aepos"] - las.rec["abpos"]).sum())
+    out = {"config": args.config, "contigs": len(d.contigs), "contig_bases": int(sum(len(c) for c in d.contigs)), "alignments": int(las.novl),
+           "segments": n_seg, "aligned_bases": aligned, "generate_s": round(gen_s, 2)}
+    ref = None
+    if not args.no_cpu:
+        t = time.time()
+        got = cc.run_reference(wd)
+        kind = "reference"
+        if got is None:
+            import oracle
+            got = cc.run_oracle(oracle.oracle_lib(), wd)
+            kind = "port"
+        out["cpu"] = {"kind": kind, "cores": 1, "wall_s": round(time.time() - t, 3)}
+        ref = got[0]
+    walls = []
+    for _ in range(3):
+        t = time.time()
+        fasta, _ = cc.run_product(wd)
+        walls.append(round(time.time() - t, 3))
+    out["gpu_cli_s_runs"] = walls
+    out["gpu_cli_s"] = sorted(walls)[1]
+    if ref is not None:
+        assert ref == fasta, "FASTA differs from the CPU side's"
+        out["byte_identical"] = True
+        out["speedup_cli"] = round(out["cpu"]["wall_s"] / out["gpu_cli_s"], 1)
+    # kernels on resident data: every alignment votes (the selection is host work outside the kernels)
+    ctx = capi.Context(0)
+    cns = capi.Consensus(ctx, os.path.join(wd, "draft"), os.path.join(wd, "reads"))
+    picks = np.arange(las.novl)
+    cns.run(las, picks)                       # warm-up (allocations)
+    ctx.profile_enable(64 * args.steps)
+    t = time.time()
+    for _ in range(args.steps):
+        cns.run(las, picks)
+    run_ms = (time.time() - t) * 1e3 / args.steps
+    rep = ctx.profile_report()
+    out["run_call_ms"] = round(run_ms, 3)     # host segment table + H2D + kernels + D2H of the strings
+    out["kernels_ms"] = {k: round(v[0] / args.steps, 4) for k, v in rep.items() if k.startswith("k_cns") and v[1]}
+    ksum = sum(out["kernels_ms"].values())
+    out["kernels_ms_sum"] = round(ksum, 4)
+    out["aligned_bases_per_s_kernels"] = aligned / (ksum * 1e-3) if ksum else None
+    out["segments_per_s_realign"] = n_seg / (out["kernels_ms"].get("k_cns_realign", 0) * 1e-3) if out["kernels_ms"].get("k_cns_realign") else None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
