@@ -1311,7 +1311,7 @@ __device__ unsigned long long* g_k2_trace = nullptr;
 // goes to cov_tot (it falls out of the prefix scan: cov0[k] = PB[2k-1] - PE[2k-1] is zero behind the last event, so the sum of the
 // scan's values at the odd indices is the sum over the read's bins), and a read that is not decided for every MIN_COV in
 // [pred - band, pred + band] emits nothing and goes on the guard-band list.
-template <bool PACKED, bool COVOUT, int CUT20, bool SPEC>
+template <bool PACKED, bool COVOUT, int CUT20, int SPEC /*0: a pass with the exact MIN_COV; 1: first sweep of a one-sweep pass, band 1 (a constant: MIN_COV +- band cost no registers); 2: any band*/>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off_arg, int mulpath_thr /*min(MIN_RA, MAX_RA) >= 0: the
                                                              division-free annotation test applies (a launch condition)*/,
                                                              int nhr /*NO_HINGE_REGION*/, int cov_mask_off /*INT_MIN if the coverage mask takes part in the mask, else 1 << 29*/,
@@ -1322,7 +1322,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                              int* __restrict__ cov_out /*COVOUT: the coverage-bin output*/,
                                                              const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
                                                              unsigned* __restrict__ heads, int n_heads, K2Heads bases,
-                                                             int* __restrict__ cov_tot /*SPEC*/, int band /*SPEC*/) {
+                                                             int* __restrict__ cov_tot /*SPEC*/, int band_arg /*SPEC == 2*/) {
+    const int band = SPEC == 1 ? 1 : band_arg;
     extern __shared__ int lds[];
     constexpr int HOT = 4;    // words per lane the slot has room for behind the profile (candidate list of the last phase)
     constexpr int HOTW = 2;   // of which hot words: W0 = begins in bin 0 | ends in bin qe - 1 << 16, W1 = begins in bin 1 | ends in bin qe << 16
@@ -1566,7 +1567,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             w.x += excl; w.y += excl; w.z += excl; w.w += excl;
             if (t < Qn) *reinterpret_cast<int4*>(Pq + t) = v;
             if (t + 4 < Qn) *reinterpret_cast<int4*>(Pq + t + 4) = w;
-            if constexpr (SPEC && !COVOUT) {
+            if constexpr (SPEC != 0 && !COVOUT) {
                 auto cv = [&](int pre) { return (pre & 0xffff) - (int)((unsigned)pre >> 16); };
                 tot_l += cv(v.y) + cv(v.w) + cv(w.y) + cv(w.w);
             }
@@ -1582,7 +1583,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 struct __attribute__((packed, aligned(4))) Bins4 { int a, b, c, d; };
                 const Bins4 b4{cv(v.y), cv(v.w), cv(w.y), cv(w.w)};
                 if (k1 < K0) *reinterpret_cast<Bins4*>(cov_dst + k1) = b4;
-                if constexpr (SPEC) tot_l += (b4.a + b4.b) + (b4.c + b4.d);   // (lanes past the last event hold begins = ends: zero)
+                if constexpr (SPEC != 0) tot_l += (b4.a + b4.b) + (b4.c + b4.d);   // (lanes past the last event hold begins = ends: zero)
             }
             carry += wave_last(incl);
         }
@@ -1590,7 +1591,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             if (K0 > 0) cov_dst[0] = 0;                      // cov0[0]: nothing is consumed before position 0
             store_at32(cov_nbins, in_vgpr((unsigned)(i - cov_base)) << 2, K0);
         }
-        if constexpr (SPEC) {   // the last lane of the scan holds the wavefront's sum: it stores it (no broadcast)
+        if constexpr (SPEC != 0) {   // the last lane of the scan holds the wavefront's sum: it stores it (no broadcast)
             const int tot = wave_incl_scan(tot_l);
             if (lane == WAVE - 1) store_at32(cov_tot, in_vgpr((unsigned)i) << 2, tot);
         }
@@ -1646,7 +1647,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             // (loaded by every lane: LDS reads do not fault)
             for (; base + WAVE <= KC; base += WAVE, pcb += 2 * WAVE, pce += 2 * WAVE) {
                 const int cvv = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16);
-                if constexpr (SPEC) {
+                if constexpr (SPEC != 0) {
                     // 64 bins above the band's upper end: positive whatever the exact MIN_COV turns out to be
                     const unsigned long long MH = ballot_of(cvv > MIN_COV + band);
                     if (MH == ~0ull) { pc = 1; continue; }
@@ -1663,7 +1664,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                // none, and a run that is still open at the last valid bin is not counted, as in the reference's loop)
                 const bool valid = base + lane < KC;
                 const int cvv = (*pcb & 0xffff) - (int)((unsigned)*pce >> 16);
-                if constexpr (SPEC) {
+                if constexpr (SPEC != 0) {
                     if (ballot_of(valid && cvv > MIN_COV - band) != ballot_of(valid && cvv > MIN_COV + band)) near_band = true;
                 }
                 const bool p = !valid || cvv > MIN_COV;
@@ -1671,7 +1672,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 if (!closes_none(base, M)) word(base, p, M);
             }
         }
-        if constexpr (SPEC) {
+        if constexpr (SPEC != 0) {
             if (near_band) {   // (wave-uniform) nothing emitted: the guard-band list takes the read
                 if (lane == 0) {
                     const unsigned at = atomicAdd(C->redo_count, 1u);
@@ -1694,8 +1695,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         typedef const K2Const __attribute__((address_space(4))) K2ConstK;   // constant address space: scalar loads
         K2ConstK& kc = *(K2ConstK*)(unsigned long long)c;
         int used = __builtin_amdgcn_readfirstlane(mask_gate_annotate(kc.P, reso, MIN_COV, i, lane, K0, run, cov0, covc, cand_apart ? hot : Pq, kc.o, (long long)s, n,
-                                                                     true, !cand_apart, flag_words, SPEC ? band : 0));
-        if constexpr (SPEC) {
+                                                                     true, !cand_apart, flag_words, SPEC != 0 ? band : 0));
+        if constexpr (SPEC != 0) {
             if (used & SPEC_DEFERRED) {   // an annotation threshold inside the band: the guard-band list takes the read
                 used &= ~SPEC_DEFERRED;
                 if (lane == 0) {

@@ -62,6 +62,7 @@ struct hinge_ctx {
     bool final_batch_valid = false;
     size_t lds_attr_final = 0;
     int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
+    int hinge_count_wave = 1;                 // HINGE_COUNT_WAVE=0: k_hinge_count (a workgroup per work-list read) instead of k_hinge_count_w
     DevBuf cov_tot, redo_list, spec_sample;   // int[n_reads] coverage sums, int[n_reads] guard-band list, int[spec_ns] sample means
     int spec_band = 1;        // the sweep is exact for every MIN_COV within +- this of the prediction (HINGE_SPEC_BAND)
     int spec_ns = 4096;       // reads k_spec_predict samples per part (HINGE_SPEC_SAMPLE)
@@ -267,6 +268,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (const char* g = getenv("HINGE_ONE_SWEEP")) ctx->one_sweep = atoi(g);
     if (const char* g = getenv("HINGE_FINAL_BATCH")) ctx->final_batched = atoi(g);
+    if (const char* g = getenv("HINGE_COUNT_WAVE")) ctx->hinge_count_wave = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
     if (const char* g = getenv("HINGE_SPEC_SAMPLE")) ctx->spec_ns = std::max(1, atoi(g));
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -933,8 +935,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p, in
         const size_t lds_all = lds20;
         if (ctx->k2_occ_lds != (int)lds_all) {
             int nb = 0;
-            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true, true, 15, false>, BLOCK, lds_all));
-            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false, true, 15, false>, BLOCK, lds_all));
+            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true, true, 15, 0>, BLOCK, lds_all));
+            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false, true, 15, 0>, BLOCK, lds_all));
             ctx->k2_occ = std::max(nb, 1);
             ctx->k2_occ_lds = (int)lds_all;
         }
@@ -1022,10 +1024,10 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p, in
 #define LAUNCH_K2S(PACKED, COVOUT, CUT20, SPEC, SPANS)                                                                                                      \
         hipLaunchKernelGGL((k_mask_annotate_q20<PACKED, COVOUT, CUT20, SPEC>), dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off,  \
                            mulpath_thr, p->no_hinge_region, cov_mask_off, (const int*)ctx->bucket_list.p, n1, n2, n4, (const int64_t*)ctx->row_ptr.p, SPANS, \
-                           (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, (const int*)(SPEC ? &sc(ctx)->spec_min_cov : &sc(ctx)->min_cov), slot, cov_out, \
+                           (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, (const int*)((SPEC) != 0 ? &sc(ctx)->spec_min_cov : &sc(ctx)->min_cov), slot, cov_out, \
                            (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (unsigned*)ctx->k2_heads.p, n_heads, bases,                \
                            (int*)ctx->cov_tot.p, ctx->spec_band)
-#define LAUNCH_K2C(PACKED, COVOUT, CUT20, SPANS) do { if (mode == MODE_SPEC) LAUNCH_K2S(PACKED, COVOUT, CUT20, true, SPANS); else LAUNCH_K2S(PACKED, COVOUT, CUT20, false, SPANS); } while (0)
+#define LAUNCH_K2C(PACKED, COVOUT, CUT20, SPANS) do { if (mode == MODE_SPEC) { if (ctx->spec_band == 1) LAUNCH_K2S(PACKED, COVOUT, CUT20, 1, SPANS); else LAUNCH_K2S(PACKED, COVOUT, CUT20, 2, SPANS); } else LAUNCH_K2S(PACKED, COVOUT, CUT20, 0, SPANS); } while (0)
 #define LAUNCH_K2(PACKED, COVOUT, SPANS) do { if (p->cut_off == 300) LAUNCH_K2C(PACKED, COVOUT, 15, SPANS); else LAUNCH_K2C(PACKED, COVOUT, -1, SPANS); } while (0)
         if (ctx->use_span16) { if (cov_out) LAUNCH_K2(true, true, (const unsigned*)ctx->span16.p); else LAUNCH_K2(true, false, (const unsigned*)ctx->span16.p); }
         else { if (cov_out) LAUNCH_K2(false, true, (const int2*)ctx->a_span.p); else LAUNCH_K2(false, false, (const int2*)ctx->a_span.p); }
@@ -1112,8 +1114,11 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         any_big = any_big || ctxs[k]->max_pile > (unsigned)PO_CAP_SMALL;
     }
     const int g_count = std::max(n, (ctx->n_cu * 8 / n) * n);
+    bool wave_form = ctx->hinge_count_wave != 0;        // HINGE_COUNT_WAVE=0: the workgroup-per-read k_hinge_count of rounds 1-3
+    for (int k = 0; k < n; k++) wave_form = wave_form && ctxs[k]->max_pile < 65536u;
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
-    hipLaunchKernelGGL(k_hinge_count, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
+    if (wave_form) hipLaunchKernelGGL(k_hinge_count_w, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B);
+    else hipLaunchKernelGGL(k_hinge_count, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
     CK(hipGetLastError());
     // Undecided annotations: pile-ups of up to PO_CAP_SMALL overlaps go through the 72 KiB instance, two workgroups per CU (one
     // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if a part has
