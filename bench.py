@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--workload", default="cfg2_ecoli160")
     ap.add_argument("--parts", type=int, default=4, help="distinct resident read sets a step passes over (>= 3 keeps the Infinity Cache cold)")
     ap.add_argument("--gather-groups", type=int, default=1, help="all-gathers of the masks per step (1: all parts at once; 2: the first half's runs under the second half's kernels)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every GPU keeps one config-2-sized block per part (teams of two, the default the driver's scaling run "
+                         "measures); strong = ONE config-2 data set per part split into N DB blocks (3.3 M overlaps per GPU and part at N = 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     return ap.parse_args()
@@ -183,8 +186,9 @@ def main():
             raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if not benchsets.supported_world(world):
-        raise SystemExit("bench.py: 1 GPU or an even number of GPUs (the ranks work in teams of two, hinge_amd/benchsets.py)")
+    if not benchsets.supported_world(world, args.scaling):
+        raise SystemExit("bench.py: 1 GPU or an even number of GPUs (the ranks work in teams of two, hinge_amd/benchsets.py); --scaling strong takes any N")
+    strong = args.scaling == "strong" and world > 1
     # test rig for a 1-GPU box: HINGE_BENCH_ONE_DEVICE=1 puts every rank on device 0 and HINGE_BENCH_BACKEND=gloo moves the
     # collectives through host memory (RCCL refuses two ranks on one device).  Results are asserted as usual; times mean nothing.
     one_device = os.environ.get("HINGE_BENCH_ONE_DEVICE", "0") == "1"
@@ -218,11 +222,11 @@ def main():
     first_data = None
     parts = []
     for p in range(R):
-        spec, _ = benchsets.part_spec(base, world, rank, p)
+        spec, _ = benchsets.part_spec(base, world, rank, p, args.scaling)
         d = synth.generate(spec)
         if p == 0 and world == 1:
             first_data = d
-        parts.append(benchsets.rank_part(base, world, rank, p, data=d))
+        parts.append(benchsets.rank_part(base, world, rank, p, data=d, scaling=args.scaling))
         del d
     t_gen = time.perf_counter() - t_gen
     # every block gets the same number of read ids (the largest block's over all ranks and parts; the ids behind a block's
@@ -294,6 +298,7 @@ def main():
 
     # ---- results, outside the timed region: exchange 3 (the (read, pos, type) rows of every part from every rank, on every
     # rank) and the per-rank counters --------------------------------------------------------------------------------
+    spec_stats = [[int(v) for v in ctx.spec_stats()] for ctx in ctxs]   # one-sweep pass: verifications, mispredictions, guard-band reads
     lists = [t.cpu().numpy() for t in batch.hinge_lists()]
     work_reads = sum(int(ctx.counters()[0]) for ctx in ctxs)
     exact_annos = sum(int(ctx.counters()[1]) for ctx in ctxs)
@@ -376,15 +381,33 @@ def main():
         # ---- results are checked, not just printed: at EVERY N, every part of every rank against the CPU oracle's hinge count
         # and row digest (tests/golden/bench_expect.json, tools/make_bench_expect.py) ----------------------------------
         expect_path = os.environ.get("HINGE_BENCH_EXPECT") or os.path.join(ROOT, "tests", "golden", "bench_expect.json")
-        expect = json.load(open(expect_path)).get(args.workload, {}).get("worlds", {}).get(str(world), {}) if os.path.exists(expect_path) else {}
-        checks = {"hinges_per_part_and_rank": [[e["hinges"] for e in pr] for pr in got], "parts_checked": 0,
+        expect = json.load(open(expect_path)).get(args.workload, {}).get("worlds", {}).get("1" if strong else str(world), {}) if os.path.exists(expect_path) else {}
+        if strong:
+            # strong scaling: the N blocks are ONE config-2 data set, merged-las semantics - the union of the ranks' rows, in
+            # the data set's own read ids, must be the N = 1 result (the committed expectation of world 1)
+            merged = []
+            for p in range(R):
+                first = np.concatenate([[0], np.cumsum([sizes[r][p] for r in range(world)])])
+                rows = lists[p].astype(np.int64)
+                out_rows = []
+                for r in range(world):
+                    lo = batch.id_base(p, r)
+                    sel = (rows[:, 0] >= lo) & (rows[:, 0] < lo + S)
+                    loc = rows[sel].copy()
+                    loc[:, 0] += int(first[r]) - lo
+                    out_rows.append(loc)
+                allr = np.concatenate(out_rows) if out_rows else np.zeros((0, 3), np.int64)
+                merged.append([{"hinges": int(len(allr)), "digest": benchsets.digest(allr)}])
+            per_rank_got, got = got, merged
+            sizes = [[sum(sizes[r][p] for r in range(world)) for p in range(2 * R)]]
+        checks = {"hinges_per_part_and_rank": [[e["hinges"] for e in pr] for pr in (per_rank_got if strong else got)], "parts_checked": 0,
                   "mask_tables_identical_on_all_ranks": all(s_ == all_sums[0] for s_ in all_sums)}
         assert checks["mask_tables_identical_on_all_ranks"], "exchange 2 left different mask tables on different ranks: %s" % (all_sums,)
         for p in range(R):
             want = expect.get(str(p))
             if want is None or os.environ.get("HINGE_BENCH_NO_ASSERT") == "1":     # (NO_ASSERT: ablation builds produce garbage on purpose)
                 continue
-            have_sizes = ([sizes[r][p] for r in range(world)], [sizes[r][R + p] for r in range(world)])
+            have_sizes = ([sizes[r][p] for r in range(len(sizes))], [sizes[r][R + p] for r in range(len(sizes))])
             assert (want["reads"], want["records"]) == have_sizes, "part %d: the generated read sets %s are not the ones the expectations were made for %s" % (p, have_sizes, (want["reads"], want["records"]))
             assert want["ranks"] == got[p], "part %d: hinges (count, digest) per rank %s differ from the CPU oracle's %s" % (p, got[p], want["ranks"])
             checks["parts_checked"] += 1
@@ -408,7 +431,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
@@ -427,7 +450,12 @@ def main():
                             % (R, R * 16, len(batch.groups))) if collectives else "no collective (one rank)"),
                 "collectives_per_step": (1 + len(batch.groups)) if collectives else 0,
                 "process_group": (pg_backend + (" (test rig: all ranks on one device)" if one_device else "")) if use_pg else None,
-                "kernels_in_step": "k_cov_stats, k_median_hist, k_mask_annotate (+ coverage bins), k_hinge_count, k_hinge_call per part; none outside",
+                "kernels_in_step": "one-sweep pass: k_spec_predict (MIN_COV from a sample of each part), k_mask_annotate per part (+ coverage bins, + the per-read coverage sums), "
+                                   "k_median_hist (the exact median: verification), k_mask_annotate_final (the guard-band reads; every read of a part whose prediction missed the band), "
+                                   "k_hinge_count, k_hinge_call - the last four one launch for all parts; none outside.  HINGE_ONE_SWEEP=0: k_cov_stats first (rounds 1-3)",
+                "one_sweep": {"per_part": [{"passes_verified": s_[0], "exact_differs_from_prediction": s_[1], "prediction_outside_band_whole_part_redone": s_[2],
+                                            "guard_band_reads_last_pass": s_[3], "predicted_min_cov": s_[4], "exact_min_cov": s_[5]} for s_ in spec_stats],
+                              "note": "cumulative over warm-up, breakdown and timed steps; redone parts and guard-band launches are inside the timed region"},
                 "reads_in_hinge_pass": work_reads,
                 "annotations_on_exact_path": exact_annos,
                 "generate_s": t_gen,

@@ -26,14 +26,18 @@ TEAM = 2
 DIGEST_MOD = (1 << 61) - 1
 
 
-def supported_world(world: int) -> bool:
-    return world == 1 or (world > 1 and world % TEAM == 0)
+def supported_world(world: int, scaling: str = "weak") -> bool:
+    return world == 1 or (world > 1 and (scaling == "strong" or world % TEAM == 0))
 
 
-def part_spec(base: synth.SynthSpec, world: int, rank: int, part: int):
-    """(generator spec, block of it this rank holds)."""
+def part_spec(base: synth.SynthSpec, world: int, rank: int, part: int, scaling: str = "weak"):
+    """(generator spec, block of it this rank holds).  scaling = "strong": ONE config-2 data set per part - the very reads and
+    overlaps of the N = 1 run - DBsplit into `world` blocks, rank r holds block r (merged-las semantics: the union of the ranks'
+    results is the N = 1 result, which is what bench.py asserts)."""
     if world == 1:
         return dataclasses.replace(base, n_blocks=1, seed=base.seed + 17 * part), 0
+    if scaling == "strong":
+        return dataclasses.replace(base, n_blocks=world, seed=base.seed + 17 * part), rank
     assert supported_world(world), "bench data sets are defined for 1 GPU or an even number of GPUs"
     q = rank // TEAM
     spec = dataclasses.replace(base, genome_len=TEAM * base.genome_len, n_blocks=TEAM, n_repeat_families=TEAM * base.n_repeat_families,
@@ -63,8 +67,8 @@ class RankPart:
         return int(self.comp.shape[0])
 
 
-def rank_part(base: synth.SynthSpec, world: int, rank: int, part: int, data: synth.SynthData = None) -> RankPart:
-    spec, k = part_spec(base, world, rank, part)
+def rank_part(base: synth.SynthSpec, world: int, rank: int, part: int, data: synth.SynthData = None, scaling: str = "weak") -> RankPart:
+    spec, k = part_spec(base, world, rank, part, scaling)
     d = synth.generate(spec) if data is None else data
     pile = synth.to_pileups(d)
     bf = np.asarray(d.block_first, dtype=np.int64)
@@ -72,7 +76,7 @@ def rank_part(base: synth.SynthSpec, world: int, rank: int, part: int, data: syn
     s, e = int(pile.row_ptr[lo]), int(pile.row_ptr[hi])
     b = (pile.b_flag[s:e] & np.uint32(0x7FFFFFFF)).astype(np.int64)
     kb = np.searchsorted(bf, b, side="right") - 1                     # block of every B read
-    first_rank = (rank // TEAM) * TEAM if world > 1 else 0
+    first_rank = (rank // TEAM) * TEAM if (world > 1 and scaling != "strong") else 0
     r0, r1 = np.searchsorted(d.aread, [lo, hi])
     return RankPart(rlen=np.ascontiguousarray(d.rlen[lo:hi], dtype=np.int32),
                     row_ptr=(pile.row_ptr[lo:hi + 1] - s).astype(np.int64),

@@ -220,174 +220,6 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K3a, round 4: the same count-only sweep with ONE WAVEFRONT per work-list read.
-// k_hinge_count's length is (work-list reads / resident workgroups) x one read's chain of dependent round trips: it needs 134
-// VGPRs (eight overlaps per lane in flight with their B-side fields and mask rows), i.e. three workgroups per CU = 768 reads
-// in flight for the ~5 300 work-list reads of four bench parts: seven rounds of ~8 us.  Here a read is one wavefront's:
-//   phase 1  streams the spans only (8 bytes per overlap, eight loads per lane in flight) and appends the overlaps whose near
-//            end lies in an annotation's +-HINGE_TOLERANCE window - a few per cent of a pile-up - to a list in LDS (ballot +
-//            prefix: wave-local, no barrier), pile-ups of up to HCW_CHUNK overlaps at once;
-//   phase 2  walks the list, HCW_GATHER entries per lane in flight: B-side fields, then mask[B] (two dependent round trips per
-//            HCW_GATHER * 64 near overlaps instead of three per 512 overlaps of the pile-up), counts per annotation and per
-//            slice of the pile-up (the four contiguous slices k_hinge_call's wavefronts gather from: HeavyItem::base).
-// ~56 VGPRs and 4 KiB of LDS per wavefront: eight wavefronts per SIMD, every work-list read of the launch resident at once.
-// Same outputs as k_hinge_count, bit for bit (hinge_flag, the heavy items' slots, counts and order-independent fields; the ORDER
-// of the heavy list differs, as it does from launch to launch: the items are independent).  Pile-ups of 65 536+ overlaps keep
-// k_hinge_count (the host chooses: the packed per-slice counters below are 16 bits wide).
-// ------------------------------------------------------------------------------------------------
-constexpr int HCW_CHUNK = 2048;    // overlaps per pass over the LDS list (16-bit entries: 4 KiB per wavefront)
-constexpr int HCW_GATHER = 4;      // list entries a lane of phase 2 keeps in flight
-__global__ __launch_bounds__(BLOCK) void k_hinge_count_w(FilterDev P, HingeBatch B) {
-    const unsigned n_parts = (unsigned)B.n;
-    const HingePart& A = B.part[blockIdx.x % n_parts];
-    const unsigned bx = blockIdx.x / n_parts, gx = gridDim.x / n_parts;
-    const int2* __restrict__ a_span = A.a_span; const int2* __restrict__ b_span = A.b_span;
-    const unsigned* __restrict__ b_flag = A.b_flag; const int2* __restrict__ mask = A.mask; const int2* __restrict__ anno_buf = A.anno_buf;
-    const WorkItem* __restrict__ work_list = A.work_list; const unsigned* __restrict__ counters = A.counters;
-    unsigned char* __restrict__ hinge_flag = A.hinge_flag; HeavyItem* __restrict__ heavy = A.heavy;
-    unsigned* __restrict__ heavy_count = A.heavy_count; unsigned* __restrict__ heavy_count_big = A.heavy_count_big;
-    const unsigned heavy_cap = A.heavy_cap; const int force_exact = A.force_exact; unsigned* __restrict__ dbg = A.dbg;
-    __shared__ unsigned short s_list[WAVES_PER_BLOCK][HCW_CHUNK];
-    const int lane = lane_id();
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (bx >= gx) return;
-    unsigned short* __restrict__ list = s_list[wib];
-    const unsigned wave = bx * WAVES_PER_BLOCK + (unsigned)wib, nwaves = gx * WAVES_PER_BLOCK;
-    WorkItem wi_first;
-    if (wave < A.work_cap) wi_first = work_list[wave];
-    const unsigned nwork = counters[1];
-    for (unsigned w = wave; w < nwork; w += nwaves) {
-        const WorkItem wi = wi_first;
-        if (w + nwaves < nwork) wi_first = work_list[w + nwaves];
-        const int i = __builtin_amdgcn_readfirstlane(wi.read);
-        const int n = __builtin_amdgcn_readfirstlane(wi.n);
-        const int64_t s = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wi.row >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)wi.row));
-        const int2 mk = make_int2(__builtin_amdgcn_readfirstlane(wi.mask_lo), __builtin_amdgcn_readfirstlane(wi.mask_hi));
-        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.off);
-        const int cnt = __builtin_amdgcn_readfirstlane(wi.cnt);
-        const int q = slice_len(n);
-        const int2* __restrict__ row = a_span + s;
-        for (int a0 = 0; a0 < cnt; a0 += PRE_MAXA) {
-            const int na = min(PRE_MAXA, cnt - a0);
-            int apos[PRE_MAXA], atype[PRE_MAXA];
-            int c01[PRE_MAXA], c23[PRE_MAXA], cnear[PRE_MAXA];   // supporters in slices 0 | 1 << 16 and 2 | 3 << 16; of which near the mask's end
-#pragma unroll
-            for (int a = 0; a < PRE_MAXA; a++) {
-                int2 an = make_int2(0, 0);
-                if (a < na) an = a0 == 0 ? wi.anno[a] : anno_buf[off + a0 + a];
-                apos[a] = __builtin_amdgcn_readfirstlane(an.x); atype[a] = __builtin_amdgcn_readfirstlane(an.y);
-                c01[a] = 0; c23[a] = 0; cnear[a] = 0;
-            }
-            // the window of every annotation as one unsigned range test on the coordinate it looks at: c in (pos - tol, pos + tol)
-            for (int c0 = 0; c0 < n; c0 += HCW_CHUNK) {
-                const int cn = min(HCW_CHUNK, n - c0);
-                int nlist = 0;                               // (wave-uniform)
-                for (int k0 = 0; k0 < cn; k0 += GATHER_LOADS * WAVE) {
-                    int2 av[GATHER_LOADS];
-#pragma unroll
-                    for (int u = 0; u < GATHER_LOADS; u++) {
-                        const int k = k0 + u * WAVE + lane;
-                        av[u] = row[c0 + min(k, cn - 1)];
-                    }
-#pragma unroll
-                    for (int u = 0; u < GATHER_LOADS; u++) {
-                        if (k0 + u * WAVE >= cn) break;      // wave-uniform
-                        const int k = k0 + u * WAVE + lane;
-                        bool nr = false;
-#pragma unroll
-                        for (int a = 0; a < PRE_MAXA; a++) {
-                            if (a >= na) break;
-                            const int c = atype[a] == -1 ? av[u].y : av[u].x;
-                            nr = nr || ((c > apos[a] - P.tol) && (c < apos[a] + P.tol));
-                        }
-                        nr = nr && k < cn;
-                        const unsigned long long bal = ballot_of(nr);
-                        if (bal) {
-                            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                            if (nr) list[nlist + before] = (unsigned short)k;
-                            nlist += __builtin_popcountll(bal);
-                        }
-                    }
-                }
-                // phase 2: the near overlaps of this chunk
-                for (int t0 = 0; t0 < nlist; t0 += HCW_GATHER * WAVE) {
-                    int kk[HCW_GATHER];
-                    int2 av[HCW_GATHER], bs[HCW_GATHER], mb[HCW_GATHER];
-                    unsigned bf[HCW_GATHER];
-#pragma unroll
-                    for (int u = 0; u < HCW_GATHER; u++) {
-                        const int t = t0 + u * WAVE + lane;
-                        kk[u] = t < nlist ? c0 + (int)list[t] : -1;
-                    }
-#pragma unroll
-                    for (int u = 0; u < HCW_GATHER; u++) {
-                        const int64_t k = s + max(kk[u], 0);
-                        av[u] = a_span[k]; bf[u] = b_flag[k]; bs[u] = b_span[k];
-                    }
-#pragma unroll
-                    for (int u = 0; u < HCW_GATHER; u++) mb[u] = mask[bf[u] & 0x7fffffffu];
-#pragma unroll
-                    for (int u = 0; u < HCW_GATHER; u++) {
-                        if (kk[u] < 0) continue;
-                        int L, R;
-                        overhangs(bs[u], (int)(bf[u] >> 31), mb[u], L, R);
-                        const int sl = kk[u] / q;            // slice of the pile-up (k_hinge_call's wavefront)
-                        const int add01 = sl == 0 ? 1 : (sl == 1 ? 0x10000 : 0), add23 = sl == 2 ? 1 : (sl == 3 ? 0x10000 : 0);
-#pragma unroll
-                        for (int a = 0; a < PRE_MAXA; a++) {
-                            if (a >= na) break;
-                            const int c = atype[a] == -1 ? av[u].y : av[u].x;
-                            if ((c > apos[a] - P.tol) && (c < apos[a] + P.tol)) {
-                                const bool sup = atype[a] == -1 ? (R > P.theta) : (L > P.theta);
-                                if (sup) {
-                                    c01[a] += add01; c23[a] += add23;
-                                    const int f = atype[a] == -1 ? av[u].x : -av[u].y;
-                                    const int m0 = atype[a] == -1 ? mk.x : -mk.y;
-                                    cnear[a] += (f - m0 < P.bin_len);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            int t01[PRE_MAXA], t23[PRE_MAXA], tnear[PRE_MAXA];
-#pragma unroll
-            for (int a = 0; a < PRE_MAXA; a++) {
-                t01[a] = 0; t23[a] = 0; tnear[a] = 0;
-                if (a >= na) continue;
-                t01[a] = wave_sum(c01[a]); t23[a] = wave_sum(c23[a]); tnear[a] = wave_sum(cnear[a]);   // (a pile-up has < 65 536 overlaps: the halves never meet)
-            }
-            if (lane < na) {
-                static_assert(PRE_MAXA == 4, "select chains below");
-                const int x01 = lane == 0 ? t01[0] : lane == 1 ? t01[1] : lane == 2 ? t01[2] : t01[3];
-                const int x23 = lane == 0 ? t23[0] : lane == 1 ? t23[1] : lane == 2 ? t23[2] : t23[3];
-                const int pnear = lane == 0 ? tnear[0] : lane == 1 ? tnear[1] : lane == 2 ? tnear[2] : tnear[3];
-                const int b1 = x01 & 0xffff, b2 = b1 + (int)((unsigned)x01 >> 16), b3 = b2 + (x23 & 0xffff);
-                const int psup = b3 + (int)((unsigned)x23 >> 16);
-                int quick = 2;
-                if (force_exact == 0) {
-                    if (psup <= P.sup) quick = 0;
-                    else if (P.unb >= 0 && pnear > P.unb) quick = 1;
-                }
-                hinge_flag[off + a0 + lane] = (unsigned char)quick;
-                if (quick == 2) {
-                    HeavyItem it;
-                    it.read = i; it.anno = a0 + lane;
-                    it.base[0] = b1; it.base[1] = b2; it.base[2] = b3;
-                    it.sup = psup; it.near_end = pnear; it.pad = 0;
-                    it.n = n; it.row = s; it.mask_lo = mk.x; it.mask_hi = mk.y;
-                    it.pos = lane == 0 ? apos[0] : lane == 1 ? apos[1] : lane == 2 ? apos[2] : apos[3];
-                    it.type = lane == 0 ? atype[0] : lane == 1 ? atype[1] : lane == 2 ? atype[2] : atype[3];
-                    it.slot = off + a0 + lane;
-                    if (it.n <= PO_CAP_SMALL) heavy[atomicAdd(heavy_count, 1u)] = it;
-                    else heavy[heavy_cap - 1u - atomicAdd(heavy_count_big, 1u)] = it;
-                } else if (dbg) atomicAdd(&dbg[quick ? 3 : 0], 1u);
-            }
-        }
-    }
-}
-
 // CAP: capacity of the LDS lists (pile-up size, supporters) = half the number of 1-bp bins.  The host launches the
 // PO_CAP_SMALL instance (72 KiB of LDS: two workgroups per CU) over the items whose pile-up fits it - they are appended from
 // the front of `heavy` - and the PO_CAP instance (one workgroup per CU) over the rest, appended from the back (`from_back`).

@@ -62,7 +62,6 @@ struct hinge_ctx {
     bool final_batch_valid = false;
     size_t lds_attr_final = 0;
     int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
-    int hinge_count_wave = 1;                 // HINGE_COUNT_WAVE=0: k_hinge_count (a workgroup per work-list read) instead of k_hinge_count_w
     DevBuf cov_tot, redo_list, spec_sample;   // int[n_reads] coverage sums, int[n_reads] guard-band list, int[spec_ns] sample means
     int spec_band = 1;        // the sweep is exact for every MIN_COV within +- this of the prediction (HINGE_SPEC_BAND)
     int spec_ns = 4096;       // reads k_spec_predict samples per part (HINGE_SPEC_SAMPLE)
@@ -268,7 +267,6 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (const char* g = getenv("HINGE_ONE_SWEEP")) ctx->one_sweep = atoi(g);
     if (const char* g = getenv("HINGE_FINAL_BATCH")) ctx->final_batched = atoi(g);
-    if (const char* g = getenv("HINGE_COUNT_WAVE")) ctx->hinge_count_wave = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
     if (const char* g = getenv("HINGE_SPEC_SAMPLE")) ctx->spec_ns = std::max(1, atoi(g));
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -1114,11 +1112,8 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         any_big = any_big || ctxs[k]->max_pile > (unsigned)PO_CAP_SMALL;
     }
     const int g_count = std::max(n, (ctx->n_cu * 8 / n) * n);
-    bool wave_form = ctx->hinge_count_wave != 0;        // HINGE_COUNT_WAVE=0: the workgroup-per-read k_hinge_count of rounds 1-3
-    for (int k = 0; k < n; k++) wave_form = wave_form && ctxs[k]->max_pile < 65536u;
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
-    if (wave_form) hipLaunchKernelGGL(k_hinge_count_w, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B);
-    else hipLaunchKernelGGL(k_hinge_count, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
+    hipLaunchKernelGGL(k_hinge_count, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
     CK(hipGetLastError());
     // Undecided annotations: pile-ups of up to PO_CAP_SMALL overlaps go through the 72 KiB instance, two workgroups per CU (one
     // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if a part has

@@ -23,6 +23,49 @@ def _pass(ctx, P, lo, hi):
     return est
 
 
+def test_cfg5_share_against_the_oracle_digest():
+    """The WHOLE one-rank share of BASELINE config 5 (52 Mb at 100x: 742 857 reads, 1.33e8 overlaps) against the CPU oracle AT
+    SIZE: tests/golden/cfg5_share_digest.json holds sha256 digests of the oracle's mask / cmask rows, repeat annotations and
+    hinge rows (tests/golden/make_cfg5_digest.py: 800 s in the build container - 290 s of generating and writing the 16 GB .las,
+    510 s of single-thread oracle - which the GPU box does not spend).  The pile-ups are regenerated with torch's CPU generator
+    (its stream does not depend on the machine; the input is digested too), moved to the GPU and run through the one-sweep
+    pass + hinge calling."""
+    import json
+    import sys
+    import time
+    import torch
+    from hinge_amd import capi, synth, synth_device
+    from hinge_amd.config import default_filter_params
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_cfg5_digest as mk
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg5_share_digest.json")))
+    spec = dataclasses.replace(synth.CONFIGS["cfg5_share"], genome_len=want["genome"])
+    t0 = time.time()
+    p = synth_device.generate_pileups(spec, "cpu", span16_pad=0)
+    n, m = p.n_reads, p.n_ovl
+    assert (n, m) == (want["reads"], want["overlaps"])
+    assert mk.input_digest(p) == want["input_sha256"], "the CPU generator no longer produces the pile-ups the digests were made on (torch %s there, %s here)" % (want["torch"], torch.__version__)
+    print("cfg5 share generated on the host in %.0f s" % (time.time() - t0))
+    dev = torch.device("cuda", 0)
+    row_ptr, a_span, b_span, b_flag = (t.to(dev) for t in (p.row_ptr, p.a_span, p.b_span, p.b_flag))
+    span16, max_pile, in_range = capi.pack_spans(p.row_ptr.numpy(), p.a_span.numpy(), p.rlen)
+    span16 = torch.from_numpy(span16.view(np.int32)).to(dev)
+    P = default_filter_params()
+    ctx = capi.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_reads(p.rlen, None)
+    ctx.set_pileups_packed(0, n - 1, row_ptr, a_span, b_span, b_flag, span16, max_pile, in_range, n_ovl=m, on_device=True)
+    ctx.set_min_cov(P.min_cov)
+    ctx.filter_sweep(P, fetch=True)
+    ctx.filter_hinges(P)
+    mask, cmask, _ = ctx.get_masks()
+    off, pos, typ, ish = ctx.get_annotations()
+    got = mk.result_digests(n, mask, cmask, off, pos, typ, ish)
+    for key in ("n_annotations", "n_hinges", "mask", "cmask", "repeat", "hinges"):
+        assert got[key] == want[key], "%s differs from the oracle's at full size" % key
+    ctx.close()
+
+
 def test_cfg5_share_full_size(oracle_lib, tmp_path):
     import torch
     from hinge_amd import capi, synth, synth_device
