@@ -12,7 +12,7 @@ LIB  = hinge_amd/lib/libhinge_hip.so
 BIN  = hinge_amd/bin
 HOST = hinge_amd/host
 HOSTDEPS = $(wildcard $(HOST)/*.h) include/hinge_hip.h $(LIB)
-PROGS = $(BIN)/Reads_filter $(BIN)/get_maximal_reads $(BIN)/hinging $(BIN)/consensus $(BIN)/hinge
+PROGS = $(BIN)/Reads_filter $(BIN)/get_maximal_reads $(BIN)/hinging $(BIN)/consensus $(BIN)/hinge_pipeline $(BIN)/hinge
 
 SYNTHIO = hinge_amd/lib/libhinge_synthio.so
 
@@ -30,6 +30,10 @@ $(BIN)/hinging: $(HOST)/layout_main.cpp $(HOSTDEPS)
 	mkdir -p $(BIN)
 	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
 
+$(BIN)/hinge_pipeline: $(HOST)/pipeline_main.cpp $(wildcard $(HOST)/*.cpp) $(HOSTDEPS)
+	mkdir -p $(BIN)
+	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
+
 $(BIN)/consensus: $(HOST)/consensus_main.cpp $(HOSTDEPS)
 	mkdir -p $(BIN)
 	$(HIPCC) -O2 -std=c++17 -w -pthread -o $@ $< -Lhinge_amd/lib -lhinge_hip -lz -Wl,-rpath,'$$ORIGIN/../lib'
@@ -41,7 +45,7 @@ $(BIN)/hinge: $(HOST)/hinge
 
 $(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.inc) include/hinge_hip.h
 	mkdir -p hinge_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hinge_capi.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hinge_capi.hip -ldl
 
 # test / bench tooling: fast writer of synthetic .las files (no GPU code)
 $(SYNTHIO): hinge_amd/tools_c/synth_io.c

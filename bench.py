@@ -140,6 +140,15 @@ def end_to_end(d, workload):
                 assert r.returncode == 0, r.stderr.decode()[-1000:]
             g[sub] = sorted(g_runs[sub])[1]
         differing = [s for s in E2E_FILES if not filecmp.cmp(os.path.join(tmp, "O" + s), os.path.join(tmp, "H" + s), shallow=False)]
+        # ... and the three stages in ONE process (`hinge pipeline`: one HIP start-up, one ingest, one teardown), prefix P
+        pipe_runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = subprocess.run([hinge, "pipeline", "--db", "G", "--las", "G.las", "-x", "P", "--config", "nominal.ini", "-o", "P"], cwd=tmp,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            pipe_runs.append(time.perf_counter() - t0)
+            assert r.returncode == 0, r.stderr.decode()[-1000:]
+        differing += ["pipeline:" + s for s in E2E_FILES if not filecmp.cmp(os.path.join(tmp, "O" + s), os.path.join(tmp, "P" + s), shallow=False)]
         oracle_hinges = count_pairs(os.path.join(tmp, "O.hinges.txt"))
         e2e = {
             "what": "wall clock of `hinge filter|maximal|layout` (C++ executables over libhinge_hip; .las ingest, H2D, kernels, D2H, text output) "
@@ -149,6 +158,10 @@ def end_to_end(d, workload):
             "gpu_cli_s": g,
             "gpu_cli_s_runs": g_runs,
             "gpu_cli_s_note": "median of three consecutive runs of each stage (every sample listed); the oracle runs once",
+            "pipeline_one_process_s": sorted(pipe_runs)[1],
+            "pipeline_one_process_s_runs": pipe_runs,
+            "pipeline_note": "`hinge pipeline`: the same three stages in one process (files byte-identical, compared above); reported beside the per-stage numbers, not instead",
+            "speedup_all_three_one_process": sum(t.values()) / sorted(pipe_runs)[1],
             "speedup_filter_layout": (t["filter"] + t["layout"]) / (g["filter"] + g["layout"]),
             "speedup_all_three": sum(t.values()) / sum(g.values()),
             "byte_identical": not differing,

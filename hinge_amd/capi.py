@@ -82,6 +82,9 @@ SYMBOLS = [
     ("hinge_filter_get_coverage", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64]),
     ("hinge_filter_counters", C.c_int, [_VP, _VP]),
     ("hinge_set_traces", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int, C.c_int]),
+    ("hinge_device_upload", C.c_int, [C.c_int32, _VP, C.c_int64, C.c_int64, C.POINTER(_VP)]),
+    ("hinge_device_free", C.c_int, [C.c_int32, _VP]),
+    ("hinge_set_traces_resident", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ("hinge_set_eff_reads", C.c_int, [_VP, _VP]),
     ("hinge_set_trim", C.c_int, [_VP, C.c_int]),
     ("hinge_trim_classify", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
@@ -100,6 +103,8 @@ SYMBOLS = [
     ("hinge_resolve_containment", C.c_int, [C.c_int32, _VP, C.c_int64, _VP, _VP]),
     ("hinge_sort_order_desc", C.c_int, [C.c_int32, _VP, C.c_int32, _VP]),
     ("hinge_pick_pairs", C.c_int64, [C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
+    ("hinge_comm_create", C.c_int, [C.POINTER(_VP), C.c_int32]),
+    ("hinge_comm_exchange_mask_rows", C.c_int, [C.POINTER(_VP), C.c_int32, _VP, _VP, C.c_int32]),
     ("hinge_consensus_set_db", C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int64]),
     ("hinge_consensus_run", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int64, C.c_int32]),
     ("hinge_consensus_get_contig", C.c_int, [_VP, C.c_int32, _VP, C.c_int64, C.POINTER(C.c_int64), _VP]),

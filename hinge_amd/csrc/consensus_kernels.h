@@ -57,7 +57,7 @@ struct CnsPair {                   // the two sequences of one alignment, addres
 // ---- wave storage of one lane ---------------------------------------------------------------------------------------------
 // Row D (= -2, -1, 0, 1, ...) holds the diagonals k in [lo0 - ext(D) - 1, hi0 + ext(D) + 1], ext(D) = max(D, 0) / 2, lo0 = min(0, del),
 // hi0 = max(0, del): exactly what iter_np's wave D touches, sentinels included (the reference's rows are tspace + nmax + 3 wide
-// and never read outside this range either - checked with a probe in oracle/consensus_oracle.cpp).  A cell is furthest << 8 | move.
+// and never read outside this range either - checked with a probe in the test restatement of the same loop).  A cell is furthest << 8 | move.
 struct CnsWaves {
     int* W; int w0, lo0, cap_cells;
     __device__ __forceinline__ int row_off(int D) const { const int d = D > 0 ? D : 0; return (D + 2) * w0 + 2 * (((d - 1) * (d - 1)) >> 2); }

@@ -120,6 +120,9 @@ struct hinge_ctx {
     std::vector<int> prof_kid;
 
     struct CnsState* cns = nullptr;     // `hinge consensus` (consensus_capi.inc)
+    void* comm = nullptr;               // ncclComm_t of this context among the contexts of its process (comm_capi.inc)
+    int comm_rank = -1, comm_size = 0;
+    DevBuf comm_stage;                  // all-gathered mask rows [comm_size + 1][S][2]
 };
 
 enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY,
@@ -279,10 +282,12 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
 }
 
 static void cns_release(hinge_ctx* ctx);
+static void comm_release(hinge_ctx* ctx);
 void hinge_ctx_destroy(hinge_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     cns_release(ctx);
+    comm_release(ctx);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
@@ -1598,6 +1603,7 @@ int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms) {
 
 #include "align_capi.inc"
 #include "consensus_capi.inc"
+#include "comm_capi.inc"
 
 #ifdef HINGE_K2_TRACE
 // Trace builds only (tools/k2_trace.py): a device buffer of 5 * n_items time stamps for k_mask_annotate_q20.

@@ -7,7 +7,10 @@
 
 using namespace hh;
 
-int main(int argc, char* argv[]) {
+#ifndef HINGE_STAGE_MAIN
+#define HINGE_STAGE_MAIN main
+#endif
+int HINGE_STAGE_MAIN(int argc, char* argv[]) {
     CmdLine cmdp;
     cmdp.add_string("db", 'b', "db file name", false, "");
     cmdp.add_string("las", 'l', "las file name", false, "");
@@ -84,9 +87,17 @@ int main(int argc, char* argv[]) {
     loader.pairs = !reads_to_keep.empty();   // the neighbours of the listed reads need the per-record B column
     loader.paf = fa_and_paf;
     loader.span16 = true;
+    loader.single = las_list.size() == 1;
     if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
+    if (pipeline().on && loader.shared && !pipeline().d_las_upload.joinable() && !getenv("HINGE_PIPELINE_NO_PREUPLOAD")) {
+        // `hinge pipeline`: the .las' bytes (3.5 GB on the bench set: 0.13 s from pageable memory) go to the GPU now, under this
+        // stage's kernels and text output; `hinge maximal` then finds its trace points resident
+        PipelineState& pl = pipeline();
+        const Mapped* file = &pl.part0->file;
+        pl.d_las_upload = std::thread([&pl, file] { pl.d_las_bytes = (int64_t)file->n; pl.d_las_rc = hinge_device_upload(0, file->p, (int64_t)file->n, 8, &pl.d_las); });
+    }
     std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
     ctxs[0] = gpu.ctx;
     if (n_ranks > 1) {
@@ -95,6 +106,9 @@ int main(int argc, char* argv[]) {
             if (hinge_ctx_create(r % ndev, &ctxs[(size_t)r]) != HINGE_OK) { console.error("cannot create a context on device %d", r % ndev); return 2; }
     }
     hinge_ctx* ctx = ctxs[0];
+    // one RCCL communicator over the ranks' GPUs; refused (ranks share a device, no librccl, HINGE_HOST_EXCHANGE=1): host exchanges
+    const bool use_rccl = n_ranks > 1 && hinge_comm_create(ctxs.data(), n_ranks) == HINGE_OK;
+    if (n_ranks > 1) console.info("%d ranks, mask rows %s", n_ranks, use_rccl ? "over RCCL (one all-gather per wave)" : "through the host");
     for (int r = 0; r < n_ranks; r++) {
         HH_CHECK(ctxs[(size_t)r], hinge_set_reads(ctxs[(size_t)r], n_read, db.rlen.data(), has_qv ? qvm.data() : nullptr));
         HH_CHECK(ctxs[(size_t)r], hinge_filter_set_min_cov(ctxs[(size_t)r], P.min_cov));
@@ -141,7 +155,7 @@ int main(int argc, char* argv[]) {
     // phase A of a part: ingest, upload, coverage statistics, the part's own median
     auto phase_a = [&](hinge_ctx* cx, size_t part, PartOut& o) {
         int lrc = 0;
-        o.las.reset(loader.take(part, las_list[part], db.rlen, lrc));
+        o.las.reset(loader.take(part, las_list[part], db.rlen, lrc));   // (`hinge pipeline`, single .las: the process's part - the wave that holds it is never freed, see below)
         LasPart& las = *o.las;
         if (lrc == -2) PART_FAIL(o, 2, "%s is not sorted by A read", las_list[part].c_str());
         if (lrc == -3) PART_FAIL(o, 1, "%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str());
@@ -276,8 +290,19 @@ int main(int argc, char* argv[]) {
         for (size_t k = 0; k < n_good; k++) if (outs[k].code != 0) { n_good = k; break; }
         // exchange 2: mask rows.  While part p is in hinge calling, the table holds the masks of the parts up to p and (0, 0) for
         // the later ones (filter.cpp:534 / :778-787 in a sequential loop); afterwards every context gets the rest of the wave.
+        // Ranks on distinct GPUs: ONE ncclAllGather over xGMI per wave (hinge_comm_exchange_mask_rows); ranks that share a device
+        // (HINGE_RANKS on a small box, the tests) or a ragged / failed wave: through the host.
+        const bool wave_rccl = use_rccl && nw == (size_t)n_ranks && n_good == nw;
+        std::vector<int32_t> row_lo(nw, 0), row_hi(nw, -1);
+        for (size_t k = 0; k < n_good; k++) { row_lo[k] = outs[k].r_begin; row_hi[k] = outs[k].r_end; }
+        auto rccl_rows = [&](int phase) {
+            if (hinge_comm_exchange_mask_rows(ctxs.data(), n_ranks, row_lo.data(), row_hi.data(), phase) == HINGE_OK) return true;
+            console.error("mask rows over RCCL: %s", hinge_last_error(ctxs[0]));
+            return false;
+        };
         if (n_ranks > 1) {
-            on_ranks([&](size_t k) {
+            if (wave_rccl) { if (!rccl_rows(0)) return 2; }
+            else on_ranks([&](size_t k) {
                 if (k >= n_good) return;
                 for (size_t q = 0; q < k; q++)
                     PART_CHECK(outs[k], ctxs[k], hinge_set_mask_rows(ctxs[k], outs[q].r_begin, outs[q].r_end, outs[q].mask.data()));
@@ -285,7 +310,8 @@ int main(int argc, char* argv[]) {
         }
         on_ranks([&](size_t k) { if (k < n_good && outs[k].code == 0) phase_c(ctxs[k], outs[k]); });
         if (n_ranks > 1) {
-            on_ranks([&](size_t k) {
+            if (wave_rccl) { if (!rccl_rows(1)) return 2; }
+            else on_ranks([&](size_t k) {
                 for (size_t q = k + 1; q < n_good; q++)
                     if (outs[k].code == 0) PART_CHECK(outs[k], ctxs[k], hinge_set_mask_rows(ctxs[k], outs[q].r_begin, outs[q].r_end, outs[q].mask.data()));
             });   // (ranks without a part in this - the last - wave are not used again)
@@ -296,7 +322,7 @@ int main(int argc, char* argv[]) {
             if (rc) return rc;
             write_part(w0 + k, outs[k]);
         }
-        if (w1 < las_list.size() || getenv("HINGE_SLOW_EXIT")) delete outs_heap;
+        if (w1 < las_list.size() || (getenv("HINGE_SLOW_EXIT") && !loader.shared)) delete outs_heap;
     }
     if (f_rep) fclose(f_rep);
     fclose(f_cov); fclose(f_hg); fclose(f_mask); fclose(f_cmask); fclose(f_covflag); fclose(f_selfflag);

@@ -967,6 +967,22 @@ inline void write_coverage_txt(FILE* f, int r_begin, const std::vector<int32_t>&
     }
 }
 
+// `hinge pipeline` (round 4): filter -> maximal -> layout in ONE process (host/pipeline_main.cpp includes the three stage
+// programs as functions).  What the stages then share: the HIP runtime's start-up (one hipInit instead of three: 0.15-0.3 s
+// each right after another GPU process has exited), ONE ingest of a single .las (the part is kept and handed to the later
+// stages), one process teardown.  Everything else - argv, files, exit codes - is the separate programs'.
+struct PipelineState {
+    bool on = false;
+    struct LasPart* part0 = nullptr;      // the single .las of the run, loaded once with everything any stage needs
+    std::string part0_path;
+    // its bytes on device 0 (the trace points `hinge maximal` classifies), uploaded by a helper thread while `hinge filter` works
+    void* d_las = nullptr;
+    int64_t d_las_bytes = 0;
+    int d_las_rc = HINGE_E_ARG;
+    std::thread d_las_upload;
+};
+inline PipelineState& pipeline() { static PipelineState s; return s; }
+
 // HIP runtime initialisation (80-250 ms) and the first .las part's ingest (CPU only) run side by side: the context is
 // created on a helper thread as soon as the arguments are parsed and joined right before its first use.
 struct CtxInit {
@@ -993,8 +1009,26 @@ struct PartLoader {
     bool pairs = true;   // false in `hinge filter`: see LasPart::load
     bool paf = false;    // the (single) part is a PAF file
     bool span16 = false; // `hinge filter`: also produce the 16|16 span copy (LasPart::want_span16)
-    void preload(const std::string& path, const std::vector<int32_t>& rlen) { first.reset(new LasPart()); first->want_span16 = span16; first_rc = paf ? first->load_paf(path, rlen) : first->load(path, rlen, pairs); }
-    // returns the part (ownership passes to the caller) and its load() code
+    bool shared = false; // `hinge pipeline`, single .las: the part belongs to the process, the caller must not delete it
+    void preload(const std::string& path, const std::vector<int32_t>& rlen) {
+        PipelineState& pl = pipeline();
+        if (pl.on && !paf && single) {          // one ingest for all stages: the first one loads the superset (records' B column + the 16|16 span copy)
+            if (!pl.part0 || pl.part0_path != path) {
+                LasPart* p = new LasPart();
+                p->want_span16 = true;
+                first_rc = p->load(path, rlen, true);
+                if (first_rc != 0) { first.reset(p); return; }     // (a failed load is reported by the stage as usual; nothing is kept)
+                pl.part0 = p; pl.part0_path = path;
+            } else first_rc = 0;
+            first.reset(pl.part0);
+            shared = true;
+            return;
+        }
+        first.reset(new LasPart()); first->want_span16 = span16; first_rc = paf ? first->load_paf(path, rlen) : first->load(path, rlen, pairs);
+    }
+    bool single = false; // the run has exactly one part (set by the stage before preload)
+    ~PartLoader() { if (shared) (void)first.release(); }
+    // returns the part (ownership passes to the caller - unless `shared`) and its load() code
     LasPart* take(size_t part, const std::string& path, const std::vector<int32_t>& rlen, int& rc) {
         if (part == 0 && first) { rc = first_rc; return first.release(); }
         LasPart* p = new LasPart();
@@ -1008,6 +1042,7 @@ struct PartLoader {
 // the SoA columns and the HIP runtime's own teardown: ~0.1 s of a sub-second run.  HINGE_SLOW_EXIT=1 keeps the
 // orderly path (leak checkers).
 inline int finish(hinge_ctx* ctx, PhaseTimer& tm, int code = 0) {
+    if (pipeline().on) { tm.mark("(stage end)"); hinge_ctx_destroy(ctx); return code; }   // the next stage follows in this process
     if (getenv("HINGE_SLOW_EXIT")) { hinge_ctx_destroy(ctx); return code; }
     tm.mark("(exit)");
     tm.~PhaseTimer();

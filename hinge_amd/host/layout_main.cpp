@@ -134,7 +134,10 @@ struct PackedPart {
     }
 };
 
-int main(int argc, char* argv[]) {
+#ifndef HINGE_STAGE_MAIN
+#define HINGE_STAGE_MAIN main
+#endif
+int HINGE_STAGE_MAIN(int argc, char* argv[]) {
     CmdLine cmdp;
     cmdp.add_string("db", 'b', "db file name", false, "");
     cmdp.add_string("las", 'l', "las file name", false, "");
@@ -230,6 +233,7 @@ int main(int argc, char* argv[]) {
     const int n_ranks = rank_count(las_list.size(), fa_and_paf);
     PartLoader loader;
     loader.paf = fa_and_paf;
+    loader.single = las_list.size() == 1;
     if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
     tm.mark("setup + las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
@@ -622,6 +626,6 @@ int main(int argc, char* argv[]) {
     }
     fclose(out_g1); fclose(out_g2); fclose(out_hg); fclose(out_hg2); fclose(out_greedy); fclose(out_skipped); fclose(deadend_out);
     console.info("sort and output finished");
-    if (getenv("HINGE_SLOW_EXIT")) { for (auto* p : parts) delete p; for (auto* p : packed) delete p; }
+    if (getenv("HINGE_SLOW_EXIT") || pipeline().on) { for (size_t k = 0; k < parts.size(); k++) if (!(loader.shared && k == 0)) delete parts[k]; for (auto* p : packed) delete p; }
     return finish(ctx, tm);
 }

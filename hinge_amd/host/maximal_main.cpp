@@ -8,7 +8,10 @@
 
 using namespace hh;
 
-int main(int argc, char* argv[]) {
+#ifndef HINGE_STAGE_MAIN
+#define HINGE_STAGE_MAIN main
+#endif
+int HINGE_STAGE_MAIN(int argc, char* argv[]) {
     CmdLine cmdp;
     cmdp.add_string("db", 'b', "db file name", false, "");
     cmdp.add_string("las", 'l', "las file name", false, "");
@@ -91,6 +94,7 @@ int main(int argc, char* argv[]) {
     const int n_ranks = rank_count(las_list.size(), fa_and_paf);
     PartLoader loader;
     loader.paf = fa_and_paf;
+    loader.single = las_list.size() == 1;
     if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
@@ -134,8 +138,9 @@ int main(int argc, char* argv[]) {
     std::thread cov_writer;
     auto part_work = [&](hinge_ctx* cx, size_t part, PartOut& o, bool timed) {
         int lrc = 0;
-        std::unique_ptr<LasPart> las_owner(loader.take(part, las_list[part], db.rlen, lrc));
-        LasPart& las = *las_owner;
+        const bool part_shared = loader.shared && part == 0;      // `hinge pipeline`: the process's part, not this stage's
+        struct Owner { LasPart* p; bool shared; ~Owner() { if (!shared) delete p; } } las_owner{loader.take(part, las_list[part], db.rlen, lrc), part_shared};
+        LasPart& las = *las_owner.p;
         if (lrc == -2) PART_FAIL(o, 2, "%s is not sorted by A read", las_list[part].c_str());
         if (lrc == -3) PART_FAIL(o, 1, "%s: a read name without \"/id/\" or an id outside the FASTA (the reference crashes here)", las_list[part].c_str());
         if (lrc != 0) PART_FAIL(o, -1, "get_maximal_reads: cannot read %s", las_list[part].c_str());
@@ -151,8 +156,16 @@ int main(int argc, char* argv[]) {
         auto upload_traces = [&] {
             static const uint8_t no_trace[1] = {0};   // PAF: no trace points, ProcessAlignment(trim = false)
             trace_rc = hinge_set_trim(cx, las.is_paf ? 0 : 1);
-            if (trace_rc == HINGE_OK)
-                trace_rc = hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0);
+            if (trace_rc != HINGE_OK) return;
+            PipelineState& pl = pipeline();
+            if (part_shared && pl.d_las_upload.joinable()) {       // `hinge pipeline`: uploaded while `hinge filter` ran
+                pl.d_las_upload.join();
+                if (pl.d_las_rc == HINGE_OK && pl.d_las_bytes == (int64_t)las.file.n) {
+                    trace_rc = hinge_set_traces_resident(cx, (const uint8_t*)pl.d_las, pl.d_las_bytes, las.trace_off.data(), las.tlen.data(), las.tbytes);
+                    return;
+                }
+            }
+            trace_rc = hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0);
         };
         if (!timed) { upload_traces(); PART_CHECK(o, cx, trace_rc); }
         if (timed) tm.mark("set_pileups (H2D)");

@@ -206,6 +206,13 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
  * trace_off[n_ovl] = byte offset of each overlap's trace, tlen[n_ovl] = Path.tlen (align.h:126-132).  */
 int hinge_set_traces(hinge_ctx* ctx, const uint8_t* trace, int64_t trace_bytes, const int64_t* trace_off, const int32_t* tlen, int tbytes,
                      int on_device);
+/* A raw device copy of a host buffer, made OUTSIDE any context (`hinge pipeline`: the .las of a run is uploaded once, by a helper
+ * thread, while `hinge filter` works, and `hinge maximal` - a later context - finds its trace points resident): bytes + spare
+ * zeroed bytes.  hinge_set_traces_resident: the traces are that device copy (>= 8 spare bytes behind it), the per-overlap
+ * offsets and lengths come from the host as in hinge_set_traces.                                                               */
+int hinge_device_upload(int32_t device, const void* host, int64_t bytes, int64_t spare, void** dev_out);
+int hinge_device_free(int32_t device, void* dev);
+int hinge_set_traces_resident(hinge_ctx* ctx, const uint8_t* trace_dev, int64_t trace_bytes, const int64_t* trace_off, const int32_t* tlen, int tbytes);
 /* effective_start / effective_end of every read (the .mas file: maximal.cpp:524-531, hinging.cpp:867-874) */
 int hinge_set_eff_reads(hinge_ctx* ctx, const int32_t* eff);
 /* ProcessAlignment's `trim` argument (maximal.cpp:799-804, hinging.cpp:542-549): 1 (default) with a DAZZ_DB / .las,
@@ -281,6 +288,19 @@ int hinge_filter_hinges_async(hinge_ctx* ctx, const hinge_filter_params* p);
  * hinge calling touches 1-2 % of the reads through chains of dependent look-ups, ~19 us per kernel however small the part.   */
 int hinge_filter_hinges_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p);
 int hinge_filter_check(hinge_ctx* ctx);
+
+/* ---- RCCL between the contexts of one process (round 4) ---------------------------------------------------------------------
+ * The executables run a --mlas set on one rank (host thread + context) per visible GPU; what the
+ * reference's sequential part loop carries from part to part on the device side - the mask table, filter.cpp:534 / :778-787 -
+ * then moves between the GPUs as ONE ncclAllGather over xGMI per wave instead of n (n - 1) host-staged copies.
+ * hinge_comm_create: one communicator over the n contexts' devices (ncclCommInitAll).  HINGE_E_DEVICE when two contexts share
+ * a device (RCCL takes one rank per device), librccl.so cannot be loaded, or HINGE_HOST_EXCHANGE=1: the caller then keeps
+ * exchanging through the host (hinge_set_mask_rows).
+ * hinge_comm_exchange_mask_rows: context k owns rows [lo[k], hi[k]] of its mask table (hi < lo: none).  phase 0: the all-gather,
+ * after which context k's table also holds the rows of the contexts BEFORE it (the state in which part k's hinges are called);
+ * phase 1: the rows of the contexts after it (no further collective).  Synchronises every context's stream.                   */
+int hinge_comm_create(hinge_ctx** ctxs, int32_t n);
+int hinge_comm_exchange_mask_rows(hinge_ctx** ctxs, int32_t n, const int32_t* lo, const int32_t* hi, int32_t phase);
 
 /* ---- hinge consensus (consensus/consensus.cpp:77-288) --------------------------------------------------
  * The per-contig pile-up vote over base-level realignments.  Replaces, for the alignments the caller selected:

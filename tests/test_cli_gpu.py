@@ -237,3 +237,24 @@ def test_cli_mlas_on_several_ranks(oracle_lib, tmp_path, ranks):
     assert 0 < sum(1 for _ in open(os.path.join(wd_o, "G.max"))) < d.n_reads
     assert os.path.getsize(os.path.join(wd_o, "G.edges.hinges")) > 0
     assert sum((len(l.split()) - 1) // 2 for l in open(os.path.join(wd_o, "G.hinges.txt"))) > 0
+
+
+@pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("long_repeat", False), ("chimera", False), ("tiny_mlas", True)])
+def test_hinge_pipeline_in_one_process(datasets, oracle_lib, tmp_path, name, mlas):
+    """`hinge pipeline` = filter, maximal and layout in ONE process (one HIP start-up, one ingest of a single .las, the part handed
+    from stage to stage): every file byte-identical to the oracle's - i.e. to the three separate runs, which the case list above
+    holds to the same files.  A failing first stage ends the run with that stage's exit code."""
+    src, _ = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    for wd in (wd_o, wd_h):
+        write_ini(os.path.join(wd, "v.ini"))
+    assert _oracle(oracle_lib, wd_o, mlas, "v.ini") == [0, 0, 0]
+    las = ["--las", "G", "--mlas"] if mlas else ["--las", "G.las"]
+    r = subprocess.run([HINGE, "pipeline", "--db", "G"] + las + ["-x", "G", "--config", "v.ini", "-o", "G"], cwd=wd_h, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad
+    # no config file: `hinge filter` returns 1 ("Can't load"), and so does the pipeline, before any later stage runs
+    r = subprocess.run([HINGE, "pipeline", "--db", "G"] + las + ["-x", "Q", "--config", "missing.ini", "-o", "Q"], cwd=wd_h, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 1 and not os.path.exists(os.path.join(wd_h, "Q.max"))
