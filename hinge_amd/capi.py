@@ -82,9 +82,6 @@ SYMBOLS = [
     ("hinge_filter_get_coverage", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64]),
     ("hinge_filter_counters", C.c_int, [_VP, _VP]),
     ("hinge_set_traces", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int, C.c_int]),
-    ("hinge_device_upload", C.c_int, [C.c_int32, _VP, C.c_int64, C.c_int64, C.POINTER(_VP)]),
-    ("hinge_device_free", C.c_int, [C.c_int32, _VP]),
-    ("hinge_set_traces_resident", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ("hinge_set_eff_reads", C.c_int, [_VP, _VP]),
     ("hinge_set_trim", C.c_int, [_VP, C.c_int]),
     ("hinge_trim_classify", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),

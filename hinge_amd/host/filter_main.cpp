@@ -91,13 +91,6 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
     if (!las_list.empty() && n_ranks == 1) loader.preload(las_list[0], db.rlen);
     tm.mark("las ingest (part 1) || HIP init");
     if (gpu.join() != HINGE_OK) { console.error("no usable MI355X / HIP device: this build has no CPU path"); return 2; }
-    if (pipeline().on && loader.shared && !pipeline().d_las_upload.joinable() && !getenv("HINGE_PIPELINE_NO_PREUPLOAD")) {
-        // `hinge pipeline`: the .las' bytes (3.5 GB on the bench set: 0.13 s from pageable memory) go to the GPU now, under this
-        // stage's kernels and text output; `hinge maximal` then finds its trace points resident
-        PipelineState& pl = pipeline();
-        const Mapped* file = &pl.part0->file;
-        pl.d_las_upload = std::thread([&pl, file] { pl.d_las_bytes = (int64_t)file->n; pl.d_las_rc = hinge_device_upload(0, file->p, (int64_t)file->n, 8, &pl.d_las); });
-    }
     std::vector<hinge_ctx*> ctxs((size_t)n_ranks, nullptr);
     ctxs[0] = gpu.ctx;
     if (n_ranks > 1) {

@@ -975,11 +975,6 @@ struct PipelineState {
     bool on = false;
     struct LasPart* part0 = nullptr;      // the single .las of the run, loaded once with everything any stage needs
     std::string part0_path;
-    // its bytes on device 0 (the trace points `hinge maximal` classifies), uploaded by a helper thread while `hinge filter` works
-    void* d_las = nullptr;
-    int64_t d_las_bytes = 0;
-    int d_las_rc = HINGE_E_ARG;
-    std::thread d_las_upload;
 };
 inline PipelineState& pipeline() { static PipelineState s; return s; }
 

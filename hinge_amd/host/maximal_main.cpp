@@ -156,16 +156,8 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
         auto upload_traces = [&] {
             static const uint8_t no_trace[1] = {0};   // PAF: no trace points, ProcessAlignment(trim = false)
             trace_rc = hinge_set_trim(cx, las.is_paf ? 0 : 1);
-            if (trace_rc != HINGE_OK) return;
-            PipelineState& pl = pipeline();
-            if (part_shared && pl.d_las_upload.joinable()) {       // `hinge pipeline`: uploaded while `hinge filter` ran
-                pl.d_las_upload.join();
-                if (pl.d_las_rc == HINGE_OK && pl.d_las_bytes == (int64_t)las.file.n) {
-                    trace_rc = hinge_set_traces_resident(cx, (const uint8_t*)pl.d_las, pl.d_las_bytes, las.trace_off.data(), las.tlen.data(), las.tbytes);
-                    return;
-                }
-            }
-            trace_rc = hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0);
+            if (trace_rc == HINGE_OK)
+                trace_rc = hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0);
         };
         if (!timed) { upload_traces(); PART_CHECK(o, cx, trace_rc); }
         if (timed) tm.mark("set_pileups (H2D)");

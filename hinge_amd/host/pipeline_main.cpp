@@ -3,7 +3,9 @@
 // (demo/ecoli_demo/run.sh:21-25 runs them as three).  The stages are the very programs of filter_main.cpp, maximal_main.cpp
 // and layout_main.cpp, compiled in as functions: same files, byte for byte (tests/test_cli_gpu.py); what one process saves is
 // two of the three HIP start-ups and process teardowns (0.3-0.45 s each) and two of the three ingests of
-// a single .las (the part is loaded once, with what every stage needs, and handed on).  The three separate executables stay as
+// a single .las (the part is loaded once, with what every stage needs, and handed on).  Measured and not kept: the .las' bytes
+// uploaded by a helper thread while `hinge filter` works, so that `hinge maximal` finds its trace points resident - maximal
+// 247 -> 173 ms, filter 374 -> 423 ms (the 3.5 GB copy from pageable memory competes with filter's text output), same total.  The three separate executables stay as
 // they are.  Exit code: the first stage's that is not 0.
 #include <fstream>
 #include <functional>
@@ -51,7 +53,6 @@ int main(int argc, char* argv[]) {
     int rc = run(stage_filter::filter_stage, false);
     if (rc == 0) rc = run(stage_maximal::maximal_stage, false);
     if (rc == 0) rc = run(stage_layout::layout_stage, true);
-    if (hh::pipeline().d_las_upload.joinable()) hh::pipeline().d_las_upload.join();   // (only still running if a stage failed early)
     fflush(nullptr);
     if (!getenv("HINGE_SLOW_EXIT")) _exit(rc);   // (as the stages do on their own: no unmapping of the .las, no runtime teardown)
     return rc;

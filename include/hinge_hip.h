@@ -206,13 +206,6 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
  * trace_off[n_ovl] = byte offset of each overlap's trace, tlen[n_ovl] = Path.tlen (align.h:126-132).  */
 int hinge_set_traces(hinge_ctx* ctx, const uint8_t* trace, int64_t trace_bytes, const int64_t* trace_off, const int32_t* tlen, int tbytes,
                      int on_device);
-/* A raw device copy of a host buffer, made OUTSIDE any context (`hinge pipeline`: the .las of a run is uploaded once, by a helper
- * thread, while `hinge filter` works, and `hinge maximal` - a later context - finds its trace points resident): bytes + spare
- * zeroed bytes.  hinge_set_traces_resident: the traces are that device copy (>= 8 spare bytes behind it), the per-overlap
- * offsets and lengths come from the host as in hinge_set_traces.                                                               */
-int hinge_device_upload(int32_t device, const void* host, int64_t bytes, int64_t spare, void** dev_out);
-int hinge_device_free(int32_t device, void* dev);
-int hinge_set_traces_resident(hinge_ctx* ctx, const uint8_t* trace_dev, int64_t trace_bytes, const int64_t* trace_off, const int32_t* tlen, int tbytes);
 /* effective_start / effective_end of every read (the .mas file: maximal.cpp:524-531, hinging.cpp:867-874) */
 int hinge_set_eff_reads(hinge_ctx* ctx, const int32_t* eff);
 /* ProcessAlignment's `trim` argument (maximal.cpp:799-804, hinging.cpp:542-549): 1 (default) with a DAZZ_DB / .las,
