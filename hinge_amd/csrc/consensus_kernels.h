@@ -286,13 +286,99 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_vote(CnsSeqs SB, const CnsAln
     });
 }
 
+// ---- the vote with the counters in LDS (the default) -----------------------------------------------------------------------
+// The contigs are cut into tiles of CNS_TILE(tspace) positions, a multiple of tspace: a segment never straddles a multiple of
+// tspace (computeTracePTS cuts there), so every vote of a segment lands in ITS tile - except an inserted base behind the
+// segment's last A base, whose position is the first one of the next tile: the halo slot, written to `halo` and added by
+// k_cns_call.  One workgroup per tile: the tile's segments (binned by k_cns_tile_count / k_cns_tile_fill) vote with LDS
+// atomics into 16|16-packed counters (a contig with 65 536+ voting alignments takes the global-atomics kernel above), then
+// the workgroup stores its tile's nine planes with plain, coalesced stores: no global atomic, no memset of the planes.
+__host__ __device__ inline int cns_tile_len(int tspace) { return tspace >= 2048 ? tspace : (2048 / tspace) * tspace; }
+constexpr int CNS_TILE_MAX = 4096;       // positions a tile may have (LDS: 5 words per position)
+
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_tile_count(const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, int n_seg, const int* __restrict__ tile_base,
+                                                              int tile, unsigned* __restrict__ tile_cnt) {
+    const int s = blockIdx.x * CNS_BLOCK + threadIdx.x;
+    if (s >= n_seg) return;
+    const CnsSeg g = segs[s];
+    atomicAdd(&tile_cnt[tile_base[alns[g.aln].a] + g.a0 / tile], 1u);
+}
+// tile_ptr = exclusive scan of the counts (k_cns_scan); cursor starts as a copy of it
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_tile_fill(const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, int n_seg, const int* __restrict__ tile_base,
+                                                             int tile, unsigned* __restrict__ cursor, int* __restrict__ order) {
+    const int s = blockIdx.x * CNS_BLOCK + threadIdx.x;
+    if (s >= n_seg) return;
+    const CnsSeg g = segs[s];
+    order[atomicAdd(&cursor[tile_base[alns[g.aln].a] + g.a0 / tile], 1u)] = s;
+}
+
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_vote_tiles(CnsSeqs SB, const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, const int* __restrict__ indels,
+                                                              const int* __restrict__ n_indel, const int* __restrict__ col_base, const CnsCols* __restrict__ cols,
+                                                              const long long* __restrict__ cbase, const int* __restrict__ tile_base, const int* __restrict__ contig_of_tile,
+                                                              const unsigned* __restrict__ tile_ptr, const int* __restrict__ order, int tile, int* __restrict__ counts,
+                                                              long long plane, int* __restrict__ halo) {
+    extern __shared__ unsigned cnt_lds[];            // [tile + 1][5]: A|C, G|T, '-', iA|iC, iG|iT (16 bits each)
+    const int t = blockIdx.x;
+    const int cg = contig_of_tile[t];
+    const int p0 = (t - tile_base[cg]) * tile;       // first position of the tile in its contig
+    const long long base = cbase[cg];
+    const int alen = (int)(cbase[cg + 1] - base);
+    const int np = min(tile, alen - p0);
+    for (int x = threadIdx.x; x < (tile + 1) * 5; x += CNS_BLOCK) cnt_lds[x] = 0u;
+    __syncthreads();
+    const unsigned s_lo = tile_ptr[t], s_hi = tile_ptr[t + 1];
+    const unsigned char* __restrict__ bbps = SB.bps;
+    for (unsigned x = s_lo + threadIdx.x; x < s_hi; x += CNS_BLOCK) {
+        const int s = order[x];
+        const CnsSeg g = segs[s];
+        const CnsAln al = alns[g.aln];
+        const CnsCols c = cols[g.aln];
+        const long long boff = SB.boff[al.b];
+        auto Bb = [&](int j1) { return al.comp ? 3 - cns_base(bbps, boff, al.blen - j1) : cns_base(bbps, boff, j1 - 1); };
+        auto vote = [&](int pos, int slot) {         // slot 0-3 aligned base, 4 '-', 5-8 inserted base
+            const int w = slot < 4 ? (slot >> 1) : slot == 4 ? 2 : 3 + ((slot - 5) >> 1);
+            const unsigned inc = (slot < 4 ? (slot & 1) : slot == 4 ? 0 : ((slot - 5) & 1)) ? 0x10000u : 1u;
+            atomicAdd(&cnt_lds[(pos - p0) * 5 + w], inc);
+        };
+        int col = col_base[s];
+        if (col >= c.end || col + g.m + g.out_cap < c.start) continue;
+        cns_walk(g, indels + g.out_off, n_indel[s], [&](int kind, int i, int j, int cnt) {
+            if (kind == 0) {
+                const int lo = c.start > col ? c.start - col : 0;
+                const int hi = c.end - col < cnt ? c.end - col : cnt;
+                for (int u = lo; u < hi; u++) vote(i - 1 + u, Bb(j + u));
+                col += cnt;
+            } else {
+                if (col >= c.start && col < c.end) vote(i - 1, kind == 1 ? 5 + Bb(j) : 4);
+                col += 1;
+            }
+            return col < c.end;
+        });
+    }
+    __syncthreads();
+    int* __restrict__ out = counts + base + p0;
+    for (int p = threadIdx.x; p < np; p += CNS_BLOCK) {
+        const unsigned w0 = cnt_lds[p * 5], w1 = cnt_lds[p * 5 + 1], w2 = cnt_lds[p * 5 + 2], w3 = cnt_lds[p * 5 + 3], w4 = cnt_lds[p * 5 + 4];
+        out[p] = (int)(w0 & 0xffff); out[plane + p] = (int)(w0 >> 16);
+        out[2 * plane + p] = (int)(w1 & 0xffff); out[3 * plane + p] = (int)(w1 >> 16);
+        out[4 * plane + p] = (int)(w2 & 0xffff);
+        out[5 * plane + p] = (int)(w3 & 0xffff); out[6 * plane + p] = (int)(w3 >> 16);
+        out[7 * plane + p] = (int)(w4 & 0xffff); out[8 * plane + p] = (int)(w4 >> 16);
+    }
+    if (threadIdx.x < 4) {   // the halo slot: inserted bases in front of the NEXT tile's first position
+        const unsigned w = cnt_lds[tile * 5 + 3 + (threadIdx.x >> 1)];
+        halo[(long long)t * 4 + threadIdx.x] = (int)((threadIdx.x & 1) ? (w >> 16) : (w & 0xffff));
+    }
+}
+
 struct CnsStats { long long sum_cov; int good, insertions, deletions, low_cov, clen, pad; };
 
 // one thread per contig position (consensus.cpp:228-270): packed = count | c0 << 8 | c1 << 16; per-block character counts
 constexpr int CNS_CALL_ITEMS = 8;   // positions per thread in k_cns_call / k_cns_emit (a block covers CNS_BLOCK * CNS_CALL_ITEMS)
 __global__ __launch_bounds__(CNS_BLOCK) void k_cns_call(CnsSeqs SA, const int* __restrict__ counts, long long plane, long long n_pos,
                                                         const int* __restrict__ contig_of_block, const long long* __restrict__ cbase,
-                                                        unsigned* __restrict__ packed, unsigned* __restrict__ block_sum, CnsStats* __restrict__ stats) {
+                                                        unsigned* __restrict__ packed, unsigned* __restrict__ block_sum, CnsStats* __restrict__ stats,
+                                                        const int* __restrict__ halo /*nullptr: the global-atomics vote*/, const int* __restrict__ tile_base, int tile) {
     // blocks never straddle contigs: block b works on contig contig_of_block[b], positions from its own first position on
     __shared__ int red[8];
     __shared__ long long redl;
@@ -315,6 +401,11 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_call(CnsSeqs SA, const int* _
         for (int b = 0; b < 5; b++) sc[b] = counts[(long long)b * plane + gp];
 #pragma unroll
         for (int b = 0; b < 4; b++) ib[b] = counts[(long long)(5 + b) * plane + gp];
+        if (halo && j > 0 && j % tile == 0) {        // inserted bases the previous tile's segments put in front of this position
+            const int* __restrict__ h = halo + (long long)(tile_base[cg] + (int)(j / tile) - 1) * 4;
+#pragma unroll
+            for (int b = 0; b < 4; b++) ib[b] += h[b];
+        }
         const int depth = sc[0] + sc[1] + sc[2] + sc[3] + sc[4];
         const int iscore = ib[0] + ib[1] + ib[2] + ib[3];
         sum += depth;
