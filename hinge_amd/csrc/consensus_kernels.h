@@ -46,12 +46,34 @@ __device__ __forceinline__ int cns_base(const unsigned char* __restrict__ bps, l
     const unsigned b = bps[boff + (p >> 2)];
     return (int)((b >> (6 - 2 * (p & 3))) & 3u);
 }
+// 16 consecutive bases of a packed sequence as one word, the FIRST base in the top two bits: two aligned 32-bit loads around
+// the (byte-unaligned) start, composed big-endian.  Reads up to 8 bytes behind the last base's byte (the .bps copy has spare bytes).
+__device__ __forceinline__ unsigned cns_window(const unsigned char* __restrict__ bps, long long boff, int x) {
+    const unsigned long long at = (unsigned long long)(bps + boff + (x >> 2));
+    const unsigned* __restrict__ q = reinterpret_cast<const unsigned*>(at & ~3ull);
+    const unsigned lo = q[0], hi = q[1];
+    const unsigned long long be = ((unsigned long long)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
+    return (unsigned)((be << (8u * (unsigned)(at & 3ull) + 2u * (unsigned)(x & 3))) >> 32);
+}
 struct CnsPair {                   // the two sequences of one alignment, addressed as the reference's aseq / bseq
     const unsigned char* abps; long long aoff;
     const unsigned char* bbps; long long boff;
     int comp, blen;
     __device__ __forceinline__ int A(int x) const { return cns_base(abps, aoff, x); }
     __device__ __forceinline__ int B(int x) const { return comp ? 3 - cns_base(bbps, boff, blen - 1 - x) : cns_base(bbps, boff, x); }
+    // bases x .. x + 15 of aseq / bseq, first base on top (what lies behind a sequence's end is whatever follows it in memory: callers bound their use)
+    __device__ __forceinline__ unsigned winA(int x) const { return cns_window(abps, aoff, x); }
+    __device__ __forceinline__ unsigned winB(int x) const {
+        if (!comp) return cns_window(bbps, boff, x);
+        // the complemented strand: bseq[x + t] = 3 - read[blen - 1 - x - t]: the read's bases p - 15 .. p (p = blen - 1 - x), reversed and complemented
+        const int p = blen - 1 - x;
+        unsigned v;
+        if (p >= 15) v = cns_window(bbps, boff, p - 15);
+        else { v = 0; for (int t = 0; t <= p; t++) v |= (unsigned)cns_base(bbps, boff, t) << (2 * (p - t)); }   // (near the read's first base: bases 0 .. p at the bottom)
+        v = __brev(v);                                                   // group order reversed, and the two bits of every group
+        v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);         // ... swapped back
+        return ~v;
+    }
 };
 
 // ---- wave storage of one lane ---------------------------------------------------------------------------------------------
@@ -101,7 +123,15 @@ __device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N
             const int i = M - k;
             const int lim = N < i ? N : i;
             // (j >= 0 always: every diagonal of wave D is reachable from (0, 0) - the oracle counts the exceptions: none)
-            while (j < lim && j >= 0 && S.B(b0 + j) == S.A(a0 + j + k)) j++;
+            // the slide, 16 bases per step: XOR of the two packed windows, the leading equal pairs counted
+            if (j >= 0)
+                while (j < lim) {
+                    const unsigned x = S.winA(a0 + j + k) ^ S.winB(b0 + j);
+                    const int eq = x ? (__clz((int)x) >> 1) : 16;
+                    const int room = lim - j;
+                    j += eq < room ? eq : room;
+                    if (eq < 16) break;
+                }
             F0[k] = (int)((unsigned)j << 8) | (hc & 0xff);
             return j;
         };
