@@ -245,6 +245,8 @@ def main():
     # every block gets the same number of read ids (the largest block's over all ranks and parts; the ids behind a block's
     # reads are reads of length 0 without overlaps), so the mask tables are exchanged by in-place all-gathers
     batch, ctxs = resident_batch(parts, P, dev, gather_groups=args.gather_groups, pad=int(os.environ.get("HINGE_BENCH_PAD", "0")))
+    if os.environ.get("HINGE_TEST_CORRUPT_GATHER", "0") == "1":      # tests/test_dist_gpu.py: the assertions below must catch a broken exchange 2
+        batch.after_gather = batch.corrupt_foreign_rows
     S = batch.S
     part_ovl = [rp.n_ovl for rp in parts]
     part_reads = [rp.n_reads for rp in parts]
@@ -264,9 +266,12 @@ def main():
     # rank reports a full buffer ---------------------------------------------------------------------------------------
     for p, ctx in enumerate(ctxs):
         lo = batch.id_base(p)
-        ctx.filter_stats(P)
-        ctx.filter_median(P, lo, lo + S - 1, fetch=True)
-        ctx.filter_mask_annotate(P)
+        if batch.one_sweep:
+            ctx.filter_sweep(P, fetch=True)          # (regrows the annotation buffer and repeats the pass when it overflows)
+        else:
+            ctx.filter_stats(P)
+            ctx.filter_median(P, lo, lo + S - 1, fetch=True)
+            ctx.filter_mask_annotate(P)
         ctx.filter_hinges(P)
     batch.settle()
     for _ in range(args.warmup):

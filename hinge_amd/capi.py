@@ -52,6 +52,7 @@ SYMBOLS = [
     ("hinge_set_pileups_packed", C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_uint32, C.c_int, C.c_int]),
     ("hinge_span16_pad", C.c_int, []),
     ("hinge_get_pileup_facts", C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    ("hinge_set_pile_bins", C.c_int, [_VP, C.c_int32, _VP, C.c_int]),
     ("hinge_attach_mask_table", C.c_int, [_VP, _VP]),
     ("hinge_attach_mean_cov", C.c_int, [_VP, _VP]),
     ("hinge_set_mask_rows", C.c_int, [_VP, C.c_int32, C.c_int32, _VP]),
@@ -247,6 +248,11 @@ class Context:
         self.r_begin, self.r_end = int(r_begin), int(r_end)
         self._ck(self.lib.hinge_set_pileups_packed(self.h, r_begin, r_end, int(n_ovl), _ptr(row_ptr), _ptr(a_span), _ptr(b_span), _ptr(b_flag),
                                                    _ptr(span16), int(max_pile), 1 if spans_in_range else 0, 1 if on_device else 0))
+
+    def set_pile_bins(self, nbins, reso: int = 40, on_device: bool = False):
+        """The per-read bin counts of the pile-ups just set (pile_bins()): the one-sweep pass then launches no k_cov_stats at all."""
+        self._keep.append(nbins)
+        self._ck(self.lib.hinge_set_pile_bins(self.h, int(reso), _ptr(nbins), 1 if on_device else 0))
 
     def pileup_facts(self):
         """(largest pile-up, every span inside its read) of the current part."""
@@ -614,6 +620,31 @@ def pack_spans(row_ptr: np.ndarray, a_span: np.ndarray, rlen: np.ndarray):
         span16 = np.zeros(n + span16_pad(), np.uint32)
         span16[:n] = a_span[:, 0].astype(np.uint32) | (a_span[:, 1].astype(np.uint32) << np.uint32(16))
     return span16, min(max_pile, 0x7FFFFFFF), in_range
+
+
+def pile_bins(row_ptr: np.ndarray, a_span: np.ndarray, rlen: np.ndarray, reso: int = 40) -> np.ndarray:
+    """What an ingest hands to set_pile_bins: per read of the block the bins of its plain coverage profile (0 for an empty pile-up,
+    -1 for a coordinate outside [0, rlen] or 65 536+ overlaps).  numpy restatement of LasPart::finish_facts (host_common.h)."""
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    a_span = np.asarray(a_span, dtype=np.int32).reshape(-1, 2)
+    counts = np.diff(row_ptr)
+    nr = len(counts)
+    out = np.zeros(nr, np.int32)
+    if a_span.shape[0] == 0:
+        return out
+    end = int(row_ptr[-1])                    # (row_ptr may be a slice of a larger table with absolute offsets)
+    mx = np.maximum(a_span[:end, 0], a_span[:end, 1]).astype(np.int64)
+    mn = np.minimum(a_span[:end, 0], a_span[:end, 1]).astype(np.int64)
+    if end == int(row_ptr[0]):
+        return out
+    has = counts > 0
+    starts = row_ptr[:-1][has]
+    rmx = np.maximum.reduceat(mx, starts)
+    rmn = np.minimum.reduceat(mn, starts)
+    rl = np.asarray(rlen, dtype=np.int64)[:nr][has]
+    ok = (rmn >= 0) & (rmx <= rl) & (counts[has] < 65536)
+    out[has] = np.where(ok, rmx // reso + 2, -1).astype(np.int32)
+    return out
 
 
 def pick_pairs(row_ptr, a_span, b_span, b_flag, lo: int, hi: int, accept_a=None, accept_b=None, self_before=None,

@@ -36,6 +36,18 @@ constexpr int ST_NO_LONG_READ = 16;
 constexpr int ST_MEDIAN_RANGE = 32;   // sharded median: a mean coverage outside [0, MED_BINS), the histogram exchange cannot be used
 constexpr int ST_REDO_CAP = 64;       // one-sweep pass: the guard-band list is full (cannot happen: it has room for every read)
 
+// Publication before a ticket (k_median_hist, k_spec_predict): everything a workgroup publishes before it takes its ticket is a
+// device-scope ATOMIC (fire-and-forget adds / atomic stores, performed at the device's coherence point), so what the protocol needs
+// is only that they are acknowledged first.  On gfx9 / CDNA non-returning global atomics count on vmcnt: `s_waitcnt vmcnt(0)`
+// is that acknowledgement, and it is NOT an L2 write-back + invalidate like __threadfence() (~1 us per workgroup, serialised
+// per XCD: 281 vs 32 us on a 2 048-workgroup sweep).  It is not a formal release: a PLAIN store published this
+// way would need the fence - keep such data atomic.  Other targets (vscnt on gfx10+) get the fence.
+#if defined(__gfx90a__) || defined(__gfx940__) || defined(__gfx941__) || defined(__gfx942__) || defined(__gfx950__)
+#define HINGE_ATOMICS_ACKNOWLEDGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define HINGE_ATOMICS_ACKNOWLEDGED() __threadfence()
+#endif
+
 // ---- the one-sweep pass (round 4) -----------------------------------------------------------------------------------
 // filter.cpp needs the whole part's median coverage (a GLOBAL BARRIER, filter.cpp:642-678) before it can cut a single mask:
 // MIN_COV = max(MIN_COV, cov_est / 3).  Rounds 1-3 therefore swept every pile-up twice (k_cov_stats for the means, then K2).
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(256) void k_median_hist(MedianHistBatch B, int est_
     // for their acknowledgement orders them before the ticket.  NOT __threadfence(): a release fence at device scope writes
     // back and invalidates the XCD's whole L2 (~1 us, serialised per XCD): 64 blocks doing that cost this kernel 2.5 of its
     // 19 us, and 2 048 workgroups doing it inside k_cov_stats (a fused variant, round 3) took that sweep from 32 to 281 us.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HINGE_ATOMICS_ACKNOWLEDGED();
     __syncthreads();
     if (tid == 0) {   // ONE returning atomic publishes this block and tells the last one everything it needs:
                       // bits 0-39 valid values, 40-51 blocks done, 52-63 blocks that saw an out-of-range value
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(SPEC_BLOCK) void k_spec_predict(SpecBatch B, int re
             if (l32 == 0) __hip_atomic_store(&A.sample[k], mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see k_median_hist: the stores above are performed at device scope)
+    HINGE_ATOMICS_ACKNOWLEDGED();   // (see k_median_hist: the stores above are performed at device scope)
     __syncthreads();
     if (tid == 0) s_last = (atomicAdd(A.ticket, 1u) == gx - 1) ? 1u : 0u;
     for (int b = tid; b < MED_BINS; b += SPEC_BLOCK) hist[b] = 0;

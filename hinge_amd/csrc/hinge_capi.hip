@@ -522,6 +522,16 @@ int hinge_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+int hinge_set_pile_bins(hinge_ctx* ctx, int32_t reso, const int32_t* nbins, int on_device) {
+    if (!ctx || reso <= 0 || !nbins || ctx->r_end < ctx->r_begin || !ctx->nbins0.p) return fail(ctx, HINGE_E_ARG, "hinge_set_pile_bins: bad arguments (call hinge_set_pileups first)");
+    CK(hipSetDevice(ctx->device));
+    const size_t nr = (size_t)(ctx->r_end - ctx->r_begin + 1);
+    CK(hipMemcpyAsync((int*)ctx->nbins0.p + ctx->r_begin, nbins, sizeof(int) * nr, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (!on_device) CK(hipStreamSynchronize(ctx->stream));
+    ctx->nbins0_reso = reso;
+    return HINGE_OK;
+}
+
 int hinge_set_mask_rows(hinge_ctx* ctx, int32_t r0, int32_t r1, const int32_t* rows) {
     if (!ctx || !ctx->mask || !rows || r0 < 0 || r1 >= ctx->n_reads || r1 < r0) return fail(ctx, HINGE_E_ARG, "hinge_set_mask_rows: bad arguments");
     CK(hipSetDevice(ctx->device));
@@ -1367,9 +1377,21 @@ static int same_device_and_stream(hinge_ctx** ctxs, int32_t n, int max_n, const 
             return fail(ctxs[0], HINGE_E_ARG, (std::string(who) + ": the contexts must share one device and one stream").c_str());
     return HINGE_OK;
 }
+// every context of a batched launch must have what the kernel dereferences (a null table pointer faults on the device)
+static int batch_parts_ready(hinge_ctx** ctxs, int32_t n, const char* who) {
+    for (int k = 0; k < n; k++) {
+        hinge_ctx* c = ctxs[k];
+        if (c->r_end < c->r_begin || !c->row_ptr.p) return fail(ctxs[0], HINGE_E_ARG, (std::string(who) + ": a context has no pile-ups set").c_str());
+        if (!c->mask) return fail(ctxs[0], HINGE_E_ARG, (std::string(who) + ": a context has no mask table (hinge_set_reads / hinge_attach_mask_table)").c_str());
+        if (!c->anno_buf.p || !c->anno_off.p || !c->anno_cnt.p || !c->work_list.p) return fail(ctxs[0], HINGE_E_ARG, (std::string(who) + ": a context has no annotations yet (run the mask / annotate pass first)").c_str());
+    }
+    return HINGE_OK;
+}
+// (batched kernels record their HIP-event time on the batch's FIRST context: hinge_profile_report of the others does not include them)
 int hinge_filter_hinges_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filter_params* p) {
     int rc = same_device_and_stream(ctxs, n, HINGE_BATCH_MAX, "hinge_filter_hinges_batch_async");
     if (rc) return rc;
+    if ((rc = batch_parts_ready(ctxs, n, "hinge_filter_hinges_batch_async"))) return rc;
     hinge_ctx* ctx = ctxs[0];
     if ((rc = check_params(ctx, p))) return rc;
     CK(hipSetDevice(ctx->device));

@@ -358,7 +358,7 @@ class PartBatch:
         self.means = [torch.full((self.world * len(g) * self.S,), MEAN_SENTINEL, dtype=torch.int32, device=device) for g in self.groups]
         self.hist = torch.zeros((self.R, 4096 + 2), dtype=torch.int32, device=device)
         self.backends: List[Optional[object]] = [None] * self.R
-        self._corrupt = os.environ.get("HINGE_TEST_CORRUPT_GATHER", "0") == "1"
+        self.after_gather = None     # test rigs only (bench.py's fault injection): called with the group index after exchange 2; never set by product code
         self.one_sweep = os.environ.get("HINGE_ONE_SWEEP", "1") != "0"     # 0: the two-sweep pass of rounds 1-3 (k_cov_stats first)
 
     # ---- id space ---------------------------------------------------------------------------------------------
@@ -423,8 +423,8 @@ class PartBatch:
             for gi, g in enumerate(self.groups):
                 if pending[gi] is not None:
                     pending[gi].wait()
-                if self._corrupt:
-                    self._corrupt_foreign_rows(gi)
+                if self.after_gather is not None:
+                    self.after_gather(gi)
                 B[g[0]].hinges_batch([B[p] for p in g])
             return
         if not self.collectives:              # one rank: no exchange; the parts only share their launches
@@ -472,15 +472,17 @@ class PartBatch:
         for gi, g in enumerate(self.groups):
             if pending[gi] is not None:
                 pending[gi].wait()
-            if self._corrupt:                 # test hook: a broken exchange 2 must not go unnoticed (tests/test_dist_gpu.py)
-                self._corrupt_foreign_rows(gi)
+            if self.after_gather is not None:   # (fault injection of the test rig: a broken exchange 2 must not go unnoticed, tests/test_dist_gpu.py)
+                self.after_gather(gi)
             if batched:
                 B[g[0]].hinges_batch([B[p] for p in g])
             else:
                 for p in g:
                     B[p].hinges()
 
-    def _corrupt_foreign_rows(self, gi: int) -> None:
+    def corrupt_foreign_rows(self, gi: int) -> None:
+        """Fault injection for test rigs (bench.py sets `after_gather` to this under HINGE_TEST_CORRUPT_GATHER=1): zero the other
+        ranks' mask rows of gather group gi, as a broken all-gather would leave them."""
         J = len(self.groups[gi])
         own = slice(self.rank * J * self.S, (self.rank + 1) * J * self.S)
         keep = self.masks[gi][own].clone()
@@ -578,12 +580,14 @@ def resident_batch(parts, params, device: torch.device, gather_groups: int = 1, 
         b_flag = batch.global_ids(p, rp.b_owner, rp.b_local).astype(np.uint32) | (np.asarray(rp.comp, dtype=np.uint32) << np.uint32(31))
         # what the ingest hands over besides the columns (hinge_amd/host/host_common.h LasPart::load does the same per record)
         span16, max_pile, in_range = capi.pack_spans(rp.row_ptr, rp.a_span, rp.rlen)
+        bins = np.zeros(S, np.int32)                                   # (ids behind the block's reads: empty pile-ups)
+        bins[:rp.n_reads] = capi.pile_bins(rp.row_ptr, rp.a_span, rp.rlen, int(params.reso))
         tens = (torch.from_numpy(row_ptr).to(device), torch.from_numpy(np.ascontiguousarray(rp.a_span, dtype=np.int32)).to(device),
                 torch.from_numpy(np.ascontiguousarray(rp.b_span, dtype=np.int32)).to(device), torch.from_numpy(b_flag.view(np.int32)).to(device),
                 None if span16 is None else torch.from_numpy(span16.view(np.int32)).to(device))
         ctx = capi.Context(device.index or 0)
         backend = HipBackend(ctx, params, rlen_t.cpu().numpy(), None, lo, lo + S - 1, tens[0], tens[1], tens[2], tens[3], span16=tens[4],
-                             facts=(max_pile, in_range), last_a=lo + rp.last_a, coverage_out=True)
+                             facts=(max_pile, in_range), last_a=lo + rp.last_a, coverage_out=True, pile_bins=bins)
         batch.set_backend(p, backend)
         ctxs.append(ctx)
     if batch.max_pileup() >= 4096:
@@ -597,7 +601,7 @@ class HipBackend:
     def __init__(self, ctx, params, rlen: np.ndarray, qv_mask: Optional[np.ndarray], r_begin: int, r_end: int,
                  row_ptr: torch.Tensor, a_span: torch.Tensor, b_span: torch.Tensor, b_flag: torch.Tensor,
                  span16: Optional[torch.Tensor] = None, facts: Optional[Tuple[int, bool]] = None, last_a: Optional[int] = None,
-                 coverage_out: bool = False):
+                 coverage_out: bool = False, pile_bins: Optional[np.ndarray] = None):
         """row_ptr ... b_flag: device tensors (adopted).  facts = (max_pile, spans_in_range) and span16 (device uint32/int32
         [n_ovl + capi.span16_pad()], or None) as the ingest produced them (capi.pack_spans): without facts the library sweeps the
         spans itself (k_pileup_facts).  last_a: A read of the part's last .las record (default r_end)."""
@@ -607,13 +611,16 @@ class HipBackend:
         self.r_begin, self.r_end = r_begin, r_end
         self.last_a = r_end if last_a is None else int(last_a)
         self._hist = None
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._bound_stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_stream(self._bound_stream)
         ctx.set_reads(rlen, qv_mask)
         self._tensors = (row_ptr, a_span, b_span, b_flag, span16)
         if facts is None:
             ctx.set_pileups(r_begin, r_end, row_ptr, a_span, b_span, b_flag, n_ovl=int(b_flag.shape[0]), on_device=True)
         else:
             ctx.set_pileups_packed(r_begin, r_end, row_ptr, a_span, b_span, b_flag, span16, facts[0], facts[1], n_ovl=int(b_flag.shape[0]), on_device=True)
+        if pile_bins is not None:     # the ingest's per-read bin counts (capi.pile_bins): no device sweep before the one-sweep pass
+            ctx.set_pile_bins(np.ascontiguousarray(pile_bins, dtype=np.int32), int(params.reso))
         ctx.coverage_out(coverage_out)
         ctx.set_min_cov(self.ini_min_cov)
 
@@ -649,6 +656,12 @@ class HipBackend:
         self.ctx.attach_mask_table(mask)
 
     def begin(self):
+        # the library's launches and the collectives' stream-side waits must sit on ONE stream: bind whatever torch's current
+        # stream is NOW (a caller may step under another torch.cuda.stream() than the one this backend was built under)
+        cur = torch.cuda.current_stream().cuda_stream
+        if cur != self._bound_stream:
+            self.ctx.set_stream(cur)
+            self._bound_stream = cur
         self.ctx.set_min_cov(self.ini_min_cov)    # stream-ordered 4-byte set, no host sync
 
     def stats(self):

@@ -157,6 +157,8 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
         o.r_begin = las.r_begin; o.r_end = las.r_end;
         PART_CHECK(o, cx, hinge_set_pileups_packed(cx, las.r_begin, las.r_end, las.n_kept(), las.row_ptr.data(), las.a_span.data(), las.b_span.data(),
                                                    las.b_flag.data(), las.span16_ptr(), las.max_pile, las.spans_in_range ? 1 : 0, 0));
+        if (P.reso == 40 && las.nbins40.size() == (size_t)(las.r_end - las.r_begin + 1))   // the ingest's per-read bin counts: the one-sweep pass launches no sweep before it
+            PART_CHECK(o, cx, hinge_set_pile_bins(cx, 40, las.nbins40.data(), 0));
         PART_CHECK(o, cx, hinge_filter_coverage_out(cx, 1));   // K2 also stores the cutoff-0 bins: .coverage.txt needs no sweep of its own
         if (P.delete_telomere) {   // self_match_reads, filter.cpp:552-561 (float accumulation in record order)
             std::map<int, float> cov;

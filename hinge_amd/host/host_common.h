@@ -567,10 +567,32 @@ struct LasPart {
     uint32_t max_pile = 0;                     // largest pile-up of the part
     bool spans_in_range = true;                // every (abpos, aepos) inside [0, rlen[A]]
     const uint32_t* span16_ptr() const { return span16.size() ? span16.data() : nullptr; }
-    void finish_facts(int n_reads) {
+    // ... and the bins of every read's plain coverage profile at reso 40 (hinge_set_pile_bins): 0 for an empty pile-up, else
+    // max(abpos, aepos) / 40 + 2 over its overlaps, -1 for a coordinate outside [0, rlen] or 65 536+ overlaps
+    std::vector<int32_t> nbins40;              // reads r_begin .. r_end
+    void finish_facts(int n_reads, const std::vector<int32_t>* rlen = nullptr) {
         int64_t mp = 0;
         for (int q = 0; q < n_reads; q++) mp = std::max(mp, row_ptr[(size_t)q + 1] - row_ptr[(size_t)q]);
         max_pile = (uint32_t)std::min<int64_t>(mp, 0x7fffffff);
+        nbins40.clear();
+        if (!rlen || r_end < r_begin || r_end >= n_reads) return;
+        nbins40.assign((size_t)(r_end - r_begin + 1), 0);
+        parallel_dynamic((int64_t)nbins40.size(), 512, [&](int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; k++) {
+                const int q = r_begin + (int)k;
+                const int64_t s = row_ptr[(size_t)q], e = row_ptr[(size_t)q + 1];
+                if (e == s) continue;
+                const uint32_t rl = (uint32_t)std::max((*rlen)[(size_t)q], 0);
+                int32_t mx = 0;
+                bool ok = e - s < 65536;
+                for (int64_t t = s; t < e; t++) {
+                    const int32_t ab = a_span[(size_t)(2 * t)], ae = a_span[(size_t)(2 * t + 1)];
+                    ok = ok && (uint32_t)ab <= rl && (uint32_t)ae <= rl;
+                    mx = std::max(mx, std::max(ab, ae));
+                }
+                nbins40[(size_t)k] = ok ? mx / 40 + 2 : -1;
+            }
+        });
     }
     UVec<int64_t> trace_off;                   // byte offset of the trace inside the mapped file
     UVec<int32_t> tlen;
@@ -755,7 +777,7 @@ struct LasPart {
             const uint32_t rl = (uint32_t)std::max(rlen[(size_t)r.a], 0);
             if ((uint32_t)r.ab > rl || (uint32_t)r.ae > rl) spans_in_range = false;
         }
-        finish_facts(n_reads);
+        finish_facts(n_reads, want_span16 ? &rlen : nullptr);
         if (want_span16 && kept > 0 && spans_in_range && *std::max_element(rlen.begin(), rlen.end()) < 65536) {
             span16.resize((size_t)kept + (size_t)HINGE_SPAN16_PAD);
             for (int64_t k = 0; k < kept; k++) span16[(size_t)k] = (uint32_t)a_span[(size_t)k * 2] | ((uint32_t)a_span[(size_t)k * 2 + 1] << 16);
@@ -878,7 +900,7 @@ struct LasPart {
             r_end = a_of(novl - 1);
         }
         for (int c = 0; c < chunks; c++) if (out_of_range[(size_t)c]) spans_in_range = false;
-        finish_facts(n_reads);
+        finish_facts(n_reads, want_span16 ? &rlen : nullptr);
         if (fill16) {
             if (!spans_in_range) span16.resize(0);
             else for (int t = 0; t < HINGE_SPAN16_PAD; t++) span16[(size_t)kept + (size_t)t] = 0;

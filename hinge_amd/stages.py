@@ -116,6 +116,9 @@ def run_filter(db_name: str, las_base: str, prefix: str, config: str, mlas: bool
                 from .capi import pack_spans
                 span16, max_pile, in_range = pack_spans(pile.row_ptr, pile.a_span, rlen)
                 ctx.set_pileups_packed(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag, span16, max_pile, in_range)
+                if P.reso == 40:
+                    from .capi import pile_bins
+                    ctx.set_pile_bins(pile_bins(pile.row_ptr[r_begin:r_end + 2], pile.a_span, rlen[r_begin:r_end + 1], 40), 40)
             else:
                 ctx.set_pileups(r_begin, r_end, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
             ctx.coverage_out(packed and write_coverage)

@@ -95,6 +95,12 @@ int hinge_set_pileups_packed(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int
 int hinge_span16_pad(void);
 /* The two facts about the current part, whoever produced them (the caller or the library's own sweep). */
 int hinge_get_pileup_facts(hinge_ctx* ctx, uint32_t* max_pile, int* spans_in_range);
+/* One more fact of the pile-ups an ingest can hand over (round 4: the one-sweep pass then needs NO device sweep before it):
+ * nbins[k], k = 0 .. r_end - r_begin: the bins of read r_begin + k's plain coverage profile at `reso`,
+ *   0 for an empty pile-up, else max over its overlaps of max(abpos, aepos) / reso + 2   (K of profileCoverage, LAInterface.cpp:4298-4320),
+ *   or -1 when a coordinate lies outside [0, rlen] or the pile-up has 65 536+ overlaps (the general kernel then takes the read).
+ * Without it the library makes them itself, once per hinge_set_pileups, with k_cov_stats.  After hinge_set_pileups[_packed].        */
+int hinge_set_pile_bins(hinge_ctx* ctx, int32_t reso, const int32_t* nbins, int on_device);
 /* Optional: use a caller-owned DEVICE buffer int32[n_reads][2] as the all-read mask table (so a
  * collective can fill other ranks' rows in place).  NULL returns to the library-owned table.      */
 int hinge_attach_mask_table(hinge_ctx* ctx, int32_t* d_mask_all);

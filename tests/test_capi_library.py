@@ -51,3 +51,18 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"^\s*(import|from)\s+oracle\b|libhinge_oracle|oracle/|#include\s+\"oracle", txt, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_pile_bins_restates_profile_coverage_bin_count():
+    """capi.pile_bins (what an ingest hands to hinge_set_pile_bins): K of profileCoverage per read (LAInterface.cpp:4298-4320: the
+    largest event / reso + 2; 0 for an empty pile-up), -1 where the fast kernel must not take the read."""
+    import numpy as np
+    from hinge_amd import capi
+    rlen = np.array([5000, 4000, 100, 7000, 3000], np.int32)
+    row_ptr = np.array([0, 2, 2, 3, 5, 6], np.int64)
+    a_span = np.array([[0, 4100], [300, 1999], [10, 90], [0, 7000], [6999, 7001], [-1, 50]], np.int32)
+    got = capi.pile_bins(row_ptr, a_span, rlen)
+    assert got.tolist() == [4100 // 40 + 2, 0, 90 // 40 + 2, -1, -1]          # read 3: 7001 > rlen; read 4: a negative coordinate
+    # a slice of a larger table (absolute offsets), as hinge_amd/stages.py passes it
+    assert capi.pile_bins(row_ptr[2:5], a_span, rlen[2:4]).tolist() == [90 // 40 + 2, -1]
+    assert capi.pile_bins(np.array([0, 0], np.int64), np.zeros((0, 2), np.int32), rlen[:1]).tolist() == [0]

@@ -232,3 +232,46 @@ def test_prefix_rule_and_usage(tmp_path, capsys):
     ini = tmp_path / "n.ini"
     ini.write_text("[layout]\ndel_telomeres = 1\n")
     assert clip.clip_settings(str(ini))["del_telomeres"] is True
+
+
+def test_cov_flag_lines_that_name_no_read(tmp_path):
+    """A `.cov.flag` line that is not a read id names no vertex: the reference's string look-ups miss it (pruning_and_clipping.py
+    :1072-1083); so does this reader (it used to raise ValueError on int())."""
+    g = StrandGraph()
+    chain(g, [5, 8, 9])
+    (tmp_path / "G.cov.flag").write_text("8\n\nnot-a-read\n 9 \n3.5\n")
+    assert clip.flag_bad_coverage(g, str(tmp_path / "G.cov.flag")) == 2
+    assert g.attr[(8, 0)]["CFLAG"] and g.attr[(9, 1)]["CFLAG"] and not g.attr[(5, 0)]["CFLAG"]
+
+
+def test_asymmetric_input_takes_the_tolerant_removal_paths():
+    """An input whose strands are not mirror images (a vertex missing on one strand): where networkx 1.9's remove_node would raise
+    on the absent mirror image the module goes on (StrandGraph.remove_node returns False) - documented, and covered here: the
+    clipping operations run to the end and never leave an edge to a vertex that is gone."""
+    g, spur = backbone_with_spur(4)
+    assert g.remove_node((spur[1], 1)) and not g.is_strand_symmetric()
+    h = clip.clip_dead_ends(g, 10)
+    g1, g0 = clip.clip_z_edges(h, 6)
+    g1 = clip.burst_bubbles(g1, 10)
+    for gr in (h, g0, g1):
+        for u, v, _ in gr.edges():
+            assert u in gr and v in gr
+    assert (spur[0], 0) not in h                       # the spur's forward strand still goes
+    assert not h.remove_node((spur[1], 1))             # (already absent: tolerated)
+
+
+def test_partial_run_is_explicit(tmp_path, monkeypatch, capsys):
+    """`hinge clip` writes G0 / G1 only: it says so (stderr, a .PARTIAL marker beside the graphs) and, under HINGE_CLIP_STRICT=1,
+    ends with exit code 3 so that a pipeline that needs the later graphs stops there."""
+    e = tmp_path / "G.edges.hinges"
+    rows = []
+    for a, b in zip(range(1, 30), range(2, 31)):
+        rows.append(line(a, b, 1000, 0, 0, 0, (0, 900), (100, 1000), (0, 1000), (0, 1000), (0, 900), (100, 1000)))
+    e.write_text("\n".join(rows) + "\n")
+    (tmp_path / "G.hinge.list").write_text("")
+    monkeypatch.chdir(tmp_path)
+    assert clip.main(["G.edges.hinges", "G.hinge.list", ".x"]) == 0
+    assert os.path.exists("G.x.G0.graphml") and os.path.exists("G.x.G1.graphml")
+    assert "G2" in open("G.x.PARTIAL").read() and "PARTIAL" in capsys.readouterr().err
+    monkeypatch.setenv("HINGE_CLIP_STRICT", "1")
+    assert clip.main(["G.edges.hinges", "G.hinge.list", ".x"]) == 3
