@@ -361,6 +361,7 @@ def main():
             # what the kernel has to move: the 16|16 span copy (4 B per overlap, packed by the ingest), the per-read tables and,
             # for the mask / annotate kernel, the coverage bins it stores
             phys_bytes = (4 * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads + (4 * sum(part_bins) if kname == "k_mask_annotate" else 0)) / R
+        one_sweep = bool(getattr(batch, "one_sweep", False)) and "k_cov_stats" not in {k for k, v in breakdown.items() if v[1] > 0}
         traffic, traffic_src = pmc_traffic(kname)
         resident = sum(part_ovl) * (8 + 8 + 4 + 4) + sum(part_bins) * 4
         roofline = {
@@ -379,6 +380,10 @@ def main():
             "achieved_physical": (phys_bytes / (avg_ms * 1e-3) / 1e9) if phys_bytes else None,
             "frac_physical": (phys_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if phys_bytes else None,
             "waste_ratio": (traffic / phys_bytes) if (traffic and phys_bytes) else None,
+            "one_sweep_note": ("the dominant kernel is the FIRST AND ONLY sweep of the pass (DESIGN.md 3.6): it does the work SURVEY 8(d) prices as pass 1 (8 B per overlap) "
+                               "plus pass 2's span read (8 B per overlap); `frac` keeps crediting it 8 B per overlap - what one sweep has to read - so it is "
+                               "comparable with rounds 1-3, where a second kernel (k_cov_stats, 32 us per part) was credited the other 8") if one_sweep else None,
+            "frac_if_credited_both_passes": ((alg_bytes + 8 * n_ovl / R + 20 * n_reads / R) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (one_sweep and achieved is not None and kname == "k_mask_annotate") else None,
             "physical_note": "`frac` credits SURVEY 8(d)'s 8 B per overlap (the int32 span pair); the kernel reads the ingest's 16|16 copy (4 B per "
                              "overlap) and, unlike 8(d)'s accounting, writes the coverage bins: physical = 4 B x overlaps + per-read tables + bins; "
                              "waste_ratio = counter traffic / physical",
@@ -388,9 +393,9 @@ def main():
             "kernels_ms_per_step": {k: v[0] / n_break for k, v in breakdown.items() if v[1] > 0},
             "kernels_ms_note": "untimed breakdown pass with events around every kernel (includes event overhead), summed over the %d parts of a step; "
                                "avg_launch_ms is from the timed region" % R,
-            "working_set": "%d distinct resident parts, %.2f GB of pile-up columns + span copies + bin output in total; the two streaming kernels of a "
-                           "pass read %.0f MB (16|16 span copy) each and K2 writes %.0f MB of bins; %.2f GB pass through between two visits of the same part "
-                           "(Infinity Cache: 256 MiB)" % (R, resident / 1e9, 4 * n_ovl / R / 1e6, 4 * sum(part_bins) / R / 1e6, (R - 1) * (2 * 4 * n_ovl / R + 4 * sum(part_bins) / R) / 1e9),
+            "working_set": "%d distinct resident parts, %.2f GB of pile-up columns + span copies + bin output in total; a pass's sweep(s) "
+                           "read %.0f MB (16|16 span copy) per part and K2 writes %.0f MB of bins; %.2f GB pass through between two visits of the same part "
+                           "(Infinity Cache: 256 MiB)" % (R, resident / 1e9, 4 * n_ovl / R / 1e6, 4 * sum(part_bins) / R / 1e6, (R - 1) * (4 * n_ovl / R + 4 * sum(part_bins) / R) / 1e9),
             "path_bytes_per_overlap": PATH_BYTES_PER_OVERLAP,
             "path_credit_GBs": PATH_BYTES_PER_OVERLAP * n_ovl / (ms_per_step * 1e-3) / 1e9,
             "path_credit_note": "SURVEY 8(d)'s 40 B per overlap x overlaps / step time: a figure of merit for the whole path, NOT achieved bandwidth "
@@ -439,6 +444,18 @@ def main():
             assert e2e["byte_identical"], "executables differ from the oracle: %s" % e2e["files_differing"]
             if args.no_cpu_baseline:
                 cpu = None
+        consensus = None
+        if world == 1 and not args.no_e2e:
+            # SURVEY 8(f-4), reported beside the headline metric: `hinge consensus` at E. coli size (tools/cns_bench.py) - the
+            # reference's own program (oracle/_ref/consensus, where it was built) against the executable and the kernels; FASTA
+            # byte-identical or the run fails
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cns_bench.py")] + (["--no-cpu"] if args.no_cpu_baseline else []),
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                assert r.returncode == 0, r.stderr.decode()[-1500:]
+                consensus = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            except Exception as ex:      # (reported, not fatal: the headline metric is the filter path's)
+                consensus = {"error": str(ex)[-800:]}
         collectives = batch.collectives
         out = {
             "metric": "overlaps/sec through filter+hinge-detect, E. coli 160x",
@@ -481,6 +498,7 @@ def main():
             "roofline": roofline,
             "checks": checks,
             "e2e": e2e,
+            "consensus": consensus,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -67,3 +67,32 @@ def test_inconsistent_diffs_are_refused(tmp_path):
     with pytest.raises(capi.HingeError) as e:
         cns.run(las, list(range(len(las.rec))))
     assert e.value.code == capi.HINGE_E_RANGE
+
+
+def test_consensus_cli_error_paths(tmp_path):
+    """An unreadable config: "Can't load <name>" on stdout and exit code 1 as consensus.cpp:88-93 (the output file exists by then:
+    the ofstream is the program's first statement); too few arguments: usage, exit 1 (the reference reads argv[5] unchecked)."""
+    import subprocess
+    wd = str(tmp_path)
+    cc.make("cns_tiny", wd)
+    r = subprocess.run([cc.EXE, "draft", "reads", "draft.reads.las", "o.fasta", "missing.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and r.stdout == b"Can't load missing.ini\n" and os.path.getsize(os.path.join(wd, "o.fasta")) == 0
+    if os.path.exists(cc.REF_BIN):
+        q = subprocess.run([cc.REF_BIN, "draft", "reads", "draft.reads.las", "p.fasta", "missing.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert (q.returncode, q.stdout) == (r.returncode, r.stdout)
+    assert subprocess.run([cc.EXE, "draft", "reads"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1
+
+
+def test_consensus_through_the_dispatcher_and_min_length(oracle_lib, tmp_path):
+    """`hinge consensus ...` (src/hinge:33-35) and another [consensus] min_length: fewer alignments vote, the files still equal the
+    reference program's."""
+    import subprocess
+    wd = str(tmp_path)
+    cc.make("cns_small", wd)
+    with open(os.path.join(wd, "nominal.ini"), "w") as f:
+        f.write("[consensus]\nmin_length = 3000;\n")
+    hinge = os.path.join(cc.ROOT, "hinge_amd", "bin", "hinge")
+    r = subprocess.run([hinge, "consensus", "draft", "reads", "draft.reads.las", "hip.fasta", "nominal.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    ref = cc.run_reference(wd) or cc.run_oracle(oracle_lib, wd)      # (the reference's own program where it was built, else the restatement pinned to it)
+    assert open(os.path.join(wd, "hip.fasta"), "rb").read() == ref[0] and r.stdout == ref[1]
