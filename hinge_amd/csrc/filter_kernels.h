@@ -34,6 +34,16 @@ constexpr int ST_QUEUE_CAP = 4;    // exact queue full
 constexpr int ST_ARENA_CAP = 8;    // exact-path scratch arena full
 constexpr int ST_NO_LONG_READ = 16;
 constexpr int ST_MEDIAN_RANGE = 32;   // sharded median: a mean coverage outside [0, MED_BINS), the histogram exchange cannot be used
+// The annotation allocator and the work list are SHARDED (round 4): a returning device-scope atomic on ONE word serialises at
+// ~12 ns, and both used to be single words - nothing at the 1.5 % of reads with annotations of the E. coli set, but a repeat-rich
+// part (BASELINE config 3: a quarter of the reads have annotations) spent 0.36 of K2's 0.42 ms queueing on them
+// (profiles/r4l_cfg3_* against r4n).  N_SHARD counters 128 bytes apart, the shard picked by the workgroup: shard s allocates
+// annotation slots from ITS region [s R, (s + 1) R) of the buffer (R = anno_cap / N_SHARD), and files work items at positions
+// s, s + N_SHARD, s + 2 N_SHARD ... of the work list, so that k_hinge_count still walks one array: slot w is in use iff
+// w / N_SHARD < count[w % N_SHARD].  (The heavy list k_hinge_count appends to and k_hinge_call's cursor were sharded the same
+// way and measured: no gain - on config 3 those kernels are at 5 TB/s of pile-up re-reads, not in the atomic queue - not kept.)
+constexpr int N_SHARD = 64;
+constexpr int SHARD_STRIDE = 32;      // unsigneds between two shard counters (128 bytes)
 constexpr int ST_REDO_CAP = 64;       // one-sweep pass: the guard-band list is full (cannot happen: it has room for every read)
 
 // Publication before a ticket (k_median_hist, k_spec_predict): everything a workgroup publishes before it takes its ticket is a
@@ -68,7 +78,7 @@ struct SpecVerify {               // per part; spec_min_cov == nullptr: a classi
     const int* spec_min_cov;      // MIN_COV the sweep ran with
     int band;
     int* spec_state;              // out: 0 = the exact MIN_COV lies inside the band, 1 = outside (everything is redone)
-    unsigned* counters;           // annotation allocator, work-list length: reset when everything is redone
+    unsigned* shards;             // annotation allocators and work-list lengths ([2][N_SHARD] counters, SHARD_STRIDE apart): reset when everything is redone
     unsigned* stats;              // cumulative: [0] passes verified, [1] exact != predicted, [2] outside the band
 };
 __device__ __forceinline__ void spec_verify(const SpecVerify& v, int exact) {
@@ -78,7 +88,10 @@ __device__ __forceinline__ void spec_verify(const SpecVerify& v, int exact) {
     *v.spec_state = miss;
     atomicAdd(&v.stats[0], 1u);
     if (exact != pred) atomicAdd(&v.stats[1], 1u);
-    if (miss) { atomicAdd(&v.stats[2], 1u); v.counters[0] = 0u; v.counters[1] = 0u; }
+    if (miss) {
+        atomicAdd(&v.stats[2], 1u);
+        for (int k = 0; k < 2 * N_SHARD; k++) v.shards[k * SHARD_STRIDE] = 0u;
+    }
 }
 
 #ifdef HINGE_ABLATE
@@ -840,7 +853,10 @@ struct AnnoOut {   // per-part outputs of K2
     unsigned char* hinge_flag;
     unsigned* anno_off;
     int* anno_cnt;
-    unsigned* counters;   // [0] = annotation allocator, [1] = work-list length
+    unsigned* anno_shard; // N_SHARD annotation allocators (SHARD_STRIDE apart): shard s owns slots [s * anno_region, (s + 1) * anno_region)
+    unsigned* work_shard; // N_SHARD work-list lengths: shard s files its items at s, s + N_SHARD, ...
+    unsigned anno_region; // anno_cap / N_SHARD
+    unsigned work_cap;    // slots of work_list
     unsigned anno_cap;
     WorkItem* work_list;
     int* status;
@@ -1047,19 +1063,24 @@ __device__ __forceinline__ int mask_gate_annotate(const PT& P, const int reso, c
     }
     unsigned off = 0;
     if (lane == 0) {
+        const unsigned shard = (unsigned)blockIdx.x & (unsigned)(N_SHARD - 1);
         if (m > 0) {
-            off = atomicAdd(&o.counters[0], (unsigned)m);
-            if (off + (unsigned)m > o.anno_cap) { atomicOr(o.status, ST_ANNO_CAP); m = 0; }
+            const unsigned local = atomicAdd(&o.anno_shard[shard * SHARD_STRIDE], (unsigned)m);
+            off = shard * o.anno_region + local;
+            if (local + (unsigned)m > o.anno_region) { atomicOr(o.status, ST_ANNO_CAP); m = 0; off = 0; }
         }
         store_at32(anno_offp, iv << 2, off);
         store_at32(anno_cntp, iv << 2, m);
         if (m > 0 && !gate_skip) {
-            const unsigned w = atomicAdd(&o.counters[1], 1u);
-            WorkItem it;
-            it.read = i; it.n = n_pile; it.row = row; it.mask_lo = mk.x; it.mask_hi = mk.y; it.off = off; it.cnt = m;
+            const unsigned w = shard + (unsigned)N_SHARD * atomicAdd(&o.work_shard[shard * SHARD_STRIDE], 1u);
+            if (w >= o.work_cap) atomicOr(o.status, ST_ANNO_CAP);   // (the host grows both buffers and repeats the pass)
+            else {
+                WorkItem it;
+                it.read = i; it.n = n_pile; it.row = row; it.mask_lo = mk.x; it.mask_hi = mk.y; it.off = off; it.cnt = m;
 #pragma unroll
-            for (int t = 0; t < 4; t++) { const int cd = t < m ? cand[t] : 0; it.anno[t] = make_int2(cd >> 1, (cd & 1) ? 1 : -1); }
-            o.work_list[w] = it;
+                for (int t = 0; t < 4; t++) { const int cd = t < m ? cand[t] : 0; it.anno[t] = make_int2(cd >> 1, (cd & 1) ? 1 : -1); }
+                o.work_list[w] = it;
+            }
         }
     }
     m = __builtin_amdgcn_readfirstlane(m);

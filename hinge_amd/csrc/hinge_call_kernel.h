@@ -46,7 +46,7 @@ __device__ __forceinline__ int slice_len(int n) { return ((n + 4 * WAVE - 1) / (
 struct HingePart {
     const int64_t* row_ptr; const int2* a_span; const int2* b_span; const unsigned* b_flag; const int2* mask;
     const int2* anno_buf; const unsigned* anno_off; const int* anno_cnt;
-    const WorkItem* work_list; unsigned work_cap; const unsigned* counters;
+    const WorkItem* work_list; unsigned work_cap; const unsigned* work_shard;   // (sharded list: filter_kernels.h N_SHARD)
     unsigned char* hinge_flag;
     HeavyItem* heavy; unsigned* heavy_count; unsigned* heavy_count_big; unsigned heavy_cap;
     int2* exact_queue; unsigned* exact_count; unsigned exact_cap;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
     const unsigned bx = blockIdx.x / n_parts, gx = gridDim.x / n_parts;
     const int64_t* __restrict__ row_ptr = A.row_ptr; const int2* __restrict__ a_span = A.a_span; const int2* __restrict__ b_span = A.b_span;
     const unsigned* __restrict__ b_flag = A.b_flag; const int2* __restrict__ mask = A.mask; const int2* __restrict__ anno_buf = A.anno_buf;
-    const WorkItem* __restrict__ work_list = A.work_list; const unsigned* __restrict__ counters = A.counters;
+    const WorkItem* __restrict__ work_list = A.work_list; const unsigned* __restrict__ work_shard = A.work_shard;
     unsigned char* __restrict__ hinge_flag = A.hinge_flag; HeavyItem* __restrict__ heavy = A.heavy;
     unsigned* __restrict__ heavy_count = A.heavy_count; unsigned* __restrict__ heavy_count_big = A.heavy_count_big;
     const unsigned heavy_cap = A.heavy_cap; const int force_exact = A.force_exact; unsigned* __restrict__ dbg = A.dbg;
@@ -106,13 +106,17 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
     // fetched together with the number of items (the list has work_cap slots: the read is legal whether or not the slot is in use)
     WorkItem wi_first;
     if (bx < A.work_cap) wi_first = work_list[bx];
-    const unsigned nwork = counters[1];
+    // the sharded work list: slot w is in use iff w / N_SHARD < count[w % N_SHARD]; lane l keeps shard l's count
+    static_assert(N_SHARD == WAVE, "one shard count per lane");
+    const unsigned my_count = work_shard[lane * SHARD_STRIDE];
+    const unsigned nwork = min((unsigned)N_SHARD * (unsigned)wave_max((int)my_count), A.work_cap);
     for (unsigned w = bx; w < nwork; w += gx) {   // one workgroup per work-list read
 #ifdef HINGE_TIMING
         const unsigned long long tc0 = wall_clock64();
 #endif
         const WorkItem wi = wi_first;
         if (w + gx < nwork) wi_first = work_list[w + gx];   // the next item travels while this one is worked on
+        if ((w >> 6) >= (unsigned)__builtin_amdgcn_readlane((int)my_count, (int)(w & (N_SHARD - 1)))) continue;   // (a hole of a shorter shard; uniform)
         const int i = wi.read;
         const int64_t s = wi.row, e = wi.row + wi.n;
         const int2 mk = make_int2(wi.mask_lo, wi.mask_hi);

@@ -50,7 +50,8 @@ struct hinge_ctx {
     int no_span16 = 0;         // HINGE_NO_SPAN16=1: keep the streaming kernels on the int32 spans
     bool has_keep = false;
     DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list, k2_heads;
-    unsigned anno_cap = 0;
+    unsigned anno_cap = 0;               // annotation slots (a multiple of N_SHARD: every shard allocates from its own 1 / N_SHARD of them)
+    unsigned work_cap = 0;               // work-list slots (the list is interleaved over the shards: n_reads + room for their imbalance)
     DevBuf exact_queue;
     unsigned exact_cap = 0;
     DevBuf arena;
@@ -166,8 +167,8 @@ struct Scalars {
     // ---- cleared by ONE memset at the start of every pass (SCALARS_RESET_BYTES) ----
     unsigned long long totals[2];       // total_cov, num_slot
     unsigned long long arena_used;
-    unsigned counters[2];               // annotation alloc, work count
-    unsigned fallback_count;            // reads k_mask_annotate_q20 handed back to the general kernel (directly after counters)
+    unsigned shards[2 * N_SHARD * SHARD_STRIDE];   // [0][s]: annotation allocator of shard s, [1][s]: its work-list length (filter_kernels.h N_SHARD; counters 128 bytes apart)
+    unsigned fallback_count;            // reads k_mask_annotate_q20 handed back to the general kernel
     unsigned exact_count;
     unsigned work_next;                 // k_hinge_call's work-list cursor
     unsigned heavy_count;               // annotations the count-only sweep could not decide, pile-up <= PO_CAP_SMALL (front of heavy_list)
@@ -198,6 +199,9 @@ static const size_t SCALARS_RESET_BYTES = offsetof(Scalars, est);
             return HINGE_E_DEVICE;                                                                       \
         }                                                                                                \
     } while (0)
+
+// totals of the sharded counters of a Scalars copy
+static unsigned shard_sum(const unsigned* shards, int which) { unsigned t = 0; for (int k = 0; k < N_SHARD; k++) t += shards[(which * N_SHARD + k) * SHARD_STRIDE]; return t; }
 
 static int fail(hinge_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -339,7 +343,8 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->nbins0, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_off, sizeof(unsigned) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
-    if ((rc = ensure(ctx, ctx->work_list, sizeof(WorkItem) * n))) return rc;
+    ctx->work_cap = (unsigned)std::min<size_t>(n + (size_t)N_SHARD * 256, 0x7fffffffu);
+    if ((rc = ensure(ctx, ctx->work_list, sizeof(WorkItem) * (size_t)ctx->work_cap))) return rc;
     if ((rc = ensure(ctx, ctx->fallback_list, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->cov_tot, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->redo_list, sizeof(int) * n))) return rc;
@@ -390,7 +395,7 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
     if ((rc = adopt(ctx, ctx->b_flag, b_flag, sizeof(unsigned) * (size_t)n_ovl, on_device))) return rc;
     // annotation storage: grows on overflow
     if (ctx->anno_cap == 0) {
-        ctx->anno_cap = (unsigned)std::max<int64_t>(1024, 4LL * (r_end - r_begin + 1));
+        ctx->anno_cap = (unsigned)((std::max<int64_t>(N_SHARD * 32, 4LL * (r_end - r_begin + 1)) + N_SHARD - 1) / N_SHARD * N_SHARD);
         if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
@@ -694,7 +699,7 @@ static SpecVerify spec_verify_of(hinge_ctx* ctx) {
     memset(&v, 0, sizeof(v));
     if (ctx->pass_mode != 0) {
         v.spec_min_cov = &sc(ctx)->spec_min_cov; v.band = ctx->spec_band; v.spec_state = &sc(ctx)->spec_state;
-        v.counters = sc(ctx)->counters; v.stats = sc(ctx)->spec_stats;
+        v.shards = sc(ctx)->shards; v.stats = sc(ctx)->spec_stats;
     }
     return v;
 }
@@ -842,7 +847,8 @@ static AnnoOut anno_out(hinge_ctx* ctx) {
     o.hinge_flag = (unsigned char*)ctx->hinge_flag.p;
     o.anno_off = (unsigned*)ctx->anno_off.p;
     o.anno_cnt = (int*)ctx->anno_cnt.p;
-    o.counters = sc(ctx)->counters;
+    o.anno_shard = sc(ctx)->shards; o.work_shard = sc(ctx)->shards + N_SHARD * SHARD_STRIDE;
+    o.anno_region = ctx->anno_cap / N_SHARD; o.work_cap = ctx->work_cap;
     o.anno_cap = ctx->anno_cap;
     o.work_list = (WorkItem*)ctx->work_list.p;
     o.status = &sc(ctx)->status;
@@ -878,6 +884,17 @@ static int spec_args_of(hinge_ctx* ctx, int mode, int grid, SpecArgs* out) {
 
 // Layout of K2's coverage-bin output: read i of the part gets (rlen + cut_off) / reso + 3 slots, the most bins a profile the
 // kernels accept can have (more raises ST_RANGE).  Host-computable, so no device prefix sum and no second launch.
+// ST_ANNO_CAP: a shard ran out of annotation slots or the interleaved work list of room - both buffers double, the pass is repeated
+static int grow_annotations(hinge_ctx* ctx) {
+    int rc;
+    ctx->anno_cap = ctx->anno_cap * 2;       // (stays a multiple of N_SHARD)
+    if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
+    if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
+    if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+    ctx->work_cap = ctx->work_cap * 2;
+    return ensure(ctx, ctx->work_list, sizeof(WorkItem) * (size_t)ctx->work_cap);
+}
+
 static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
     if (!ctx->cov_out_on) return HINGE_OK;
     const int key[4] = {ctx->r_begin, ctx->r_end, p->reso, p->cut_off};
@@ -1083,7 +1100,7 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 8; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(sc(ctx)->counters, 0, 3 * sizeof(unsigned), ctx->stream));   // + fallback_count
+        CK(hipMemsetAsync(sc(ctx)->shards, 0, sizeof(sc(ctx)->shards) + sizeof(unsigned), ctx->stream));   // + fallback_count (directly behind them)
         if ((rc = launch_mask_annotate(ctx, p))) return rc;
         // the annotation buffer is sized optimistically; grow + rerun on overflow (rare)
         Scalars h;
@@ -1091,10 +1108,7 @@ int hinge_filter_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p) {
         CK(hipStreamSynchronize(ctx->stream));
         if (h.status & ST_RANGE) return fail(ctx, HINGE_E_RANGE, "overlap coordinate beyond read length + cut_off");
         if (!(h.status & ST_ANNO_CAP)) return HINGE_OK;
-        ctx->anno_cap = std::max(ctx->anno_cap * 2, h.counters[0] + 1024);
-        if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
-        if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
-        if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = grow_annotations(ctx))) return rc;
     }
     return fail(ctx, HINGE_E_CAPACITY, "annotation buffer kept overflowing");
 }
@@ -1105,7 +1119,7 @@ static HingePart hinge_part_of(hinge_ctx* ctx) {
     a.row_ptr = (const int64_t*)ctx->row_ptr.p; a.a_span = (const int2*)ctx->a_span.p; a.b_span = (const int2*)ctx->b_span.p;
     a.b_flag = (const unsigned*)ctx->b_flag.p; a.mask = (const int2*)ctx->mask;
     a.anno_buf = (const int2*)ctx->anno_buf.p; a.anno_off = (const unsigned*)ctx->anno_off.p; a.anno_cnt = (const int*)ctx->anno_cnt.p;
-    a.work_list = (const WorkItem*)ctx->work_list.p; a.work_cap = (unsigned)ctx->n_reads; a.counters = (const unsigned*)sc(ctx)->counters;
+    a.work_list = (const WorkItem*)ctx->work_list.p; a.work_cap = ctx->work_cap; a.work_shard = (const unsigned*)(sc(ctx)->shards + N_SHARD * SHARD_STRIDE);
     a.hinge_flag = (unsigned char*)ctx->hinge_flag.p;
     a.heavy = (HeavyItem*)ctx->heavy_list.p; a.heavy_count = &sc(ctx)->heavy_count; a.heavy_count_big = &sc(ctx)->heavy_count_big; a.heavy_cap = ctx->anno_cap;
     a.exact_queue = (int2*)ctx->exact_queue.p; a.exact_count = &sc(ctx)->exact_count; a.exact_cap = ctx->exact_cap;
@@ -1244,7 +1258,8 @@ int hinge_filter_get_annotations(hinge_ctx* ctx, int64_t* off, int32_t* pos, int
     off[0] = 0;
     for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + acnt[i];
     if (!pos) return HINGE_OK;
-    const size_t tot = h.counters[0];
+    size_t tot = 0;                                  // (the shards' regions are not contiguous: copy up to the last slot in use)
+    for (size_t i = 0; i < n; i++) if (acnt[i] > 0) tot = std::max(tot, (size_t)aoff[i] + (size_t)acnt[i]);
     std::vector<int2> buf(tot);
     std::vector<unsigned char> hf(tot);
     if (tot) {
@@ -1338,14 +1353,19 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     Scalars h;
     CK(hipMemcpyAsync(&h, ctx->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    out[0] = h.counters[1];
+    out[0] = shard_sum(h.shards, 1);
     out[1] = std::min(h.exact_count, ctx->exact_cap);
-    out[2] = h.counters[0];
-    size_t tot = h.counters[0];
-    std::vector<unsigned char> hf(tot);
-    if (tot) CK(hipMemcpy(hf.data(), ctx->hinge_flag.p, tot, hipMemcpyDeviceToHost));
+    out[2] = shard_sum(h.shards, 0);
     int64_t nh = 0;
-    for (unsigned char c : hf) nh += c;
+    {   // hinges = flags set in the slots the shards handed out
+        const size_t R = ctx->anno_cap / N_SHARD;
+        std::vector<unsigned char> hf((size_t)ctx->anno_cap);
+        if (out[2]) CK(hipMemcpy(hf.data(), ctx->hinge_flag.p, hf.size(), hipMemcpyDeviceToHost));
+        for (int sh = 0; sh < N_SHARD; sh++) {
+            const size_t used = std::min<size_t>(h.shards[(size_t)sh * SHARD_STRIDE], R);
+            for (size_t k = 0; k < used; k++) nh += hf[(size_t)sh * R + k];
+        }
+    }
     out[3] = nh;
     if (getenv("HINGE_DEBUG_PATHS"))
         fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u | last pass: %u items in the half-size instance, %u in the full-size one\n",
@@ -1546,10 +1566,7 @@ int hinge_filter_sweep(hinge_ctx* ctx, const hinge_filter_params* p, hinge_cov_e
         if (h.status & ST_REDO_CAP) return fail(ctx, HINGE_E_CAPACITY, "guard-band list overflow (cannot happen: it has a slot per read)");
         if (!(h.status & ST_ANNO_CAP)) return HINGE_OK;
         // the annotation buffer is sized optimistically; grow + rerun the pass on overflow (rare; MIN_COV's update is idempotent)
-        ctx->anno_cap = std::max(ctx->anno_cap * 2, h.counters[0] + 1024);
-        if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
-        if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
-        if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = grow_annotations(ctx))) return rc;
     }
     return fail(ctx, HINGE_E_CAPACITY, "annotation buffer kept overflowing");
 }

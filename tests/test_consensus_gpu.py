@@ -96,3 +96,16 @@ def test_consensus_through_the_dispatcher_and_min_length(oracle_lib, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-1000:]
     ref = cc.run_reference(wd) or cc.run_oracle(oracle_lib, wd)      # (the reference's own program where it was built, else the restatement pinned to it)
     assert open(os.path.join(wd, "hip.fasta"), "rb").read() == ref[0] and r.stdout == ref[1]
+
+
+def test_consensus_at_bench_size(oracle_lib, tmp_path):
+    """An E. coli-sized draft (4 contigs of ~1.1 Mb at 30x: 18 820 alignments, 1.33 M trace-point segments, 131 M aligned bases)
+    through the executable against the reference's own program on the same files: 4.5 MB of FASTA and the whole stdout text
+    (18 820 chop offsets among it), byte for byte."""
+    wd = str(tmp_path)
+    d = cc.make("cns_bench", wd)
+    assert d.n_alignments > 15_000
+    fasta, out = cc.run_product(wd)
+    ref = cc.run_reference(wd) or cc.run_oracle(oracle_lib, wd)
+    assert fasta == ref[0] and out == ref[1]
+    assert len(fasta) > 4_000_000
