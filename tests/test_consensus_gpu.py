@@ -109,3 +109,36 @@ def test_consensus_at_bench_size(oracle_lib, tmp_path):
     ref = cc.run_reference(wd) or cc.run_oracle(oracle_lib, wd)
     assert fasta == ref[0] and out == ref[1]
     assert len(fasta) > 4_000_000
+
+
+def _sharded_worker(rank, world, port, wd, ret):
+    import torch.distributed as dist
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hinge_amd import consensus
+        rc, text = consensus.run_consensus(os.path.join(wd, "draft"), os.path.join(wd, "reads"), os.path.join(wd, "draft.reads.las"),
+                                           os.path.join(wd, "sharded.fasta"), os.path.join(wd, "nominal.ini"), device=0)
+        dist.barrier()
+        ret.put((rank, rc, text))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_python_driver_and_contig_sharding_on_the_gpu(oracle_lib, tmp_path):
+    """hinge_amd/consensus.py over the HIP backend: one rank, and two ranks that share the contigs (both on this box's one GPU, gloo
+    for the final gather): the reference program's FASTA and its whole stdout text."""
+    import torch.multiprocessing as mp
+    from hinge_amd import consensus
+    wd = str(tmp_path)
+    cc.make("cns_midsize", wd)
+    ref = cc.run_reference(wd) or cc.run_oracle(oracle_lib, wd)
+    rc, text = consensus.run_consensus(os.path.join(wd, "draft"), os.path.join(wd, "reads"), os.path.join(wd, "draft.reads.las"), os.path.join(wd, "py.fasta"),
+                                       os.path.join(wd, "nominal.ini"), device=0)
+    assert rc == 0 and open(os.path.join(wd, "py.fasta"), "rb").read() == ref[0] and text == ref[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    mp.spawn(_sharded_worker, args=(2, 37950 + os.getpid() % 40, wd, ret), nprocs=2, join=True)
+    got = sorted(ret.get() for _ in range(2))
+    assert [g[1] for g in got] == [0, 0] and got[0][2] == ref[1] and got[1][2] == ref[1]
+    assert open(os.path.join(wd, "sharded.fasta"), "rb").read() == ref[0]
