@@ -20,6 +20,9 @@ python tools/pmc_summary.py $(find $OUT/pmc_fetch $OUT/pmc_write -name "*counter
 python tools/pmc_summary.py $(find $OUT/pmc_sq -name "*counter_collection.csv") > $OUT/${TAG}_rocprofv3_sq_summary.csv
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
 cp $OUT/bench.json $OUT/${TAG}_bench.json
+# `hinge consensus`: its kernels under the tracer, E. coli-sized draft
+(cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/trace_cns -o ${TAG}_cns --output-format csv -- python $R/tools/cns_bench.py --no-cpu --steps 5 > $OUT/trace_cns.log 2>&1)
+cp $(find $OUT/trace_cns -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cns_rocprofv3_kernel_stats.csv 2>/dev/null
 tail -1 $OUT/bench.json | cut -c1-400
 head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv
 cat $OUT/${TAG}_rocprofv3_pmc_summary.csv
