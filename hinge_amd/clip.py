@@ -1,6 +1,7 @@
 """`hinge clip` - the first consumer of `hinge layout`'s files: graph construction from `.edges.hinges` /
-`.hinge.list`, dead-end clipping, Z-edge clipping and bubble bursting on the strand-symmetric read graph, `G0` / `G1` written as
-GraphML.
+`.hinge.list`, dead-end clipping, Z-edge clipping and bubble bursting on the strand-symmetric read graph (`G0` / `G1`), loop
+resolution (`G2`) and, with `[layout] aggressive_pruning`, Y pruning (`G3`), written as GraphML: every graph of the reference's
+script that does not go through its random condensation.
 
 Restated from the BEHAVIOUR of the reference's scripts/pruning_and_clipping.py (its reader :1295-1419 and the three operations
 :197-262, :331-390, :561-622 as its main body applies them, :1436-1480), not from its text: this module has its own graph type
@@ -19,8 +20,11 @@ vertices in order of first appearance in `.edges.hinges`, successors in order of
 the three operations on hand-built graphs, the strand symmetry of every result, and order-independence on the layout output
 of the synthetic data sets (three of four are order-free; `long_repeat` has two competing Z edges).
 
-Not built: the later stages of the script (loop resolution :705-839, random condensation :456-500, strand overlay, Y pruning,
-ground-truth and colour annotation) and the files they write (G2, Gs, G2s, Gc, G2c, G3*).
+Round 4: loop resolution (:625-839 -> `resolve_loops`, `resolve_repeat`) and Y pruning (:841-893 -> `prune_ys`), from their
+behaviour as well; the copies loop resolution makes of a repeat's vertices are (read, strand, 'B') here, 'B' + name there.
+Not built: random condensation (:456-500: `random.choice` on Python 2's Mersenne-Twister stream over hash-ordered lists), the strand
+overlay on top of it, ground-truth and colour annotation, and the files they write (Gs, G2s, Gc, G2c, G3s, G3c).  A run says so
+(`<prefix><suffix>.PARTIAL`, stderr; HINGE_CLIP_STRICT=1: exit code 3).
 
     python -m hinge_amd.clip G.edges.hinges G.hinge.list <suffix> [nominal.ini]
 """
@@ -36,12 +40,13 @@ Node = Tuple[int, int]          # (read id, strand)
 
 
 def mirror(v: Node) -> Node:
-    """The same read end seen from the other strand (pruning_and_clipping.py:191-194)."""
-    return (v[0], 1 - v[1])
+    """The same read end seen from the other strand (pruning_and_clipping.py:191-194).  A vertex is (read, strand) or - the copy
+    loop resolution makes of a repeat's vertices, the reference's 'B' + name - (read, strand, 'B')."""
+    return (v[0], 1 - v[1]) + tuple(v[2:])
 
 
 def node_name(v: Node) -> str:
-    return "%d_%d" % v
+    return "".join(v[2:]) + "%d_%d" % (v[0], v[1])
 
 
 class StrandGraph:
@@ -100,6 +105,9 @@ class StrandGraph:
 
     def successors(self, v: Node) -> List[Node]:
         return list(self.out[v])
+
+    def predecessors(self, v: Node) -> List[Node]:
+        return list(self.inn[v])
 
     def out_degree(self, v: Node) -> int:
         return len(self.out[v])
@@ -326,6 +334,134 @@ def burst_bubbles(h: StrandGraph, threshold: int, order: Optional[Iterable[Node]
 _GRAPHML_TYPE = {bool: "boolean", int: "int", float: "double", str: "string"}
 
 
+_COPIED = ("length", "read_a_match_start", "read_a_match_end", "read_b_match_start", "read_b_match_end", "read_a_match_start_raw",
+           "read_a_match_end_raw", "read_b_match_start_raw", "read_b_match_end_raw")
+
+
+def _dup(v: Node) -> Node:
+    return tuple(v[:2]) + ("B",) + tuple(v[2:])
+
+
+def resolve_repeat(g: StrandGraph, rep: List[Node], in_node: Node, out_node: Node) -> None:
+    """pruning_and_clipping.py:625-700 (resolve_rep): the loop's way through the repeat gets its OWN copy of the repeat's vertices -
+    in_node -> B rep[0] -> ... -> B rep[-1] -> out_node, with the nine coordinate attributes of the edges it replaces - and the two
+    edges by which the loop entered and left the shared copy go; the same on the other strand."""
+    def cp(u, v):
+        return {k: g.out[u][v][k] for k in _COPIED if k in g.out[u][v]}
+    a = cp(in_node, rep[0])
+    g.add_edge(in_node, _dup(rep[0]), **a)
+    g.remove_edge(in_node, rep[0])
+    a = cp(rep[-1], out_node)
+    g.add_edge(_dup(rep[-1]), out_node, **a)
+    g.remove_edge(rep[-1], out_node)
+    a = cp(mirror(rep[0]), mirror(in_node))
+    g.add_edge(mirror(_dup(rep[0])), mirror(in_node), **a)
+    g.remove_edge(mirror(rep[0]), mirror(in_node))
+    a = cp(mirror(out_node), mirror(rep[-1]))
+    g.add_edge(mirror(out_node), mirror(_dup(rep[-1])), **a)
+    g.remove_edge(mirror(out_node), mirror(rep[-1]))
+    for x, y in zip(rep, rep[1:]):
+        g.add_edge(_dup(x), _dup(y), **cp(x, y))
+        g.add_edge(mirror(_dup(y)), mirror(_dup(x)), **cp(mirror(y), mirror(x)))
+
+
+def resolve_loops(g: StrandGraph, max_nodes: int = 500, flank: int = 50, max_plasmid_length: int = 500000,
+                  order: Optional[Iterable[Node]] = None) -> List[List[Node]]:
+    """pruning_and_clipping.py:705-839 (loop_resolution), IN PLACE.  From a vertex with two ways out: one way is followed along
+    unbranched vertices (at most max_nodes) to the first vertex that is not - the repeat's first vertex; if another path enters
+    there it must come out of at least `flank` unbranched vertices, and so must the start's other way out go on; the repeat is
+    then followed (a vertex with two ways in and one out first, then unbranched vertices) and, if it ends at the START vertex after
+    more than max_plasmid_length bases in all - a loop through a collapsed repeat that is too long to be a plasmid -, the loop gets
+    its own copy of the repeat (resolve_repeat).  Lengths are |a_start of the next edge - b_start of the previous one| summed along
+    the way (the reference's measure, kept as it is - including that, inside the repeat, `prev_edge` stays the repeat's first edge).
+    Returns the resolved repeats of fewer than five vertices (what the reference lists in tandem.txt).  `order` = the starting
+    vertices' order (default: the graph's insertion order; the reference walks a hash order - parity unpinned, module docstring)."""
+    tandem: List[List[Node]] = []
+    starts = [v for v in (g.nodes() if order is None else order) if v in g and g.out_degree(v) == 2]
+    for st in starts:
+        if st not in g or g.out_degree(st) != 2:
+            continue
+        for first in g.successors(st):
+            if g.out_degree(st) != 2 or not g.has_edge(st, first):
+                continue
+            other = [x for x in g.successors(st) if x != first][0]
+            nxt, in_node = first, st
+            prev_edge = g.out[st][nxt]
+            loop_len = cnt = 0
+            while g.in_degree(nxt) == 1 and g.out_degree(nxt) == 1 and cnt < max_nodes:
+                cnt += 1
+                in_node = nxt
+                nxt = g.successors(nxt)[0]
+                loop_len += abs(g.out[in_node][nxt]["read_a_match_start"] - prev_edge["read_b_match_start"])
+                prev_edge = g.out[in_node][nxt]
+            if cnt >= max_nodes:
+                continue
+            first_of_repeat = nxt
+            if g.in_degree(nxt) == 2:
+                prev = [x for x in g.predecessors(nxt) if x != in_node][0]
+                cnt = 0
+                while g.in_degree(prev) == 1 and g.out_degree(prev) == 1:
+                    cnt += 1
+                    prev = g.predecessors(prev)[0]
+                    if cnt >= flank:
+                        break
+                if cnt < flank:
+                    continue
+            nxt, cnt = other, 0
+            while g.in_degree(nxt) == 1 and g.out_degree(nxt) == 1:
+                cnt += 1
+                nxt = g.successors(nxt)[0]
+                if cnt >= flank:
+                    break
+            if cnt < flank:
+                continue
+            rep = [first_of_repeat]
+            nxt, cnt = first_of_repeat, 0
+            if g.in_degree(nxt) == 2 and g.out_degree(nxt) == 1:
+                dbl = g.successors(nxt)[0]
+                rep.append(dbl)
+                prev_edge = g.out[nxt][dbl]
+            else:
+                dbl = nxt
+                if g.in_degree(dbl) == 1 and g.out_degree(dbl) == 1:
+                    raise AssertionError("loop resolution: the walk stopped at an unbranched vertex (%s)" % node_name(dbl))
+            while g.in_degree(dbl) == 1 and g.out_degree(dbl) == 1 and cnt < max_nodes:
+                cnt += 1
+                succ = g.successors(dbl)[0]
+                loop_len += abs(g.out[dbl][succ]["read_a_match_start"] - prev_edge["read_b_match_start"])
+                dbl = succ
+                rep.append(dbl)
+            if dbl == st and loop_len > max_plasmid_length:
+                resolve_repeat(g, rep, in_node, other)
+                if cnt < 5:
+                    tandem.append(rep)
+    return tandem
+
+
+def prune_ys(g: StrandGraph, flank: int = 10, order: Optional[Iterable[Node]] = None) -> StrandGraph:
+    """pruning_and_clipping.py:841-893 (y_pruning): at a vertex with one way in and several out that is reached over at least `flank`
+    unbranched vertices - a Y, not a collapsed repeat - the branches into vertices flagged for bad coverage (CFLAG) are cut, with
+    their mirror images.  Returns a copy."""
+    h = g.copy()
+    ys = [v for v in (h.nodes() if order is None else order) if v in h and h.out_degree(v) > 1 and h.in_degree(v) == 1]
+    for st in ys:
+        if h.in_degree(st) < 1:
+            continue
+        prev, cnt = h.predecessors(st)[0], 0
+        while h.in_degree(prev) == 1 and h.out_degree(prev) == 1:
+            cnt += 1
+            prev = h.predecessors(prev)[0]
+            if cnt >= flank:
+                break
+        if cnt < flank:
+            continue
+        for v in h.successors(st):
+            if h.attr[v].get("CFLAG") is True:
+                if h.remove_edge(st, v):
+                    h.remove_edge(mirror(v), mirror(st))
+    return h
+
+
 def write_graphml(g: StrandGraph, path: str) -> None:
     """GraphML as graph libraries read it (one <key> per attribute name and domain, typed; vertices named `read_strand`).
     Vertices, edges and keys are written in this graph's own order - the reference's file has the same content in its graph
@@ -431,13 +567,26 @@ def main(argv: Optional[List[str]] = None) -> int:
     out = layout_prefix(edges_path) + suffix
     write_graphml(g0, out + ".G0.graphml")
     write_graphml(g1, out + ".G1.graphml")
-    # A PARTIAL run of the reference's script, and explicit about it: the graphs draft-path / consensus consume are not written.
-    missing = ["G2", "Gs", "G2s", "Gc", "G2c", "G3", "G3c", "G4", "G4c"]
+    # G2 = G1 after loop resolution (pruning_and_clipping.py:1488-1497); with [layout] aggressive_pruning = 1 also G3 = G2 after Y
+    # pruning and one more dead-end clipping (:1521-1527).  Everything else the script writes goes through random_condensation_sym.
+    g2 = g1.copy()
+    tandem = resolve_loops(g2, 500, 50, cfg["max_plasmid_length"])
+    if tandem:
+        with open("tandem.txt", "w") as f:
+            for rep in tandem:
+                f.write(str([node_name(v) for v in rep]))
+    write_graphml(g2, out + ".G2.graphml")
+    written = "G0, G1, G2"
+    if cfg["aggressive_pruning"]:
+        write_graphml(clip_dead_ends(prune_ys(g2, 10), 10), out + ".G3.graphml")
+        written += ", G3"
+    # A PARTIAL run of the reference's script, and explicit about it: the condensed / overlaid graphs are not written.
+    missing = ["Gs", "G2s", "Gc", "G2c"] + (["G3s", "G3c"] if cfg["aggressive_pruning"] else [])
     with open(out + ".PARTIAL", "w") as f:
-        f.write("hinge clip (hinge_amd/clip.py) wrote G0 and G1 only; not written: %s\n" % " ".join(missing))
-    sys.stderr.write("[clip] PARTIAL: G0, G1 written; the later stages of the reference's script (loop resolution, condensation, strand overlay: %s) are not part of this build (%s.PARTIAL)\n"
-                     % (" ".join(missing), out))
-    print("[clip] Done (G0, G1)")
+        f.write("hinge clip (hinge_amd/clip.py) wrote %s; not written (they go through the script's random condensation): %s\n" % (written, " ".join(missing)))
+    sys.stderr.write("[clip] PARTIAL: %s written; the condensed and strand-overlaid graphs of the reference's script (%s) are not part of this build (%s.PARTIAL)\n"
+                     % (written, " ".join(missing), out))
+    print("[clip] Done (%s)" % written)
     return 3 if os.environ.get("HINGE_CLIP_STRICT", "0") == "1" else 0      # HINGE_CLIP_STRICT=1: pipelines that need the later graphs fail here
 
 

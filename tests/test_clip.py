@@ -272,6 +272,79 @@ def test_partial_run_is_explicit(tmp_path, monkeypatch, capsys):
     monkeypatch.chdir(tmp_path)
     assert clip.main(["G.edges.hinges", "G.hinge.list", ".x"]) == 0
     assert os.path.exists("G.x.G0.graphml") and os.path.exists("G.x.G1.graphml")
-    assert "G2" in open("G.x.PARTIAL").read() and "PARTIAL" in capsys.readouterr().err
+    assert os.path.exists("G.x.G2.graphml") and not os.path.exists("G.x.G3.graphml")
+    assert "Gs" in open("G.x.PARTIAL").read() and "PARTIAL" in capsys.readouterr().err
     monkeypatch.setenv("HINGE_CLIP_STRICT", "1")
     assert clip.main(["G.edges.hinges", "G.hinge.list", ".x"]) == 3
+
+
+def coord_chain(g, ids, strand=0, step=1000):
+    """a chain whose edges carry the coordinates loop resolution measures with: |a_start(next) - b_start(previous)| = step per edge"""
+    for a, b in zip(ids, ids[1:]):
+        sym_edge(g, (a, strand), (b, strand), length=step, read_a_match_start=0, read_a_match_end=step, read_b_match_start=step, read_b_match_end=2 * step,
+                 read_a_match_start_raw=0, read_a_match_end_raw=step, read_b_match_start_raw=step, read_b_match_end_raw=2 * step)
+
+
+def collapsed_repeat(flank=60, rep=6, loop=20):
+    """A -> R -> B -> R -> C with the two copies of R collapsed: flank A (1000..) -> r (2000..) -> loop B (3000..) -> back into r; r's last
+    vertex also leaves into flank C (4000..)."""
+    g = StrandGraph()
+    A = list(range(1000, 1000 + flank))
+    R = list(range(2000, 2000 + rep))
+    B = list(range(3000, 3000 + loop))
+    C = list(range(4000, 4000 + flank))
+    coord_chain(g, A + R + B + [R[0]])
+    coord_chain(g, [R[-1]] + C)
+    return g, A, R, B, C
+
+
+def test_loop_resolution_gives_the_loop_its_own_repeat_copy():
+    g, A, R, B, C = collapsed_repeat()
+    n_edges = g.n_edges()
+    assert clip.resolve_loops(g, 500, 50, max_plasmid_length=10**9) == [] and g.n_edges() == n_edges        # too short to be anything but a plasmid: untouched
+    tandem = clip.resolve_loops(g, 500, 50, max_plasmid_length=5000)
+    assert g.is_strand_symmetric()
+    # one unbranched path per strand now: A -> R -> B -> R -> C, one of the two passes through R over the copy (which pass gets the copy
+    # depends on which strand's start vertex is visited first: both are the same graph up to the copy's name)
+    assert all(g.out_degree(v) <= 1 and g.in_degree(v) <= 1 for v in g.nodes())
+    path, v = [], (A[0], 0)
+    while True:
+        path.append(v)
+        nx = g.successors(v)
+        if not nx:
+            break
+        v = nx[0]
+    reads = [p_[0] for p_ in path]
+    assert reads == A + R + B + R + C
+    copies = [p_ for p_ in path if len(p_) == 3]
+    assert [c[0] for c in copies] == R and all(c[2] == "B" for c in copies)
+    assert len([v for v in g.nodes() if len(v) == 3]) == 2 * len(R)
+    assert clip.node_name(copies[0]) == "B%d_0" % R[0] and clip.node_name(clip.mirror(copies[0])) == "B%d_1" % R[0]
+    assert all(a["read_b_match_start"] == 1000 for _, _, a in g.edges())      # the copied edges carry the replaced edges' coordinates
+    assert len(tandem) == 1 and sorted(v[0] for v in tandem[0]) == R          # (walked in four steps: the reference lists repeats of fewer than five in tandem.txt)
+    g3, _, R3, *_ = collapsed_repeat(rep=9)
+    assert clip.resolve_loops(g3, 500, 50, max_plasmid_length=5000) == [] and len([v for v in g3.nodes() if len(v) == 3]) == 2 * len(R3)
+    # flanks shorter than `flank`: could be a collapsed repeat inside something else - left alone
+    g2, *_ = collapsed_repeat(flank=20)
+    e2 = edge_set(g2)
+    clip.resolve_loops(g2, 500, 50, max_plasmid_length=5000)
+    assert edge_set(g2) == e2
+
+
+def test_y_pruning_cuts_the_flagged_branch():
+    g = StrandGraph()
+    chain(g, list(range(100, 120)) + [200])              # 19 unbranched vertices in front of the Y at 119
+    chain(g, [119, 300, 301, 302])
+    chain(g, [200, 201, 202])
+    for v in g.nodes():
+        g.attr[v]["CFLAG"] = False
+    g.attr[(300, 0)]["CFLAG"] = g.attr[(300, 1)]["CFLAG"] = True
+    h = clip.prune_ys(g, 10)
+    assert not h.has_edge((119, 0), (300, 0)) and not h.has_edge((300, 1), (119, 1)) and h.has_edge((119, 0), (200, 0))
+    assert g.has_edge((119, 0), (300, 0))                 # a copy: the input is left alone
+    short = StrandGraph()
+    chain(short, list(range(110, 120)) + [200])          # only 9 unbranched vertices in front: could be a collapsed repeat, not a Y
+    chain(short, [119, 300])
+    for v in short.nodes():
+        short.attr[v]["CFLAG"] = v[0] == 300
+    assert clip.prune_ys(short, 10).has_edge((119, 0), (300, 0))
