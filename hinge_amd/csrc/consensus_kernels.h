@@ -80,30 +80,32 @@ struct CnsPair {                   // the two sequences of one alignment, addres
 // Row D (= -2, -1, 0, 1, ...) holds the diagonals k in [lo0 - ext(D) - 1, hi0 + ext(D) + 1], ext(D) = max(D, 0) / 2, lo0 = min(0, del),
 // hi0 = max(0, del): exactly what iter_np's wave D touches, sentinels included (the reference's rows are tspace + nmax + 3 wide
 // and never read outside this range either - checked with a probe in the test restatement of the same loop).  A cell is furthest << 8 | move.
+// Layout: cell (D, k) of lane l of a wavefront sits at ((D + 2) * width + (k - klo(D))) * 64 + l of the WAVEFRONT's stretch, `width`
+// one row's cells for the whole launch.  The 64 lanes walk their waves in lock step and their columns k - klo(D) differ only by
+// their segments' |M - N| - a few cells -, so one wavefront access touches a handful of 256-byte lines instead of 64 (each lane a
+// stretch of its own: 64 lines per access, every one an L2 round trip).
 struct CnsWaves {
-    int* W; int w0, lo0, cap_cells;
-    __device__ __forceinline__ int row_off(int D) const { const int d = D > 0 ? D : 0; return (D + 2) * w0 + 2 * (((d - 1) * (d - 1)) >> 2); }
+    int* W; int width, lo0;
     __device__ __forceinline__ int klo(int D) const { return lo0 - (D > 0 ? (D >> 1) : 0) - 1; }
-    __device__ __forceinline__ int* row(int D) const { return W + row_off(D) - klo(D); }   // row(D)[k]
-    __device__ __forceinline__ int v(int D, int k) const { return row(D)[k] >> 8; }
-    __device__ __forceinline__ int h(int D, int k) const { return (int)(signed char)(row(D)[k] & 0xff); }
-    __device__ __forceinline__ void set_v(int D, int k, int val) { int* p = row(D) + k; *p = (int)((unsigned)val << 8) | (*p & 0xff); }
-    __device__ __forceinline__ void set_h(int D, int k, int e) { int* p = row(D) + k; *p = (*p & ~0xff) | (e & 0xff); }
+    __device__ __forceinline__ int* at(int D, int k) const { return W + (((D + 2) * width + (k - klo(D))) << 6); }
+    __device__ __forceinline__ int* row(int D) const { return at(D, 0); }                   // row(D)[k << 6]
+    __device__ __forceinline__ int v(int D, int k) const { return *at(D, k) >> 8; }
+    __device__ __forceinline__ int h(int D, int k) const { return (int)(signed char)(*at(D, k) & 0xff); }
+    __device__ __forceinline__ void set_v(int D, int k, int val) { int* p = at(D, k); *p = (int)((unsigned)val << 8) | (*p & 0xff); }
+    __device__ __forceinline__ void set_h(int D, int k, int e) { int* p = at(D, k); *p = (*p & ~0xff) | (e & 0xff); }
 };
-__host__ __device__ inline long long cns_cells(int dcap, int del_abs) {   // cells of rows -2 .. dcap
-    const long long d = dcap + 1;
-    return (d + 2) * (long long)(del_abs + 3) + 2 * (((d - 1) * (d - 1)) >> 2);
-}
+__host__ __device__ inline int cns_row_width(int dcap, int del_abs) { return del_abs + 2 * ((dcap + 1) / 2) + 3; }   // cells of the widest row (D = dcap)
+__host__ __device__ inline long long cns_cells(int dcap, int width) { return (long long)(dcap + 3) * width; }            // rows -2 .. dcap
 
 // iter_np (LAInterface.cpp:3152-3404) for the segment A[a0, a0 + M) x B[b0, b0 + N).  Writes the indel list (1-based absolute
 // positions: +B position for a gap in B, -(A position) for a gap in A) to out[0..), returns its length, or -1 / -2 on overflow.
 __device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N, CnsWaves w, int dcap, int* __restrict__ out, int out_cap, int& n_ins) {
     const int del = M - N;
     int low = del >= 0 ? 0 : del, hgh = del >= 0 ? del : 0;
-    w.lo0 = low; w.w0 = (del >= 0 ? del : -del) + 3;
+    w.lo0 = low;
     {
         int* r2 = w.row(-2); int* r1 = w.row(-1);
-        for (int k = low - 1; k <= hgh + 1; k++) { r2[k] = -512; r1[k] = -512; }
+        for (int k = low - 1; k <= hgh + 1; k++) { r2[k << 6] = -512; r1[k << 6] = -512; }
         r1[0] = -256;
     }
     low += 1; hgh -= 1;
@@ -114,9 +116,9 @@ __device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N
         int* __restrict__ F0 = w.row(D);
         const int* __restrict__ F1 = w.row(D - 1);
         const int* __restrict__ F2 = w.row(D - 2);
-        F0[hgh + 1] = -512; F0[low - 1] = -512;
+        F0[(hgh + 1) << 6] = -512; F0[(low - 1) << 6] = -512;
         auto move = [&](int k, int am, int ap, int mdir, int pdir) {
-            const int ac = (F1[k] >> 8) + 1;
+            const int ac = (F1[k << 6] >> 8) + 1;
             int j, hc;
             if (ac < am) { if (ap < am) { hc = mdir; j = am; } else { hc = pdir; j = ap; } }
             else { if (ap < ac) { hc = 0; j = ac; } else { hc = pdir; j = ap; } }
@@ -132,14 +134,14 @@ __device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N
                     j += eq < room ? eq : room;
                     if (eq < 16) break;
                 }
-            F0[k] = (int)((unsigned)j << 8) | (hc & 0xff);
+            F0[k << 6] = (int)((unsigned)j << 8) | (hc & 0xff);
             return j;
         };
         int j = -2;
-        for (int k = hgh; k > del; k--) j = move(k, F2[k - 1] >> 8, j + 1, -1, 4);
+        for (int k = hgh; k > del; k--) j = move(k, F2[(k - 1) << 6] >> 8, j + 1, -1, 4);
         j = -2;
-        for (int k = low; k < del; k++) j = move(k, j, (F2[k + 1] >> 8) + 1, 2, 1);
-        j = move(del, j, (F0[del + 1] >> 8) + 1, 2, 4);
+        for (int k = low; k < del; k++) j = move(k, j, (F2[(k + 1) << 6] >> 8) + 1, 2, 1);
+        j = move(del, j, (F0[(del + 1) << 6] >> 8) + 1, 2, 4);
         if (j >= N) break;
     }
     // trace-back with re-sliding (LAInterface.cpp:3285-3352)
@@ -203,12 +205,12 @@ __device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N
 constexpr int CNS_BLOCK = 256;
 
 __global__ __launch_bounds__(CNS_BLOCK) void k_cns_realign(CnsSeqs SA, CnsSeqs SB, const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, int n_seg,
-                                                           int* __restrict__ scratch, long long cells_per_lane, int* __restrict__ indels,
+                                                           int* __restrict__ scratch, int row_width, int rows, int* __restrict__ indels,
                                                            int* __restrict__ n_indel, int* __restrict__ n_ins_out, int* __restrict__ status) {
     const long long lane_g = (long long)blockIdx.x * CNS_BLOCK + threadIdx.x;
     const long long n_lanes = (long long)gridDim.x * CNS_BLOCK;
     CnsWaves w;
-    w.W = scratch + lane_g * cells_per_lane; w.cap_cells = (int)cells_per_lane; w.w0 = 0; w.lo0 = 0;
+    w.W = scratch + (lane_g >> 6) * ((long long)rows * row_width * 64) + (lane_g & 63); w.width = row_width; w.lo0 = 0;
     for (long long s = lane_g; s < n_seg; s += n_lanes) {
         const CnsSeg g = segs[s];
         const CnsAln al = alns[g.aln];
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_realign(CnsSeqs SA, CnsSeqs S
         S.abps = SA.bps; S.aoff = SA.boff[al.a]; S.bbps = SB.bps; S.boff = SB.boff[al.b]; S.comp = al.comp; S.blen = al.blen;
         const int del_abs = g.m >= g.n ? g.m - g.n : g.n - g.m;
         int dcap = al.dcap;
-        if (cns_cells(dcap, del_abs) > cells_per_lane) { atomicOr(status, CNS_ST_WAVES); n_indel[s] = 0; n_ins_out[s] = 0; continue; }
+        if (cns_row_width(dcap, del_abs) > row_width || dcap + 3 > rows) { atomicOr(status, CNS_ST_WAVES); n_indel[s] = 0; n_ins_out[s] = 0; continue; }
         int nins = 0;
         const int cnt = cns_iter_np(S, g.a0, g.m, g.b0, g.n, w, dcap, indels + g.out_off, g.out_cap, nins);
         if (cnt < 0) { atomicOr(status, cnt == -1 ? CNS_ST_WAVES : CNS_ST_INDELS); n_indel[s] = 0; n_ins_out[s] = 0; continue; }
