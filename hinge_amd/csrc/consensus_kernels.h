@@ -5,12 +5,13 @@
 // Roofline: NOT HBM.  The work is Myers' O(np) wave algorithm between successive trace points - a serial recurrence along each
 // wave (a diagonal needs its neighbour of the SAME wave) - so the unit of parallelism is the trace-point segment (~100 x ~100
 // bases), one LANE per segment, tens of thousands of segments per contig.  Bound by instruction issue and the latency of the
-// lane-private wave arrays; bytes moved are a few hundred per segment.
+// wave arrays in L2-resident scratch; bytes moved from HBM are a few hundred per segment.
 //
 // Kernels:
 //   k_cns_realign   one lane per segment: forward waves, the reference's trace-back with re-sliding, the indel list
 //   k_cns_columns   one thread per alignment: column offsets of its segments, chop_end's start / offset / end
-//   k_cns_vote      one lane per segment: replays the columns, votes into the per-position counters (global atomics)
+//   k_cns_vote_tiles one workgroup per tile of contig positions: its segments replay their columns and vote with LDS atomics
+//                   (k_cns_tile_count / k_cns_tile_fill bin the segments; k_cns_vote: the same with global atomics, the fallback)
 //   k_cns_call      one thread per contig position: the reference's base calls (0-2 characters), block sums
 //   k_cns_scan      exclusive scan of the block sums;  k_cns_emit  writes the characters at their final offsets
 #pragma once
