@@ -113,21 +113,47 @@ int main(int argc, char* argv[]) {
     if (hinge_consensus_set_db(ctx, 0, n_contigs, db1.rlen.data(), db1.boff.data(), bps1.p, (int64_t)bps1.n) != HINGE_OK) die("draft DB");
     if (hinge_consensus_set_db(ctx, 1, n_reads, db2.rlen.data(), db2.boff.data(), bps2.p, (int64_t)bps2.n) != HINGE_OK) die("read DB");
     tm.mark("H2D bases");
-    if (hinge_consensus_run(ctx, (int64_t)used.size(), used.data(), trace.data(), (int64_t)trace.size(), tspace) != HINGE_OK) die("consensus");
-    tm.mark("realign + vote + call");
+    // Contigs go to the GPU in batches: one hinge_consensus_run holds an indel slot per (segment, recorded difference) - 240 MB for an
+    // E. coli-sized draft at 30x, beyond 2^32 slots for a few hundred Mb - so a batch ends where its estimate reaches
+    // HINGE_CNS_SLOT_BUDGET (default 1.5e9 slots = 6 GB); a batch is whole contigs, their results are kept, the text is written at the end
+    // in contig order.  (A contig without voting alignments comes out of every run as its own lower-case bases.)
+    long long budget = 1500000000ll;
+    if (const char* g = getenv("HINGE_CNS_SLOT_BUDGET")) budget = std::max(1ll, atoll(g));
+    auto slots_of = [&](const hinge_cns_alignment& a) {
+        int dmax = 0;
+        for (int d = 0; d < a.tlen; d += 2) dmax = std::max(dmax, (int)trace[(size_t)a.trace_off + (size_t)d]);
+        return (long long)std::max(a.tlen / 2, 1) * (dmax + 16);
+    };
+    std::vector<std::string> text((size_t)n_contigs);
+    std::vector<hinge_cns_stats> stats((size_t)n_contigs);
     std::vector<int32_t> offsets(std::max<size_t>(used.size(), 1));
-    if (!used.empty() && hinge_consensus_get_offsets(ctx, offsets.data()) != HINGE_OK) die("offsets");
+    int n_batches = 0;
+    for (int c0 = 0; c0 < n_contigs;) {
+        int c1 = c0;
+        long long est = 0;
+        do {
+            for (int64_t k = first_used[(size_t)c1]; k < first_used[(size_t)c1 + 1]; k++) est += slots_of(used[(size_t)k]);
+            c1++;
+        } while (c1 < n_contigs && est < budget);
+        const int64_t k0 = first_used[(size_t)c0], k1 = first_used[(size_t)c1];
+        if (hinge_consensus_run(ctx, k1 - k0, used.data() + k0, trace.data(), (int64_t)trace.size(), tspace) != HINGE_OK) die("consensus");
+        if (k1 > k0 && hinge_consensus_get_offsets(ctx, offsets.data() + k0) != HINGE_OK) die("offsets");
+        for (int i = c0; i < c1; i++) {
+            int64_t len = 0;
+            if (hinge_consensus_get_contig(ctx, i, nullptr, 0, &len, &stats[(size_t)i]) != HINGE_OK) die("contig");
+            text[(size_t)i].resize((size_t)len);
+            if (len && hinge_consensus_get_contig(ctx, i, &text[(size_t)i][0], len, &len, &stats[(size_t)i]) != HINGE_OK) die("contig");
+        }
+        n_batches++;
+        c0 = c1;
+    }
+    tm.mark("realign + vote + call");
 
-    std::vector<char> buf;
     for (int i = 0; i < n_contigs; i++) {
         printf("Contig %d: %d reads\n", i, seq_count[(size_t)i]);
-        int64_t len = 0;
-        hinge_cns_stats st;
-        if (hinge_consensus_get_contig(ctx, i, nullptr, 0, &len, &st) != HINGE_OK) die("contig");
-        buf.resize((size_t)len + 1);
-        if (hinge_consensus_get_contig(ctx, i, buf.data(), len, &len, &st) != HINGE_OK) die("contig");
+        const hinge_cns_stats& st = stats[(size_t)i];
         fprintf(out, ">Consensus%d\n", i);
-        fwrite(buf.data(), 1, (size_t)len, out);
+        fwrite(text[(size_t)i].data(), 1, text[(size_t)i].size(), out);
         fputc('\n', out);
         if (seq_count[(size_t)i] == 0) continue;      // (printed as it is, consensus.cpp:158-162: no statistics)
         for (int64_t k = first_used[(size_t)i]; k < first_used[(size_t)i + 1]; k++) printf("%d\n", offsets[(size_t)k]);
@@ -139,6 +165,7 @@ int main(int argc, char* argv[]) {
         printf("Low coverage bases: %d/%d\n", st.low_coverage_bases, alen);
         printf("Consensus length: %d\n", st.consensus_length);
     }
+    if (getenv("HINGE_HOST_TIMING")) fprintf(stderr, "[timing] consensus: %d contig batch(es)\n", n_batches);
     fclose(out);
     tm.mark("text");
     return finish(ctx, tm, 0);

@@ -142,3 +142,17 @@ def test_python_driver_and_contig_sharding_on_the_gpu(oracle_lib, tmp_path):
     got = sorted(ret.get() for _ in range(2))
     assert [g[1] for g in got] == [0, 0] and got[0][2] == ref[1] and got[1][2] == ref[1]
     assert open(os.path.join(wd, "sharded.fasta"), "rb").read() == ref[0]
+
+
+def test_contigs_in_several_batches(oracle_lib, tmp_path):
+    """HINGE_CNS_SLOT_BUDGET small enough for one contig per hinge_consensus_run (what a draft of hundreds of Mb triggers by itself):
+    the files are those of the single run."""
+    wd = str(tmp_path)
+    cc.make("cns_small", wd)
+    ref = cc.run_reference(wd) or cc.run_oracle(oracle_lib, wd)
+    import subprocess
+    r = subprocess.run([cc.EXE, "draft", "reads", "draft.reads.las", "b.fasta", "nominal.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, HINGE_CNS_SLOT_BUDGET="1", HINGE_HOST_TIMING="1"))
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    assert b"4 contig batch(es)" in r.stderr
+    assert open(os.path.join(wd, "b.fasta"), "rb").read() == ref[0] and r.stdout == ref[1]
