@@ -66,3 +66,41 @@ def test_pile_bins_restates_profile_coverage_bin_count():
     # a slice of a larger table (absolute offsets), as hinge_amd/stages.py passes it
     assert capi.pile_bins(row_ptr[2:5], a_span, rlen[2:4]).tolist() == [90 // 40 + 2, -1]
     assert capi.pile_bins(np.array([0, 0], np.int64), np.zeros((0, 2), np.int32), rlen[:1]).tolist() == [0]
+
+
+@pytest.mark.gpu
+def test_rccl_between_contexts_one_rank():
+    """hinge_comm_create / hinge_comm_exchange_mask_rows (the executables' RCCL exchange of mask rows) as far as a 1-GPU
+    box can run them: librccl is dlopen'ed, ncclCommInitAll makes a one-rank communicator, the grouped ncclAllGather runs on the
+    context's stream, the own rows survive; two contexts on ONE device are refused (RCCL takes one rank per device), which is
+    where the executables fall back to host exchanges."""
+    import ctypes as C
+    import numpy as np
+    from hinge_amd import capi
+    lib = capi.load_library()
+    n = 1000
+    rlen = np.full(n, 6000, np.int32)
+    row_ptr = np.arange(n + 1, dtype=np.int64)
+    a_span = np.tile(np.array([[0, 5000]], np.int32), (n, 1))
+    b_span = a_span.copy()
+    b_flag = ((np.arange(n) + 1) % n).astype(np.uint32)
+    ctx = capi.Context(0)
+    ctx.set_reads(rlen, None)
+    ctx.set_pileups(0, n - 1, row_ptr, a_span, b_span, b_flag)
+    rows = np.arange(2 * n, dtype=np.int32).reshape(n, 2)
+    ctx._ck(lib.hinge_set_mask_rows(ctx.h, 0, n - 1, rows.ctypes.data_as(C.c_void_p)))
+    arr = (C.c_void_p * 1)(ctx.h)
+    rc = lib.hinge_comm_create(arr, 1)
+    assert rc == 0, lib.hinge_last_error(ctx.h)
+    lo, hi = np.array([100], np.int32), np.array([899], np.int32)
+    for phase in (0, 1):
+        rc = lib.hinge_comm_exchange_mask_rows(arr, 1, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), phase)
+        assert rc == 0, lib.hinge_last_error(ctx.h)
+    mask, _, _ = ctx.get_masks()
+    assert np.array_equal(mask, rows)
+    other = capi.Context(0)
+    two = (C.c_void_p * 2)(ctx.h, other.h)
+    assert lib.hinge_comm_create(two, 2) == capi.HINGE_E_DEVICE
+    assert b"share a device" in lib.hinge_last_error(ctx.h)
+    other.close()
+    ctx.close()
