@@ -351,16 +351,19 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_ovl * args.steps / elapsed
         kname = dominant
-        avg_ms = prof_ms / max(prof_cnt, 1)              # mean launch time over the launches of all R parts
+        avg_ms = prof_ms / max(prof_cnt, 1)              # mean launch time over the timed region's launches
+        # parts per launch: 1 when every part has a launch of its own, R when one launch sweeps all resident parts (the batched
+        # k_mask_annotate_q20) - from the launch count itself, so reruns of a part count as launches
+        ppl = R * args.steps / max(prof_cnt, 1)
         n_reads = sum(part_reads)
         if kname not in KERNEL_BYTES_PER_OVERLAP:
             alg_bytes = achieved = phys_bytes = None      # sparse kernel: touches only the work-list reads
         else:
-            alg_bytes = (KERNEL_BYTES_PER_OVERLAP[kname] * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads) / R   # mean per launch
+            alg_bytes = (KERNEL_BYTES_PER_OVERLAP[kname] * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads) / R * ppl   # mean per launch
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             # what the kernel has to move: the 16|16 span copy (4 B per overlap, packed by the ingest), the per-read tables and,
             # for the mask / annotate kernel, the coverage bins it stores
-            phys_bytes = (4 * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads + (4 * sum(part_bins) if kname == "k_mask_annotate" else 0)) / R
+            phys_bytes = (4 * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads + (4 * sum(part_bins) if kname == "k_mask_annotate" else 0)) / R * ppl
         one_sweep = bool(getattr(batch, "one_sweep", False)) and "k_cov_stats" not in {k for k, v in breakdown.items() if v[1] > 0}
         traffic, traffic_src = pmc_traffic(kname)
         resident = sum(part_ovl) * (8 + 8 + 4 + 4) + sum(part_bins) * 4
@@ -375,6 +378,7 @@ def main():
             "traffic_source": traffic_src,
             "avg_launch_ms": avg_ms,
             "launches_timed": prof_cnt,
+            "parts_per_launch": ppl,
             "algorithmic_bytes_per_launch": alg_bytes,
             "physical_bytes_per_launch": phys_bytes,
             "achieved_physical": (phys_bytes / (avg_ms * 1e-3) / 1e9) if phys_bytes else None,
@@ -383,11 +387,11 @@ def main():
             "one_sweep_note": ("the dominant kernel is the FIRST AND ONLY sweep of the pass (DESIGN.md 3.6): it does the work SURVEY 8(d) prices as pass 1 (8 B per overlap) "
                                "plus pass 2's span read (8 B per overlap); `frac` keeps crediting it 8 B per overlap - what one sweep has to read - so it is "
                                "comparable with rounds 1-3, where a second kernel (k_cov_stats, 32 us per part) was credited the other 8") if one_sweep else None,
-            "frac_if_credited_both_passes": ((alg_bytes + 8 * n_ovl / R + 20 * n_reads / R) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (one_sweep and achieved is not None and kname == "k_mask_annotate") else None,
+            "frac_if_credited_both_passes": ((alg_bytes + (8 * n_ovl / R + 20 * n_reads / R) * ppl) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (one_sweep and achieved is not None and kname == "k_mask_annotate") else None,
             "physical_note": "`frac` credits SURVEY 8(d)'s 8 B per overlap (the int32 span pair); the kernel reads the ingest's 16|16 copy (4 B per "
                              "overlap) and, unlike 8(d)'s accounting, writes the coverage bins: physical = 4 B x overlaps + per-read tables + bins; "
                              "waste_ratio = counter traffic / physical",
-            "coverage_bins_bytes_per_launch": 4 * sum(part_bins) / R if kname == "k_mask_annotate" else None,
+            "coverage_bins_bytes_per_launch": 4 * sum(part_bins) / R * ppl if kname == "k_mask_annotate" else None,
             "coverage_bins_note": "k_mask_annotate also stores the cutoff-0 coverage bins (.coverage.txt payload, ~4 B x (rlen/40 + 2) per read); "
                                   "they are NOT counted in `achieved`",
             "kernels_ms_per_step": {k: v[0] / n_break for k, v in breakdown.items() if v[1] > 0},

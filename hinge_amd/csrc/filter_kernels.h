@@ -1345,7 +1345,7 @@ __device__ unsigned long long* g_k2_trace = nullptr;
 // scan's values at the odd indices is the sum over the read's bins), and a read that is not decided for every MIN_COV in
 // [pred - band, pred + band] emits nothing and goes on the guard-band list.
 template <bool PACKED, bool COVOUT, int CUT20, int SPEC /*0: a pass with the exact MIN_COV; 1: first sweep of a one-sweep pass, band 1 (a constant: MIN_COV +- band cost no registers); 2: any band*/>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off_arg, int mulpath_thr /*min(MIN_RA, MAX_RA) >= 0: the
+__device__ __forceinline__ void k2_q20_body(const int vblock /*the workgroup's index among its PART's workgroups*/, const K2Const* __restrict__ C, int cut_off_arg, int mulpath_thr /*min(MIN_RA, MAX_RA) >= 0: the
                                                              division-free annotation test applies (a launch condition)*/,
                                                              int nhr /*NO_HINGE_REGION*/, int cov_mask_off /*INT_MIN if the coverage mask takes part in the mask, else 1 << 29*/,
                                                              const int* __restrict__ read_list, int n1, int n2, int n4,
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                              const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints,
                                                              int* __restrict__ cov_out /*COVOUT: the coverage-bin output*/,
                                                              const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
-                                                             unsigned* __restrict__ heads, int n_heads, K2Heads bases,
+                                                             unsigned* __restrict__ heads, int n_heads, const unsigned* __restrict__ head_bases /*value of every item counter before this launch*/,
                                                              int* __restrict__ cov_tot /*SPEC*/, int band_arg /*SPEC == 2*/) {
     const int band = SPEC == 1 ? 1 : band_arg;
     extern __shared__ int lds[];
@@ -1384,13 +1384,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     unsigned grab = 0, head_base = 0;
     int head = 0;
     unsigned* head_ptr = nullptr;
-    if ((int)blockIdx.x < g4) { width = 4; if (wib != 0) return; item = n1 + n2 + (int)blockIdx.x; item_end = item + 1; }
-    else if ((int)blockIdx.x < g4 + g2) { width = 2; if (wib & 1) return; item = ((int)blockIdx.x - g4) * 2 + (wib >> 1); if (item >= n2) return; item += n1; item_end = item + 1; }
+    if (vblock < g4) { width = 4; if (wib != 0) return; item = n1 + n2 + vblock; item_end = item + 1; }
+    else if (vblock < g4 + g2) { width = 2; if (wib & 1) return; item = (vblock - g4) * 2 + (wib >> 1); if (item >= n2) return; item += n1; item_end = item + 1; }
     else {
         width = 1; dyn = true; item = 0; item_end = n1;
-        head = ((int)blockIdx.x - g4 - g2) % n_heads;
+        head = (vblock - g4 - g2) % n_heads;
         head_ptr = heads + head * 32;
-        head_base = bases.base[head];
+        head_base = head_bases[head];
         if (lane == 0) grab = atomicAdd(head_ptr, 1u);   // (its latency is covered by the set-up below)
     }
     constexpr int reso = 40;
@@ -1743,6 +1743,66 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             for (int h = 0; h < HOTW; h++) hot[h * WAVE + lane] = 0;
         }
         HINGE_K2_STAMP(4);
+    }
+}
+
+// the kernel for ONE part: everything in kernel arguments
+template <bool PACKED, bool COVOUT, int CUT20, int SPEC>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20(const K2Const* __restrict__ C, int cut_off_arg, int mulpath_thr, int nhr, int cov_mask_off,
+                                                             const int* __restrict__ read_list, int n1, int n2, int n4, const int64_t* __restrict__ row_ptr,
+                                                             const typename SpanLoad<PACKED>::raw* __restrict__ a_span, const int* __restrict__ rlen,
+                                                             const int* __restrict__ nbins0, const int* __restrict__ d_min_cov, int slot_ints, int* __restrict__ cov_out,
+                                                             const long long* __restrict__ cov_off, int* __restrict__ cov_nbins, int cov_base,
+                                                             unsigned* __restrict__ heads, int n_heads, K2Heads bases, int* __restrict__ cov_tot, int band_arg) {
+    k2_q20_body<PACKED, COVOUT, CUT20, SPEC>((int)blockIdx.x, C, cut_off_arg, mulpath_thr, nhr, cov_mask_off, read_list, n1, n2, n4, row_ptr, a_span, rlen, nbins0, d_min_cov,
+                                             slot_ints, cov_out, cov_off, cov_nbins, cov_base, heads, n_heads, bases.base, cov_tot, band_arg);
+}
+// ... and for up to K2_BATCH_MAX resident parts in ONE launch (round 4): the parts' workgroups lie one range after the other in the
+// grid, every part with its share of the persistent workgroups (all resident at once), its own lists, counters and outputs.  Four
+// launches pay four ramps, four tails behind a part's slowest reads and three launch boundaries; one launch pays one of each.
+// The parts' arguments travel BY VALUE (3 KB of kernel arguments for eight parts: scalar loads, wave-uniform like any argument,
+// and nothing to upload between launches although the counters' base values change with every launch).
+constexpr int K2_BATCH_MAX = 8;
+struct K2Part {
+    const K2Const* C;
+    const int* read_list; const int64_t* row_ptr; const void* a_span; const int* rlen; const int* nbins0; const int* d_min_cov;
+    int* cov_out; const long long* cov_off; int* cov_nbins; unsigned* heads; int* cov_tot;
+    int n1, n2, n4, slot_ints, cov_base, n_heads;
+    int first_block, n_blocks;      // the part's workgroups are [first_block, first_block + n_blocks) (first_block a multiple of 8: the XCD of a workgroup is the same as in a launch of its own)
+    unsigned head_bases[K2_MAX_HEADS];
+};
+struct K2Batch { int n; int pad; K2Part part[K2_BATCH_MAX]; };
+// A part's persistent workgroups do not stop when their own part's short reads run out: wavefront by wavefront they move on to the
+// next part of the batch (ring order) and draw from ITS counters - the whole launch has one tail, not one per part at a fraction of
+// the chip (without this the batched launch is SLOWER than the launches it replaces: 296 against 4 x 68 us).  Persistent workgroup j
+// of part p serves head (j + rot_p - rot_q) mod n_heads_q of part q, rot = (g4 + g2) % 8: the XCD its own deal put it on is the XCD
+// of that head's slice of q's span copy.  Every wavefront visits every part and makes exactly one failing draw per visit, so the
+// host still knows where each counter stands after the launch.  All parts use ONE slot size (the batch's largest): wavefronts of one
+// workgroup work on different parts at the same time.
+__host__ __device__ inline int k2_visit_head(int j, int rot_from, int rot_to, int n_heads_to) {
+    int m = (j + rot_from - rot_to) % n_heads_to;
+    return m < 0 ? m + n_heads_to : m;
+}
+template <bool PACKED, bool COVOUT, int CUT20, int SPEC>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mask_annotate_q20_batch(const K2Batch B, int cut_off_arg, int mulpath_thr, int nhr, int cov_mask_off, int band_arg,
+                                                                                                             int visit /*1: own part only*/) {
+    int p = 0;
+    for (int q = 1; q < B.n; q++) p += (int)blockIdx.x >= B.part[q].first_block ? 1 : 0;     // (uniform; n <= 8)
+    const int vblock = (int)blockIdx.x - B.part[p].first_block;
+    if (vblock >= B.part[p].n_blocks) return;                                                  // (the padding to the next multiple of 8)
+    const int fixed_p = B.part[p].n4 + (B.part[p].n2 + 1) / 2;
+    const int j = vblock - fixed_p;                                                            // >= 0: a persistent workgroup
+    const int first = (visit & 256) && j >= 0 ? 0 : p;      // bit 8: every persistent workgroup starts with part 0 (the chip sweeps one part after the other)
+    for (int t = 0; t < (visit & 255); t++) {
+        int q = first + t;
+        if (q >= B.n) q -= B.n;
+        const K2Part& A = B.part[q];
+        const int fixed_q = A.n4 + (A.n2 + 1) / 2;
+        const int vb = q == p ? vblock : fixed_q + k2_visit_head(j, fixed_p & 7, fixed_q & 7, A.n_heads);
+        k2_q20_body<PACKED, COVOUT, CUT20, SPEC>(vb, A.C, cut_off_arg, mulpath_thr, nhr, cov_mask_off, A.read_list, A.n1, A.n2, A.n4, A.row_ptr,
+                                                 (const typename SpanLoad<PACKED>::raw*)A.a_span, A.rlen, A.nbins0, A.d_min_cov, A.slot_ints, A.cov_out, A.cov_off, A.cov_nbins,
+                                                 A.cov_base, A.heads, A.n_heads, A.head_bases, A.cov_tot, band_arg);
+        if (j < 0) return;                                                                     // (a long read's workgroup: that read only)
     }
 }
 

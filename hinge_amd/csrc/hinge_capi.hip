@@ -63,6 +63,8 @@ struct hinge_ctx {
     bool final_batch_valid = false;
     size_t lds_attr_final = 0;
     int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
+    int k2_batch = 1;                         // HINGE_K2_BATCH=0: one k_mask_annotate_q20 launch per part of a batched sweep
+    int k2_steal = 2;                         // the persistent workgroups of a batched launch: 0 stay with their own part, 1 go round the parts from their own, 2 all sweep part 0, 1, ... (HINGE_K2_STEAL)
     DevBuf cov_tot, redo_list, spec_sample;   // int[n_reads] coverage sums, int[n_reads] guard-band list, int[spec_ns] sample means
     int spec_band = 1;        // the sweep is exact for every MIN_COV within +- this of the prediction (HINGE_SPEC_BAND)
     int spec_ns = 4096;       // reads k_spec_predict samples per part (HINGE_SPEC_SAMPLE)
@@ -274,6 +276,8 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     ctx->debug_paths = getenv("HINGE_DEBUG_PATHS") != nullptr;
     if (const char* g = getenv("HINGE_ONE_SWEEP")) ctx->one_sweep = atoi(g);
     if (const char* g = getenv("HINGE_FINAL_BATCH")) ctx->final_batched = atoi(g);
+    if (const char* g = getenv("HINGE_K2_BATCH")) ctx->k2_batch = atoi(g);
+    if (const char* g = getenv("HINGE_K2_STEAL")) ctx->k2_steal = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
     if (const char* g = getenv("HINGE_SPEC_SAMPLE")) ctx->spec_ns = std::max(1, atoi(g));
     if (hipMalloc(&ctx->med.p, sizeof(unsigned) * MED_WORDS) != hipSuccess) { (void)hipFree(ctx->scalars.p); delete ctx; return HINGE_E_DEVICE; }
@@ -915,6 +919,177 @@ static int prepare_cov_out(hinge_ctx* ctx, const hinge_filter_params* p) {
     return HINGE_OK;
 }
 
+// ---- K2 (k_mask_annotate_q20): what a launch needs, worked out per part; then one launch per part or one for all of them ----
+struct K2Prep {
+    int n1, n2, n4, g, n_heads, slot, mulpath_thr, cov_mask_off, variant;
+    size_t lds;
+    int* cov_out;
+    unsigned base[K2_MAX_HEADS], next_base[K2_MAX_HEADS];   // the host mirror of the device counters moves on only once the launch is known to be queued
+};
+static bool k2_applies(hinge_ctx* ctx, const hinge_filter_params* p, int* mulpath_thr_out) {
+    // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
+    // (it takes the bin count and the well-formedness of each pile-up from k_cov_stats<40> of this pass)
+    // ... and the division-free annotation test of mask_gate_annotate applies: then |gradient| > min(MIN_RA, MAX_RA) is necessary for an
+    // annotation, which is what the fast kernel's scan flags its 64-bin words with (the threshold is added to a count there: < 2^28)
+    const int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
+                                ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
+    *mulpath_thr_out = mulpath_thr;
+    return p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0 && ctx->nbins0_reso == 40 &&
+           mulpath_thr >= 0 && mulpath_thr < (1 << 28);
+}
+// `share`: how many parts divide the chip's resident workgroups between them (1: a launch of its own)
+static int k2_prepare(hinge_ctx* ctx, const hinge_filter_params* p, int mode, int share, K2Prep* q) {
+    {
+    // bins + hot words (the read classes of hinge_set_pileups are cut for this much) + the zero / total pads of this cut_off
+    const int SH = p->cut_off / 20;
+    const int slot = k2_slot_ints(ctx) + ((SH + 2 + 3) & ~3) + ((2 * SH + 4 + 3) & ~3);
+    const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // 19.8 KiB for reads of up to 19 kb: eight workgroups (32 wavefronts) per CU
+    const size_t lds_all = lds20;
+    if (ctx->k2_occ_lds != (int)lds_all) {
+        int nb = 0;
+        if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true, true, 15, 0>, BLOCK, lds_all));
+        else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false, true, 15, 0>, BLOCK, lds_all));
+        ctx->k2_occ = std::max(nb, 1);
+        ctx->k2_occ_lds = (int)lds_all;
+    }
+    const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
+    // persistent workgroups for the short reads: as many as are resident at once (HINGE_K2_WGS overrides), in a multiple of the
+    // number of item counters so that every counter serves the same number of workgroups
+    int gp = n1 > 0 ? std::min((n1 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, std::max((ctx->k2_wgs > 0 ? ctx->k2_wgs : ctx->k2_occ * ctx->n_cu) / share, 1)) : 0;
+    int n_heads = 1;
+    if (gp >= 2 * K2_MAX_HEADS) { n_heads = K2_MAX_HEADS; gp -= gp % K2_MAX_HEADS; }
+    else for (int h = std::min(gp, K2_MAX_HEADS); h >= 1; h--) if (gp % h == 0) { n_heads = h; break; }
+    const int g = std::max(1, n4 + (n2 + 1) / 2 + gp);
+    // XCD-contiguous deal (HINGE_K2_DEAL=1): workgroups go round-robin to the 8 XCDs, each with its own L2; head h is served by
+    // the workgroups g4 + g2 + h, + n_heads, ... - all on XCD (g4 + g2 + h) % 8 when n_heads is a multiple of 8 - and takes the
+    // list positions h, h + n_heads, ...  So the LIST is arranged such that the positions of one XCD's heads hold one contiguous
+    // eighth of the reads in storage order: that L2 then sees one eighth of the span copy and of the per-read tables, and the
+    // rows it fetches next to each other in memory are worked on next to each other in time.
+    if (ctx->k2_deal && n1 > 0 && n_heads % 8 == 0 && (ctx->k2_deal_heads != n_heads || ctx->k2_deal_rot != (n4 + (n2 + 1) / 2) % 8)) {
+        const int rot = (n4 + (n2 + 1) / 2) % 8;
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at[8];
+        for (int pz = 0; pz < n1; pz++) cnt[((pz % n_heads) + rot) % 8]++;
+        for (int x = 0, run = 0; x < 8; x++) { at[x] = run; run += cnt[x]; }
+        std::vector<int> c1(ctx->k2_c1);
+        if (ctx->k2_heavy_mode) {
+            // Where an XCD's DEEP pile-ups go in its sequence.  A read's time is ~1.3 us + 12 ns per overlap (per-read time stamps,
+            // tools/k2_trace.py: 5 us on average, 20-30 us for the 2 000 overlaps of a read inside a repeat), and one that is drawn in
+            // the last third of the launch ends long after everything else: the launch's last 7 us ran at falling occupancy behind
+            // a handful of them.  All of them FIRST is far worse (66 -> 90 us): hundreds of their overlaps begin or end in the same
+            // 20-bp bin, a same-address LDS atomic costs 0.83 ns of the CU's LDS pipe per lane that shares the word
+            // (tools/probes/lds_atomic_probe.cpp), and a CU full of them stalls on it; already over the first 50 % of the
+            // sequence they are too dense (69 us).  At even intervals over the first 60 %: 67.2 -> 64.4 us.
+            auto heavy = [&](int i) { return ctx->k2_heavy[(size_t)(i - ctx->r_begin)] != 0; };
+            for (int x = 0; x < 8; x++) {
+                std::vector<int> seg(c1.begin() + at[x], c1.begin() + at[x] + cnt[x]), hv, rest;
+                for (int i : seg) (heavy(i) ? hv : rest).push_back(i);
+                size_t o = (size_t)at[x], ih = 0, ir = 0;
+                const size_t span = ctx->k2_heavy_mode == 2 ? (size_t)(0.6 * seg.size()) : hv.size();
+                for (size_t k = 0; k < seg.size(); k++) {
+                    const bool take_h = ih < hv.size() && (ir >= rest.size() || (k < span && ih * span <= k * hv.size()));
+                    c1[o + k] = take_h ? hv[ih++] : rest[ir++];
+                }
+            }
+        }
+        for (int pz = 0; pz < n1; pz++) ctx->k2_list[(size_t)pz] = c1[(size_t)at[((pz % n_heads) + rot) % 8]++];
+        CK(hipMemcpyAsync(ctx->bucket_list.p, ctx->k2_list.data(), sizeof(int) * (size_t)n1, hipMemcpyHostToDevice, ctx->stream));
+        ctx->k2_deal_heads = n_heads; ctx->k2_deal_rot = rot;
+    }
+    {
+        if (!ctx->k2_heads.p) {
+            int rc = ensure(ctx, ctx->k2_heads, sizeof(unsigned) * 32 * K2_MAX_HEADS);
+            if (rc) return rc;
+            CK(hipMemsetAsync(ctx->k2_heads.p, 0, sizeof(unsigned) * 32 * K2_MAX_HEADS, ctx->stream));
+        }
+        const int gp_run = g - n4 - (n2 + 1) / 2;   // (g >= 1: an empty part still launches one workgroup)
+        for (int h = 0; h < K2_MAX_HEADS; h++) {
+            q->base[h] = q->next_base[h] = ctx->k2_head_base[h];
+            if (h >= n_heads) continue;
+            // one draw per wavefront of the head's workgroups + one per item of the head
+            const unsigned wgs_h = (unsigned)(gp_run / n_heads + (h < gp_run % n_heads));
+            const unsigned items_h = (unsigned)(n1 / n_heads + (h < n1 % n_heads));
+            q->next_base[h] += wgs_h * WAVES_PER_BLOCK + items_h;
+        }
+    }
+    {   // the kernel's constants (parameters, output pointers): a 200-byte block in device memory, uploaded when it changes
+        K2Const hc;
+        memset(&hc, 0, sizeof(hc));
+        hc.P = to_dev(p);
+        hc.o = anno_out(ctx);
+        hc.fallback_list = (int*)ctx->fallback_list.p;
+        hc.fallback_count = &sc(ctx)->fallback_count;
+        hc.redo_list = (int*)ctx->redo_list.p;
+        hc.redo_count = &sc(ctx)->redo_count;
+        hc.redo_cap = (unsigned)ctx->n_reads;
+        int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
+        if (rc) return rc;
+        if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
+            ctx->k2c_host = hc;
+            CK(hipMemcpyAsync(ctx->k2c.p, &ctx->k2c_host, sizeof(K2Const), hipMemcpyHostToDevice, ctx->stream));
+            ctx->k2c_valid = true;
+        }
+    }
+    q->n1 = n1; q->n2 = n2; q->n4 = n4; q->g = g; q->n_heads = n_heads; q->slot = slot; q->lds = lds_all;
+    q->cov_out = ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr;
+    q->cov_mask_off = p->use_coverage_mask != 0 ? INT_MIN : (1 << 29);
+    const int spec = mode == MODE_SPEC ? (ctx->spec_band == 1 ? 1 : 2) : 0;
+    q->variant = (ctx->use_span16 ? 1 : 0) | (q->cov_out ? 2 : 0) | (p->cut_off == 300 ? 4 : 0) | (spec << 3);
+    }
+    return HINGE_OK;
+}
+// the template instance of a variant word: PACKED | COVOUT << 1 | (cut_off == 300) << 2 | SPEC << 3
+#define K2_DISPATCH(variant, CALL)                                                                                                            \
+    do {                                                                                                                                      \
+        switch (variant) {                                                                                                                    \
+            K2_CASES(0, CALL) K2_CASES(1, CALL) K2_CASES(2, CALL)                                                                             \
+            default: return fail(ctx, HINGE_E_ARG, "k_mask_annotate_q20: unknown variant");                                              \
+        }                                                                                                                                     \
+    } while (0)
+#define K2_CASES(SPEC, CALL)                                                                                                                  \
+    case ((SPEC) << 3) | 0: CALL(false, false, -1, SPEC); break; case ((SPEC) << 3) | 1: CALL(true, false, -1, SPEC); break;                  \
+    case ((SPEC) << 3) | 2: CALL(false, true, -1, SPEC); break;  case ((SPEC) << 3) | 3: CALL(true, true, -1, SPEC); break;                   \
+    case ((SPEC) << 3) | 4: CALL(false, false, 15, SPEC); break; case ((SPEC) << 3) | 5: CALL(true, false, 15, SPEC); break;                  \
+    case ((SPEC) << 3) | 6: CALL(false, true, 15, SPEC); break;  case ((SPEC) << 3) | 7: CALL(true, true, 15, SPEC); break;
+static int k2_launch_one(hinge_ctx* ctx, const hinge_filter_params* p, const K2Prep& q) {
+    K2Heads bases;
+    memcpy(bases.base, q.base, sizeof(bases.base));
+    const void* spans = ctx->use_span16 ? (const void*)ctx->span16.p : (const void*)ctx->a_span.p;
+    const int* min_cov = (q.variant >> 3) != 0 ? &sc(ctx)->spec_min_cov : &sc(ctx)->min_cov;
+    ProfScope _ps(ctx, KID_MASK_ANNOTATE);
+#define K2_ONE(PACKED, COVOUT, CUT20, SPEC)                                                                                                                   \
+    hipLaunchKernelGGL((k_mask_annotate_q20<PACKED, COVOUT, CUT20, SPEC>), dim3(q.g), dim3(BLOCK), q.lds, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off, \
+                       q.mulpath_thr, p->no_hinge_region, q.cov_mask_off, (const int*)ctx->bucket_list.p, q.n1, q.n2, q.n4, (const int64_t*)ctx->row_ptr.p,   \
+                       (const typename SpanLoad<PACKED>::raw*)spans, (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, min_cov, q.slot, q.cov_out,           \
+                       (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (unsigned*)ctx->k2_heads.p, q.n_heads, bases,                    \
+                       (int*)ctx->cov_tot.p, ctx->spec_band)
+    K2_DISPATCH(q.variant, K2_ONE);
+#undef K2_ONE
+    CK(hipGetLastError());
+    memcpy(ctx->k2_head_base, q.next_base, sizeof(ctx->k2_head_base));
+    return HINGE_OK;
+}
+// reads handed back by K2 (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots) go through the general
+// kernel: the launch is skipped when the part's facts rule all three out
+static int k2_fallback(hinge_ctx* ctx, const hinge_filter_params* p, int mode, int grid) {
+    const bool no_handback = ctx->max_pile < 65536u && ctx->spans_in_range && ctx->max_rlen / 20 < WAVES_PER_BLOCK * k2_slot_ints(ctx) - 4 * WAVE;   // (bins-only slots: conservative)
+    if (no_handback) return HINGE_OK;
+    SpecArgs sa;
+    int rc = spec_args_of(ctx, mode, std::min(grid, 64), &sa);
+    if (rc) return rc;
+    const int kcap = kcap_for(ctx, p);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * 2 * kcap * sizeof(int);
+    if (lds > 160 * 1024) return fail(ctx, HINGE_E_RANGE, "read too long for the LDS histogram (max ~200 kb)");
+    if (lds > 48 * 1024 && lds > ctx->lds_attr_set) {
+        CK(hipFuncSetAttribute((const void*)k_mask_annotate<40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute((const void*)k_mask_annotate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->lds_attr_set = lds;
+    }
+    ProfScope _ps2(ctx, KID_MASK_FALLBACK);
+    LAUNCH_MASK_ANNOTATE(40, std::min(grid, 64), (const int*)ctx->fallback_list.p, (const unsigned*)&sc(ctx)->fallback_count, sa);
+    CK(hipGetLastError());
+    return HINGE_OK;
+}
+
 static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p, int mode = MODE_CLASSIC) {
     {
         int rc = flush_min_cov(ctx);
@@ -934,14 +1109,8 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p, in
     // the general kernel: one read per wavefront, no grid cap - the hardware dispatcher balances uneven pile-ups better than a
     // grid-stride loop does (measured 137 -> 119 us at 87 k reads; the fast kernel below draws its reads instead)
     const int grid = std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20));
-    // shipped configuration (reso 40, cut_off = 300): one 20-bp begin|end histogram per read
-    // (it takes the bin count and the well-formedness of each pile-up from k_cov_stats<40> of this pass)
-    // ... and the division-free annotation test of mask_gate_annotate applies: then |gradient| > min(MIN_RA, MAX_RA) is necessary for an
-    // annotation, which is what the fast kernel's scan flags its 64-bin words with (the threshold is added to a count there: < 2^28)
-    const int mulpath_thr = (p->coverage_fraction > 0 && p->coverage_fraction < 8192 && p->min_repeat_annotation >= 0 && p->max_repeat_annotation >= 0)
-                                ? std::min(p->min_repeat_annotation, p->max_repeat_annotation) : -1;
-    const bool q20 = p->reso == 40 && p->cut_off >= 0 && p->cut_off % 20 == 0 && p->cut_off <= 1200 && ctx->force_general_mask == 0 && ctx->nbins0_reso == 40 &&
-                     mulpath_thr >= 0 && mulpath_thr < (1 << 28);
+    int mulpath_thr;
+    const bool q20 = k2_applies(ctx, p, &mulpath_thr);
     if (mode == MODE_FINAL) {
         // the guard-band list of a one-sweep pass (about 1 % of the part's reads; every read if the prediction missed the band),
         // one read per wavefront through the general kernel
@@ -957,129 +1126,12 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p, in
     }
     if (mode == MODE_SPEC) ctx->pass_mode = q20 ? 1 : 2;
     if (q20) {
-        // bins + hot words (the read classes of hinge_set_pileups are cut for this much) + the zero / total pads of this cut_off
-        const int SH = p->cut_off / 20;
-        const int slot = k2_slot_ints(ctx) + ((SH + 2 + 3) & ~3) + ((2 * SH + 4 + 3) & ~3);
-        const size_t lds20 = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);   // 19.8 KiB for reads of up to 19 kb: eight workgroups (32 wavefronts) per CU
-        ProfScope _ps(ctx, KID_MASK_ANNOTATE);
-        const size_t lds_all = lds20;
-        if (ctx->k2_occ_lds != (int)lds_all) {
-            int nb = 0;
-            if (ctx->use_span16) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<true, true, 15, 0>, BLOCK, lds_all));
-            else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mask_annotate_q20<false, true, 15, 0>, BLOCK, lds_all));
-            ctx->k2_occ = std::max(nb, 1);
-            ctx->k2_occ_lds = (int)lds_all;
-        }
-        const int n1 = ctx->n_class[0], n2 = ctx->n_class[1], n4 = ctx->n_class[2];
-        // persistent workgroups for the short reads: as many as are resident at once (HINGE_K2_WGS overrides), in a multiple of the
-        // number of item counters so that every counter serves the same number of workgroups
-        int gp = n1 > 0 ? std::min((n1 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, ctx->k2_wgs > 0 ? ctx->k2_wgs : ctx->k2_occ * ctx->n_cu) : 0;
-        int n_heads = 1;
-        if (gp >= 2 * K2_MAX_HEADS) { n_heads = K2_MAX_HEADS; gp -= gp % K2_MAX_HEADS; }
-        else for (int h = std::min(gp, K2_MAX_HEADS); h >= 1; h--) if (gp % h == 0) { n_heads = h; break; }
-        const int g = std::max(1, n4 + (n2 + 1) / 2 + gp);
-        // XCD-contiguous deal (HINGE_K2_DEAL=1): workgroups go round-robin to the 8 XCDs, each with its own L2; head h is served by
-        // the workgroups g4 + g2 + h, + n_heads, ... - all on XCD (g4 + g2 + h) % 8 when n_heads is a multiple of 8 - and takes the
-        // list positions h, h + n_heads, ...  So the LIST is arranged such that the positions of one XCD's heads hold one contiguous
-        // eighth of the reads in storage order: that L2 then sees one eighth of the span copy and of the per-read tables, and the
-        // rows it fetches next to each other in memory are worked on next to each other in time.
-        if (ctx->k2_deal && n1 > 0 && n_heads % 8 == 0 && (ctx->k2_deal_heads != n_heads || ctx->k2_deal_rot != (n4 + (n2 + 1) / 2) % 8)) {
-            const int rot = (n4 + (n2 + 1) / 2) % 8;
-            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at[8];
-            for (int pz = 0; pz < n1; pz++) cnt[((pz % n_heads) + rot) % 8]++;
-            for (int x = 0, run = 0; x < 8; x++) { at[x] = run; run += cnt[x]; }
-            std::vector<int> c1(ctx->k2_c1);
-            if (ctx->k2_heavy_mode) {
-                // Where an XCD's DEEP pile-ups go in its sequence.  A read's time is ~1.3 us + 12 ns per overlap (per-read time stamps,
-                // tools/k2_trace.py: 5 us on average, 20-30 us for the 2 000 overlaps of a read inside a repeat), and one that is drawn in
-                // the last third of the launch ends long after everything else: the launch's last 7 us ran at falling occupancy behind
-                // a handful of them.  All of them FIRST is far worse (66 -> 90 us): hundreds of their overlaps begin or end in the same
-                // 20-bp bin, a same-address LDS atomic costs 0.83 ns of the CU's LDS pipe per lane that shares the word
-                // (tools/probes/lds_atomic_probe.cpp), and a CU full of them stalls on it; already over the first 50 % of the
-                // sequence they are too dense (69 us).  At even intervals over the first 60 %: 67.2 -> 64.4 us.
-                auto heavy = [&](int i) { return ctx->k2_heavy[(size_t)(i - ctx->r_begin)] != 0; };
-                for (int x = 0; x < 8; x++) {
-                    std::vector<int> seg(c1.begin() + at[x], c1.begin() + at[x] + cnt[x]), hv, rest;
-                    for (int i : seg) (heavy(i) ? hv : rest).push_back(i);
-                    size_t o = (size_t)at[x], ih = 0, ir = 0;
-                    const size_t span = ctx->k2_heavy_mode == 2 ? (size_t)(0.6 * seg.size()) : hv.size();
-                    for (size_t k = 0; k < seg.size(); k++) {
-                        const bool take_h = ih < hv.size() && (ir >= rest.size() || (k < span && ih * span <= k * hv.size()));
-                        c1[o + k] = take_h ? hv[ih++] : rest[ir++];
-                    }
-                }
-            }
-            for (int pz = 0; pz < n1; pz++) ctx->k2_list[(size_t)pz] = c1[(size_t)at[((pz % n_heads) + rot) % 8]++];
-            CK(hipMemcpyAsync(ctx->bucket_list.p, ctx->k2_list.data(), sizeof(int) * (size_t)n1, hipMemcpyHostToDevice, ctx->stream));
-            ctx->k2_deal_heads = n_heads; ctx->k2_deal_rot = rot;
-        }
-        K2Heads bases;
-        unsigned next_base[K2_MAX_HEADS];   // the host mirror of the device counters moves on only once the launch is known to be queued
-        {
-            if (!ctx->k2_heads.p) {
-                int rc = ensure(ctx, ctx->k2_heads, sizeof(unsigned) * 32 * K2_MAX_HEADS);
-                if (rc) return rc;
-                CK(hipMemsetAsync(ctx->k2_heads.p, 0, sizeof(unsigned) * 32 * K2_MAX_HEADS, ctx->stream));
-            }
-            const int gp_run = g - n4 - (n2 + 1) / 2;   // (g >= 1: an empty part still launches one workgroup)
-            for (int h = 0; h < K2_MAX_HEADS; h++) {
-                bases.base[h] = next_base[h] = ctx->k2_head_base[h];
-                if (h >= n_heads) continue;
-                // one draw per wavefront of the head's workgroups + one per item of the head
-                const unsigned wgs_h = (unsigned)(gp_run / n_heads + (h < gp_run % n_heads));
-                const unsigned items_h = (unsigned)(n1 / n_heads + (h < n1 % n_heads));
-                next_base[h] += wgs_h * WAVES_PER_BLOCK + items_h;
-            }
-        }
-        {   // the kernel's constants (parameters, output pointers): a 200-byte block in device memory, uploaded when it changes
-            K2Const hc;
-            memset(&hc, 0, sizeof(hc));
-            hc.P = to_dev(p);
-            hc.o = anno_out(ctx);
-            hc.fallback_list = (int*)ctx->fallback_list.p;
-            hc.fallback_count = &sc(ctx)->fallback_count;
-            hc.redo_list = (int*)ctx->redo_list.p;
-            hc.redo_count = &sc(ctx)->redo_count;
-            hc.redo_cap = (unsigned)ctx->n_reads;
-            int rc = ensure(ctx, ctx->k2c, sizeof(K2Const));
-            if (rc) return rc;
-            if (!ctx->k2c_valid || memcmp(&hc, &ctx->k2c_host, sizeof(K2Const)) != 0) {
-                ctx->k2c_host = hc;
-                CK(hipMemcpyAsync(ctx->k2c.p, &ctx->k2c_host, sizeof(K2Const), hipMemcpyHostToDevice, ctx->stream));
-                ctx->k2c_valid = true;
-            }
-        }
-        int* cov_out = ctx->cov_out_on ? (int*)ctx->cov_buf.p : (int*)nullptr;
-        const int cov_mask_off = p->use_coverage_mask != 0 ? INT_MIN : (1 << 29);
-#define LAUNCH_K2S(PACKED, COVOUT, CUT20, SPEC, SPANS)                                                                                                      \
-        hipLaunchKernelGGL((k_mask_annotate_q20<PACKED, COVOUT, CUT20, SPEC>), dim3(g), dim3(BLOCK), lds_all, ctx->stream, (const K2Const*)ctx->k2c.p, p->cut_off,  \
-                           mulpath_thr, p->no_hinge_region, cov_mask_off, (const int*)ctx->bucket_list.p, n1, n2, n4, (const int64_t*)ctx->row_ptr.p, SPANS, \
-                           (const int*)ctx->rlen.p, (const int*)ctx->nbins0.p, (const int*)((SPEC) != 0 ? &sc(ctx)->spec_min_cov : &sc(ctx)->min_cov), slot, cov_out, \
-                           (const long long*)ctx->cov_off_d.p, (int*)ctx->cov_nb.p, ctx->r_begin, (unsigned*)ctx->k2_heads.p, n_heads, bases,                \
-                           (int*)ctx->cov_tot.p, ctx->spec_band)
-#define LAUNCH_K2C(PACKED, COVOUT, CUT20, SPANS) do { if (mode == MODE_SPEC) { if (ctx->spec_band == 1) LAUNCH_K2S(PACKED, COVOUT, CUT20, 1, SPANS); else LAUNCH_K2S(PACKED, COVOUT, CUT20, 2, SPANS); } else LAUNCH_K2S(PACKED, COVOUT, CUT20, 0, SPANS); } while (0)
-#define LAUNCH_K2(PACKED, COVOUT, SPANS) do { if (p->cut_off == 300) LAUNCH_K2C(PACKED, COVOUT, 15, SPANS); else LAUNCH_K2C(PACKED, COVOUT, -1, SPANS); } while (0)
-        if (ctx->use_span16) { if (cov_out) LAUNCH_K2(true, true, (const unsigned*)ctx->span16.p); else LAUNCH_K2(true, false, (const unsigned*)ctx->span16.p); }
-        else { if (cov_out) LAUNCH_K2(false, true, (const int2*)ctx->a_span.p); else LAUNCH_K2(false, false, (const int2*)ctx->a_span.p); }
-#undef LAUNCH_K2
-#undef LAUNCH_K2C
-#undef LAUNCH_K2S
-        CK(hipGetLastError());
-        for (int h = 0; h < K2_MAX_HEADS; h++) ctx->k2_head_base[h] = next_base[h];
-        _ps.stop();
-        // reads handed back (65536+ overlaps, coordinates outside [0, rlen], longer than four LDS slots): the launch is
-        // skipped when the part's facts rule all three out
-        const bool no_handback = ctx->max_pile < 65536u && ctx->spans_in_range && ctx->max_rlen / 20 < WAVES_PER_BLOCK * k2_slot_ints(ctx) - 4 * WAVE;   // (bins-only slots: conservative)
-        if (no_handback) return HINGE_OK;
-        SpecArgs sa;
-        {
-            int rc = spec_args_of(ctx, mode, std::min(grid, 64), &sa);
-            if (rc) return rc;
-        }
-        ProfScope _ps2(ctx, KID_MASK_FALLBACK);
-        LAUNCH_MASK_ANNOTATE(40, std::min(grid, 64), (const int*)ctx->fallback_list.p, (const unsigned*)&sc(ctx)->fallback_count, sa);
-        CK(hipGetLastError());
-        return HINGE_OK;
+        K2Prep q;
+        int rc = k2_prepare(ctx, p, mode, 1, &q);
+        if (rc) return rc;
+        q.mulpath_thr = mulpath_thr;
+        if ((rc = k2_launch_one(ctx, p, q))) return rc;
+        return k2_fallback(ctx, p, mode, grid);
     }
     SpecArgs sa;
     {
@@ -1090,6 +1142,85 @@ static int launch_mask_annotate(hinge_ctx* ctx, const hinge_filter_params* p, in
     if (p->reso == 40) LAUNCH_MASK_ANNOTATE(40, grid, (const int*)nullptr, (const unsigned*)nullptr, sa);
     else LAUNCH_MASK_ANNOTATE(0, grid, (const int*)nullptr, (const unsigned*)nullptr, sa);
     CK(hipGetLastError());
+    return HINGE_OK;
+}
+
+// The mask / annotation sweep over n resident parts (contexts on one device and one stream): ONE k_mask_annotate_q20_batch launch
+// when the fast kernel takes all of them in the same variant, else a launch per part.
+static int launch_mask_annotate_parts(hinge_ctx** ctxs, int n, const hinge_filter_params* p, int mode) {
+    hinge_ctx* ctx = ctxs[0];
+    int rc, thr = -1;
+    if (n > K2_BATCH_MAX) {
+        for (int k0 = 0; k0 < n; k0 += K2_BATCH_MAX)
+            if ((rc = launch_mask_annotate_parts(ctxs + k0, std::min(n - k0, (int)K2_BATCH_MAX), p, mode))) return rc;
+        return HINGE_OK;
+    }
+    bool batch = ctx->k2_batch != 0 && n > 1 && mode != MODE_FINAL;
+    for (int k = 0; k < n && batch; k++) batch = k2_applies(ctxs[k], p, &thr);
+    if (!batch) {
+        for (int k = 0; k < n; k++)
+            if ((rc = launch_mask_annotate(ctxs[k], p, mode))) return rc;
+        return HINGE_OK;
+    }
+    K2Prep q[K2_BATCH_MAX];
+    bool same = true;
+    for (int k = 0; k < n; k++) {
+        hinge_ctx* c = ctxs[k];
+        if ((rc = flush_min_cov(c))) return rc;
+        if ((rc = prepare_cov_out(c, p))) return rc;
+        if (mode == MODE_SPEC) { c->n_wave_totals = 0; c->pass_mode = 1; }
+        if ((rc = k2_prepare(c, p, mode, n, &q[k]))) return rc;
+        q[k].mulpath_thr = thr;
+        same = same && q[k].variant == q[0].variant && c->spec_band == ctx->spec_band;
+    }
+    if (!same) {
+        for (int k = 0; k < n; k++)
+            if ((rc = k2_launch_one(ctxs[k], p, q[k]))) return rc;
+    } else {
+        K2Batch B;
+        memset(&B, 0, sizeof(B));
+        B.n = n;
+        int blocks = 0, slot = 0;
+        for (int k = 0; k < n; k++) slot = std::max(slot, q[k].slot);
+        const size_t lds = (size_t)WAVES_PER_BLOCK * slot * sizeof(int);
+        const int visit = ctx->k2_steal ? n : 1;
+        for (int k = 0; k < n; k++) {
+            hinge_ctx* c = ctxs[k];
+            K2Part& a = B.part[k];
+            a.C = (const K2Const*)c->k2c.p;
+            a.read_list = (const int*)c->bucket_list.p; a.row_ptr = (const int64_t*)c->row_ptr.p;
+            a.a_span = c->use_span16 ? (const void*)c->span16.p : (const void*)c->a_span.p;
+            a.rlen = (const int*)c->rlen.p; a.nbins0 = (const int*)c->nbins0.p;
+            a.d_min_cov = (q[k].variant >> 3) != 0 ? &sc(c)->spec_min_cov : &sc(c)->min_cov;
+            a.cov_out = q[k].cov_out; a.cov_off = (const long long*)c->cov_off_d.p; a.cov_nbins = (int*)c->cov_nb.p;
+            a.heads = (unsigned*)c->k2_heads.p; a.cov_tot = (int*)c->cov_tot.p;
+            a.n1 = q[k].n1; a.n2 = q[k].n2; a.n4 = q[k].n4; a.slot_ints = slot; a.cov_base = c->r_begin; a.n_heads = q[k].n_heads;
+            a.first_block = blocks; a.n_blocks = q[k].g;
+            memcpy(a.head_bases, q[k].base, sizeof(a.head_bases));
+            blocks += (q[k].g + 7) & ~7;
+            // where the part's counters stand after the launch: one draw per item + one failing draw per wavefront that visits the head
+            const int nh = q[k].n_heads, fixed_k = q[k].n4 + (q[k].n2 + 1) / 2;
+            for (int h = 0; h < nh; h++) q[k].next_base[h] = q[k].base[h] + (unsigned)(q[k].n1 / nh + (h < q[k].n1 % nh));
+            for (int t = 0; t < visit; t++) {
+                const int from = (k - t + n) % n, fixed_f = q[from].n4 + (q[from].n2 + 1) / 2;
+                for (int j = 0; j < q[from].g - fixed_f; j++)
+                    q[k].next_base[t == 0 ? j % nh : k2_visit_head(j, fixed_f & 7, fixed_k & 7, nh)] += WAVES_PER_BLOCK;
+            }
+        }
+        ProfScope _ps(ctx, KID_MASK_ANNOTATE);
+#define K2_ALL(PACKED, COVOUT, CUT20, SPEC)                                                                                                             \
+        hipLaunchKernelGGL((k_mask_annotate_q20_batch<PACKED, COVOUT, CUT20, SPEC>), dim3(blocks), dim3(BLOCK), lds, ctx->stream, B, p->cut_off, thr, \
+                           p->no_hinge_region, q[0].cov_mask_off, ctx->spec_band, visit | (ctx->k2_steal == 2 && visit > 1 ? 256 : 0))
+        K2_DISPATCH(q[0].variant, K2_ALL);
+#undef K2_ALL
+        CK(hipGetLastError());
+        for (int k = 0; k < n; k++) memcpy(ctxs[k]->k2_head_base, q[k].next_base, sizeof(ctxs[k]->k2_head_base));
+    }
+    for (int k = 0; k < n; k++) {
+        hinge_ctx* c = ctxs[k];
+        const int nr = c->r_end - c->r_begin + 1;
+        if ((rc = k2_fallback(c, p, mode, std::max(1, std::min((nr + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1 << 20))))) return rc;
+    }
     return HINGE_OK;
 }
 
@@ -1486,8 +1617,7 @@ int hinge_filter_sweep_batch_async(hinge_ctx** ctxs, int32_t n, const hinge_filt
     for (int k = 0; k < n; k++)
         if ((rc = ensure_pile_bins(ctxs[k], p))) return rc;
     if ((rc = launch_spec_predict(ctxs, n, p))) return rc;
-    for (int k = 0; k < n; k++)
-        if ((rc = launch_mask_annotate(ctxs[k], p, MODE_SPEC))) return rc;
+    if ((rc = launch_mask_annotate_parts(ctxs, n, p, MODE_SPEC))) return rc;
     return launch_median_batch(ctxs, n, p, lo, hi, hist_dev ? hd : nullptr);
 }
 

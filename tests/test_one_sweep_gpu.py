@@ -142,3 +142,76 @@ def test_two_sweep_pass_behind_the_same_calls_with_delete_telomere(datasets, ora
     assert ctx.spec_stats()[3] == -1
     _compare(wd_o, wd_h)
     ctx.close()
+
+
+def _ragged_parts(datasets):
+    """The chimera data set cut into four parts of very different sizes (the last one a single read) + the tiny data set's
+    reads behind them: what a batched sweep has to cope with."""
+    from hinge_amd import capi, formats
+    src, d = datasets("chimera")
+    rlen = formats.read_db_index(os.path.join(src, "G"))["rlen"]
+    recs = formats.read_las(os.path.join(src, "G.las"))
+    pile = formats.pileups_from_las(recs, rlen)
+    n = len(rlen)
+    cuts = [0, n // 2, n // 2 + n // 3, n - 1, n]
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        s, e = int(pile.row_ptr[a]), int(pile.row_ptr[b])
+        rp = np.ascontiguousarray(np.clip(pile.row_ptr, s, e) - s)       # (n_reads + 1 entries: empty rows outside the part)
+        parts.append((a, b - 1, rp, pile.a_span[s:e].copy(), pile.b_span[s:e].copy(), pile.b_flag[s:e].copy()))
+    return rlen, parts
+
+
+@pytest.mark.parametrize("env", [{"HINGE_K2_BATCH": "0"}, {"HINGE_K2_BATCH": "1", "HINGE_K2_STEAL": "0"}, {"HINGE_K2_BATCH": "1", "HINGE_K2_STEAL": "1"},
+                                 {"HINGE_K2_BATCH": "1", "HINGE_K2_STEAL": "2"}, {}])
+def test_batched_sweep_is_the_per_part_sweep(datasets, monkeypatch, env):
+    """hinge_filter_sweep_batch_async over ragged parts - one k_mask_annotate_q20_batch launch, its workgroups moving from part to
+    part - against hinge_filter_sweep of every part on its own: estimate, MIN_COV, masks, bins, annotations, hinges; twice, the
+    second time on the advanced item counters."""
+    from hinge_amd import capi
+    from hinge_amd.config import default_filter_params
+    rlen, parts = _ragged_parts(datasets)
+    P = default_filter_params()
+
+    def fetch(ctx):
+        mask, cmask, flags = ctx.get_masks()
+        off, pos, typ, ish = ctx.get_annotations()
+        nb, cov = ctx.get_coverage()
+        return dict(min_cov=ctx.get_min_cov(), mask=mask, cmask=cmask, flags=flags, off=off, pos=pos, typ=typ, ish=ish, nb=nb, cov=cov, counters=tuple(ctx.counters()))
+
+    def make(part):
+        r0, r1, rp, a, b, f = part
+        ctx = capi.Context(0)
+        ctx.set_reads(rlen, None)
+        ctx.set_min_cov(P.min_cov)
+        ctx.set_pileups(r0, r1, rp, a, b, f)
+        ctx.coverage_out(True)
+        return ctx
+
+    want = []
+    monkeypatch.setenv("HINGE_K2_BATCH", "0")
+    for part in parts:
+        ctx = make(part)
+        ctx.filter_sweep(P)
+        ctx.filter_hinges(P)
+        want.append(fetch(ctx))
+        ctx.close()
+    monkeypatch.delenv("HINGE_K2_BATCH")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctxs = [make(part) for part in parts]
+    for _ in range(2):
+        for c in ctxs:
+            c.set_min_cov(P.min_cov)
+        capi.sweep_batch_async(ctxs, P)
+        capi.finish_batch_async(ctxs, P)
+        capi.hinges_batch_async(ctxs, P)
+        for c, w in zip(ctxs, want):
+            c.check()
+            got = fetch(c)
+            assert got["min_cov"] == w["min_cov"] and got["counters"] == w["counters"]
+            for k in ("mask", "cmask", "flags", "off", "pos", "typ", "ish", "nb", "cov"):
+                assert np.array_equal(got[k], w[k]), k
+    assert sum(len(w["pos"]) for w in want) > 0
+    for c in ctxs:
+        c.close()
