@@ -271,13 +271,16 @@ __device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, cons
     const int q_first = sign * b_first, q_last = sign * b_last;
     bool s_found = false, e_found = false;
     int s_idx = np, s_a = 0, s_q = 0, e_idx = 0, e_a = 0, e_q = 0;
+#ifndef HINGE_K4_ABLATE
+#define HINGE_K4_ABLATE 0   // timing-only builds (tools/probes/k4_ablate.sh; results are WRONG by construction): 1 no forward walk, 2 no backward walk, 4 no advance sum
+#endif
     if (np > 0) {
-        const int T = sum_adv(ninner);
+        const int T = (HINGE_K4_ABLATE & 4) ? ninner * 100 : sum_adv(ninner);
         // first point (ascending index) with a >= ea.x and q >= qlo
         if (av.x >= ea.x && q_first >= qlo) { s_found = true; s_idx = 0; s_a = av.x; s_q = q_first; }
         else {
             int q = q_first;
-            for (int i = 1; i <= ninner; i++) {
+            for (int i = 1; i <= ((HINGE_K4_ABLATE & 1) ? 0 : ninner); i++) {
                 q += adv(i - 1);
                 const int a = a_base + 100 * i;
                 if (a >= ea.x && q >= qlo) { s_found = true; s_idx = i; s_a = a; s_q = q; break; }
@@ -288,7 +291,7 @@ __device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, cons
         if (av.y <= ea.y && q_last <= qhi) { e_found = true; e_idx = np - 1; e_a = av.y; e_q = q_last; }
         else {
             int q = q_first + T;
-            for (int i = ninner; i >= 1; i--) {
+            for (int i = ninner; i >= ((HINGE_K4_ABLATE & 2) ? ninner + 1 : 1); i--) {
                 const int a = a_base + 100 * i;
                 if (a <= ea.y && q <= qhi) { e_found = true; e_idx = i; e_a = a; e_q = q; break; }
                 q -= adv(i - 1);
