@@ -67,7 +67,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_traffic(kname):
+def pmc_traffic(kname, batched=False):
     """HBM bytes per launch of `kname` from the newest committed PMC summary (profiles/*_pmc_summary.csv).
 
     The counters come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same
@@ -82,8 +82,11 @@ def pmc_traffic(kname):
     fetch = write = None
     with open(files[-1], newline="") as f:
         for row in csv.DictReader(f):
-            if not row["kernel"].split("::")[-1].split("<")[0].startswith(kname):
+            base = row["kernel"].split("::")[-1].split("<")[0]
+            if not base.startswith(kname):
                 continue   # k_mask_annotate covers k_mask_annotate_q20 and the general k_mask_annotate<RESO>
+            if base.endswith("_batch") != batched:
+                continue   # one launch per part (warm-up, HINGE_K2_BATCH=0) and one launch for all parts are different kernels
             v = float(row.get("mean_value_KB") or row.get("mean_value"))
             if row["counter"] == "FETCH_SIZE":
                 fetch = (fetch or 0.0) + v
@@ -365,7 +368,7 @@ def main():
             # for the mask / annotate kernel, the coverage bins it stores
             phys_bytes = (4 * n_ovl + KERNEL_BYTES_PER_READ[kname] * n_reads + (4 * sum(part_bins) if kname == "k_mask_annotate" else 0)) / R * ppl
         one_sweep = bool(getattr(batch, "one_sweep", False)) and "k_cov_stats" not in {k for k, v in breakdown.items() if v[1] > 0}
-        traffic, traffic_src = pmc_traffic(kname)
+        traffic, traffic_src = pmc_traffic(kname, batched=ppl > 1.5)
         resident = sum(part_ovl) * (8 + 8 + 4 + 4) + sum(part_bins) * 4
         roofline = {
             "bound": "hbm",
@@ -489,9 +492,9 @@ def main():
                             % (R, R * 16, len(batch.groups))) if collectives else "no collective (one rank)"),
                 "collectives_per_step": (1 + len(batch.groups)) if collectives else 0,
                 "process_group": (pg_backend + (" (test rig: all ranks on one device)" if one_device else "")) if use_pg else None,
-                "kernels_in_step": "one-sweep pass: k_spec_predict (MIN_COV from a sample of each part), k_mask_annotate per part (+ coverage bins, + the per-read coverage sums), "
+                "kernels_in_step": "one-sweep pass: k_spec_predict (MIN_COV from a sample of each part), k_mask_annotate (k_mask_annotate_q20_batch: + coverage bins, + the per-read coverage sums), "
                                    "k_median_hist (the exact median: verification), k_mask_annotate_final (the guard-band reads; every read of a part whose prediction missed the band), "
-                                   "k_hinge_count, k_hinge_call - the last four one launch for all parts; none outside.  HINGE_ONE_SWEEP=0: k_cov_stats first (rounds 1-3)",
+                                   "k_hinge_count, k_hinge_call - every one of them ONE launch for all parts; none outside.  HINGE_K2_BATCH=0: a k_mask_annotate launch per part; HINGE_ONE_SWEEP=0: k_cov_stats first (rounds 1-3)",
                 "one_sweep": {"per_part": [{"passes_verified": s_[0], "exact_differs_from_prediction": s_[1], "prediction_outside_band_whole_part_redone": s_[2],
                                             "guard_band_reads_last_pass": s_[3], "predicted_min_cov": s_[4], "exact_min_cov": s_[5]} for s_ in spec_stats],
                               "note": "cumulative over warm-up, breakdown and timed steps; redone parts and guard-band launches are inside the timed region"},
