@@ -163,7 +163,7 @@ def _ragged_parts(datasets):
 
 
 @pytest.mark.parametrize("env", [{"HINGE_K2_BATCH": "0"}, {"HINGE_K2_BATCH": "1", "HINGE_K2_STEAL": "0"}, {"HINGE_K2_BATCH": "1", "HINGE_K2_STEAL": "1"},
-                                 {"HINGE_K2_BATCH": "1", "HINGE_K2_STEAL": "2"}, {}])
+                                 {"HINGE_K2_BATCH": "1", "HINGE_K2_STEAL": "2"}, {}, {"MIXED": "1"}])
 def test_batched_sweep_is_the_per_part_sweep(datasets, monkeypatch, env):
     """hinge_filter_sweep_batch_async over ragged parts - one k_mask_annotate_q20_batch launch, its workgroups moving from part to
     part - against hinge_filter_sweep of every part on its own: estimate, MIN_COV, masks, bins, annotations, hinges; twice, the
@@ -179,12 +179,18 @@ def test_batched_sweep_is_the_per_part_sweep(datasets, monkeypatch, env):
         nb, cov = ctx.get_coverage()
         return dict(min_cov=ctx.get_min_cov(), mask=mask, cmask=cmask, flags=flags, off=off, pos=pos, typ=typ, ish=ish, nb=nb, cov=cov, counters=tuple(ctx.counters()))
 
-    def make(part):
+    mixed = env.pop("MIXED", None) is not None     # every other part with the ingest's 16|16 span copy: two kernel variants, so a launch per part
+
+    def make(part, packed=False):
         r0, r1, rp, a, b, f = part
         ctx = capi.Context(0)
         ctx.set_reads(rlen, None)
         ctx.set_min_cov(P.min_cov)
-        ctx.set_pileups(r0, r1, rp, a, b, f)
+        if packed:
+            span16, max_pile, in_range = capi.pack_spans(rp, a, rlen)
+            ctx.set_pileups_packed(r0, r1, rp, a, b, f, span16, max_pile, in_range)
+        else:
+            ctx.set_pileups(r0, r1, rp, a, b, f)
         ctx.coverage_out(True)
         return ctx
 
@@ -199,7 +205,7 @@ def test_batched_sweep_is_the_per_part_sweep(datasets, monkeypatch, env):
     monkeypatch.delenv("HINGE_K2_BATCH")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    ctxs = [make(part) for part in parts]
+    ctxs = [make(part, packed=mixed and k % 2 == 1) for k, part in enumerate(parts)]
     for _ in range(2):
         for c in ctxs:
             c.set_min_cov(P.min_cov)
