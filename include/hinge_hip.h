@@ -165,7 +165,9 @@ int hinge_filter_run(hinge_ctx* ctx, const hinge_filter_params* p);
  * runs the exact median on those sums as VERIFICATION (MIN_COV is updated as by hinge_filter_median).  finish_batch() runs
  * the listed reads with the exact MIN_COV (all reads if it fell outside the band).  Results are those of
  * stats + median + mask_annotate, bit for bit.  n <= 16 parts (contexts on one device and one stream), each over its own
- * reads [r_begin, r_end]; asynchronous; status through hinge_filter_check / the getters.
+ * reads [r_begin, r_end]; asynchronous; status through hinge_filter_check / the getters.  The sweep of up to 8 parts is ONE
+ * kernel launch (k_mask_annotate_q20_batch: the chip sweeps part after part without a launch boundary; parts the fast kernel
+ * does not take, or in different kernel variants, get a launch each; HINGE_K2_BATCH=0: always).
  *   hist_dev == NULL: the median is finished on this GPU.  hist_dev != NULL (sharded runs): part k's histogram goes to
  *   hist_dev + k * row_stride as by hinge_filter_median_hist; the caller all-reduces and calls
  *   hinge_filter_median_from_hist_batch (which verifies) before finish_batch().
