@@ -1,5 +1,5 @@
 #!/bin/bash
-# Static look at k_mask_annotate_q20<true, true, 15> without a GPU: registers, spills, instruction classes, spill reloads inside the read loop.
+# Static look at k_mask_annotate_q20<true, true, 15, 1> (the one-sweep form; the batched launch inlines the same body) without a GPU: registers, spills, instruction classes, spill reloads inside the read loop.
 #   tools/k2_isa.sh [out.s]      (the kernel's ISA is left in /tmp/isa/q20.s or the given file)
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/isa
@@ -10,7 +10,7 @@ import re, sys
 s = open('/tmp/isa/k.s').read().split('\n')
 name = None
 for i, l in enumerate(s):
-    if re.match(r'^_ZN5hinge19k_mask_annotate_q20ILb1ELb1ELi15EE.*:\s', l):
+    if re.match(r'^_ZN5hinge19k_mask_annotate_q20ILb1ELb1ELi15ELi1EE.*:\s', l):
         name = l.split(':')[0]; a = i
     if name and l.startswith('\t.amdhsa_kernel ' + name): b = i; break
 body = s[a:b]
