@@ -36,7 +36,7 @@ struct alignas(16) HeavyItem {   // everything k_hinge_call needs, so that it st
     int mask_lo, mask_hi;
     int pos, type;       // the annotation
     unsigned slot;       // anno_off[read] + anno: index into hinge_flag
-    int pad;
+    int f0;              // smallest other end among the supporters (the origin of k_hinge_call_light's bins)
 };
 __device__ __forceinline__ int slice_len(int n) { return ((n + 4 * WAVE - 1) / (4 * WAVE)) * WAVE; }
 
@@ -53,6 +53,8 @@ struct HingePart {
     int* status; unsigned* work_next; unsigned* work_next_big;
     unsigned* dbg;
     int force_exact;
+    // second tier (round 4): what k_hinge_call_light could not settle, for k_hinge_call<CAP> (front / back by pile-up size as in `heavy`)
+    HeavyItem* heavy2; unsigned* heavy2_count; unsigned* heavy2_count_big; unsigned* work_next_light;
 };
 constexpr int HINGE_BATCH_MAX = 8;
 struct HingeBatch {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
     unsigned* __restrict__ heavy_count = A.heavy_count; unsigned* __restrict__ heavy_count_big = A.heavy_count_big;
     const unsigned heavy_cap = A.heavy_cap; const int force_exact = A.force_exact; unsigned* __restrict__ dbg = A.dbg;
     (void)row_ptr;
-    __shared__ int s_sup[PRE_MAXA][WAVES_PER_BLOCK], s_near[PRE_MAXA][WAVES_PER_BLOCK];
+    __shared__ int s_sup[PRE_MAXA][WAVES_PER_BLOCK], s_near[PRE_MAXA][WAVES_PER_BLOCK], s_minf[PRE_MAXA][WAVES_PER_BLOCK];
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,11 +128,11 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
         const int64_t k_lo = s + (int64_t)wib * q, k_hi = min(e, k_lo + q);   // this wavefront's slice
         for (int a0 = 0; a0 < cnt; a0 += PRE_MAXA) {
             const int na = min(PRE_MAXA, cnt - a0);
-            int apos[PRE_MAXA], atype[PRE_MAXA], csup[PRE_MAXA], cnear[PRE_MAXA];
+            int apos[PRE_MAXA], atype[PRE_MAXA], csup[PRE_MAXA], cnear[PRE_MAXA], cminf[PRE_MAXA];
 #pragma unroll
             for (int a = 0; a < PRE_MAXA; a++) {
                 const int2 an = a < na ? (a0 == 0 ? wi.anno[a] : anno_buf[off + a0 + a]) : make_int2(0, 0);
-                apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0;
+                apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0; cminf[a] = INT_MAX;
             }
             for (int64_t k0 = k_lo; k0 < k_hi; k0 += GATHER_LOADS * WAVE) {
                 // three dependent round trips per GATHER_LOADS * 64 overlaps (spans, B-side fields, mask[B]) instead of per 64
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
                                 const int f = atype[a] == -1 ? av[u].x : -av[u].y;
                                 const int m0 = atype[a] == -1 ? mk.x : -mk.y;
                                 cnear[a] += (f - m0 < P.bin_len);
+                                cminf[a] = min(cminf[a], f);
                             }
                         }
                     }
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
 #pragma unroll
             for (int a = 0; a < PRE_MAXA; a++) {
                 if (a >= na) break;
-                const int psup = wave_sum(csup[a]), pnear = wave_sum(cnear[a]);
-                if (lane == 0) { s_sup[a][wib] = psup; s_near[a][wib] = pnear; }
+                const int psup = wave_sum(csup[a]), pnear = wave_sum(cnear[a]), pminf = -wave_max(-cminf[a]);
+                if (lane == 0) { s_sup[a][wib] = psup; s_near[a][wib] = pnear; s_minf[a][wib] = pminf; }
             }
             __syncthreads();
             if (tid < na) {
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
                     HeavyItem it;
                     it.read = i; it.anno = a0 + tid;
                     it.base[0] = b1; it.base[1] = b2; it.base[2] = b3;
-                    it.sup = psup; it.near_end = pnear; it.pad = 0;
+                    it.sup = psup; it.near_end = pnear;
+                    it.f0 = min(min(s_minf[tid][0], s_minf[tid][1]), min(s_minf[tid][2], s_minf[tid][3]));
                     it.n = (int)(e - s); it.row = s; it.mask_lo = mk.x; it.mask_hi = mk.y;
                     {   // (the annotation is in registers already - indexed by a lane-varying tid, so by selects - not a dependent re-load)
                         static_assert(PRE_MAXA == 4, "select chain below");
@@ -224,16 +228,234 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3b (round 4): the ORDER-INDEPENDENT evaluation of an open annotation in 18 KiB of LDS, so that every open annotation of a pass
+// is worked on at once.  k_hinge_call<2048> sizes its LDS for the exact replay of a pile-up's std::sort (72 KiB: two workgroups per
+// CU, 512 items in flight) although on the E. coli restatement no item ever needs the replay; its items - pile-ups of 1 666 overlaps
+// with 784 supporters on average, 11 us each - queue up 2.4 deep behind those 512 slots (one workgroup per CU: 78 us, two: 51).
+// Same rules as k_hinge_call's "sort-free evaluation" below, word for word, on a leaner structure:
+//   * the supporters are binned AS THEY ARE GATHERED (no supporter lists): the bins start at the smallest other end, which
+//     k_hinge_count finds in its sweep and hands over in the item - known before the first load returns; one 32-bit word per 1-bp
+//     bin: g2 | g3 << 10 | g0 << 20 (at most LIGHT_CAP = 1023 supporters);
+//   * the bins are a counting sort of the other ends: the non-empty ones are compacted in bin order (thread t walks its sixteen
+//     bins) with their inclusive prefixes cat-2/3 | all << 16 - at most as many groups as supporters, not 4096 bins to evaluate
+//     (a first form that evaluated every bin against per-block prefixes spent 12 us per item on it, divergent and vector-bound);
+//   * every group: g2 / g3 / g from its word, `before` from its prefix, W from the prefix of the last group within BIN - 1 of it
+//     (a binary search over the compacted bins), the four properties, the smallest bin that has each.
+// What it cannot settle - the tie order decides, more than LIGHT_CAP supporters, an other end beyond the LIGHT_BINS bins - goes on to
+// the second-tier list (`heavy2`) for k_hinge_call<CAP>, untouched.  (A bitonic sort of the other ends instead of bins - no span
+// limit - was built first: 20 us per item for the sort alone with every item in flight; the bins take 2.)
+// ------------------------------------------------------------------------------------------------
+constexpr int LIGHT_CAP = 1023;
+constexpr int LIGHT_BINS = 4096;      // 1-bp bins behind m0 + BIN
+#ifndef HINGE_LIGHT_LOADS
+#define HINGE_LIGHT_LOADS 8
+#endif
+constexpr int LIGHT_LOADS = HINGE_LIGHT_LOADS;   // pile-up loads in flight per lane
+struct alignas(32) HingeLightLds {
+    alignas(32) unsigned cnt[LIGHT_BINS];          // g2 | g3 << 10 | g0 << 20 of the supporters with other end m0 + BIN + bin
+    unsigned g_cnt[LIGHT_CAP + 1], g_pre[LIGHT_CAP + 1];   // the non-empty bins in bin order: their word, and the inclusive prefix cat-2/3 | all << 16
+    unsigned short g_bin[LIGHT_CAP + 1];
+    int wsum[2][WAVES_PER_BLOCK];
+    int groups, over, ev_ucan, ev_bcan, ev_umust, ev_bmust;
+    unsigned next_item;
+};
+__global__ __launch_bounds__(BLOCK) void k_hinge_call_light(FilterDev P, HingeBatch B) {
+    const HingePart& A = B.part[blockIdx.x % (unsigned)B.n];
+    const int2* __restrict__ a_span = A.a_span; const int2* __restrict__ b_span = A.b_span;
+    const unsigned* __restrict__ b_flag = A.b_flag; const int2* __restrict__ mask = A.mask;
+    const HeavyItem* __restrict__ heavy = A.heavy; HeavyItem* __restrict__ heavy2 = A.heavy2;
+    unsigned char* __restrict__ hinge_flag = A.hinge_flag;
+    const unsigned heavy_cap = A.heavy_cap;
+    __shared__ HingeLightLds S;
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned n_small = *A.heavy_count, n_big = *A.heavy_count_big, nwork = n_small + n_big;
+#ifdef HINGE_TIMING
+    const unsigned long long t_start = wall_clock64();
+#endif
+    auto pass_on = [&](const HeavyItem& it) {   // (one thread)
+        if (it.n <= PO_CAP_SMALL) heavy2[atomicAdd(A.heavy2_count, 1u)] = it;
+        else heavy2[heavy_cap - 1u - atomicAdd(A.heavy2_count_big, 1u)] = it;
+    };
+    {   // the bins are zero between items: cleared here once, and after an item only where it counted
+        uint4* z = reinterpret_cast<uint4*>(S.cnt);
+        for (int t = tid; t < LIGHT_BINS / 4; t += BLOCK) z[t] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    auto g23_of = [](unsigned c) { return (int)((c & 1023u) + ((c >> 10) & 1023u)); };
+    auto all_of = [](unsigned c) { return (int)((c & 1023u) + ((c >> 10) & 1023u) + (c >> 20)); };
+    while (true) {
+        __syncthreads();
+        if (tid == 0) S.next_item = atomicAdd(A.work_next_light, 1u);
+        __syncthreads();
+        const unsigned w = S.next_item;
+        if (w >= nwork) break;
+#ifdef HINGE_TIMING
+        const unsigned long long tm0 = wall_clock64();
+#endif
+        const HeavyItem item = heavy[w < n_small ? w : heavy_cap - 1u - (w - n_small)];
+        const int sup = item.sup;
+        if (sup <= P.sup || (P.unb >= 0 && item.near_end > P.unb)) {   // (k_hinge_count settles these itself; kept for symmetry with k_hinge_call)
+            if (tid == 0) hinge_flag[item.slot] = sup <= P.sup ? 0 : 1;
+            continue;
+        }
+        if (sup > LIGHT_CAP || P.bin_len < 1 || P.bin_len >= LIGHT_BINS) {
+            if (tid == 0) pass_on(item);
+            continue;
+        }
+        const int64_t s = item.row;
+        const int n = item.n;
+        const int64_t e = s + n;
+        const int2 mk = make_int2(item.mask_lo, item.mask_hi);
+        const int pos = item.pos, type = item.type;
+        const int m0 = type == -1 ? mk.x : -mk.y;
+        const int origin = item.f0;                               // other end of bin 0: the smallest among the supporters (k_hinge_count found it)
+        if (tid == 0) { S.over = 0; S.ev_ucan = INT_MAX; S.ev_bcan = INT_MAX; S.ev_umust = INT_MAX; S.ev_bmust = INT_MAX; }
+        __syncthreads();
+        // ---- gather + bin: every wavefront streams its own slice of the pile-up (the slices of k_hinge_count: any cut would do) ----
+        {
+            const int q = slice_len(n);
+            const int64_t k_lo = s + (int64_t)wib * q, k_hi = min(e, k_lo + q);
+            bool over_l = false;
+            for (int64_t k0 = k_lo; k0 < k_hi; k0 += LIGHT_LOADS * WAVE) {
+                int2 av[LIGHT_LOADS], bs[LIGHT_LOADS], mb[LIGHT_LOADS];
+                unsigned bf[LIGHT_LOADS];
+                bool nearw[LIGHT_LOADS];
+#pragma unroll
+                for (int u = 0; u < LIGHT_LOADS; u++) {
+                    const int64_t k = k0 + u * WAVE + lane;
+                    const bool in = k < k_hi;
+                    av[u] = in ? a_span[k] : make_int2(0, 0);
+                    bf[u] = in ? b_flag[k] : 0u;
+                    bs[u] = in ? b_span[k] : make_int2(0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < LIGHT_LOADS; u++) {
+                    const int64_t k = k0 + u * WAVE + lane;
+                    const int c = type == -1 ? av[u].y : av[u].x;
+                    nearw[u] = k < k_hi && (c > pos - P.tol) && (c < pos + P.tol);
+                }
+#pragma unroll
+                for (int u = 0; u < LIGHT_LOADS; u++) mb[u] = nearw[u] ? mask[bf[u] & 0x7fffffffu] : make_int2(0, 0);
+#pragma unroll
+                for (int u = 0; u < LIGHT_LOADS; u++) {
+                    if (!nearw[u]) continue;
+                    int L, R;
+                    overhangs(bs[u], (int)(bf[u] >> 31), mb[u], L, R);
+                    bool sp;
+                    int f, sec;
+                    if (type == -1) { sp = R > P.theta; f = av[u].x; sec = L; }
+                    else { sp = L > P.theta; f = -av[u].y; sec = R; }
+                    if (!sp) continue;
+                    if (f - m0 < P.bin_len) continue;              // first-branch prefix: in no group (k_hinge_count counted it: near_end)
+                    const int rel = f - origin;                     // >= 0
+                    if (rel >= LIGHT_BINS) over_l = true;
+                    else atomicAdd(&S.cnt[rel], sec < P.theta ? 1u : sec > P.theta ? (1u << 10) : (1u << 20));
+                }
+            }
+            if (__any(over_l) && lane == 0) S.over = 1;
+        }
+        __syncthreads();
+#ifdef HINGE_TIMING
+        const unsigned long long tm1 = wall_clock64();
+        if (tid == 0 && A.dbg) { atomicAdd(&A.dbg[8], (unsigned)(tm1 - tm0)); atomicAdd(&A.dbg[9], (unsigned)n); atomicAdd(&A.dbg[10], 1u); atomicAdd(&A.dbg[12], (unsigned)sup); }
+#endif
+        if (S.over) {   // (uniform) an other end beyond the bins
+            if (tid == 0) pass_on(item);
+            uint4* z = reinterpret_cast<uint4*>(S.cnt);
+            for (int t = tid; t < LIGHT_BINS / 4; t += BLOCK) z[t] = make_uint4(0u, 0u, 0u, 0u);
+            continue;
+        }
+        // ---- the non-empty bins, in bin order, with their inclusive prefixes (cat-2/3 | all << 16): thread t owns bins 16 t .. 16 t + 15 ----
+        // (the bins are a counting sort of the other ends; what follows works on the <= sup groups, not on 4096 bins)
+        {
+            const uint4* c4 = reinterpret_cast<const uint4*>(S.cnt) + 4 * tid;
+            unsigned c[16];
+#pragma unroll
+            for (int h = 0; h < 4; h++) { const uint4 x = c4[h]; c[4 * h] = x.x; c[4 * h + 1] = x.y; c[4 * h + 2] = x.z; c[4 * h + 3] = x.w; }
+            int nz = 0, sum = 0;
+            if ((c[0] | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7] | c[8] | c[9] | c[10] | c[11] | c[12] | c[13] | c[14] | c[15]) != 0u) {
+#pragma unroll
+                for (int h = 0; h < 16; h++)
+                    if (c[h] != 0u) { nz++; sum += g23_of(c[h]) | (all_of(c[h]) << 16); S.cnt[16 * tid + h] = 0u; }   // (and the bin is clear for the next item)
+            }
+            const int nz_incl = wave_incl_scan(nz), sum_incl = wave_incl_scan(sum);      // (sum: both halves <= 1023)
+            if (lane == WAVE - 1) { S.wsum[0][wib] = nz_incl; S.wsum[1][wib] = sum_incl; }
+            __syncthreads();
+            int at = nz_incl - nz, run = sum_incl - sum;
+            for (int v = 0; v < wib; v++) { at += S.wsum[0][v]; run += S.wsum[1][v]; }
+            if (tid == BLOCK - 1) S.groups = at + nz;
+#pragma unroll
+            for (int h = 0; h < 16; h++) {
+                if (c[h] == 0u) continue;
+                run += g23_of(c[h]) | (all_of(c[h]) << 16);
+                S.g_bin[at] = (unsigned short)(16 * tid + h);
+                S.g_cnt[at] = c[h];
+                S.g_pre[at] = (unsigned)run;
+                at++;
+            }
+        }
+        __syncthreads();
+#ifdef HINGE_TIMING
+        const unsigned long long tm2 = wall_clock64();
+        if (tid == 0 && A.dbg) atomicAdd(&A.dbg[13], (unsigned)(tm2 - tm1));
+#endif
+        // ---- every non-empty bin is a group ----
+        {
+            const int c1 = item.near_end, m = S.groups;
+            int m_ucan = INT_MAX, m_bcan = INT_MAX, m_umust = INT_MAX, m_bmust = INT_MAX;
+            for (int e = tid; e < m; e += BLOCK) {
+                const int b = (int)S.g_bin[e];
+                const unsigned c = S.g_cnt[e], pre = S.g_pre[e];
+                const int g2 = (int)(c & 1023u), g3 = (int)((c >> 10) & 1023u), g = g2 + g3 + (int)(c >> 20);
+                const int before = (int)(pre & 0xffffu) - (g2 + g3);
+                // W = supporters with f < f' < f + BIN: up to the last group whose bin is <= b + BIN - 1
+                int lo = e, hi = m - 1;                              // (the answer is in [e, m - 1])
+                const int lim = b + P.bin_len - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)S.g_bin[mid] <= lim) lo = mid; else hi = mid - 1; }
+                const int W = (int)(S.g_pre[lo] >> 16) - (int)(pre >> 16);
+                const bool far = b > P.bin_len;                      // f - f[0] > BIN
+                const bool ucan = far && g2 >= 1 && (c1 + before + g2 + g3 > P.unb);
+                const bool bcan = g3 >= 1 && (g + W > P.pil);
+                const bool umust = far && g2 >= 1 && (c1 + before + g2 > P.unb) && !bcan;
+                const bool bmust = g3 >= 1 && (g3 + W > P.pil) && !ucan;
+                if (ucan) m_ucan = min(m_ucan, b);
+                if (bcan) m_bcan = min(m_bcan, b);
+                if (umust) m_umust = min(m_umust, b);
+                if (bmust) m_bmust = min(m_bmust, b);
+            }
+            m_ucan = -wave_max(-m_ucan); m_bcan = -wave_max(-m_bcan); m_umust = -wave_max(-m_umust); m_bmust = -wave_max(-m_bmust);
+            if (lane == 0) {
+                if (m_ucan != INT_MAX) atomicMin(&S.ev_ucan, m_ucan);
+                if (m_bcan != INT_MAX) atomicMin(&S.ev_bcan, m_bcan);
+                if (m_umust != INT_MAX) atomicMin(&S.ev_umust, m_umust);
+                if (m_bmust != INT_MAX) atomicMin(&S.ev_bmust, m_bmust);
+            }
+        }
+        __syncthreads();
+#ifdef HINGE_TIMING
+        if (tid == 0 && A.dbg) { atomicAdd(&A.dbg[14], (unsigned)(wall_clock64() - tm2)); atomicAdd(&A.dbg[11], (unsigned)(wall_clock64() - tm1)); atomicMax(&A.dbg[15], (unsigned)(wall_clock64() - tm0)); atomicMax(&A.dbg[7], (unsigned)n);
+                                 atomicMax(&A.dbg[6], (unsigned)(wall_clock64() - t_start)); }
+#endif
+        if (tid == 0) {
+            if (S.ev_ucan == INT_MAX || S.ev_bmust < S.ev_ucan) hinge_flag[item.slot] = 0;     // bridged
+            else if (S.ev_umust < S.ev_bcan) hinge_flag[item.slot] = 1;                          // unbridged whatever the tie order
+            else pass_on(item);                                                                  // the tie order decides: exact replay
+        }
+    }
+}
+
 // CAP: capacity of the LDS lists (pile-up size, supporters) = half the number of 1-bp bins.  The host launches the
 // PO_CAP_SMALL instance (72 KiB of LDS: two workgroups per CU) over the items whose pile-up fits it - they are appended from
 // the front of `heavy` - and the PO_CAP instance (one workgroup per CU) over the rest, appended from the back (`from_back`).
 template <int CAP>
-__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B, int from_back) {
+__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B, int from_back, int tier2 /*1: the items k_hinge_call_light passed on*/) {
     const HingePart& A = B.part[blockIdx.x % (unsigned)B.n];
     const int64_t* __restrict__ row_ptr = A.row_ptr; const int2* __restrict__ a_span = A.a_span; const int2* __restrict__ b_span = A.b_span;
     const unsigned* __restrict__ b_flag = A.b_flag; const int2* __restrict__ mask = A.mask; const int2* __restrict__ anno_buf = A.anno_buf;
-    const unsigned* __restrict__ anno_off = A.anno_off; const HeavyItem* __restrict__ heavy = A.heavy;
-    const unsigned* __restrict__ heavy_count = from_back ? A.heavy_count_big : A.heavy_count;
+    const unsigned* __restrict__ anno_off = A.anno_off; const HeavyItem* __restrict__ heavy = tier2 ? A.heavy2 : A.heavy;
+    const unsigned* __restrict__ heavy_count = tier2 ? (from_back ? A.heavy2_count_big : A.heavy2_count) : (from_back ? A.heavy_count_big : A.heavy_count);
     unsigned char* __restrict__ hinge_flag = A.hinge_flag; int2* __restrict__ exact_queue = A.exact_queue;
     unsigned* __restrict__ exact_count = A.exact_count; const unsigned exact_cap = A.exact_cap; const int force_exact = A.force_exact;
     int* __restrict__ status = A.status; unsigned* __restrict__ work_next = from_back ? A.work_next_big : A.work_next;

@@ -49,7 +49,7 @@ struct hinge_ctx {
     bool use_span16 = false;   // every read < 65536 bp and every coordinate inside its read (k_pileup_facts)
     int no_span16 = 0;         // HINGE_NO_SPAN16=1: keep the streaming kernels on the int32 spans
     bool has_keep = false;
-    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, fallback_list, bucket_list, k2_heads;
+    DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, heavy2_list, fallback_list, bucket_list, k2_heads;
     unsigned anno_cap = 0;               // annotation slots (a multiple of N_SHARD: every shard allocates from its own 1 / N_SHARD of them)
     unsigned work_cap = 0;               // work-list slots (the list is interleaved over the shards: n_reads + room for their imbalance)
     DevBuf exact_queue;
@@ -63,6 +63,8 @@ struct hinge_ctx {
     bool final_batch_valid = false;
     size_t lds_attr_final = 0;
     int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
+    int hinge_light = 1;                      // HINGE_CALL_LIGHT=0: every open annotation straight to k_hinge_call<CAP> (rounds 1-3)
+    int light_occ = 0;
     int k2_batch = 1;                         // HINGE_K2_BATCH=0: one k_mask_annotate_q20 launch per part of a batched sweep
     int k2_steal = 2;                         // the persistent workgroups of a batched launch: 0 stay with their own part, 1 go round the parts from their own, 2 all sweep part 0, 1, ... (HINGE_K2_STEAL)
     DevBuf cov_tot, redo_list, spec_sample;   // int[n_reads] coverage sums, int[n_reads] guard-band list, int[spec_ns] sample means
@@ -176,6 +178,9 @@ struct Scalars {
     unsigned heavy_count;               // annotations the count-only sweep could not decide, pile-up <= PO_CAP_SMALL (front of heavy_list)
     unsigned work_next_big;             // the same two for the pile-ups beyond PO_CAP_SMALL (back of heavy_list, PO_CAP instance)
     unsigned heavy_count_big;
+    unsigned work_next_light;           // k_hinge_call_light's cursor over both ends of heavy_list
+    unsigned heavy2_count;              // what it passed on to k_hinge_call<CAP>: front / back of heavy2_list
+    unsigned heavy2_count_big;
     unsigned redo_count;                // one-sweep pass: length of the guard-band list
     int spec_state;                     // one-sweep pass: 1 = the exact MIN_COV fell outside the band (SpecVerify)
     int status;
@@ -277,6 +282,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_ONE_SWEEP")) ctx->one_sweep = atoi(g);
     if (const char* g = getenv("HINGE_FINAL_BATCH")) ctx->final_batched = atoi(g);
     if (const char* g = getenv("HINGE_K2_BATCH")) ctx->k2_batch = atoi(g);
+    if (const char* g = getenv("HINGE_CALL_LIGHT")) ctx->hinge_light = atoi(g);
     if (const char* g = getenv("HINGE_K2_STEAL")) ctx->k2_steal = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
     if (const char* g = getenv("HINGE_SPEC_SAMPLE")) ctx->spec_ns = std::max(1, atoi(g));
@@ -300,7 +306,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c,
-                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch};
+                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch, &ctx->heavy2_list};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -403,6 +409,7 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
         if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->heavy2_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
     }
     if (ctx->exact_cap == 0) {
         ctx->exact_cap = 4096;
@@ -895,6 +902,7 @@ static int grow_annotations(hinge_ctx* ctx) {
     if ((rc = ensure(ctx, ctx->anno_buf, sizeof(int2) * (size_t)ctx->anno_cap))) return rc;
     if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
     if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+    if ((rc = ensure(ctx, ctx->heavy2_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
     ctx->work_cap = ctx->work_cap * 2;
     return ensure(ctx, ctx->work_list, sizeof(WorkItem) * (size_t)ctx->work_cap);
 }
@@ -1253,6 +1261,7 @@ static HingePart hinge_part_of(hinge_ctx* ctx) {
     a.work_list = (const WorkItem*)ctx->work_list.p; a.work_cap = ctx->work_cap; a.work_shard = (const unsigned*)(sc(ctx)->shards + N_SHARD * SHARD_STRIDE);
     a.hinge_flag = (unsigned char*)ctx->hinge_flag.p;
     a.heavy = (HeavyItem*)ctx->heavy_list.p; a.heavy_count = &sc(ctx)->heavy_count; a.heavy_count_big = &sc(ctx)->heavy_count_big; a.heavy_cap = ctx->anno_cap;
+    a.heavy2 = (HeavyItem*)ctx->heavy2_list.p; a.heavy2_count = &sc(ctx)->heavy2_count; a.heavy2_count_big = &sc(ctx)->heavy2_count_big; a.work_next_light = &sc(ctx)->work_next_light;
     a.exact_queue = (int2*)ctx->exact_queue.p; a.exact_count = &sc(ctx)->exact_count; a.exact_cap = ctx->exact_cap;
     a.status = &sc(ctx)->status; a.work_next = &sc(ctx)->work_next; a.work_next_big = &sc(ctx)->work_next_big;
     a.dbg = ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr;
@@ -1278,9 +1287,23 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
     // Undecided annotations: pile-ups of up to PO_CAP_SMALL overlaps go through the 72 KiB instance, two workgroups per CU (one
     // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if a part has
     // such a pile-up (k_pileup_facts).
+    // Open annotations: first the order-independent evaluation in 16 KiB of LDS for all of them at once (k_hinge_call_light); what
+    // it passes on - the tie order decides, or more than LIGHT_CAP supporters - goes through the instances that can replay the sort
+    bool light = ctx->hinge_light != 0;
+    for (int k = 0; k < n; k++) light = light && ctxs[k]->force_exact == 0;
     { ProfScope _ps(ctx, KID_HINGE_CALL);
-    hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0);
-    if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1); }
+    if (light) {
+        if (ctx->light_occ == 0) {
+            int nb = 0;
+            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hinge_call_light, BLOCK, 0));
+            ctx->light_occ = std::max(nb, 1);
+            if (const char* g = getenv("HINGE_LIGHT_WGS_PER_CU")) ctx->light_occ = std::max(atoi(g), 1);
+            if (getenv("HINGE_DEBUG_PATHS")) fprintf(stderr, "[hinge] k_hinge_call_light: %d workgroups per CU (occupancy calculator: %d)\n", ctx->light_occ, nb);
+        }
+        hipLaunchKernelGGL(k_hinge_call_light, dim3(std::max(n, (ctx->light_occ * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B);
+    }
+    hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0);
+    if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, light ? 1 : 0); }
     CK(hipGetLastError());
     // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1): per part
     for (int k = 0; k < n; k++) {
@@ -1325,7 +1348,7 @@ int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 16; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 5 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count, work_next_big, heavy_count_big
+        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 8 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count, work_next_big, heavy_count_big, work_next_light, heavy2_count, heavy2_count_big
         CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
         if ((rc = launch_hinges(ctx, p))) return rc;
         int rerun = 0;
@@ -1501,8 +1524,12 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     if (getenv("HINGE_DEBUG_PATHS"))
         fprintf(stderr, "[hinge] cumulative hinge-call paths: none=%u lds=%u exact=%u shortcut=%u | pile-up sorts=%u ordered=%u max_sup=%u max_anno=%u | last pass: %u items in the half-size instance, %u in the full-size one\n",
                 h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5], h.dbg[6], h.dbg[7], h.heavy_count, h.heavy_count_big);
+    if (getenv("HINGE_DEBUG_PATHS"))
+        fprintf(stderr, "[hinge] last pass: k_hinge_call_light drew %u times and passed %u + %u items on to k_hinge_call<CAP> (cursors there: %u, %u)\n", h.work_next_light, h.heavy2_count, h.heavy2_count_big, h.work_next, h.work_next_big);
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[15])
         fprintf(stderr, "[hinge] k_hinge_count per read (HINGE_TIMING builds): reads=%u mean %.1f us max %.1f us, largest pile-up %u\n", h.dbg[5], h.dbg[4] * 0.01 / std::max(1u, h.dbg[5]), h.dbg[15] * 0.01, h.dbg[7]);
+    if (getenv("HINGE_DEBUG_PATHS") && h.dbg[10] && h.dbg[15])
+        fprintf(stderr, "[hinge] k_hinge_call_light (HINGE_TIMING builds): slowest item %.1f us, largest pile-up among the items %u, last item done %.1f us after its workgroup started\n", h.dbg[15] * 0.01, h.dbg[7], h.dbg[6] * 0.01);
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[10])
         fprintf(stderr, "[hinge] timing (10 ns ticks, cumulative): items=%u gather=%u (mean %.1f us) eval=%u (mean %.1f us) mean_n=%.0f mean_sup=%.0f | bin %.1f us scan %.1f us\n", h.dbg[10],
                 h.dbg[8], h.dbg[8] * 0.01 / h.dbg[10], h.dbg[11], h.dbg[11] * 0.01 / h.dbg[10], (double)h.dbg[9] / h.dbg[10], (double)h.dbg[12] / h.dbg[10], h.dbg[13] * 0.01 / h.dbg[10], h.dbg[14] * 0.01 / h.dbg[10]);

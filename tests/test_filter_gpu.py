@@ -30,8 +30,14 @@ def _compare(wd_o, wd_h):
 
 @pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("tiny_mlas", True), ("tiny_mlas", False),
                                        ("ties", False), ("chimera", False), ("long_repeat", False), ("tspace200", False), ("edges", False)])
-@pytest.mark.parametrize("exact", [0, 1, 2])
-def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, name, mlas, exact):
+@pytest.mark.parametrize("exact", [0, 1, 2, 3])
+def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, monkeypatch, name, mlas, exact):
+    """exact: 0 the shipped route (k_hinge_count, then k_hinge_call_light - the order-independent evaluation on sorted supporters -,
+    then k_hinge_call<CAP> for what is left), 1 the serial exact kernel, 2 the exact replay in LDS, 3 without the light kernel
+    (k_hinge_call<CAP>'s own binned evaluation, rounds 1-3)."""
+    if exact == 3:
+        monkeypatch.setenv("HINGE_CALL_LIGHT", "0")
+        exact = 0
     src, _ = datasets(name)
     wd_o = clone_dataset(src, str(tmp_path / "oracle"))
     wd_h = clone_dataset(src, str(tmp_path / "hip"))
