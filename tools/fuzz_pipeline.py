@@ -84,6 +84,8 @@ def random_paths(rng, spec):
         env["HINGE_K2_WGS"] = str(int(rng.choice([1, 2, 5, 8, 16])))   # few persistent workgroups: every wavefront of k_mask_annotate_q20 takes several reads
                                                                           # (8, 16: a multiple of the 8 XCDs, so the XCD-contiguous deal of the reads is on)
     if rng.random() < 0.2:
+        env["HINGE_CALL_LIGHT"] = "0"                # open annotations straight to k_hinge_call<CAP> (no light kernel in front)
+    if rng.random() < 0.2:
         env["HINGE_K2_DEAL"] = "0"                   # round 2's longest-first order of the drawn reads
     if rng.random() < 0.2:
         env["HINGE_K2_HEAVY"] = str(int(rng.choice([0, 1])))   # the deep pile-ups first / left in storage order (default: spread over the first 60 %)
