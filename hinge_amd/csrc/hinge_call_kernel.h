@@ -88,7 +88,12 @@ struct HingeCallLdsT {
 // (support <= SUP: no hinge;  first-branch count > UNB: unbridged whatever the order, filter.cpp:920-931).
 // Undecided annotations get hinge_flag = 2 and their read goes to the heavy list for k_hinge_call.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B) {
+// CW wavefronts per workgroup (= per work-list read): four, one slice each, or two with two consecutive slices each - half the
+// wavefronts per read, twice the reads in flight (the kernel is bound by the reads it has in flight: a chain of round trips per read)
+template <int CW>
+__global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBatch B) {
+    static_assert(CW == 2 || CW == 4, "two or four wavefronts per read");
+    constexpr int SPW = WAVES_PER_BLOCK / CW;   // slices per wavefront
     const unsigned n_parts = (unsigned)B.n;
     const HingePart& A = B.part[blockIdx.x % n_parts];              // (uniform: scalar loads from the kernel arguments)
     const unsigned bx = blockIdx.x / n_parts, gx = gridDim.x / n_parts;
@@ -125,14 +130,15 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
         const unsigned off = wi.off;
         const int cnt = wi.cnt;
         const int q = slice_len((int)(e - s));
-        const int64_t k_lo = s + (int64_t)wib * q, k_hi = min(e, k_lo + q);   // this wavefront's slice
+        const int64_t k_lo = s + (int64_t)wib * SPW * q, k_hi = min(e, k_lo + (int64_t)SPW * q);   // this wavefront's slice(s)
+        const int64_t k_mid = k_lo + q;                                                                   // (SPW == 2: where its second slice begins)
         for (int a0 = 0; a0 < cnt; a0 += PRE_MAXA) {
             const int na = min(PRE_MAXA, cnt - a0);
-            int apos[PRE_MAXA], atype[PRE_MAXA], csup[PRE_MAXA], cnear[PRE_MAXA], cminf[PRE_MAXA];
+            int apos[PRE_MAXA], atype[PRE_MAXA], csup[PRE_MAXA], cnear[PRE_MAXA], cminf[PRE_MAXA], csup_hi[PRE_MAXA];   // csup_hi: of csup, in the wavefront's second slice
 #pragma unroll
             for (int a = 0; a < PRE_MAXA; a++) {
                 const int2 an = a < na ? (a0 == 0 ? wi.anno[a] : anno_buf[off + a0 + a]) : make_int2(0, 0);
-                apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0; cminf[a] = INT_MAX;
+                apos[a] = an.x; atype[a] = an.y; csup[a] = 0; cnear[a] = 0; cminf[a] = INT_MAX; csup_hi[a] = 0;
             }
             for (int64_t k0 = k_lo; k0 < k_hi; k0 += GATHER_LOADS * WAVE) {
                 // three dependent round trips per GATHER_LOADS * 64 overlaps (spans, B-side fields, mask[B]) instead of per 64
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
                             const bool sup = atype[a] == -1 ? (R > P.theta) : (L > P.theta);
                             if (sup) {
                                 csup[a]++;
+                                if (SPW == 2) csup_hi[a] += (k0 + u * WAVE + lane >= k_mid);
                                 const int f = atype[a] == -1 ? av[u].x : -av[u].y;
                                 const int m0 = atype[a] == -1 ? mk.x : -mk.y;
                                 cnear[a] += (f - m0 < P.bin_len);
@@ -189,7 +196,12 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_count(FilterDev P, HingeBatch B
             for (int a = 0; a < PRE_MAXA; a++) {
                 if (a >= na) break;
                 const int psup = wave_sum(csup[a]), pnear = wave_sum(cnear[a]), pminf = -wave_max(-cminf[a]);
-                if (lane == 0) { s_sup[a][wib] = psup; s_near[a][wib] = pnear; s_minf[a][wib] = pminf; }
+                if (SPW == 1) { if (lane == 0) { s_sup[a][wib] = psup; s_near[a][wib] = pnear; s_minf[a][wib] = pminf; } }
+                else {
+                    const int phi = wave_sum(csup_hi[a]);
+                    if (lane == 0) { s_sup[a][2 * wib] = psup - phi; s_sup[a][2 * wib + 1] = phi; s_near[a][2 * wib] = pnear; s_near[a][2 * wib + 1] = 0;
+                                     s_minf[a][2 * wib] = pminf; s_minf[a][2 * wib + 1] = INT_MAX; }
+                }
             }
             __syncthreads();
             if (tid < na) {

@@ -63,6 +63,7 @@ struct hinge_ctx {
     bool final_batch_valid = false;
     size_t lds_attr_final = 0;
     int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
+    int count_waves = 2;                      // wavefronts per work-list read in k_hinge_count (HINGE_COUNT_WAVES=4: rounds 1-3)
     int hinge_light = 1;                      // HINGE_CALL_LIGHT=0: every open annotation straight to k_hinge_call<CAP> (rounds 1-3)
     int light_occ = 0;
     int k2_batch = 1;                         // HINGE_K2_BATCH=0: one k_mask_annotate_q20 launch per part of a batched sweep
@@ -283,6 +284,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_FINAL_BATCH")) ctx->final_batched = atoi(g);
     if (const char* g = getenv("HINGE_K2_BATCH")) ctx->k2_batch = atoi(g);
     if (const char* g = getenv("HINGE_CALL_LIGHT")) ctx->hinge_light = atoi(g);
+    if (const char* g = getenv("HINGE_COUNT_WAVES")) ctx->count_waves = atoi(g) == 4 ? 4 : 2;
     if (const char* g = getenv("HINGE_K2_STEAL")) ctx->k2_steal = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
     if (const char* g = getenv("HINGE_SPEC_SAMPLE")) ctx->spec_ns = std::max(1, atoi(g));
@@ -1280,9 +1282,9 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         B.part[k] = hinge_part_of(ctxs[k]);
         any_big = any_big || ctxs[k]->max_pile > (unsigned)PO_CAP_SMALL;
     }
-    const int g_count = std::max(n, (ctx->n_cu * 8 / n) * n);
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
-    hipLaunchKernelGGL(k_hinge_count, dim3(g_count), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
+    if (ctx->count_waves == 2) hipLaunchKernelGGL(k_hinge_count<2>, dim3(std::max(n, (ctx->n_cu * 16 / n) * n)), dim3(2 * WAVE), 0, ctx->stream, to_dev(p), B);
+    else hipLaunchKernelGGL(k_hinge_count<4>, dim3(std::max(n, (ctx->n_cu * 8 / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
     CK(hipGetLastError());
     // Undecided annotations: pile-ups of up to PO_CAP_SMALL overlaps go through the 72 KiB instance, two workgroups per CU (one
     // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if a part has
