@@ -479,7 +479,10 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long lmask = (1ull << lane) - 1ull;
-    const unsigned nwork = *heavy_count;
+    // tier2 == 2: ONE instance for both ends of the second-tier list (behind k_hinge_call_light little is left, and an empty launch
+    // costs 5 us): first the back (the pile-ups only this instance holds), then the front
+    const unsigned n_first = *heavy_count, n_other = tier2 == 2 ? *(from_back ? A.heavy2_count : A.heavy2_count_big) : 0u;
+    const unsigned nwork = n_first + n_other;
     while (true) {
         // dynamic work distribution: annotations differ by orders of magnitude in cost
         __syncthreads();
@@ -490,7 +493,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
 #ifdef HINGE_TIMING
         const unsigned long long tm0 = wall_clock64();
 #endif
-        const HeavyItem item = heavy[from_back ? heavy_cap - 1u - w : w];
+        const bool back = w < n_first ? from_back != 0 : from_back == 0;
+        const unsigned wi_ = w < n_first ? w : w - n_first;
+        const HeavyItem item = heavy[back ? heavy_cap - 1u - wi_ : wi_];
         const int i = item.read, a = item.anno;
         const int64_t s = item.row;
         const int n = item.n;

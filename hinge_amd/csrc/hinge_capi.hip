@@ -1304,8 +1304,13 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         }
         hipLaunchKernelGGL(k_hinge_call_light, dim3(std::max(n, (ctx->light_occ * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B);
     }
-    hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0);
-    if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, light ? 1 : 0); }
+    if (light && any_big) {
+        // behind the light kernel ONE second-tier launch: the full-size instance takes both ends of the list (an empty launch is 5 us)
+        hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 2);
+    } else {
+        hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0);
+        if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 0);
+    } }
     CK(hipGetLastError());
     // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1): per part
     for (int k = 0; k < n; k++) {
