@@ -1282,6 +1282,31 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         B.part[k] = hinge_part_of(ctxs[k]);
         any_big = any_big || ctxs[k]->max_pile > (unsigned)PO_CAP_SMALL;
     }
+#ifdef HINGE_PROBE_SORTED_WORK
+    // probe builds only (tools/probes/sorted_work_probe.sh): the work lists rewritten in STORAGE order (dense, sorted by row) before
+    // k_hinge_count reads them - does the order in which the pile-ups are visited matter (address translation, DRAM pages)?
+    if (getenv("HINGE_PROBE_SORTED_WORK")) {
+        for (int k = 0; k < n; k++) {
+            hinge_ctx* c = ctxs[k];
+            Scalars h;
+            CK(hipMemcpyAsync(&h, c->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, c->stream));
+            CK(hipStreamSynchronize(c->stream));
+            std::vector<WorkItem> all((size_t)c->work_cap), live;
+            CK(hipMemcpy(all.data(), c->work_list.p, sizeof(WorkItem) * all.size(), hipMemcpyDeviceToHost));
+            const unsigned* cnt = h.shards + N_SHARD * SHARD_STRIDE;
+            for (size_t w = 0; w < all.size(); w++)
+                if ((unsigned)(w / N_SHARD) < cnt[(w % N_SHARD) * SHARD_STRIDE]) live.push_back(all[w]);
+            const int mode = atoi(getenv("HINGE_PROBE_SORTED_WORK"));
+            if (mode == 1) std::sort(live.begin(), live.end(), [](const WorkItem& a, const WorkItem& b) { return a.row < b.row; });
+            if (mode == 2) std::sort(live.begin(), live.end(), [](const WorkItem& a, const WorkItem& b) { return a.n * (long long)((a.cnt + 3) / 4) > b.n * (long long)((b.cnt + 3) / 4); });
+            const size_t M = live.size();
+            for (size_t w = 0; w < M; w++) all[w] = live[w];
+            for (int sh = 0; sh < N_SHARD; sh++) h.shards[(N_SHARD + sh) * SHARD_STRIDE] = (unsigned)((M + N_SHARD - 1 - sh) / N_SHARD);
+            CK(hipMemcpy(c->work_list.p, all.data(), sizeof(WorkItem) * all.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy((char*)c->scalars.p + offsetof(Scalars, shards), h.shards, sizeof(h.shards), hipMemcpyHostToDevice));
+        }
+    }
+#endif
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
     if (ctx->count_waves == 2) hipLaunchKernelGGL(k_hinge_count<2>, dim3(std::max(n, (ctx->n_cu * 16 / n) * n)), dim3(2 * WAVE), 0, ctx->stream, to_dev(p), B);
     else hipLaunchKernelGGL(k_hinge_count<4>, dim3(std::max(n, (ctx->n_cu * 8 / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
