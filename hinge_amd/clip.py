@@ -378,6 +378,10 @@ def resolve_loops(g: StrandGraph, max_nodes: int = 500, flank: int = 50, max_pla
     vertices' order (default: the graph's insertion order; the reference walks a hash order - parity unpinned, module docstring)."""
     tandem: List[List[Node]] = []
     starts = [v for v in (g.nodes() if order is None else order) if v in g and g.out_degree(v) == 2]
+    # `in_node` lives as long as the reference's variable does (function scope, pruning_and_clipping.py:745): it is only assigned
+    # inside the unbranched walk, so when a way out of the start is branched right away the predecessor filter below and
+    # resolve_repeat see the value the PREVIOUS walk left - and the reference dies with a NameError when there was none.
+    in_node: Optional[Node] = None
     for st in starts:
         if st not in g or g.out_degree(st) != 2:
             continue
@@ -385,7 +389,7 @@ def resolve_loops(g: StrandGraph, max_nodes: int = 500, flank: int = 50, max_pla
             if g.out_degree(st) != 2 or not g.has_edge(st, first):
                 continue
             other = [x for x in g.successors(st) if x != first][0]
-            nxt, in_node = first, st
+            nxt = first
             prev_edge = g.out[st][nxt]
             loop_len = cnt = 0
             while g.in_degree(nxt) == 1 and g.out_degree(nxt) == 1 and cnt < max_nodes:
@@ -398,6 +402,9 @@ def resolve_loops(g: StrandGraph, max_nodes: int = 500, flank: int = 50, max_pla
                 continue
             first_of_repeat = nxt
             if g.in_degree(nxt) == 2:
+                if in_node is None:
+                    raise NameError("loop resolution: the first way out of the first start vertex is branched (the reference's "
+                                    "in_node is unbound here, pruning_and_clipping.py:762)")
                 prev = [x for x in g.predecessors(nxt) if x != in_node][0]
                 cnt = 0
                 while g.in_degree(prev) == 1 and g.out_degree(prev) == 1:
@@ -432,6 +439,8 @@ def resolve_loops(g: StrandGraph, max_nodes: int = 500, flank: int = 50, max_pla
                 dbl = succ
                 rep.append(dbl)
             if dbl == st and loop_len > max_plasmid_length:
+                if in_node is None:
+                    raise NameError("loop resolution: in_node is unbound (pruning_and_clipping.py:829)")
                 resolve_repeat(g, rep, in_node, other)
                 if cnt < 5:
                     tandem.append(rep)

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_vote(CnsSeqs SB, const CnsAln
     const long long boff = SB.boff[al.b];
     auto Bb = [&](int j1) { return al.comp ? 3 - cns_base(bbps, boff, al.blen - j1) : cns_base(bbps, boff, j1 - 1); };   // 1-based position
     int* __restrict__ cnt0 = counts + cbase[al.a];
+    const long long alen_a = cbase[al.a + 1] - cbase[al.a];
     int col = col_base[s];
     if (col >= c.end || col + g.m + 2 * g.out_cap < c.start) return;   // (cheap reject; the exact test is per column)
     cns_walk(g, indels + g.out_off, n_indel[s], [&](int kind, int i, int j, int cnt) {
@@ -310,7 +311,10 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_vote(CnsSeqs SB, const CnsAln
             col += cnt;
         } else {
             if (col >= c.start && col < c.end) {
-                if (kind == 1) atomicAdd(cnt0 + (long long)(5 + Bb(j)) * plane + (i - 1), 1);
+                // (an inserted base behind the contig's LAST base - i - 1 == alen, only where an unchopped alignment ends at the
+                // contig's end - has no position: the reference indexes insertion_score[alen] out of bounds there, the tiled vote
+                // drops the slot, and so does this one instead of voting on the next contig's first position)
+                if (kind == 1) { if (i - 1 < alen_a) atomicAdd(cnt0 + (long long)(5 + Bb(j)) * plane + (i - 1), 1); }
                 else atomicAdd(cnt0 + 4ll * plane + (i - 1), 1);
             }
             col += 1;
@@ -429,16 +433,15 @@ struct CnsStats { long long sum_cov; int good, insertions, deletions, low_cov, c
 // one thread per contig position (consensus.cpp:228-270): packed = count | c0 << 8 | c1 << 16; per-block character counts
 constexpr int CNS_CALL_ITEMS = 8;   // positions per thread in k_cns_call / k_cns_emit (a block covers CNS_BLOCK * CNS_CALL_ITEMS)
 __global__ __launch_bounds__(CNS_BLOCK) void k_cns_call(CnsSeqs SA, const int* __restrict__ counts, long long plane, long long n_pos,
-                                                        const int* __restrict__ contig_of_block, const long long* __restrict__ cbase,
+                                                        const int2* __restrict__ contig_of_block /*(contig, its first block)*/, const long long* __restrict__ cbase,
                                                         unsigned* __restrict__ packed, unsigned* __restrict__ block_sum, CnsStats* __restrict__ stats,
                                                         const int* __restrict__ halo /*nullptr: the global-atomics vote*/, const int* __restrict__ tile_base, int tile) {
     // blocks never straddle contigs: block b works on contig contig_of_block[b], positions from its own first position on
     __shared__ int red[8];
     __shared__ long long redl;
-    const int cg = contig_of_block[blockIdx.x];
-    // first block of this contig
-    int b0 = blockIdx.x;
-    while (b0 > 0 && contig_of_block[b0 - 1] == cg) b0--;   // (a few hundred steps at most per block; contigs are long)
+    const int2 cb = contig_of_block[blockIdx.x];
+    const int cg = cb.x, b0 = cb.y;   // (the contig's first block comes from the host's table: a walk back over the block list is
+                                      // quadratic per contig - 2.4e9 dependent loads for a 100 Mb contig)
     const long long base = cbase[cg], alen = cbase[cg + 1] - base;
     const long long first = (long long)(blockIdx.x - b0) * CNS_BLOCK * CNS_CALL_ITEMS;
     const unsigned char* __restrict__ abps = SA.bps;
@@ -525,12 +528,11 @@ __global__ __launch_bounds__(1024) void k_cns_scan(unsigned* __restrict__ v, int
 }
 
 // characters to their final places: block b's output starts at block_off[b] (exclusive scan of the block sums)
-__global__ __launch_bounds__(CNS_BLOCK) void k_cns_emit(const unsigned* __restrict__ packed, const int* __restrict__ contig_of_block, const long long* __restrict__ cbase,
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_emit(const unsigned* __restrict__ packed, const int2* __restrict__ contig_of_block, const long long* __restrict__ cbase,
                                                         const unsigned* __restrict__ block_off, char* __restrict__ out) {
     __shared__ unsigned wsum_[4];
-    const int cg = contig_of_block[blockIdx.x];
-    int b0 = blockIdx.x;
-    while (b0 > 0 && contig_of_block[b0 - 1] == cg) b0--;
+    const int2 cb = contig_of_block[blockIdx.x];
+    const int cg = cb.x, b0 = cb.y;
     const long long base = cbase[cg], alen = cbase[cg + 1] - base;
     const long long first = (long long)(blockIdx.x - b0) * CNS_BLOCK * CNS_CALL_ITEMS;
     unsigned run = block_off[blockIdx.x];

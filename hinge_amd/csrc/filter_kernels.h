@@ -1108,6 +1108,11 @@ struct SpecArgs {
     int* redo_list;
     unsigned* redo_count;
     unsigned redo_cap;
+    // MODE_SPEC behind the fast kernel (its hand-backs): a read with nbins0[i] >= 0 - well formed, only too long for the fast
+    // kernel's LDS slots - is one k_median_hist derives the mean of (from cov_tot[i]) and adds to the totals itself, like every
+    // read the fast kernel kept; its sum goes to cov_tot and nothing to mean_cov / wave_totals.  nullptr: every read is this kernel's.
+    int* cov_tot;
+    const int* nbins0;
 };
 template <int RESO>
 __device__ __forceinline__ void mask_annotate_body(const FilterDev& P, int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
@@ -1241,7 +1246,9 @@ __device__ __forceinline__ void mask_annotate_body(const FilterDev& P, int r_beg
             long long t = 0;
             for (int j = lane; j < K0; j += WAVE) t += h0[j];
             t = wave_sum64(t);
-            if (lane == 0) {
+            if (lane == 0 && sa.cov_tot && sa.nbins0[i] >= 0) {
+                sa.cov_tot[i] = (int)t;            // (K0 == nbins0[i]: both are profileCoverage's K of the same pile-up)
+            } else if (lane == 0) {
                 if (rl >= 5000) {
                     sa.mean_cov[i] = (int)(t / (long long)max(1, K0));
                     blk_cov += t;

@@ -129,6 +129,8 @@ struct hinge_ctx {
     void* comm = nullptr;               // ncclComm_t of this context among the contexts of its process (comm_capi.inc)
     int comm_rank = -1, comm_size = 0;
     DevBuf comm_stage;                  // all-gathered mask rows [comm_size + 1][S][2]
+    int64_t comm_staged_S = 0;          // rows per rank of the last phase-0 exchange (0: nothing staged), and every rank's rows
+    std::vector<int32_t> comm_staged_lo, comm_staged_hi;   // in it: phase 1 places from that stage and must be given the same layout
 };
 
 enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY,
@@ -891,6 +893,7 @@ static int spec_args_of(hinge_ctx* ctx, int mode, int grid, SpecArgs* out) {
         if (rc) return rc;
     }
     a.wave_totals = (unsigned long long*)ctx->wave_totals.p;
+    if (mode == MODE_SPEC && ctx->pass_mode == 1) { a.cov_tot = (int*)ctx->cov_tot.p; a.nbins0 = (const int*)ctx->nbins0.p; }
     *out = a;
     return HINGE_OK;
 }

@@ -46,6 +46,9 @@ class SynthSpec:
     self_overlap_reads: int = 0        # reads given A == B records (filter.cpp:538-561, .self.flag)
     orphan_ends: int = 0               # this many reads at EACH end of the id range without overlaps: they fall
                                        # outside [first A, last A] and get no .mas line (filter.cpp:515-517)
+    trace_jitter: int = 0              # >0: the B advance of interior trace segments varies by up to +-trace_jitter per
+                                       # segment (real PacBio traces: ~85-115 at tspace 100), the sum preserved: a hash of
+                                       # (record, segment) moves bases between the two segments of every interior pair
 
 
 @dataclass
@@ -341,12 +344,31 @@ def generate(spec: SynthSpec) -> SynthData:
                      bb=bb, be=be, block_first=block_first, qv=qv)
 
 
+def _mix32(x):
+    """lowbias32 on uint64 arrays holding 32-bit values (the same function as mix32 in tools_c/synth_io.c)."""
+    m = np.uint64(0xFFFFFFFF)
+    x = x & m
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & m
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & m
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def trace_jitter_delta(rec, j, jitter):
+    """Bases that segment j of record `rec` (global record index) hands to segment j + 1: in [-jitter, jitter]."""
+    h = _mix32((np.asarray(rec, np.uint64) * np.uint64(0x9E3779B1)) ^ (np.asarray(j, np.uint64) * np.uint64(0x85EBCA6B)))
+    return (h % np.uint64(2 * jitter + 1)).astype(np.int64) - jitter
+
+
 def make_traces(d: SynthData, sel: Optional[np.ndarray] = None):
     """(diffs, b-advance) byte pairs per tspace-segment of A (src/include/align.h:98-110).
 
     Interior segments advance A by exactly tspace, so only the first and last pair of every overlap
     need per-record arithmetic; the B-side length difference (<= indel_max) is spread one base per
-    segment from the front."""
+    segment from the front.  With spec.trace_jitter the interior segments' B advances then vary
+    (pairs (1, 2), (3, 4), ... of interior segments exchange up to trace_jitter bases, so B's total is kept)."""
     ts = d.spec.tspace
     ab = (d.ab if sel is None else d.ab[sel]).astype(np.int64)
     ae = (d.ae if sel is None else d.ae[sel]).astype(np.int64)
@@ -376,6 +398,15 @@ def make_traces(d: SynthData, sel: Optional[np.ndarray] = None):
         if rem.any():
             m = rem > 0
             adv[off[1:][m] - 1] += (sgn[m] * rem[m]).astype(np.int16)
+        J = int(d.spec.trace_jitter)
+        if J > 0 and tot:
+            recid = np.arange(d.novl, dtype=np.int64) if sel is None else np.asarray(sel, np.int64)
+            j = np.arange(tot, dtype=np.int64) - np.repeat(off[:-1], nseg)
+            ns = np.repeat(nseg, nseg)
+            giver = np.nonzero((j % 2 == 1) & (j + 1 <= ns - 2))[0]
+            delta = trace_jitter_delta(np.repeat(recid, nseg)[giver], j[giver], J).astype(np.int16)
+            adv[giver] += delta
+            adv[giver + 1] -= delta
         assert adv.min() >= 0 and adv.max() <= (255 if ts <= formats.TRACE_XOVR else 65535), (adv.min(), adv.max())
     if ts <= formats.TRACE_XOVR:       # one byte per trace value (LAInterface.cpp:607-614)
         tr = np.empty(2 * tot, dtype=np.uint8)
@@ -422,7 +453,7 @@ def _synthio_lib():
         else:
             lib = ctypes.CDLL(path)
             lib.synth_write_las.restype = ctypes.c_int
-            lib.synth_write_las.argtypes = [ctypes.c_char_p, ctypes.c_int64] + [ctypes.c_void_p] + [ctypes.c_int32] + [ctypes.c_void_p] * 8
+            lib.synth_write_las.argtypes = [ctypes.c_char_p, ctypes.c_int64] + [ctypes.c_void_p] + [ctypes.c_int32] * 2 + [ctypes.c_void_p] * 8
             _synthio = lib
     return _synthio or None
 
@@ -436,7 +467,8 @@ def write_las_file(d: SynthData, path: str, sel: Optional[np.ndarray] = None, fa
                                                              (d.ae, np.int32), (d.bb, np.int32), (d.be, np.int32), (d.rlen, np.int32))]
         s = None if sel is None else np.ascontiguousarray(sel, dtype=np.int64)
         n = d.novl if s is None else len(s)
-        rc = lib.synth_write_las(path.encode(), n, None if s is None else s.ctypes.data, d.spec.tspace, *[c.ctypes.data for c in cols])
+        rc = lib.synth_write_las(path.encode(), n, None if s is None else s.ctypes.data, d.spec.tspace, int(d.spec.trace_jitter),
+                                 *[c.ctypes.data for c in cols])
         if rc == -2:
             raise AssertionError("trace generator cannot express this indel / trace-spacing combination")
         if rc != 0:
@@ -491,22 +523,24 @@ def to_pileups(d: SynthData) -> formats.Pileups:
     )
 
 
-# BASELINE.json configs restated
+# BASELINE.json configs restated.  Round 5: the data sets that reach ProcessAlignment /
+# GetMatchingPosition at size carry jittered traces (per-segment B advances of tspace +- 15 %, as real PacBio traces vary) -
+# `tiny`, `ties`, `deep` ... keep the near-uniform ones, so both shapes stay covered.
 CONFIGS = {
     "tiny": SynthSpec(genome_len=120_000, coverage=40, seed=7),
     "tiny_qv": SynthSpec(genome_len=120_000, coverage=40, seed=8, with_qv=True),
-    "tiny_mlas": SynthSpec(genome_len=150_000, coverage=35, seed=9, n_blocks=3, n_repeat_families=2),
+    "tiny_mlas": SynthSpec(genome_len=150_000, coverage=35, seed=9, n_blocks=3, n_repeat_families=2, trace_jitter=12),
     "ties": SynthSpec(genome_len=100_000, coverage=60, seed=10, tie_quantum=100, end_jitter=0, indel_max=0,
                       n_repeat_families=2, repeat_copies=(2, 3)),
-    "chimera": SynthSpec(genome_len=150_000, coverage=40, seed=11, chimera_frac=0.05, n_repeat_families=2),
+    "chimera": SynthSpec(genome_len=150_000, coverage=40, seed=11, chimera_frac=0.05, n_repeat_families=2, trace_jitter=15),
     "long_repeat": SynthSpec(genome_len=150_000, coverage=80, len_min=3000, len_max=8000, repeat_len=(12000, 12000),
                              repeat_copies=(2, 2), inverted_copies=False, seed=23),
     # reads from 4 kb to 120 kb: every LDS-slot class of the mask/annotate kernel (1, 2, 4 slots, and > 91 kb: general kernel)
     "long_reads": SynthSpec(genome_len=400_000, coverage=40, len_dist="lognormal", len_mean=25000, len_sigma=0.7, len_min=4000,
-                            len_max=120000, repeat_len=(9000, 9000), repeat_copies=(3, 3), seed=31),
+                            len_max=120000, repeat_len=(9000, 9000), repeat_copies=(3, 3), seed=31, trace_jitter=15),
     # trace spacing 200: two bytes per trace value on disk (tspace > 125), a QV track at that spacing
     "tspace200": SynthSpec(genome_len=150_000, coverage=45, seed=41, tspace=200, with_qv=True, n_repeat_families=2,
-                           repeat_len=(6000, 6000), repeat_copies=(2, 2)),
+                           repeat_len=(6000, 6000), repeat_copies=(2, 2), trace_jitter=28),
     # reads below length_threshold, reads without any overlap, A == B records on both sides of the
     # self-coverage flag (filter.cpp:538-561)
     "edges": SynthSpec(genome_len=130_000, coverage=42, seed=43, len_max=14000, min_ovl=500, short_reads=24,
@@ -515,16 +549,16 @@ CONFIGS = {
     "deep": SynthSpec(genome_len=50_000, coverage=450, seed=53, n_repeat_families=1, repeat_len=(5000, 5000), repeat_copies=(3, 3)),
     "orphan_ends": SynthSpec(genome_len=100_000, coverage=40, seed=47, orphan_ends=3),
     "cfg1_ecoli_demo": SynthSpec(genome_len=4_600_000, coverage=30, seed=1, n_repeat_families=5,
-                                 repeat_len=(1000, 5000), repeat_copies=(2, 3)),
+                                 repeat_len=(1000, 5000), repeat_copies=(2, 3), trace_jitter=15),
     "cfg2_ecoli160": SynthSpec(genome_len=4_600_000, coverage=160, len_dist="lognormal", len_mean=8500,
                                len_min=1500, len_max=40000, seed=2, n_repeat_families=1,
-                               repeat_len=(5000, 5000), repeat_copies=(7, 7)),
+                               repeat_len=(5000, 5000), repeat_copies=(7, 7), trace_jitter=15),
     "cfg3_nctc": SynthSpec(genome_len=5_000_000, coverage=100, len_dist="lognormal", len_mean=8000,
                            len_min=1500, len_max=40000, seed=3, n_repeat_families=40,
-                           repeat_len=(1000, 8000), repeat_copies=(2, 6), chimera_frac=0.02),
+                           repeat_len=(1000, 8000), repeat_copies=(2, 6), chimera_frac=0.02, trace_jitter=15),
     "cfg4_yeast": SynthSpec(genome_len=12_000_000, coverage=80, len_dist="lognormal", len_mean=8000,
                             len_min=1500, len_max=40000, seed=4, n_repeat_families=20,
-                            repeat_len=(1000, 6000), repeat_copies=(2, 5), n_blocks=8),
+                            repeat_len=(1000, 6000), repeat_copies=(2, 5), n_blocks=8, trace_jitter=15),
     # config 5 (HBM-roofline stress): generated on the device by hinge_amd.synth_device (no .las of this size is ever written).
     # SURVEY 8(d) quotes ~10^9 overlaps for the whole 100 Mb genome; with overlaps of >= 1 kb between 7 kb reads at 100x the
     # model gives ~170 per read, 2.4e8 in all, so "one rank's share of 10^9" (>= 1.25e8 overlaps) is the 52 Mb block below.

@@ -9,7 +9,14 @@
 #include <stdlib.h>
 #include <string.h>
 
-int synth_write_las(const char* path, int64_t n, const int64_t* sel, int32_t tspace, const int32_t* aread, const int32_t* bread,
+/* lowbias32; hinge_amd.synth._mix32 is the same function */
+static uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+/* jitter > 0: interior panels (1, 2), (3, 4), ... of a record exchange up to `jitter` bases of B advance (the sum is kept) */
+int synth_write_las(const char* path, int64_t n, const int64_t* sel, int32_t tspace, int32_t jitter, const int32_t* aread, const int32_t* bread,
                     const uint8_t* comp, const int32_t* ab, const int32_t* ae, const int32_t* bb, const int32_t* be,
                     const int32_t* rlen) {
     FILE* f = fopen(path, "wb");
@@ -49,12 +56,20 @@ int synth_write_las(const char* path, int64_t n, const int64_t* sel, int32_t tsp
         uint8_t* tr = buf + used;
         const int64_t diff = (b1 - b0) - (a1 - a0);
         const int64_t mag = diff < 0 ? -diff : diff, sgn = diff > 0 ? 1 : (diff < 0 ? -1 : 0);
+        int64_t carry = 0;                                 /* bases the panel before handed over */
         for (int64_t j = 0; j < nseg; j++) {
             int64_t adv = ts, dif = ts / 8;
             if (j == 0) { adv = first_len; dif = first_len / 8; }
             if (j == nseg - 1) { adv = last_len; dif = last_len / 8; }
             if (j < mag) adv += sgn;                       /* the length difference is spread one base per panel from the front */
             if (j == nseg - 1 && mag > nseg) adv += sgn * (mag - nseg);
+            adv -= carry;
+            carry = 0;
+            if (jitter > 0 && (j & 1) && j + 1 <= nseg - 2) {
+                const uint32_t h = mix32((uint32_t)((uint64_t)k * 0x9E3779B1ull) ^ (uint32_t)((uint64_t)j * 0x85EBCA6Bull));
+                carry = (int64_t)(h % (uint32_t)(2 * jitter + 1)) - jitter;
+                adv += carry;
+            }
             if (adv < 0 || adv > 255) { rc = -2; break; }
             tr[2 * j] = (uint8_t)dif;
             tr[2 * j + 1] = (uint8_t)adv;

@@ -127,6 +127,48 @@ int ref_matching_position(int ab, int ae, int bb, int be, int comp, const uint16
     return r;
 }
 
+// Batch forms of the three calls above (the -m gpu tests hold the HIP kernels against 10^5+ cases per primitive; one ctypes
+// call per case would be the test's time).  Same reference functions, a loop around them.
+// hdr[n][9] as for ref_process_alignment; trace = all traces back to back, toff[n + 1] in VALUES; out[n][10].
+void ref_process_alignment_batch(long n, const int* hdr, const uint16_t* trace, const long* toff, int aln_threshold, int theta, int theta2, int* out) {
+    for (long i = 0; i < n; i++)
+        ref_process_alignment(hdr + 9 * i, trace + toff[i], (int)(toff[i + 1] - toff[i]), aln_threshold, theta, theta2, out + 10 * i);
+}
+
+// q queries: overlap qi[k] (rows of hdr[n][9], of which the first five are used) at position qpos[k]
+void ref_matching_position_batch(long nq, const long* qi, const int* qpos, const int* hdr, const uint16_t* trace, const long* toff, int* out) {
+    for (long k = 0; k < nq; k++) {
+        const int* h = hdr + 9 * qi[k];
+        out[k] = ref_matching_position(h[0], h[1], h[2], h[3], h[4], trace + toff[qi[k]], (int)(toff[qi[k] + 1] - toff[qi[k]]), qpos[k]);
+    }
+}
+
+// n pile-ups: overlaps row_ptr[i] .. row_ptr[i + 1] of (ab, ae); nbins[i] = K, bins of pile-up i from cov_out[sum of K before]
+// (cov_out == NULL: only nbins).  Returns the total number of bins.
+long ref_profile_coverage_batch(long n, const long* row_ptr, const int* ab, const int* ae, int reso, int cutoff, int* nbins, int* cov_out, long cap) {
+    LAInterface la;
+    long tot = 0;
+    for (long i = 0; i < n; i++) {
+        std::vector<LOverlap*> v;
+        for (long j = row_ptr[i]; j < row_ptr[i + 1]; j++) {
+            LOverlap* o = new LOverlap();
+            o->trace_pts = NULL;
+            o->read_A_match_start_ = ab[j];
+            o->read_A_match_end_ = ae[j];
+            v.push_back(o);
+        }
+        std::vector<std::pair<int, int>> c;
+        la.profileCoverage(v, c, reso, cutoff);
+        nbins[i] = (int)c.size();
+        if (cov_out)
+            for (size_t k = 0; k < c.size(); k++)
+                if (tot + (long)k < cap) cov_out[tot + (long)k] = c[k].second;
+        tot += (long)c.size();
+        for (auto o : v) delete o;
+    }
+    return tot;
+}
+
 // mode 0: compare_overlap on LOverlap* whose length sum is key[i]; mode 1: pairAscend; mode 2: pairDescend;
 // mode 3: compare_overlap_weight
 void ref_sort_perm(int n, const int* key, int mode, int* perm) {

@@ -98,6 +98,12 @@ def test_rccl_between_contexts_one_rank():
         assert rc == 0, lib.hinge_last_error(ctx.h)
     mask, _, _ = ctx.get_masks()
     assert np.array_equal(mask, rows)
+    # phase 1 places rows from the stage of the phase-0 call of the same wave: without one, or over other rows, it is refused
+    assert lib.hinge_comm_exchange_mask_rows(arr, 1, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), 1) == capi.HINGE_E_ARG
+    assert lib.hinge_comm_exchange_mask_rows(arr, 1, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), 0) == 0
+    lo2 = np.array([50], np.int32)
+    assert lib.hinge_comm_exchange_mask_rows(arr, 1, lo2.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), 1) == capi.HINGE_E_ARG
+    assert b"phase 1 without" in lib.hinge_last_error(ctx.h)
     other = capi.Context(0)
     two = (C.c_void_p * 2)(ctx.h, other.h)
     assert lib.hinge_comm_create(two, 2) == capi.HINGE_E_DEVICE

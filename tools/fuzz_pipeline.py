@@ -39,6 +39,9 @@ def random_case(rng):
         tspace=int(rng.choice([100, 100, 100, 50, 200])), seed=int(rng.integers(1, 1 << 30)), n_blocks=int(rng.choice([1, 1, 2, 3])),
         with_qv=bool(rng.integers(0, 2)), tie_quantum=int(rng.choice([0, 0, 0, 40, 100])), short_reads=int(rng.choice([0, 0, 10])),
         orphan_reads=int(rng.choice([0, 0, 4])), self_overlap_reads=int(rng.choice([0, 0, 4])))
+    # round 5: three cases in four carry jittered traces (per-segment B advances of tspace +- 15 / 30 %); taken from the seed,
+    # so the draws below are those of the earlier rounds' cases
+    spec.trace_jitter = [0, 15, 15, 30][spec.seed % 4] * spec.tspace // 100
     filt, lay = [], []
     if rng.random() < 0.5:
         filt.append("cut_off = %d" % int(rng.choice([0, 100, 200, 300, 300, 400, 310])))
