@@ -108,6 +108,8 @@ SYMBOLS = [
     ("hinge_consensus_get_contig", C.c_int, [_VP, C.c_int32, _VP, C.c_int64, C.POINTER(C.c_int64), _VP]),
     ("hinge_consensus_get_offsets", C.c_int, [_VP, _VP]),
     ("hinge_consensus_get_indels", C.c_int, [_VP, C.c_int64, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    ("hinge_draft_mappings", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int64, C.c_int32, _VP, _VP]),
+    ("hinge_draft_ladders", C.c_int, [_VP, C.c_int64, _VP, _VP, _VP, C.c_int32, _VP, _VP, _VP]),
     ("hinge_profile_report", C.c_int, [_VP, _VP, _VP]),
     ("hinge_timer_start", C.c_int, [_VP]),
     ("hinge_timer_stop_ms", C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -561,6 +563,48 @@ class Consensus:
         if n.value:
             self.ctx._ck(self.ctx.lib.hinge_consensus_get_indels(self.ctx.h, k, _ptr(out), n.value, C.byref(n)))
         return out[:n.value]
+
+
+class Draft:
+    """`hinge draft`'s two GPU steps over the C ABI (hinge_draft_*): both DB slots hold the read DB."""
+
+    RUNG_DTYPE = np.dtype([("read", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("end", "<i4")])
+
+    def __init__(self, ctx: Context, read_db: str):
+        self.ctx = ctx
+        self.cns = Consensus(ctx, read_db, read_db)
+
+    def mappings(self, las, picks):
+        """List of uint32 arrays, one per picked record: B bases in front of every A base's column (bit 31: a gap in B there)."""
+        picks = np.asarray(picks, dtype=np.int64)
+        tb = 1 if las.tspace <= 125 else 2
+        tr16 = np.ascontiguousarray(las.trace.astype(np.uint16) if tb == 1 else np.ascontiguousarray(las.trace).view("<u2"))
+        a = np.zeros(len(picks), dtype=CNS_ALN_DTYPE)
+        r = las.rec[picks]
+        a["aread"], a["bread"], a["comp"] = r["aread"], r["bread"], r["flags"] & 1
+        a["abpos"], a["aepos"], a["bbpos"], a["bepos"], a["tlen"] = r["abpos"], r["aepos"], r["bbpos"], r["bepos"], r["tlen"]
+        a["trace_off"] = las.trace_off[picks] // tb
+        off = np.concatenate([[0], np.cumsum((r["aepos"] - r["abpos"]).astype(np.int64))]).astype(np.int64)
+        out = np.zeros(max(int(off[-1]), 1), np.uint32)
+        self.ctx._ck(self.ctx.lib.hinge_draft_mappings(self.ctx.h, len(picks), _ptr(a), _ptr(tr16), tr16.size, las.tspace, _ptr(off), _ptr(out)))
+        return [out[off[i]:off[i + 1]] for i in range(len(picks))]
+
+    def ladders(self, ladders, templates, band: int = 150):
+        """ladders: list of lists of (read, strand, start, end); templates: the template member of each.  Returns the consensus strings."""
+        n = len(ladders)
+        rung_off = np.concatenate([[0], np.cumsum([len(x) for x in ladders])]).astype(np.int64)
+        rungs = np.zeros(max(int(rung_off[-1]), 1), dtype=self.RUNG_DTYPE)
+        k = 0
+        for ld in ladders:
+            for g in ld:
+                rungs[k] = g
+                k += 1
+        tm = np.ascontiguousarray(templates, dtype=np.int32)
+        slot = np.concatenate([[0], np.cumsum([2 * (ld[t][3] - ld[t][2] + 1) for ld, t in zip(ladders, templates)])]).astype(np.int64)
+        out = np.zeros(max(int(slot[-1]), 1), np.uint8)
+        lens = np.zeros(max(n, 1), np.int32)
+        self.ctx._ck(self.ctx.lib.hinge_draft_ladders(self.ctx.h, n, _ptr(rung_off), _ptr(rungs), _ptr(tm), band, _ptr(slot), _ptr(out), _ptr(lens)))
+        return [out[slot[i]:slot[i] + lens[i]].tobytes().decode() for i in range(n)]
 
 
 def median_from_hist_batch(ctxs, p: FilterParams, hist_dev, row_stride: int) -> None:

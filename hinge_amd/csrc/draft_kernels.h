@@ -1,0 +1,282 @@
+// `hinge draft` on the GPU (second half; reference: src/consensus/draft.cpp:125-715 with lib/DW_banded.c and
+// lib/falcon.c under it).  Included by hinge_capi.hip after consensus_kernels.h (the realignment between trace points is the same
+// kernel, k_cns_realign: recoverAlignment, LAInterface.cpp:4125-4244).
+//
+//   k_draft_map     one thread per trace-point segment: its indel list -> get_mapping (draft.cpp:70-87) of the alignment's forward
+//                   tags: for every A base of the alignment the number of B bases in front of its column (+ bit 31: its column
+//                   holds a gap in B - what the host needs to turn the map around for a strand-1 edge)
+//   k_draft_align   one WAVEFRONT per (ladder, member): falcon's banded O(ND) alignment of the member against the ladder's
+//                   template (DW_banded.c:97-311) - the diagonals of one d across the lanes, V / U in LDS, the (d, k) records 4 bytes
+//                   each in HBM, the trace-back by lane 0, then the alignment tags (falcon.c:68-125, with the leading 'T' column of
+//                   draft.cpp:646-655) written run by run, a run's columns across the lanes
+//   k_draft_cns     one WAVEFRONT per ladder, one LANE per member: falcon's consensus over the members' tags (falcon.c:246-517) -
+//                   the columns (t_pos, delta, base) are visited in the reference's order, the members that share a column vote with
+//                   ballots (a link = the member's previous column; equal links are found with readlane + ballot, in member order =
+//                   the reference's insertion order, so ties fall the same way), scores as doubled integers (the reference adds
+//                   link counts and halves of the coverage: exact in either form), the best-predecessor table in HBM, the
+//                   trace-back by lane 0 - including the reference's habit of deciding the LAST base by a link index
+//
+// Everything is integer work on 2-bit bases; nothing here is GEMM-shaped.  Bound: latency (dependent look-ups along one
+// alignment path), hidden by running thousands of ladders' wavefronts side by side.
+#pragma once
+
+namespace hinge {
+
+struct DraftSeq { long long boff; int rlen, strand, start, len; };     // bases [start, start + len) of the read in its strand frame
+
+__device__ __forceinline__ int draft_base(const unsigned char* __restrict__ bps, const DraftSeq& s, int x) {
+    const int p = s.start + x;
+    return s.strand ? 3 - cns_base(bps, s.boff, s.rlen - 1 - p) : cns_base(bps, s.boff, p);
+}
+
+constexpr unsigned DRAFT_GAP = 0x80000000u;
+
+__global__ __launch_bounds__(CNS_BLOCK) void k_draft_map(const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, int n_seg, const int* __restrict__ indels,
+                                                         const int* __restrict__ n_indel, const long long* __restrict__ map_off, unsigned* __restrict__ mapping) {
+    const int s = blockIdx.x * CNS_BLOCK + threadIdx.x;
+    if (s >= n_seg) return;
+    const CnsSeg g = segs[s];
+    const CnsAln al = alns[g.aln];
+    unsigned* __restrict__ m = mapping + map_off[g.aln];
+    cns_walk(g, indels + g.out_off, n_indel[s], [&](int kind, int i, int j, int cnt) {
+        if (kind == 0) { for (int t = 0; t < cnt; t++) m[i - 1 + t - al.ab] = (unsigned)(j - 1 + t - al.bb); }
+        else if (kind == 2) m[i - 1 - al.ab] = (unsigned)(j - 1 - al.bb) | DRAFT_GAP;
+        return true;
+    });
+}
+
+// ---- falcon's aligner, one wavefront per job ---------------------------------------------------------------------------------
+struct DraftJob {
+    DraftSeq q, t;              // query = the member, target = the ladder's template
+    long long ent_off;          // its (d, k) records: ent_cap words
+    long long dtab_off;         // per d: first record, min_k  (2 * (max_d + 1) ints)
+    long long tag_off;          // its tags (q.len + t.len + 2 words) ...
+    int ent_cap, max_d;
+};
+constexpr int DRAFT_ST_CAP = 1;      // a record / tag buffer too small (host sizing bug)
+constexpr int DRAFT_ST_DELTA = 2;    // a run of 255+ inserted bases: the reference's tags are undefined there (falcon.c:96)
+constexpr int DRAFT_ST_BASE = 4;
+
+// a tag: t_pos << 11 | delta << 3 | base (0-3 A C G T, 4 '-')
+__device__ __forceinline__ unsigned draft_tag(int t_pos, int delta, int base) { return ((unsigned)t_pos << 11) | ((unsigned)delta << 3) | (unsigned)base; }
+
+__global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restrict__ bps, const DraftJob* __restrict__ jobs, int n_jobs, int band_tol,
+                                                    unsigned* __restrict__ ents, int* __restrict__ dtab, unsigned* __restrict__ tags, int* __restrict__ n_tags,
+                                                    int* __restrict__ status) {
+    extern __shared__ int lds[];
+    const int lane = threadIdx.x;
+    for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
+        const DraftJob J = jobs[jb];
+        const int q_len = J.q.len, t_len = J.t.len, max_d = J.max_d;
+        int* V = lds;                       // [2 * max_d + 1]
+        int* U = lds + (2 * max_d + 1);
+        for (int i = lane; i < 2 * (2 * max_d + 1); i += 64) lds[i] = 0;
+        __syncthreads();
+        const int k_off = max_d, band_size = band_tol * 2;
+        unsigned* __restrict__ E = ents + J.ent_off;
+        int* __restrict__ DT = dtab + J.dtab_off;
+        unsigned* __restrict__ TG = tags + J.tag_off;
+        int best_m = -1, min_k = 0, max_k = 0, n_ent = 0;
+        int fin_d = -1, fin_k = 0;
+        bool overflow = false;
+        for (int d = 0; d < max_d; d++) {
+            if (max_k - min_k > band_size) break;
+            const int nk = (max_k - min_k) / 2 + 1;
+            if (n_ent + nk > J.ent_cap) { overflow = true; break; }
+            if (lane == 0) { DT[2 * d] = n_ent; DT[2 * d + 1] = min_k; }
+            int my_best = -1;
+            unsigned long long done_any = 0ull;
+            int done_at = 0;
+            for (int it = 0; it * 64 < nk && !done_any; it++) {
+                const int idx = it * 64 + lane;
+                const bool on = idx < nk;
+                const int k = min_k + 2 * idx;
+                int x = 0, y = 0;
+                bool fin = false;
+                if (on) {
+                    unsigned pre_minus;
+                    if (k == min_k || (k != max_k && V[k - 1 + k_off] < V[k + 1 + k_off])) { pre_minus = 0u; x = V[k + 1 + k_off]; }
+                    else { pre_minus = 1u; x = V[k - 1 + k_off] + 1; }
+                    y = x - k;
+                    const int x1 = x;
+                    while (x < q_len && y < t_len && draft_base(bps, J.q, x) == draft_base(bps, J.t, y)) { x++; y++; }
+                    E[n_ent + idx] = ((unsigned)x1 << 17) | (pre_minus << 16) | (unsigned)x;      // x1 (15 bits) | came from k - 1 | x2 (16 bits)
+                    fin = x >= q_len || y >= t_len;
+                }
+                __syncthreads();            // (one wavefront: orders the LDS reads above before the writes below)
+                if (on) { V[k + k_off] = x; U[k + k_off] = x + y; my_best = max(my_best, x + y); }
+                done_any = __ballot(on && fin);
+                if (done_any) done_at = it * 64 + (int)__builtin_ctzll(done_any);
+                __syncthreads();
+            }
+            if (done_any) {                 // the reference breaks at the first k (ascending) that reaches an end
+                fin_d = d; fin_k = min_k + 2 * done_at;
+                n_ent += done_at + 1;
+                break;
+            }
+            n_ent += nk;
+            for (int o = 32; o; o >>= 1) my_best = max(my_best, __shfl_xor(my_best, o));
+            best_m = max(best_m, my_best);
+            int lo = max_k, hi = min_k;
+            for (int idx = lane; idx < nk; idx += 64) {
+                const int k2 = min_k + 2 * idx;
+                if (U[k2 + k_off] >= best_m - band_tol) { lo = min(lo, k2); hi = max(hi, k2); }
+            }
+            for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+            max_k = hi + 1; min_k = lo - 1;
+            __syncthreads();
+        }
+        if (overflow && lane == 0) atomicOr(status, DRAFT_ST_CAP);
+        // ---- tags: the leading 'T' column, then the path's columns (falcon.c:68-125 on the rows of DW_banded.c:245-300) ---------------
+        if (lane == 0) TG[0] = draft_tag(0, 0, 3);
+        int n_col = 1;
+        if (fin_d >= 0 && !overflow) {
+            // trace-back: record index of every d on the path, kept in the V / U space of LDS (no longer needed; d <= 2 * max_d ints)
+            int* path = lds;
+            __syncthreads();
+            if (lane == 0) {
+                int ck = fin_k;
+                for (int cd = fin_d; cd >= 0; cd--) {
+                    const int at = DT[2 * cd] + (ck - DT[2 * cd + 1]) / 2;
+                    path[cd] = at;
+                    ck = ((E[at] >> 16) & 1u) ? ck - 1 : ck + 1;
+                }
+            }
+            __syncthreads();
+            int jj = 0;                     // consecutive inserted bases in front of the next column
+            int py = 0;                     // target bases consumed so far
+            int px = 0;
+            bool bad_delta = false;
+            for (int cd = 0; cd <= fin_d; cd++) {
+                const unsigned e = E[path[cd]];
+                const int x1 = (int)(e >> 17), x2 = (int)(e & 0xffffu);
+                const int k = x1 - 0;       // (y1 follows from the step kind below)
+                (void)k;
+                if (cd > 0) {               // the edit step from (px, py): one column
+                    const bool x_step = (e >> 16) & 1u;          // came from k - 1: a query base against a gap
+                    if (n_col + 1 > q_len + t_len + 2) { overflow = true; break; }
+                    if (x_step) {
+                        jj += 1;
+                        if (jj >= 255) bad_delta = true;
+                        if (lane == 0) TG[n_col] = draft_tag(py, jj & 255, draft_base(bps, J.q, px));
+                        px += 1;
+                    } else {
+                        jj = 0;
+                        py += 1;
+                        if (lane == 0) TG[n_col] = draft_tag(py, 0, 4);
+                    }
+                    n_col += 1;
+                }
+                const int run = x2 - x1;    // the snake: run matched pairs
+                if (run > 0) {
+                    if (n_col + run > q_len + t_len + 2) { overflow = true; break; }
+                    for (int t = lane; t < run; t += 64) TG[n_col + t] = draft_tag(py + 1 + t, 0, draft_base(bps, J.q, px + t));
+                    n_col += run; px += run; py += run; jj = 0;
+                }
+            }
+            if (lane == 0 && bad_delta) atomicOr(status, DRAFT_ST_DELTA);
+            if (lane == 0 && overflow) atomicOr(status, DRAFT_ST_CAP);
+        }
+        if (lane == 0) n_tags[jb] = n_col;
+        __syncthreads();
+    }
+}
+
+// ---- falcon's consensus, one wavefront per ladder ---------------------------------------------------------------------------
+struct DraftLadder {
+    int job0, n;                // its jobs (members), n <= 64
+    int t_len;                  // template length + 1
+    long long col_off;          // best-predecessor table: col_cap words
+    long long tb_off;           // per t: first (t, delta) slot, coverage  (2 * t_len ints)
+    long long out_off;          // its consensus: up to 2 * t_len characters
+    int col_cap;
+};
+constexpr unsigned DRAFT_NONE = 0xffffffffu;
+
+__global__ __launch_bounds__(64) void k_draft_cns(const DraftJob* __restrict__ jobs, const DraftLadder* __restrict__ ladders, int n_ladders, const unsigned* __restrict__ tags,
+                                                  const int* __restrict__ n_tags, unsigned* __restrict__ cols, int* __restrict__ tbase, char* __restrict__ out,
+                                                  int* __restrict__ out_len, unsigned min_cov, int* __restrict__ status) {
+    __shared__ int S2[2][256][5];           // doubled scores of the columns of the current and the previous template position
+    const int lane = threadIdx.x;
+    for (int ld = blockIdx.x; ld < n_ladders; ld += gridDim.x) {
+        const DraftLadder L = ladders[ld];
+        const bool member = lane < L.n;
+        const unsigned* __restrict__ TG = member ? tags + jobs[L.job0 + lane].tag_off : tags;
+        const int nt = member ? n_tags[L.job0 + lane] : 0;
+        unsigned* __restrict__ C = cols + L.col_off;
+        int* __restrict__ TB = tbase + L.tb_off;
+        int p = 0;                           // next tag of this lane
+        unsigned prev = DRAFT_NONE;          // this lane's previous column (a tag word), DRAFT_NONE in front of its first
+        int slot = 0;                        // (t, delta) slots so far
+        int g_best = -2, g_ck = 0, g_t = 0;
+        unsigned g_col = DRAFT_NONE;         // slot * 5 + base of the best column
+        int best_ck = -1;
+        bool cap_hit = false;
+        for (int t = 0; t < L.t_len; t++) {
+            int cov = 0;
+            if (lane == 0) TB[2 * t] = slot;
+            for (int delta = 0;; delta++) {
+                const unsigned tg = p < nt ? TG[p] : DRAFT_NONE;
+                const bool has = tg != DRAFT_NONE && (int)(tg >> 11) == t && (int)((tg >> 3) & 255u) == delta;
+                const unsigned long long H = __ballot(has);
+                if (delta == 0) { cov = __popcll(H); if (lane == 0) TB[2 * t + 1] = cov; }
+                if (!H) break;
+                if ((slot + 1) * 5 > L.col_cap || delta > 255) { cap_hit = true; break; }
+                const int base = (int)(tg & 7u);
+                // this lane's predecessor score (doubled); a first tag has none
+                int ps = 0;
+                if (has && prev != DRAFT_NONE) ps = S2[(prev >> 11) & 1u][(prev >> 3) & 255u][prev & 7u];
+                for (int kk = 0; kk < 5; kk++) {
+                    unsigned long long M = __ballot(has && base == kk);
+                    int best = -2;
+                    unsigned best_p = 0u;            // (the reference leaves best_p_* of a column without links at zero)
+                    int ck = 0;
+                    while (M) {
+                        const int lead = (int)__builtin_ctzll(M);
+                        const unsigned lp = __shfl(prev, lead);
+                        const int ls = __shfl(ps, lead);
+                        const unsigned long long same = __ballot(has && base == kk && prev == lp);
+                        const int score = (lp == DRAFT_NONE ? 0 : ls) + 2 * __popcll(same) - cov;
+                        if (score > best) { best = score; best_p = lp; best_ck = ck; }
+                        ck++;
+                        M &= ~same;
+                    }
+                    if (lane == 0) { S2[t & 1][delta][kk] = best; C[slot * 5 + kk] = best_p; }
+                    if (best > g_best) { g_best = best; g_col = (unsigned)(slot * 5 + kk); g_ck = best_ck; g_t = t; }
+                }
+                __syncthreads();
+                if (has) { prev = tg; p++; }
+                slot++;
+            }
+            if (cap_hit) break;
+        }
+        if (cap_hit && lane == 0) atomicOr(status, DRAFT_ST_CAP);
+        // ---- the sequence, back to front (falcon.c:440-478), then turned around ----------------------------------------------------
+        int len = 0;
+        if (lane == 0) {
+            char* __restrict__ o = out + L.out_off;
+            if (g_col != DRAFT_NONE && !cap_hit) {
+                char bb = '$';
+                int ck = g_ck, i = g_t;
+                unsigned col = g_col;
+                while (true) {
+                    if (ck >= 0 && ck < 5) bb = (unsigned)TB[2 * i + 1] > min_cov ? "ACGT-"[ck] : "acgt-"[ck];
+                    const unsigned bp = C[col];
+                    if (bp == DRAFT_NONE || len >= 2 * L.t_len) break;
+                    i = (int)(bp >> 11);
+                    const int j = (int)((bp >> 3) & 255u);
+                    ck = (int)(bp & 7u);
+                    col = (unsigned)((TB[2 * i] + j) * 5 + ck);
+                    if (bb != '-') o[len++] = bb;
+                }
+                for (int a = 0, b = len - 1; a < b; a++, b--) { const char c = o[a]; o[a] = o[b]; o[b] = c; }
+            } else if (!cap_hit) {
+                atomicOr(status, DRAFT_ST_BASE);       // (the reference's assert(g_best_score != -1))
+            }
+            out_len[ld] = len;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace hinge

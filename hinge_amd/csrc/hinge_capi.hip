@@ -14,6 +14,7 @@
 #include "align_kernels.h"
 #include "select_kernel.h"
 #include "consensus_kernels.h"
+#include "draft_kernels.h"
 
 using namespace hinge;
 
@@ -126,6 +127,7 @@ struct hinge_ctx {
     std::vector<int> prof_kid;
 
     struct CnsState* cns = nullptr;     // `hinge consensus` (consensus_capi.inc)
+    struct DraftState* draft = nullptr; // `hinge draft` (draft_capi.inc)
     void* comm = nullptr;               // ncclComm_t of this context among the contexts of its process (comm_capi.inc)
     int comm_rank = -1, comm_size = 0;
     DevBuf comm_stage;                  // all-gathered mask rows [comm_size + 1][S][2]
@@ -134,10 +136,10 @@ struct hinge_ctx {
 };
 
 enum KernelId { KID_STATS = 0, KID_MEDIAN, KID_MASK_ANNOTATE, KID_MASK_FALLBACK, KID_HINGE_COUNT, KID_HINGE_CALL, KID_HINGE_EXACT, KID_COVERAGE_BINS, KID_TRIM_CLASSIFY,
-                KID_PILEUP_FACTS, KID_MATCHING_POSITION, KID_SELECT_EDGES, KID_SPEC_PREDICT, KID_MASK_FINAL, KID_CNS_REALIGN, KID_CNS_COLUMNS, KID_CNS_VOTE, KID_CNS_CALL, KID_COUNT };
+                KID_PILEUP_FACTS, KID_MATCHING_POSITION, KID_SELECT_EDGES, KID_SPEC_PREDICT, KID_MASK_FINAL, KID_CNS_REALIGN, KID_CNS_COLUMNS, KID_CNS_VOTE, KID_CNS_CALL, KID_DRAFT_ALIGN, KID_DRAFT_CNS, KID_COUNT };
 static const char* const KERNEL_NAMES[KID_COUNT] = {"k_cov_stats", "k_median_hist", "k_mask_annotate", "k_mask_annotate_fallback", "k_hinge_count", "k_hinge_call", "k_hinge_exact",
                                                      "k_coverage_bins", "k_trim_classify", "k_pileup_facts", "k_matching_position", "k_select_edges", "k_spec_predict",
-                                                     "k_mask_annotate_final", "k_cns_realign", "k_cns_columns", "k_cns_vote", "k_cns_call"};
+                                                     "k_mask_annotate_final", "k_cns_realign", "k_cns_columns", "k_cns_vote", "k_cns_call", "k_draft_align", "k_draft_cns"};
 
 struct ProfScope {
     hinge_ctx* c;
@@ -300,11 +302,13 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
 }
 
 static void cns_release(hinge_ctx* ctx);
+static void draft_release(hinge_ctx* ctx);
 static void comm_release(hinge_ctx* ctx);
 void hinge_ctx_destroy(hinge_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     cns_release(ctx);
+    draft_release(ctx);
     comm_release(ctx);
     DevBuf* all[] = {&ctx->rlen, &ctx->qv_mask, &ctx->row_ptr, &ctx->a_span, &ctx->b_span, &ctx->b_flag, &ctx->mask_own, &ctx->mean_own,
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
@@ -1834,6 +1838,7 @@ int hinge_timer_stop_ms(hinge_ctx* ctx, float* ms) {
 
 #include "align_capi.inc"
 #include "consensus_capi.inc"
+#include "draft_capi.inc"
 #include "comm_capi.inc"
 
 #ifdef HINGE_K2_TRACE

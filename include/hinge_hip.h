@@ -339,6 +339,33 @@ int hinge_consensus_get_offsets(hinge_ctx* ctx, int32_t* offsets);
 /* Tests: the recovered indel list of one alignment (LAlignment::trace after recoverAlignment).                                */
 int hinge_consensus_get_indels(hinge_ctx* ctx, int64_t aln, int32_t* out, int64_t cap, int64_t* n);
 
+/* ---- hinge draft (consensus/draft.cpp:125-715) ----------------------------------------------------------
+ * The base-level work of stitching a contig from the reads along a path of the layout graph.  Both DB slots of
+ * hinge_consensus_set_db hold the READ DB (a draft aligns reads with reads).  What stays with the caller
+ * (hinge_amd/host/draft_main.cpp): the .edges.list path file, which alignment belongs to which edge (draft.cpp:162-178, :262-275),
+ * the way points and lanes carried from read to read through the mappings (:415-495), the ladders (:540-556), the coverage
+ * profile that picks a ladder's template (:573-590), prefix / suffix / overhang and the cuts (:520-531, :700-712), the FASTA.
+ *
+ * hinge_draft_mappings: LAInterface::recoverAlignment + getAlignmentTags + get_mapping (LAInterface.cpp:4125-4244, :3709-3905,
+ *   draft.cpp:70-87, :213-216, :394-397) for n_aln alignments (as hinge_consensus_run takes them).  mapping[map_off[i] + k], k <
+ *   aepos - abpos (map_off[i + 1] - map_off[i] must be that): the number of B bases in the columns in front of the column of A
+ *   base abpos + k - the forward-strand map; bit 31 is set when that column holds a gap in B (with it the caller derives the
+ *   map of the reverse-complemented tags of a strand-1 edge: draft.cpp:292-298).  HINGE_E_RANGE as hinge_consensus_run. */
+int hinge_draft_mappings(hinge_ctx* ctx, int64_t n_aln, const hinge_cns_alignment* alns, const uint16_t* trace, int64_t n_trace, int32_t tspace,
+                         const int64_t* map_off, uint32_t* mapping);
+/* One member of a ladder: bases [start, end) of read `read` in its strand frame (strand 1: of its reverse complement). */
+typedef struct hinge_draft_rung { int32_t read, strand, start, end; } hinge_draft_rung;
+/* hinge_draft_ladders: for every ladder (members rungs[rung_off[l] .. rung_off[l + 1]), 1 .. 64 of them) the consensus of
+ *   draft.cpp:597-691: every member aligned to member template_rung[l] with falcon's banded O(ND) aligner (lib/DW_banded.c:97-311,
+ *   band_tolerance = 150 in the reference), alignment tags with a leading 'T' column (lib/falcon.c:68-125), get_cns_from_align_tags
+ *   over template length + 1 positions with min_cov 1 (lib/falcon.c:246-517) - ties, the link-index quirk of its last base and the
+ *   lower case of thinly covered bases included.  out_off[l] = where ladder l's string goes in `out` (caller-laid-out slots of at
+ *   least 2 * (template length + 1) bytes: out_off[n_ladders] = the buffer's size), out_len[l] = its length.
+ *   HINGE_E_CAPACITY: more than 64 members / a member of 32768+ bases; HINGE_E_RANGE: 255+ inserted bases in a row (the
+ *   reference's tags are undefined there); HINGE_E_UNDEFINED: its assert(g_best_score != -1). */
+int hinge_draft_ladders(hinge_ctx* ctx, int64_t n_ladders, const int64_t* rung_off, const hinge_draft_rung* rungs, const int32_t* template_rung, int32_t band_tolerance,
+                        const int64_t* out_off, char* out, int32_t* out_len);
+
 /* Per-kernel timing with HIP events recorded around every launch on the context's stream.
  * enable(max_launches > 0) starts a fresh recording; report() synchronises and returns total ms and
  * launch count per kernel id in [0, hinge_profile_kernels()).  select() restricts the events to the

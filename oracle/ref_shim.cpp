@@ -17,6 +17,10 @@
 #include <unordered_map>
 #include "LAInterface.h"
 #include "INIReader.h"
+#include <cctype>
+extern "C" {
+#include "common.h"
+}
 
 extern "C" {
 
@@ -167,6 +171,67 @@ long ref_profile_coverage_batch(long n, const long* row_ptr, const int* ab, cons
         for (auto o : v) delete o;
     }
     return tot;
+}
+
+// One ladder of `hinge draft` through the reference's OWN falcon code (lib/DW_banded.c _align, lib/falcon.c get_align_tags /
+// get_cns_from_align_tags): the marshalling of draft.cpp:597-691 around them - member mx is the template, every member is aligned
+// to it with band tolerance 150, both rows get a leading 'T' and go to upper case, consensus over alen + 1 positions with
+// min_cov 1.  Returns the consensus length (NUL-terminated into out if it fits).
+long ref_falcon_ladder(int n, const char** seqs, int mx, char* out, long cap) {
+    const int alen = (int)strlen(seqs[mx]);
+    align_tags_t** tags_list = (align_tags_t**)calloc((size_t)n, sizeof(align_tags_t*));
+    for (int j = 0; j < n; j++) {
+        const int blen = (int)strlen(seqs[j]);
+        char* aseq = (char*)malloc((size_t)alen + 20);
+        char* bseq = (char*)malloc((size_t)blen + 20);
+        strcpy(aseq, seqs[mx]);
+        strcpy(bseq, seqs[j]);
+        aln_range* arange = (aln_range*)calloc(1, sizeof(aln_range));
+        arange->s1 = 0; arange->e1 = (int)strlen(bseq); arange->s2 = 0; arange->e2 = (int)strlen(aseq); arange->score = 5;
+        alignment* alng = _align(bseq, blen, aseq, alen, 150, 1);
+        char* q = (char*)malloc(5 + strlen(alng->q_aln_str));
+        char* t = (char*)malloc(5 + strlen(alng->t_aln_str));
+        strcpy(q + 1, alng->q_aln_str);
+        strcpy(t + 1, alng->t_aln_str);
+        q[0] = 'T'; t[0] = 'T';
+        for (size_t p = 0; p < strlen(q); p++) q[p] = (char)toupper(q[p]);
+        for (size_t p = 0; p < strlen(t); p++) t[p] = (char)toupper(t[p]);
+        tags_list[j] = get_align_tags(q, t, (seq_coor_t)strlen(alng->q_aln_str) + 1, arange, (unsigned)j, 0);
+        free(q); free(t); free(aseq); free(bseq); free(arange);
+        free_alignment(alng);
+    }
+    consensus_data* c = get_cns_from_align_tags(tags_list, (unsigned)n, (unsigned)alen + 1, 1);
+    const long len = (long)strlen(c->sequence);
+    if (len + 1 <= cap) memcpy(out, c->sequence, (size_t)len + 1);
+    free_consensus_data(c);
+    for (int j = 0; j < n; j++) free_align_tags(tags_list[j]);
+    free(tags_list);
+    return len;
+}
+
+// falcon's aligner alone: the two gapped rows; returns their length (0 when it does not align)
+long ref_falcon_align(const char* query, const char* target, int band, char* q_out, char* t_out, long cap) {
+    alignment* a = _align((char*)query, (seq_coor_t)strlen(query), (char*)target, (seq_coor_t)strlen(target), band, 1);
+    const long len = (long)strlen(a->q_aln_str);
+    if (len + 1 <= cap) { memcpy(q_out, a->q_aln_str, (size_t)len + 1); memcpy(t_out, a->t_aln_str, (size_t)len + 1); }
+    free_alignment(a);
+    return len;
+}
+
+// LAInterface::getCoverage (LOverlap form), LAInterface.cpp:4254-4263: cov[alen] from n (abpos, aepos)
+void ref_get_coverage(int n, const int* ab, const int* ae, int alen, int* cov) {
+    LAInterface la;
+    std::vector<LOverlap*> v;
+    for (int i = 0; i < n; i++) {
+        LOverlap* o = new LOverlap();
+        o->trace_pts = NULL;
+        o->read_A_match_start_ = ab[i]; o->read_A_match_end_ = ae[i]; o->alen = alen;
+        v.push_back(o);
+    }
+    std::vector<int>* r = la.getCoverage(v);
+    for (int i = 0; i < alen; i++) cov[i] = (*r)[i];
+    delete r;
+    for (auto o : v) delete o;
 }
 
 // mode 0: compare_overlap on LOverlap* whose length sum is key[i]; mode 1: pairAscend; mode 2: pairDescend;

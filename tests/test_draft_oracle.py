@@ -1,0 +1,137 @@
+"""`hinge draft` on the CPU side: oracle/draft_oracle.cpp's restatement of falcon's aligner + consensus against the REFERENCE's own
+falcon code (golden vectors everywhere, live where oracle/_ref exists), getCoverage, the chain synth -> filter -> maximal ->
+layout -> clip -> draft-path -> draft on noise-free reads where physics pins the result (the draft IS the genome, up to the
+reference's own documented habits), and `hinge draft-path`'s records on hand-built graphs."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import draft_common as dc
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "draft_falcon_golden.json")))
+
+
+def test_falcon_restatement_matches_the_reference_golden(oracle_lib):
+    lib = dc.bind(oracle_lib)
+    for c in GOLD:
+        n, cns = dc.ladder_call(lib.oracle_falcon_ladder, c["members"], c["mx"])
+        assert (n, cns) == (len(c["cns"]), c["cns"])
+        cap = 3 * max(len(m) for m in c["members"]) + 100
+        q, t = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(cap)
+        a = lib.oracle_falcon_align(c["members"][0].encode(), c["members"][c["mx"]].encode(), 150, q, t, cap)
+        if a == -1:
+            assert c["aln_len"] == 0
+        else:
+            assert (a, q.value.decode(), t.value.decode()) == (c["aln_len"], c["q"], c["t"])
+    assert sum(1 for c in GOLD if any(ch.islower() for ch in c["cns"])) > 0, "thinly covered (lower-case) bases should occur"
+
+
+def test_falcon_restatement_matches_the_reference_live(oracle_lib, ref_lib):
+    lib, ref = dc.bind(oracle_lib), dc.bind_ref(ref_lib)
+    rng = np.random.default_rng(77)
+    for case in range(400):
+        mem, mx = dc.random_ladder(rng, case)
+        assert dc.ladder_call(lib.oracle_falcon_ladder, mem, mx) == dc.ladder_call(ref.ref_falcon_ladder, mem, mx), case
+    ip = ctypes.POINTER(ctypes.c_int)
+    for _ in range(50):                                   # getCoverage (LAInterface.cpp:4254-4263) as draft_oracle.cpp sums it
+        alen = int(rng.integers(100, 5000))
+        n = int(rng.integers(1, 60))
+        ab = rng.integers(0, alen - 1, size=n).astype(np.int32)
+        ae = np.minimum(alen, ab + rng.integers(1, alen, size=n)).astype(np.int32)
+        cov = np.zeros(alen, np.int32)
+        ref.ref_get_coverage(n, ab.ctypes.data_as(ip), ae.ctypes.data_as(ip), alen, cov.ctypes.data_as(ip))
+        want = np.zeros(alen + 1, np.int64)
+        np.add.at(want, ab, 1)
+        np.add.at(want, ae, -1)
+        assert np.array_equal(cov, np.cumsum(want)[:alen])
+
+
+@pytest.mark.parametrize("name", ["draft_clean", "draft_clean_circular"])
+def test_chain_on_noise_free_reads_gives_the_genome_back(oracle_lib, tmp_path, name):
+    """filter -> maximal -> layout -> clip -> draft-path -> draft (all oracle / host code) on reads without errors: away from its
+    two ends every contig equals the genome except for ONE base per ladder of several reads - the last base falcon's trace-back
+    emits is decided by a link index (falcon.c: g_best_ck), so it reads 'A' whatever the column says: mismatches are at least a
+    ladder (tspace - slack) apart and fewer than one per 800 bases."""
+    lib = dc.bind(oracle_lib)
+    d = dc.prepare(lib, name, str(tmp_path))
+    fasta, log = dc.run_oracle(lib, str(tmp_path))
+    ctgs = dc.contigs_of(fasta)
+    assert len(ctgs) >= 2 and len(ctgs) % 2 == 0
+    long_ones = [c for c in ctgs if len(c[1]) > 0.6 * d.spec.genome_len]
+    assert len(long_ones) >= 2, [len(c[1]) for c in ctgs]
+    for nm, seq in long_ones:
+        got = dc.inner_mismatches(d, seq, margin=12000)     # (prefix: up to the first way point; suffix: the rest of the last read)
+        assert got is not None, "contig %s does not anchor on the genome" % nm
+        mm, strand = got
+        assert len(mm) * 800 < len(seq), (nm, len(mm))
+        assert len(mm) > 0 and (np.diff(mm) >= 600).all(), np.diff(mm)[:20]
+        assert all(seq[p] in "Aa" for p in mm), "the odd base is the link-index 'A'"
+    assert b"In total" in log and b"ctg size:" in log
+
+
+def test_chain_on_noisy_reads_runs_and_is_colinear(oracle_lib, tmp_path):
+    """Noisy reads (10 % errors): the draft is rough by design (`hinge consensus` polishes it); what can be checked without an
+    aligner: its length is the genome's within the insertion / deletion drift, and exact 14-mers of the genome occur in it in
+    order."""
+    lib = dc.bind(oracle_lib)
+    d = dc.prepare(lib, "draft_noisy", str(tmp_path))
+    fasta, _ = dc.run_oracle(lib, str(tmp_path))
+    ctgs = [c for c in dc.contigs_of(fasta) if len(c[1]) > 0.6 * d.spec.genome_len]
+    assert len(ctgs) >= 2
+    gs = "".join("acgt"[x] for x in d.genome)
+    comp = {"a": "t", "c": "g", "g": "c", "t": "a"}
+    grc = "".join(comp[c] for c in reversed(gs))
+    for nm, seq in ctgs:
+        s = seq.lower()
+        assert 0.9 * d.spec.genome_len < len(s) < 1.1 * d.spec.genome_len
+        best = 0
+        for g in (gs, grc):
+            hits = [(p, g.find(s[p:p + 14])) for p in range(5000, len(s) - 5000, 250)]
+            hits = [(p, q) for p, q in hits if q >= 0 and g.find(s[p:p + 14], q + 1) < 0]
+            if len(hits) > best:
+                best = len(hits)
+                qs = [q for _, q in hits]
+                mono = sum(1 for a, b in zip(qs, qs[1:]) if b > a)
+        assert best >= 20 and mono >= 0.95 * (best - 1), (nm, best, mono)
+
+
+def _graph(edges):
+    """A StrandGraph from (u, v, length, a_start, b_start) with read-strand tuples, mirror edges included."""
+    from hinge_amd.clip import StrandGraph, mirror
+    g = StrandGraph()
+    for u, v, ln, ra, rb in edges:
+        g.add_edge(u, v, length=ln, read_a_match_start=ra, read_b_match_start=rb)
+        g.add_edge(mirror(v), mirror(u), length=ln, read_a_match_start=rb, read_b_match_start=ra)
+    return g
+
+
+def test_draft_path_records_on_hand_built_graphs(tmp_path):
+    from hinge_amd import draft_path as dp
+    rlen = {i: 1000 + 10 * i for i in range(12)}
+    # a chain of four reads: one contig S / T / E and its reverse complement
+    g = _graph([((0, 0), (1, 0), 111, 300, 5), ((1, 0), (2, 1), 222, 400, 6), ((2, 1), (3, 0), 333, 500, 7)])
+    h, lines = dp.draft_path(g, rlen)
+    assert lines == [">Unitig0", "S 0 0 1 0 111 0", "T 1 0 2 1 222", "E 2 1 3 0 333 1030",
+                     ">Unitig1", "S 3 1 2 0 333 0", "T 2 0 1 1 222", "E 1 1 0 1 111 1000"]
+    # two reads: D records; a read on its own: O records
+    g = _graph([((4, 0), (5, 1), 77, 100, 9)])
+    g.add_node((6, 0)); g.add_node((6, 1))
+    _, lines = dp.draft_path(g, rlen)
+    assert lines[:4] == [">Unitig0", "D 4 0 5 1 77 0 1050", ">Unitig1", "D 5 0 4 1 77 0 1040"]
+    assert lines[4:] == [">Unitig2", "O 6 0 6 0 0 1060", ">Unitig3", "O 6 1 6 1 0 1060"]
+    # a fork: 0 -> 1 -> {2, 3}: the contig 0;1 ends where its EARLIEST way out begins (cut_end = min read_a_match_start)
+    g = _graph([((0, 0), (1, 0), 10, 200, 3), ((1, 0), (2, 0), 20, 700, 4), ((1, 0), (3, 0), 30, 650, 5)])
+    _, lines = dp.draft_path(g, rlen)
+    assert ">Unitig0" in lines and "D 0 0 1 0 10 0 650" in lines
+    # GraphML round trip (what `hinge clip` writes is what draft-path reads), 'B' copies of loop resolution included
+    from hinge_amd.clip import write_graphml
+    g = _graph([((0, 0), (1, 0), 111, 300, 5)])
+    g.add_edge((7, 0, "B"), (8, 1), length=5, read_a_match_start=1, read_b_match_start=2)
+    p = str(tmp_path / "g.graphml")
+    write_graphml(g, p)
+    g2 = dp.read_graphml(p)
+    assert sorted(g2.nodes(), key=str) == sorted(g.nodes(), key=str)
+    assert g2.out[(7, 0, "B")][(8, 1)]["length"] == 5 and g2.out[(0, 0)][(1, 0)]["read_a_match_start"] == 300
