@@ -55,7 +55,10 @@ struct HingePart {
     int force_exact;
     // second tier (round 4): what k_hinge_call_light could not settle, for k_hinge_call<CAP> (front / back by pile-up size as in `heavy`)
     HeavyItem* heavy2; unsigned* heavy2_count; unsigned* heavy2_count_big; unsigned* work_next_light;
+    unsigned* work_next_small;     // round 5: the cursor of the PO_CAP_MINI instance
 };
+constexpr int HEAVY_TIES = 0x40000000;   // in HeavyItem::anno of a second-tier item: k_hinge_call_light evaluated it and the tie order decides
+                                         // (the same evaluation in k_hinge_call<CAP> would say the same: it goes straight to the replay)
 constexpr int HINGE_BATCH_MAX = 8;
 struct HingeBatch {
     HingePart part[HINGE_BATCH_MAX];
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call_light(FilterDev P, HingeBa
         if (tid == 0) {
             if (S.ev_ucan == INT_MAX || S.ev_bmust < S.ev_ucan) hinge_flag[item.slot] = 0;     // bridged
             else if (S.ev_umust < S.ev_bcan) hinge_flag[item.slot] = 1;                          // unbridged whatever the tie order
-            else pass_on(item);                                                                  // the tie order decides: exact replay
+            else { HeavyItem it2 = item; it2.anno |= HEAVY_TIES; pass_on(it2); }                 // the tie order decides: exact replay
         }
     }
 }
@@ -462,7 +465,8 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call_light(FilterDev P, HingeBa
 // PO_CAP_SMALL instance (72 KiB of LDS: two workgroups per CU) over the items whose pile-up fits it - they are appended from
 // the front of `heavy` - and the PO_CAP instance (one workgroup per CU) over the rest, appended from the back (`from_back`).
 template <int CAP>
-__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B, int from_back, int tier2 /*1: the items k_hinge_call_light passed on*/) {
+__global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B, int from_back, int tier2 /*1: the items k_hinge_call_light passed on*/,
+                                                      int n_min, int n_max /*only items with n_min <= pile-up size <= n_max*/, int small_cursor) {
     const HingePart& A = B.part[blockIdx.x % (unsigned)B.n];
     const int64_t* __restrict__ row_ptr = A.row_ptr; const int2* __restrict__ a_span = A.a_span; const int2* __restrict__ b_span = A.b_span;
     const unsigned* __restrict__ b_flag = A.b_flag; const int2* __restrict__ mask = A.mask; const int2* __restrict__ anno_buf = A.anno_buf;
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
     const unsigned* __restrict__ heavy_count = tier2 ? (from_back ? A.heavy2_count_big : A.heavy2_count) : (from_back ? A.heavy_count_big : A.heavy_count);
     unsigned char* __restrict__ hinge_flag = A.hinge_flag; int2* __restrict__ exact_queue = A.exact_queue;
     unsigned* __restrict__ exact_count = A.exact_count; const unsigned exact_cap = A.exact_cap; const int force_exact = A.force_exact;
-    int* __restrict__ status = A.status; unsigned* __restrict__ work_next = from_back ? A.work_next_big : A.work_next;
+    int* __restrict__ status = A.status; unsigned* __restrict__ work_next = small_cursor ? A.work_next_small : from_back ? A.work_next_big : A.work_next;
     unsigned* __restrict__ dbg = A.dbg; const unsigned heavy_cap = A.heavy_cap;
     (void)row_ptr; (void)anno_off; (void)anno_buf;
     constexpr int SF_BINS = 2 * CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
@@ -496,9 +500,11 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
         const bool back = w < n_first ? from_back != 0 : from_back == 0;
         const unsigned wi_ = w < n_first ? w : w - n_first;
         const HeavyItem item = heavy[back ? heavy_cap - 1u - wi_ : wi_];
-        const int i = item.read, a = item.anno;
+        const int i = item.read, a = item.anno & ~HEAVY_TIES;
+        const bool ties_known = (item.anno & HEAVY_TIES) != 0;
         const int64_t s = item.row;
         const int n = item.n;
+        if (n < n_min || n > n_max) continue;     // another instance's item (block-uniform)
         const int64_t e = s + n;
         const int2 mk = make_int2(item.mask_lo, item.mask_hi);
         {
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
             else if (sup > CAP || force_exact == 1) action = 2;
             else action = 1;
             bool need_order = false;
-            if (action == 1 && force_exact == 0 && sup <= CAP) {
+            if (action == 1 && force_exact == 0 && sup <= CAP && !ties_known) {
                 // ---- sort-free evaluation of the scan (filter.cpp:932-963 / 1031-1062) -----------------
                 // Past the first-branch prefix (c1 = near_end <= UNB elements) the scan walks the remaining
                 // supporters by ascending f.  With cat = 2 (sec < TH), 3 (sec > TH), 0 (sec == TH):
@@ -740,6 +746,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                 continue;
             }
             // ---- exact pile-up order, once per read ---------------------------------------------
+#ifdef HINGE_TIMING
+            const unsigned long long tr0 = wall_clock64();
+#endif
             if (need_order) {
                 if (tid == 0 && dbg) atomicAdd(&dbg[4], 1u);
                 for (int64_t k = s + tid; k < e; k += BLOCK) {
@@ -753,6 +762,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                 __syncthreads();
             }
             if (tid == 0 && dbg && need_order) atomicAdd(&dbg[5], 1u);
+#ifdef HINGE_TIMING
+            const unsigned long long tr1 = wall_clock64();
+#endif
             // ---- supporters in pile-up order -> wF / wS (one wave) --------------------------------
             if (wib == 0) {
                 if (need_order) {
@@ -785,6 +797,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                 }
             }
             __syncthreads();
+#ifdef HINGE_TIMING
+            const unsigned long long tr2 = wall_clock64();
+#endif
             // ---- std::sort(pairAscend / pairDescend): ascending f == descending -f --------------------
             for (int t = tid; t < sup; t += BLOCK) S.ws.key[t] = -S.wF[t];
             __syncthreads();
@@ -795,9 +810,20 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                 S.sS[p] = S.wS[t];
             }
             __syncthreads();
+#ifdef HINGE_TIMING
+            const unsigned long long tr3 = wall_clock64();
+#endif
             if (tid == 0) {
                 const int r = hinge_scan(S.sF, S.sS, nullptr, sup, m0, P.bin_len, P.theta, P.unb, P.pil);
                 hinge_flag[item.slot] = r == 0 ? 1 : 0;   // emit iff not bridged (support > SUP holds)
+#ifdef HINGE_TIMING
+                if (dbg) {
+                    const unsigned long long tr4 = wall_clock64();
+                    atomicAdd(&dbg[16], (unsigned)(tr1 - tr0)); atomicAdd(&dbg[17], (unsigned)(tr2 - tr1)); atomicAdd(&dbg[18], (unsigned)(tr3 - tr2));
+                    atomicAdd(&dbg[19], (unsigned)(tr4 - tr3)); atomicAdd(&dbg[20], 1u); atomicAdd(&dbg[21], (unsigned)n); atomicAdd(&dbg[22], (unsigned)sup);
+                    atomicMax(&dbg[23], (unsigned)(tr4 - tm0));
+                }
+#endif
             }
         }
     }

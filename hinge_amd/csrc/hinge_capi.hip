@@ -66,6 +66,7 @@ struct hinge_ctx {
     int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
     int count_waves = 2;                      // wavefronts per work-list read in k_hinge_count (HINGE_COUNT_WAVES=4: rounds 1-3)
     int hinge_light = 1;                      // HINGE_CALL_LIGHT=0: every open annotation straight to k_hinge_call<CAP> (rounds 1-3)
+    int hinge_mini = 0;                       // HINGE_CALL_MINI=1: a quarter-size (1024-overlap) instance behind the light kernel, four workgroups per CU (measured: no gain - the replay is bound by its slowest item, not by the workgroups in flight)
     int light_occ = 0;
     int k2_batch = 1;                         // HINGE_K2_BATCH=0: one k_mask_annotate_q20 launch per part of a batched sweep
     int k2_steal = 2;                         // the persistent workgroups of a batched launch: 0 stay with their own part, 1 go round the parts from their own, 2 all sweep part 0, 1, ... (HINGE_K2_STEAL)
@@ -186,6 +187,7 @@ struct Scalars {
     unsigned work_next_light;           // k_hinge_call_light's cursor over both ends of heavy_list
     unsigned heavy2_count;              // what it passed on to k_hinge_call<CAP>: front / back of heavy2_list
     unsigned heavy2_count_big;
+    unsigned work_next_small;           // the 1024-overlap instance's cursor over the front of heavy2_list (round 5)
     unsigned redo_count;                // one-sweep pass: length of the guard-band list
     int spec_state;                     // one-sweep pass: 1 = the exact MIN_COV fell outside the band (SpecVerify)
     int status;
@@ -196,7 +198,7 @@ struct Scalars {
     unsigned facts[2];                  // k_pileup_facts: largest pile-up, out-of-range flag
     int bins_status;                    // hinge_filter_coverage_bins' own range flag
     int pad2;
-    unsigned dbg[16];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds
+    unsigned dbg[24];                   // k_hinge_call path counters (cumulative; diagnostics only); [8..] HINGE_TIMING builds ([16..]: the replay's phases)
     int spec_min_cov;                   // one-sweep pass: the MIN_COV the sweep ran with (k_spec_predict)
     unsigned spec_ticket;               // k_spec_predict's workgroup counter (zero between launches)
     unsigned spec_stats[3];             // cumulative: passes verified, exact != predicted, exact outside the band
@@ -288,6 +290,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_FINAL_BATCH")) ctx->final_batched = atoi(g);
     if (const char* g = getenv("HINGE_K2_BATCH")) ctx->k2_batch = atoi(g);
     if (const char* g = getenv("HINGE_CALL_LIGHT")) ctx->hinge_light = atoi(g);
+    if (const char* g = getenv("HINGE_CALL_MINI")) ctx->hinge_mini = atoi(g);
     if (const char* g = getenv("HINGE_COUNT_WAVES")) ctx->count_waves = atoi(g) == 4 ? 4 : 2;
     if (const char* g = getenv("HINGE_K2_STEAL")) ctx->k2_steal = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
@@ -1272,7 +1275,7 @@ static HingePart hinge_part_of(hinge_ctx* ctx) {
     a.heavy = (HeavyItem*)ctx->heavy_list.p; a.heavy_count = &sc(ctx)->heavy_count; a.heavy_count_big = &sc(ctx)->heavy_count_big; a.heavy_cap = ctx->anno_cap;
     a.heavy2 = (HeavyItem*)ctx->heavy2_list.p; a.heavy2_count = &sc(ctx)->heavy2_count; a.heavy2_count_big = &sc(ctx)->heavy2_count_big; a.work_next_light = &sc(ctx)->work_next_light;
     a.exact_queue = (int2*)ctx->exact_queue.p; a.exact_count = &sc(ctx)->exact_count; a.exact_cap = ctx->exact_cap;
-    a.status = &sc(ctx)->status; a.work_next = &sc(ctx)->work_next; a.work_next_big = &sc(ctx)->work_next_big;
+    a.status = &sc(ctx)->status; a.work_next = &sc(ctx)->work_next; a.work_next_big = &sc(ctx)->work_next_big; a.work_next_small = &sc(ctx)->work_next_small;
     a.dbg = ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr;
     a.force_exact = ctx->force_exact;
     return a;
@@ -1336,12 +1339,22 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         }
         hipLaunchKernelGGL(k_hinge_call_light, dim3(std::max(n, (ctx->light_occ * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B);
     }
-    if (light && any_big) {
+    // HINGE_CALL_MINI=1 (round 5, measured, off): items whose pile-up has at most PO_CAP_MINI overlaps through a 37 KiB instance, FOUR
+    // workgroups per CU, the instance behind it only takes the rest.  No gain on the repeat-rich config (the replay is bound by its
+    // slowest item, and an item gets slower with more workgroups on its CU), +5 us of empty launch on config 2.
+    const bool mini = light && ctx->hinge_mini != 0;
+    if (mini) hipLaunchKernelGGL(k_hinge_call<PO_CAP_MINI>, dim3(std::max(n, (4 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, 1, 0, PO_CAP_MINI, 1);
+    bool any_mid = false;
+    for (int k = 0; k < n; k++) any_mid = any_mid || ctxs[k]->max_pile > (unsigned)PO_CAP_MINI;
+    const int n_min = mini ? PO_CAP_MINI + 1 : 0;
+    if (mini && !any_mid) {
+        // every pile-up fits the small instance: nothing is left for another launch
+    } else if (light && any_big) {
         // behind the light kernel ONE second-tier launch: the full-size instance takes both ends of the list (an empty launch is 5 us)
-        hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 2);
+        hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 2, n_min, INT_MAX, 0);
     } else {
-        hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0);
-        if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 0);
+        hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0, n_min, INT_MAX, 0);
+        if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 0, 0, INT_MAX, 0);
     } }
     CK(hipGetLastError());
     // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1): per part
@@ -1387,7 +1400,7 @@ int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 16; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 8 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count, work_next_big, heavy_count_big, work_next_light, heavy2_count, heavy2_count_big
+        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 9 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count, work_next_big, heavy_count_big, work_next_light, heavy2_count, heavy2_count_big, work_next_small
         CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
         if ((rc = launch_hinges(ctx, p))) return rc;
         int rerun = 0;
@@ -1572,6 +1585,10 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]) {
     if (getenv("HINGE_DEBUG_PATHS") && h.dbg[10])
         fprintf(stderr, "[hinge] timing (10 ns ticks, cumulative): items=%u gather=%u (mean %.1f us) eval=%u (mean %.1f us) mean_n=%.0f mean_sup=%.0f | bin %.1f us scan %.1f us\n", h.dbg[10],
                 h.dbg[8], h.dbg[8] * 0.01 / h.dbg[10], h.dbg[11], h.dbg[11] * 0.01 / h.dbg[10], (double)h.dbg[9] / h.dbg[10], (double)h.dbg[12] / h.dbg[10], h.dbg[13] * 0.01 / h.dbg[10], h.dbg[14] * 0.01 / h.dbg[10]);
+    if (getenv("HINGE_DEBUG_PATHS") && h.dbg[20])
+        fprintf(stderr, "[hinge] replay (HINGE_TIMING builds, cumulative): items=%u mean_n=%.0f mean_sup=%.0f | keys + pile-up sort %.1f us, supporters into pile-up order %.1f us, supporter sort %.1f us, scan %.1f us per item; slowest item (draw to flag) %.1f us\n",
+                h.dbg[20], (double)h.dbg[21] / h.dbg[20], (double)h.dbg[22] / h.dbg[20], h.dbg[16] * 0.01 / h.dbg[20], h.dbg[17] * 0.01 / h.dbg[20], h.dbg[18] * 0.01 / h.dbg[20],
+                h.dbg[19] * 0.01 / h.dbg[20], h.dbg[23] * 0.01);
     return HINGE_OK;
 }
 

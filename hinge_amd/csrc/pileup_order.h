@@ -34,6 +34,7 @@ namespace hinge {
 
 constexpr int PO_CAP = 4096;            // longest list sorted in LDS
 constexpr int PO_CAP_SMALL = 2048;      // the half-size instance: two workgroups of k_hinge_call per CU
+constexpr int PO_CAP_MINI = 1024;       // the quarter-size instance behind k_hinge_call_light: four per CU
 
 template <int CAP>
 struct WaveSortLdsT {
@@ -47,6 +48,10 @@ struct WaveSortLdsT {
     unsigned short seg_first[2][SEG_CAP], seg_last[2][SEG_CAP];
     unsigned char seg_depth[2][SEG_CAP];
     int seg_cnt[2];
+    // round 5: segments of 17 .. 64 elements leave the level-by-level walk and are finished by ONE wavefront in registers
+    unsigned short small_first[SEG_CAP], small_last[SEG_CAP];
+    unsigned char small_depth[SEG_CAP];
+    int small_cnt;
 };
 typedef WaveSortLdsT<PO_CAP> WaveSortLds;
 
@@ -54,6 +59,101 @@ template <typename WS>
 __device__ __forceinline__ void mark_leaf(WS& o, int first, int last, int lane) {
     for (int p = first + lane; p < last; p += 64) { o.seglo[p] = (unsigned short)first; o.seghi[p] = (unsigned short)last; }
 }
+
+// position of the (k + 1)-th set bit of m counted from bit 0 (k < popcount(m))
+__device__ __forceinline__ int nth_bit_up(unsigned long long m, int k) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const int c = __popcll((m >> pos) & ((1ull << w) - 1ull));
+        if (k >= c) { k -= c; pos += w; }
+    }
+    return pos;
+}
+__device__ __forceinline__ int nth_bit_down(unsigned long long m, int k) { return 63 - nth_bit_up(__brevll(m), k); }   // ... counted from bit 63
+
+// The rest of libstdc++'s introsort loop for ONE segment [F, Lst) of 17 .. 64 elements, by one wavefront, in registers: lane l holds
+// position F + l (element id + key).  All sub-segments that still need a partition are partitioned IN THE SAME instruction stream -
+// they are disjoint lane ranges, every lane works with the ballot bits of its own range - so the loop runs once per recursion
+// LEVEL of the segment (two or three times), not once per partition, and touches LDS only to load and to store.
+//   median of three   three shuffles from per-lane source lanes (first + 1, mid, last - 1)
+//   stoppers          key <= pivot / key >= pivot as ballots; the k-th swap pairs the k-th left stopper from below with the k-th right
+//                     stopper from above and happens iff LS[k] < RS[k]: for a left stopper of rank k that is "more than k right
+//                     stoppers above me", for a right stopper (rank k from above) "more than k left stoppers below me" - two
+//                     popcounts; the partner's lane is the k-th set bit of the other ballot (nth_bit_*), the exchange one shuffle
+//   cut               min(LS[t], RS[t - 1]), t = number of swaps, from the same ballots
+// A sub-segment whose depth budget is spent takes libstdc++'s heap sort, serially (never seen on pile-ups), as in the walk above.
+template <typename WS>
+__device__ inline void wave_small_sort(WS& o, int F, int Lst, int depth0, int lane, const hinge_sort::KeyCmp& cmp) {
+    const int m = Lst - F;
+    int el = 0, key = 0;
+    if (lane < m) { el = o.perm[F + lane]; key = o.key[el]; }
+    int sf = lane < m ? 0 : lane, sl = lane < m ? m : lane;      // this lane's sub-segment, in lanes
+    int dep = depth0;
+    const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    while (true) {
+        bool act = sl - sf > 16;
+        if (!__any(act)) break;
+        if (__any(act && dep == 0)) {
+            // __partial_sort(first, last, last) of the exhausted sub-segments: through LDS, one lane
+            if (lane < m) o.perm[F + lane] = el;
+            __threadfence_block();
+            unsigned long long heads = __ballot(act && dep == 0 && lane == sf);
+            while (heads) {
+                const int h = (int)__builtin_ctzll(heads);
+                const int f = __shfl(sf, h), l = __shfl(sl, h);
+                if (lane == 0) hinge_sort::heapsort_(o.perm, F + f, F + l, cmp);
+                heads &= heads - 1ull;
+            }
+            __threadfence_block();
+            if (act && dep == 0) { el = o.perm[F + lane]; key = o.key[el]; sf = lane; sl = lane + 1; act = false; }
+            if (!__any(act)) break;
+        }
+        if (act) dep -= 1;
+        // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int mid = sf + (sl - sf) / 2;
+        const int ka = __shfl(key, act ? sf + 1 : lane), kb = __shfl(key, act ? mid : lane), kc = __shfl(key, act ? sl - 1 : lane);
+        int msel;   // comp(x, y) = x > y
+        if (ka > kb) { if (kb > kc) msel = 1; else if (ka > kc) msel = 2; else msel = 0; }
+        else if (ka > kc) msel = 0;
+        else if (kb > kc) msel = 2;
+        else msel = 1;
+        const int mpos = msel == 0 ? sf + 1 : (msel == 1 ? mid : sl - 1);
+        const int pivot = msel == 0 ? ka : (msel == 1 ? kb : kc);
+        {
+            int src = lane;
+            if (act) { if (lane == sf) src = mpos; else if (lane == mpos) src = sf; }
+            key = __shfl(key, src); el = __shfl(el, src);
+        }
+        // __unguarded_partition(first + 1, last, pivot at first)
+        const bool inr = act && lane > sf;                    // (lane < sl holds for every lane of the sub-segment)
+        const bool isL = inr && key <= pivot, isR = inr && key >= pivot;
+        const unsigned long long M = act ? (((sl >= 64) ? ~0ull : ((1ull << sl) - 1ull)) & ~((2ull << sf) - 1ull)) : 0ull;
+        const unsigned long long Ls = __ballot(isL) & M, Rs = __ballot(isR) & M;
+        const int rankL = __popcll(Ls & below), rankR = __popcll(Rs & above);
+        const bool swL = isL && __popcll(Rs & above) > rankL;
+        const bool swR = isR && __popcll(Ls & below) > rankR;
+        const int t = __popcll(__ballot(swL) & M);
+        {
+            int src = lane;
+            if (swL) src = nth_bit_down(Rs, rankL);
+            else if (swR) src = nth_bit_up(Ls, rankR);
+            key = __shfl(key, src); el = __shfl(el, src);
+        }
+        if (act) {
+            int cut = 0x7fffffff;
+            if (t < __popcll(Ls)) cut = nth_bit_up(Ls, t);
+            if (t >= 1) cut = min(cut, nth_bit_down(Rs, t - 1));
+            if (lane < cut) sl = cut; else sf = cut;
+        }
+    }
+    if (lane < m) {
+        o.perm[F + lane] = el;
+        o.seglo[F + lane] = (unsigned short)(F + sf);
+        o.seghi[F + lane] = (unsigned short)(F + sl);
+    }
+}
+constexpr int PO_SMALL_SEG = 64;        // segments up to this size are finished by wave_small_sort
 
 // Call from ALL threads of a 256-thread workgroup (contains __syncthreads).  On return
 // o.pl[e] = position of element e in std::sort(order, comp) of the list 0..n-1.
@@ -66,7 +166,11 @@ __device__ inline void block_std_sort_desc(WS& o, int n, int tid) {
     if (tid == 0) {
         o.seg_cnt[0] = 0;
         o.seg_cnt[1] = 0;
-        if (n > 16) {
+        o.small_cnt = 0;
+        if (n > 16 && n <= PO_SMALL_SEG) {
+            o.small_first[0] = 0; o.small_last[0] = (unsigned short)n; o.small_depth[0] = (unsigned char)(hinge_sort::floor_log2((unsigned)n) * 2);
+            o.small_cnt = 1;
+        } else if (n > 16) {
             o.seg_first[0][0] = 0;
             o.seg_last[0][0] = (unsigned short)n;
             o.seg_depth[0][0] = (unsigned char)(hinge_sort::floor_log2((unsigned)n) * 2);
@@ -138,9 +242,15 @@ __device__ inline void block_std_sort_desc(WS& o, int n, int tid) {
                 const int tmp = o.perm[a]; o.perm[a] = o.perm[b]; o.perm[b] = tmp;
             }
             // children: [first, cut) (the loop's continuation) and [cut, last) (the recursive call)
-            const bool big_l = cut - first > 16, big_r = last - cut > 16;
-            if (!big_l) mark_leaf(o, first, cut, lane);
-            if (!big_r) mark_leaf(o, cut, last, lane);
+            const bool big_l = cut - first > PO_SMALL_SEG, big_r = last - cut > PO_SMALL_SEG;
+            const bool sm_l = !big_l && cut - first > 16, sm_r = !big_r && last - cut > 16;
+            if (!big_l && !sm_l) mark_leaf(o, first, cut, lane);
+            if (!big_r && !sm_r) mark_leaf(o, cut, last, lane);
+            if (lane == 0 && (sm_l || sm_r)) {
+                int slot = atomicAdd(&o.small_cnt, (int)sm_l + (int)sm_r);
+                if (sm_l) { o.small_first[slot] = (unsigned short)first; o.small_last[slot] = (unsigned short)cut; o.small_depth[slot] = (unsigned char)depth; ++slot; }
+                if (sm_r) { o.small_first[slot] = (unsigned short)cut; o.small_last[slot] = (unsigned short)last; o.small_depth[slot] = (unsigned char)depth; }
+            }
             if (lane == 0 && (big_l || big_r)) {
                 int slot = atomicAdd(&o.seg_cnt[nxt], (int)big_l + (int)big_r);
                 if (big_l) { o.seg_first[nxt][slot] = (unsigned short)first; o.seg_last[nxt][slot] = (unsigned short)cut; o.seg_depth[nxt][slot] = (unsigned char)depth; ++slot; }
@@ -152,6 +262,12 @@ __device__ inline void block_std_sort_desc(WS& o, int n, int tid) {
         cur = nxt;
         __syncthreads();
     }
+    // the segments of 17 .. 64 elements: each finished by one wavefront in registers
+    {
+        const int ns = o.small_cnt;
+        for (int j = wib; j < ns; j += 4) wave_small_sort(o, o.small_first[j], o.small_last[j], o.small_depth[j], lane, cmp);
+    }
+    __syncthreads();
     // final insertion sort == stable sort inside each leaf; positions by element -> pr -> pl
     for (int p = tid; p < n; p += 256) {
         const int slo = o.seglo[p], shi = o.seghi[p];

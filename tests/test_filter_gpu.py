@@ -30,13 +30,17 @@ def _compare(wd_o, wd_h):
 
 @pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("tiny_mlas", True), ("tiny_mlas", False),
                                        ("ties", False), ("chimera", False), ("long_repeat", False), ("tspace200", False), ("edges", False)])
-@pytest.mark.parametrize("exact", [0, 1, 2, 3])
+@pytest.mark.parametrize("exact", [0, 1, 2, 3, 4])
 def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, monkeypatch, name, mlas, exact):
     """exact: 0 the shipped route (k_hinge_count, then k_hinge_call_light - the order-independent evaluation on sorted supporters -,
-    then k_hinge_call<CAP> for what is left), 1 the serial exact kernel, 2 the exact replay in LDS, 3 without the light kernel
-    (k_hinge_call<CAP>'s own binned evaluation, rounds 1-3)."""
+    then k_hinge_call<CAP> for what is left), 1 the serial exact kernel, 2 the exact replay in
+    LDS, 3 without the light kernel (k_hinge_call<CAP>'s own binned evaluation, rounds 1-3), 4 with the quarter-size instance
+    k_hinge_call<1024> in front of the second tier (HINGE_CALL_MINI=1)."""
     if exact == 3:
         monkeypatch.setenv("HINGE_CALL_LIGHT", "0")
+        exact = 0
+    if exact == 4:
+        monkeypatch.setenv("HINGE_CALL_MINI", "1")
         exact = 0
     src, _ = datasets(name)
     wd_o = clone_dataset(src, str(tmp_path / "oracle"))

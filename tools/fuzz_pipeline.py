@@ -89,6 +89,8 @@ def random_paths(rng, spec):
     if rng.random() < 0.2:
         env["HINGE_CALL_LIGHT"] = "0"                # open annotations straight to k_hinge_call<CAP> (no light kernel in front)
     if rng.random() < 0.2:
+        env["HINGE_CALL_MINI"] = "1"                 # a quarter-size instance k_hinge_call<1024> in front of the second tier
+    if rng.random() < 0.2:
         env["HINGE_K2_DEAL"] = "0"                   # round 2's longest-first order of the drawn reads
     if rng.random() < 0.2:
         env["HINGE_K2_HEAVY"] = str(int(rng.choice([0, 1])))   # the deep pile-ups first / left in storage order (default: spread over the first 60 %)
