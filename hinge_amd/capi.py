@@ -83,6 +83,7 @@ SYMBOLS = [
     ("hinge_filter_get_coverage", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64]),
     ("hinge_filter_counters", C.c_int, [_VP, _VP]),
     ("hinge_set_traces", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int, C.c_int]),
+    ("hinge_set_las_image", C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, C.c_int, C.c_int]),
     ("hinge_set_eff_reads", C.c_int, [_VP, _VP]),
     ("hinge_set_trim", C.c_int, [_VP, C.c_int]),
     ("hinge_trim_classify", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
@@ -410,6 +411,14 @@ class Context:
         tlen = np.ascontiguousarray(tlen, dtype=np.int32)
         self._keep_tr = [trace, trace_off, tlen]
         self._ck(self.lib.hinge_set_traces(self.h, _ptr(trace), int(trace.shape[0]), _ptr(trace_off), _ptr(tlen), int(tbytes), 0))
+
+    def set_las_image(self, image: np.ndarray, row_base: np.ndarray, rec_rel: np.ndarray, tbytes: int = 1):
+        """The part form straight from the .las image (hinge_set_las_image): row_base[r_end - r_begin + 2], rec_rel[n_ovl]."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        row_base = np.ascontiguousarray(row_base, dtype=np.int64)
+        rec_rel = np.ascontiguousarray(rec_rel, dtype=np.uint32)
+        self._keep_tr = [image, row_base, rec_rel]
+        self._ck(self.lib.hinge_set_las_image(self.h, _ptr(image), int(image.shape[0]), _ptr(row_base), _ptr(rec_rel), int(tbytes), 0))
 
     def set_eff_reads(self, eff: np.ndarray):
         eff = np.ascontiguousarray(eff, dtype=np.int32)

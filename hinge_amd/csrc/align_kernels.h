@@ -328,6 +328,39 @@ __device__ __forceinline__ void classify_lane(const int2 av, const int2 bs, cons
     o.end_idx = end_idx;
 }
 
+// The staging copy of the two stream kernels: `nchunk` 16-byte pieces of the image from `base` into LDS.  EVERY load of the wavefront
+// is issued before the first LDS store (STREAM_CAP / 1024 loads per lane in flight): a loop of "load, wait, store" pays the memory
+// latency once per 1 KiB - 8 round trips in a row per 64 overlaps, which is what held both kernels at 13 us per step (round 5).
+template <int STREAM_CAP>
+__device__ __forceinline__ void stage_image(uint4* __restrict__ stage4, const unsigned char* __restrict__ src, const int64_t base, const int nchunk,
+                                            const int64_t readable, const int lane) {
+    constexpr int NL = STREAM_CAP / (16 * WAVE);
+    static_assert(NL * 16 * WAVE == STREAM_CAP, "the stage buffer is a whole number of wavefront-wide 16-byte loads");
+    uint4 w[NL];
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+        const int c = lane + u * WAVE;
+        const int64_t off = base + 16ll * c;
+        w[u] = make_uint4(0, 0, 0, 0);
+        if (c < nchunk && off + 16 <= readable) w[u] = *reinterpret_cast<const uint4*>(src + off);
+    }
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+        const int c = lane + u * WAVE;
+        if (c < nchunk) stage4[c] = w[u];
+    }
+    if (base + 16ll * nchunk > readable) {   // (uniform) the image's last, partial 16 bytes: byte by byte, nothing is read past the buffer
+        for (int c = lane; c < nchunk; c += WAVE) {
+            const int64_t off = base + 16ll * c;
+            if (off + 16 <= readable) continue;
+            uint4 t = make_uint4(0, 0, 0, 0);
+            unsigned char* wb = reinterpret_cast<unsigned char*>(&t);
+            for (int q = 0; q < 16 && off + q < readable; q++) wb[q] = src[off + q];
+            stage4[c] = t;
+        }
+    }
+}
+
 template <int TB, int STREAM_CAP>
 __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
                                                                const int2* __restrict__ a_span, const int2* __restrict__ b_span,
@@ -387,13 +420,7 @@ __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int 
                 const int last = 63 - __clzll((long long)take);
                 const int64_t end = __shfl(t1, last);
                 const int nchunk = (int)((end - base + 15) >> 4);
-                for (int c = lane; c < nchunk; c += WAVE) {
-                    const int64_t off = base + 16ll * c;
-                    uint4 w = make_uint4(0, 0, 0, 0);
-                    if (off + 16 <= trace_readable) w = *reinterpret_cast<const uint4*>(trace + off);
-                    else { unsigned char* wb = reinterpret_cast<unsigned char*>(&w); for (int q = 0; q < 16 && off + q < trace_readable; q++) wb[q] = trace[off + q]; }
-                    stage4[c] = w;
-                }
+                stage_image<STREAM_CAP>(stage4, trace, base, nchunk, trace_readable, lane);
                 __syncthreads();
                 if ((take >> lane) & 1ull) {
                     const unsigned char* tp = stage + (int)(t0 - base);
@@ -433,6 +460,148 @@ __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int 
                         return T;
                     };
                     classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, sum_words, aln_threshold, theta, theta2, trim, o);
+                    if (type_out) type_out[k] = (unsigned char)o.type;
+                    if (full_out) full_out[k] = o;
+                }
+                __syncthreads();
+                pending &= ~take;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The stream form once more, reading NOTHING but the .las image (round 5).  k_trim_classify_stream stages the raw bytes of 64
+// consecutive overlaps - their 40-byte records included, they lie between the traces - and then reads the very same fields a second
+// time from the SoA columns (a_span, b_span, b_flag, tlen, trace_off: 32 B per overlap, 1.43 x the bytes the path needs).  Here the
+// lane takes tlen, abpos, bbpos, aepos, bepos, flags and bread (align.h:126-146: the Overlap record as DALIGNER writes it, without
+// its trace pointer) from the staged record in LDS and does the strand flip of LAInterface.cpp:1619-1626 itself (rlen[B] joins the
+// eff[B] gather).  What is left of the columns is ONE 32-bit word per overlap: rec_rel[k] = byte offset of overlap k's record behind
+// row_base[A] (the first record of A's pile-up in the image; row_base[r_end + 1 - r_begin] = where the last pile-up ends), because a
+// record's position is a chain through every tlen before it.  A lane's bytes end where the next kept record starts (self-overlap
+// records in between are staged along: nothing points to them).  The eff[B] / rlen[B] gathers are issued when the record has been
+// read and travel during the one walk that touches the whole trace (the advance sum, which needs neither).
+// Records start on even bytes (12 + a sum of even sizes); one that does not is read byte by byte.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_i32_h(const unsigned char* p) {   // a 32-bit field on a 2-byte boundary
+    const unsigned short* h = reinterpret_cast<const unsigned short*>(p);
+    return (int)((unsigned)h[0] | ((unsigned)h[1] << 16));
+}
+template <int TB> __device__ __forceinline__ int rec_field(const unsigned char* p, const bool aligned) {
+    if (!aligned) return (int)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));   // (never in a .las)
+    if (TB == 2) return *reinterpret_cast<const int*>(p);   // two-byte traces: every record size is a multiple of 4
+    return lds_i32_h(p);
+}
+
+template <int TB, int STREAM_CAP>
+__global__ __launch_bounds__(WAVE) void k_trim_classify_image(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
+                                                              const unsigned char* __restrict__ image, int64_t image_readable,
+                                                              const int64_t* __restrict__ row_base /*[r_end - r_begin + 2]*/,
+                                                              const unsigned* __restrict__ rec_rel /*[n_ovl]*/, const int* __restrict__ rlen,
+                                                              int n_reads, const int2* __restrict__ eff, int aln_threshold, int theta, int theta2,
+                                                              unsigned char* __restrict__ type_out /*[n_ovl] or nullptr*/,
+                                                              ClassifyOut* __restrict__ full_out /*[n_ovl] or nullptr*/) {
+    __shared__ uint4 stage4[STREAM_CAP / 16];
+    const unsigned char* stage = reinterpret_cast<const unsigned char*>(stage4);
+    const int lane = threadIdx.x;
+    for (int i = r_begin + (int)blockIdx.x; i <= r_end; i += (int)gridDim.x) {
+        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
+        if (s == e) continue;
+        const int64_t rb = row_base[i - r_begin], rend = row_base[i - r_begin + 1];
+        const int2 ea = eff[i];
+        for (int64_t k0 = s; k0 < e; k0 += WAVE) {
+            const int64_t k = k0 + lane;
+            const bool live = k < e;
+            int64_t t0 = 0, t1 = 0;   // this lane's bytes of the image: its record, its trace (and whatever lies in front of the next kept record)
+            if (live) {
+                t0 = rb + (int64_t)rec_rel[k];
+                t1 = k + 1 < e ? rb + (int64_t)rec_rel[k + 1] : rend;
+            }
+            unsigned long long pending = ballot_of(live);
+            while (pending) {
+                const int first = __ffsll((long long)pending) - 1;
+                const int64_t base = __shfl(t0, first) & ~15ll;
+                const bool mine = ((pending >> lane) & 1ull) != 0;
+                const unsigned long long fits = ballot_of(mine && t0 >= base && t1 >= t0 + 40 && (t1 - base) <= (int64_t)STREAM_CAP);
+                const unsigned long long nofit = pending & ~fits;
+                const unsigned long long take = nofit ? (fits & ((1ull << (__ffsll((long long)nofit) - 1)) - 1ull)) : fits;
+                int2 av, bs, eb;
+                int comp, tl, b;
+                ClassifyOut o;
+                auto finish_record = [&](int bb_raw, int be_raw, unsigned flags) {   // strand flip, LAInterface.cpp:1619-1626
+                    comp = (int)(flags & 1u);
+                    b = min(max(b, 0), n_reads - 1);
+                    eb = eff[b];
+                    const int bl = comp ? rlen[b] : 0;
+                    bs = comp ? make_int2(bl - be_raw, bl - bb_raw) : make_int2(bb_raw, be_raw);
+                };
+                if (take == 0ull) {
+                    // one overlap whose record + trace exceed the stage buffer (> 5000 trace points), or a table that is not an
+                    // ascending chain: its lane walks global memory
+                    if (lane == first) {
+                        const unsigned char* rp = image + t0;
+                        int f[9];
+                        for (int q = 0; q < 9; q++) { unsigned v = 0; for (int c = 0; c < 4; c++) v |= (unsigned)rp[4 * q + c] << (8 * c); f[q] = (int)v; }
+                        tl = f[0]; av = make_int2(f[2], f[4]); b = f[8];
+                        if (t1 >= t0 + 40) tl = (int)min((int64_t)tl, (t1 - t0 - 40) / TB); else tl = 0;
+                        tl = max(tl, 0);
+                        finish_record(f[3], f[5], (unsigned)f[6]);
+                        const unsigned char* tp = rp + 40;
+                        auto adv = [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); };
+                        classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, [&](int cnt) { int T = 0; for (int j = 0; j < cnt; j++) T += adv(j); return T; },
+                                          aln_threshold, theta, theta2, 1, o);
+                        if (type_out) type_out[k] = (unsigned char)o.type;
+                        if (full_out) full_out[k] = o;
+                    }
+                    pending &= ~(1ull << first);
+                    continue;
+                }
+                const int last = 63 - __clzll((long long)take);
+                const int64_t end = __shfl(t1, last);
+                const int nchunk = (int)((end - base + 15) >> 4);
+                stage_image<STREAM_CAP>(stage4, image, base, nchunk, image_readable, lane);
+                __syncthreads();
+                if ((take >> lane) & 1ull) {
+                    const unsigned char* rp = stage + (int)(t0 - base);
+                    const bool al = ((unsigned)(t0 - base) & (TB == 2 ? 3u : 1u)) == 0u;
+                    tl = rec_field<TB>(rp, al);
+                    av.x = rec_field<TB>(rp + 8, al); const int bb_raw = rec_field<TB>(rp + 12, al);
+                    av.y = rec_field<TB>(rp + 16, al); const int be_raw = rec_field<TB>(rp + 20, al);
+                    const unsigned flags = (unsigned)rec_field<TB>(rp + 24, al);
+                    b = rec_field<TB>(rp + 32, al);
+                    tl = max(min(tl, (int)((t1 - t0 - 40) / TB)), 0);   // (a record that disagrees with the table reads nothing outside its own bytes)
+                    finish_record(bb_raw, be_raw, flags);
+                    const unsigned char* tp = rp + 40;
+                    const unsigned lo = (unsigned)(t0 - base) + 40u;
+                    auto adv = [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); };
+                    auto sum_words = [&](int cnt) {   // as in k_trim_classify_stream
+                        int T = 0;
+                        if (cnt <= 0) return 0;
+                        if (!al) { for (int j = 0; j < cnt; j++) T += adv(j); return T; }
+                        if (TB == 1) {
+                            const unsigned* W = reinterpret_cast<const unsigned*>(stage);
+                            const unsigned hi = lo + 2u * (unsigned)cnt;            // exclusive end, even
+                            const unsigned w0 = lo >> 2, w1 = (hi - 1u) >> 2;
+                            unsigned m0 = (lo & 2u) ? 0xff000000u : 0xff00ff00u;
+                            const unsigned m1 = (hi & 2u) ? 0x0000ff00u : 0xff00ff00u;
+                            if (w0 == w1) return (int)__builtin_amdgcn_sad_u8(W[w0] & m0 & m1, 0u, 0u);
+                            unsigned acc = __builtin_amdgcn_sad_u8(W[w0] & m0, 0u, 0u);
+                            unsigned w = w0 + 1;
+                            for (; w + 4 <= w1; w += 4) {
+                                const unsigned x0 = W[w], x1 = W[w + 1], x2 = W[w + 2], x3 = W[w + 3];
+                                acc = __builtin_amdgcn_sad_u8(x0 & 0xff00ff00u, 0u, acc);
+                                acc = __builtin_amdgcn_sad_u8(x1 & 0xff00ff00u, 0u, acc);
+                                acc = __builtin_amdgcn_sad_u8(x2 & 0xff00ff00u, 0u, acc);
+                                acc = __builtin_amdgcn_sad_u8(x3 & 0xff00ff00u, 0u, acc);
+                            }
+                            for (; w < w1; w++) acc = __builtin_amdgcn_sad_u8(W[w] & 0xff00ff00u, 0u, acc);
+                            return (int)__builtin_amdgcn_sad_u8(W[w1] & m1, 0u, acc);
+                        }
+                        const unsigned* W = reinterpret_cast<const unsigned*>(stage) + (lo >> 2);
+                        for (int j = 0; j < cnt; j++) T += (int)(W[j] >> 16);
+                        return T;
+                    };
+                    classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, sum_words, aln_threshold, theta, theta2, 1, o);
                     if (type_out) type_out[k] = (unsigned char)o.type;
                     if (full_out) full_out[k] = o;
                 }

@@ -93,6 +93,8 @@ struct hinge_ctx {
 
     // trim / classify (maximal, layout)
     DevBuf trace, trace_off, tlen, eff_reads, pair_sel, pair_a, pair_out;
+    DevBuf img_row_base, img_rec_rel;   // hinge_set_las_image: the part form reads the .las image itself (k_trim_classify_image)
+    bool image_set = false;
     int k2_wgs = 0;              // workgroups of k_mask_annotate_q20 (0: as many as the GPU holds at once, capped by the part's reads); HINGE_K2_WGS
     int k2_order_bp = 1024;                   // bucket width of the longest-first order of the one-slot reads (HINGE_K2_ORDER_BP)
     int k2_occ_lds = -1, k2_occ = 0;          // occupancy calculator: workgroups per CU at that many bytes of dynamic LDS
@@ -317,7 +319,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c,
-                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch, &ctx->heavy2_list};
+                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch, &ctx->heavy2_list, &ctx->img_row_base, &ctx->img_rec_rel};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -407,6 +409,7 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
     if (r_begin < 0 || r_end >= ctx->n_reads || r_end < r_begin || n_ovl < 0 || !row_ptr) return fail(ctx, HINGE_E_ARG, "hinge_set_pileups: bad range");
     CK(hipSetDevice(ctx->device));
     ctx->r_begin = r_begin; ctx->r_end = r_end; ctx->n_ovl = n_ovl;
+    ctx->image_set = false;   // (a .las image belongs to the pile-ups it was set for)
     ctx->nbins0_reso = -1;
     ctx->cov_valid = false;
     int rc;

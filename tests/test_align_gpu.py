@@ -82,6 +82,61 @@ def test_trim_classify_part_equals_the_list_form(datasets, oracle_lib, tmp_path,
     ctx.close()
 
 
+def _image_ctx(datasets, oracle_lib, tmp_path, name, eff_override=None):
+    """The same part set up through hinge_set_las_image: no trace_off / tlen columns, the kernel reads the file's bytes."""
+    from hinge_amd import capi, formats
+    ctx0, recs, pile, eff, a_of, toff, tlen = _setup(datasets, oracle_lib, tmp_path, name)
+    src, d = datasets(name)
+    image = np.fromfile(os.path.join(str(tmp_path / "w"), "G.las"), dtype=np.uint8)
+    row_base, rec_rel = formats.las_image_table(recs, pile, 0, d.n_reads - 1)
+    ctx = capi.Context(0)
+    ctx.set_reads(d.rlen, None)
+    ctx.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+    ctx.set_las_image(image, row_base, rec_rel, 1 if recs.tspace <= 125 else 2)
+    ctx.set_eff_reads(eff if eff_override is None else eff_override)
+    return ctx0, ctx, pile, eff, a_of, tlen
+
+
+@pytest.mark.parametrize("name", ["tiny", "chimera", "tspace200", "edges", "long_reads"])
+def test_trim_classify_image_form_equals_the_list_form(datasets, oracle_lib, tmp_path, name):
+    """k_trim_classify_image (hinge_set_las_image: tlen, spans, strand and B read from the staged .las records, strand flip in the
+    kernel) == the list form over all overlaps (held against the oracle and the reference above), all ten fields; the data sets
+    have self-overlap records between kept ones (stepped over), both strands, two-byte traces and traces that overflow the stage."""
+    ctx0, ctx, pile, eff, a_of, tlen = _image_ctx(datasets, oracle_lib, tmp_path, name)
+    n = pile.n_ovl
+    sel = np.arange(n, dtype=np.int64)
+    for thr in ((1000, 300, 0), (2500, 50, 100)):
+        full = ctx0.trim_classify(sel, a_of, *thr)
+        img_full = ctx.trim_classify_part_full(n, *thr)
+        img_types = ctx.trim_classify_part(n, *thr)
+        bad = np.nonzero((img_full != full).any(axis=1))[0]
+        assert len(bad) == 0, (name, thr, len(bad), bad[:5], img_full[bad[:3]], full[bad[:3]])
+        assert np.array_equal(img_types, full[:, 4].astype(np.uint8))
+    assert (pile.b_flag >> 31).any() and not (pile.b_flag >> 31).all()
+    # the list forms need hinge_set_traces: with an image only they refuse
+    from hinge_amd import capi
+    with pytest.raises(capi.HingeError):
+        ctx.trim_classify(sel[:1], a_of[:1], 1000, 300, 0)
+    ctx0.close(); ctx.close()
+
+
+def test_trim_classify_image_form_with_masks_that_cut_deep(datasets, oracle_lib, tmp_path):
+    ctx0, ctx, pile, eff, a_of, tlen = _image_ctx(datasets, oracle_lib, tmp_path, "long_reads")
+    n = pile.n_ovl
+    rng = np.random.default_rng(11)
+    eff2 = eff.copy()
+    cut = rng.random(len(eff2)) < 0.5
+    eff2[cut, 0] = (eff2[cut, 0] + rng.integers(0, 6000, size=int(cut.sum()))).astype(np.int32)
+    eff2[cut, 1] = np.maximum(eff2[cut, 0], eff2[cut, 1] - rng.integers(0, 6000, size=int(cut.sum()))).astype(np.int32)
+    ctx0.set_eff_reads(eff2); ctx.set_eff_reads(eff2)
+    sel = np.arange(n, dtype=np.int64)
+    full = ctx0.trim_classify(sel, a_of, 1000, 300, 0)
+    img_full = ctx.trim_classify_part_full(n, 1000, 300, 0)
+    assert np.array_equal(img_full, full), np.nonzero((img_full != full).any(axis=1))[0][:10]
+    assert ((tlen.astype(np.int64) + 40) * 64 > 10240).any() and len(set(full[:, 4].tolist())) >= 5
+    ctx0.close(); ctx.close()
+
+
 def test_trim_classify_stream_with_masks_that_cut_deep(datasets, oracle_lib, tmp_path):
     """Masks that end in the middle of the reads (the walks of the streaming kernel then run far into the traces) and traces longer
     than the wavefront's stage buffer can hold 64 of: the stream form against the list form, all ten fields."""

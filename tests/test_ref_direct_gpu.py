@@ -64,6 +64,33 @@ class Part:
         self.ctx.set_traces(tr, toff_vals[:-1] * tbytes, tl.astype(np.int32), tbytes)
         self.ctx.set_eff_reads(eff)
         self.hdr = hdr
+        # the same overlaps as a .las image (records as DALIGNER writes them: B coordinates of complemented overlaps in the
+        # complemented frame) behind a second context: k_trim_classify_image reads nothing but these bytes and one offset each
+        comp = hdr[:, 4].astype(np.int64)
+        blen = rlen[na:].astype(np.int64)
+        rec = np.zeros((n, 10), np.int32)
+        rec[:, 0] = tl
+        rec[:, 2] = hdr[:, 0]; rec[:, 4] = hdr[:, 1]
+        rec[:, 3] = np.where(comp == 1, blen - hdr[:, 3], hdr[:, 2]); rec[:, 5] = np.where(comp == 1, blen - hdr[:, 2], hdr[:, 3])
+        rec[:, 6] = comp; rec[:, 7] = self.a_of; rec[:, 8] = np.arange(na, na + n)
+        size = 40 + tl * tbytes
+        starts = 12 + np.concatenate([[0], np.cumsum(size)]).astype(np.int64)
+        image = np.zeros(int(starts[-1]), np.uint8)
+        if n:
+            image[(starts[:-1, None] + np.arange(40)[None, :]).reshape(-1)] = rec.view(np.uint8).reshape(-1)
+            owner = np.repeat(np.arange(n), tl * tbytes)
+            within = np.arange(len(tr)) - np.repeat(toff_vals[:-1] * tbytes, tl * tbytes)
+            image[starts[owner] + 40 + within] = tr
+        row_base = np.zeros(n_reads + 1, np.int64)
+        row_base[n_reads] = starts[-1]
+        for q in range(n_reads - 1, -1, -1):
+            row_base[q] = starts[row_ptr[q]] if row_ptr[q + 1] > row_ptr[q] else row_base[q + 1]
+        a_full = np.repeat(np.arange(n_reads), counts)
+        self.ctx_img = capi.Context(0)
+        self.ctx_img.set_reads(rlen, None)
+        self.ctx_img.set_pileups(0, n_reads - 1, row_ptr, np.ascontiguousarray(hdr[:, 0:2]), np.ascontiguousarray(hdr[:, 2:4]), b_flag)
+        self.ctx_img.set_las_image(image, row_base, (starts[:-1] - row_base[a_full]).astype(np.uint32), tbytes)
+        self.ctx_img.set_eff_reads(eff)
 
     def all_forms(self, thr):
         """(list form, stream form, the types of the stream and the rows form): every kernel that computes ProcessAlignment."""
@@ -77,18 +104,21 @@ class Part:
             types_rows = self.ctx.trim_classify_part(self.n, *thr)
         finally:
             del os.environ["HINGE_K4_ROWS"]
+        self.image_full = self.ctx_img.trim_classify_part_full(self.n, *thr)
+        self.image_types = self.ctx_img.trim_classify_part(self.n, *thr)
         return full, stream, types_list, types_stream, types_rows
 
     def close(self):
         self.ctx.close()
+        self.ctx_img.close()
 
 
 def _check_classify(part, want, thr, what):
     full, stream, t_list, t_stream, t_rows = part.all_forms(thr)
-    for name, got in (("k_trim_classify", full), ("k_trim_classify_stream", stream)):
+    for name, got in (("k_trim_classify", full), ("k_trim_classify_stream", stream), ("k_trim_classify_image", part.image_full)):
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert len(bad) == 0, (what, name, len(bad), bad[:5], got[bad[:3]], want[bad[:3]], part.hdr[bad[:3]])
-    for name, got in (("types list", t_list), ("types stream", t_stream), ("k_trim_classify_rows", t_rows)):
+    for name, got in (("types list", t_list), ("types stream", t_stream), ("k_trim_classify_rows", t_rows), ("types image", part.image_types)):
         bad = np.nonzero(got != want[:, 4].astype(np.uint8))[0]
         assert len(bad) == 0, (what, name, len(bad), bad[:5])
 

@@ -53,8 +53,23 @@ def main():
     ctx.set_eff_reads(eff)
     n = pile.n_ovl
     alg = 24.0 * n + float(tlen.sum()) + 8.0 * n
+    # the form `hinge maximal` uses since round 5: the .las image + one 32-bit offset per overlap (hinge_set_las_image)
+    cimg = capi.Context(0)
+    cimg.set_reads(d.rlen, None)
+    cimg.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+    a_of = np.repeat(np.arange(d.n_reads, dtype=np.int64), np.diff(pile.row_ptr).astype(np.int64))
+    row_base = np.zeros(d.n_reads + 1, np.int64)
+    row_base[d.n_reads] = len(raw)
+    for q in range(d.n_reads - 1, -1, -1):
+        row_base[q] = rec_start[pile.row_ptr[q]] if pile.row_ptr[q + 1] > pile.row_ptr[q] else row_base[q + 1]
+    cimg.set_las_image(raw, row_base, (rec_start - row_base[a_of]).astype(np.uint32), 1)
+    cimg.set_eff_reads(eff)
     out = {}
-    for name, env in (("stream", None), ("stream 16 w/CU", "wpc16"), ("stream 32 w/CU", "wpc32"), ("stream cap 8192", "cap8192"), ("rows", "1")):
+    for name, env in (("image", "img"), ("image 16 w/CU", "imgwpc16"), ("image cap 8192", "imgcap8192"), ("image cap 12288", "imgcap12288"),
+                      ("stream", None), ("stream 16 w/CU", "wpc16"), ("stream 32 w/CU", "wpc32"), ("stream cap 8192", "cap8192"), ("rows", "1")):
+        use = ctx
+        if env and env.startswith("img"):
+            use, env = cimg, (env[3:] or None)
         os.environ.pop("HINGE_K4_ROWS", None)
         os.environ.pop("HINGE_K4_CAP", None)
         os.environ.pop("HINGE_K4_WAVES_PER_CU", None)
@@ -64,13 +79,13 @@ def main():
             os.environ["HINGE_K4_ROWS"] = env
         elif env:
             os.environ["HINGE_K4_CAP"] = env[3:]
-        types = ctx.trim_classify_part(n, 1000, 300, 0)
-        ctx.profile_select(["k_trim_classify"])
-        ctx.profile_enable(2 * args.reps + 4)
+        types = use.trim_classify_part(n, 1000, 300, 0)
+        use.profile_select(["k_trim_classify"])
+        use.profile_enable(2 * args.reps + 4)
         for _ in range(args.reps):
-            ctx.trim_classify_part(n, 1000, 300, 0)
-        ms, cnt = ctx.profile_report()["k_trim_classify"]
-        ctx.profile_enable(0)
+            use.trim_classify_part(n, 1000, 300, 0)
+        ms, cnt = use.profile_report()["k_trim_classify"]
+        use.profile_enable(0)
         out[name] = types
         t = ms / cnt
         print("%-16s %.3f ms per launch, %d overlaps, mean tlen %.1f B, algorithmic %.2f GB -> %.2f TB/s = %.2f of the HBM peak" %

@@ -18,7 +18,7 @@ cd $R
 python tools/pmc_summary.py $(find $OUT/k4_fetch $OUT/k4_write -name "*counter_collection.csv") | sed '1s/mean_value/mean_value_KB/' > $OUT/${TAG}_stages_k4_pmc_summary.csv
 python tools/pmc_summary.py $(find $OUT/k4_sq -name "*counter_collection.csv") > $OUT/${TAG}_stages_k4_sq_summary.csv
 cp $(find $OUT/k4_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_stages_k4_kernel_stats.csv
-grep -E "stream|rows|identical" $OUT/k4_trace.log > $OUT/${TAG}_stages_k4_bench.txt
+grep -E "image|stream|rows|identical" $OUT/k4_trace.log > $OUT/${TAG}_stages_k4_bench.txt
 # the executables on the bench data set
 D=/tmp/hinge_stage_data
 python tools/e2e_bench.py --genome 4600000 --exact-config --dir $D > $OUT/${TAG}_stages_e2e.json 2> $OUT/e2e.err
