@@ -412,13 +412,14 @@ class Context:
         self._keep_tr = [trace, trace_off, tlen]
         self._ck(self.lib.hinge_set_traces(self.h, _ptr(trace), int(trace.shape[0]), _ptr(trace_off), _ptr(tlen), int(tbytes), 0))
 
-    def set_las_image(self, image: np.ndarray, row_base: np.ndarray, rec_rel: np.ndarray, tbytes: int = 1):
-        """The part form straight from the .las image (hinge_set_las_image): row_base[r_end - r_begin + 2], rec_rel[n_ovl]."""
+    def set_las_image(self, image: np.ndarray, win_base: np.ndarray, rec_rel: np.ndarray, tbytes: int = 1):
+        """The part form straight from the .las image (hinge_set_las_image): win_base[(n_ovl + 63) // 64 + 1], rec_rel[n_ovl]
+        (formats.las_image_table / formats.image_windows)."""
         image = np.ascontiguousarray(image, dtype=np.uint8)
-        row_base = np.ascontiguousarray(row_base, dtype=np.int64)
+        win_base = np.ascontiguousarray(win_base, dtype=np.int64)
         rec_rel = np.ascontiguousarray(rec_rel, dtype=np.uint32)
-        self._keep_tr = [image, row_base, rec_rel]
-        self._ck(self.lib.hinge_set_las_image(self.h, _ptr(image), int(image.shape[0]), _ptr(row_base), _ptr(rec_rel), int(tbytes), 0))
+        self._keep_tr = [image, win_base, rec_rel]
+        self._ck(self.lib.hinge_set_las_image(self.h, _ptr(image), int(image.shape[0]), _ptr(win_base), _ptr(rec_rel), int(tbytes), 0))
 
     def set_eff_reads(self, eff: np.ndarray):
         eff = np.ascontiguousarray(eff, dtype=np.int32)

@@ -474,13 +474,23 @@ __global__ __launch_bounds__(WAVE) void k_trim_classify_stream(int r_begin, int 
 // The stream form once more, reading NOTHING but the .las image (round 5).  k_trim_classify_stream stages the raw bytes of 64
 // consecutive overlaps - their 40-byte records included, they lie between the traces - and then reads the very same fields a second
 // time from the SoA columns (a_span, b_span, b_flag, tlen, trace_off: 32 B per overlap, 1.43 x the bytes the path needs).  Here the
-// lane takes tlen, abpos, bbpos, aepos, bepos, flags and bread (align.h:126-146: the Overlap record as DALIGNER writes it, without
-// its trace pointer) from the staged record in LDS and does the strand flip of LAInterface.cpp:1619-1626 itself (rlen[B] joins the
-// eff[B] gather).  What is left of the columns is ONE 32-bit word per overlap: rec_rel[k] = byte offset of overlap k's record behind
-// row_base[A] (the first record of A's pile-up in the image; row_base[r_end + 1 - r_begin] = where the last pile-up ends), because a
-// record's position is a chain through every tlen before it.  A lane's bytes end where the next kept record starts (self-overlap
-// records in between are staged along: nothing points to them).  The eff[B] / rlen[B] gathers are issued when the record has been
-// read and travel during the one walk that touches the whole trace (the advance sum, which needs neither).
+// lane takes tlen, abpos, bbpos, aepos, bepos, flags, aread and bread (align.h:126-146: the Overlap record as DALIGNER writes it,
+// without its trace pointer) from the staged record in LDS and does the strand flip of LAInterface.cpp:1619-1626 itself (rlen[B]
+// joins the eff[A] / eff[B] gathers).  What is left of the columns is ONE 32-bit word per overlap - where its record starts, because
+// a record's position is a chain through every tlen before it - and the kernel no longer knows about pile-ups at all:
+//   window w = overlaps 64 w .. 64 w + 63 (storage order, whatever reads they belong to: A is in the record),
+//   win_base[w] = byte offset of the window's first record in the image (win_base[n_windows] = where the last overlap ends),
+//   rec_rel[k]  = offset of overlap k's record behind win_base[k / 64].
+// A lane's bytes end where the next kept record starts (self-overlap records in between are staged along: nothing points at them).
+//
+// A wavefront is a chain of round trips per window (offsets -> image bytes -> gathers), and its 10 KiB stage buffer caps the CU at
+// 16 of them, so the chain is what the kernel costs (9.8 us per window, 0.98 ms per 26.2 M overlaps with one window at a time).
+// Therefore the wavefronts are persistent (window g, g + G, g + 2 G ... for wavefront g of G) and software-pipelined:
+//   * the offsets of the NEXT window are loaded while this one is worked on;
+//   * the image bytes of the next sub-step travel in REGISTERS (STREAM_CAP / 1024 x 16 bytes per lane) while the walks of this one
+//     read LDS; they are stored to LDS when the walks are done;
+//   * the gathers of this sub-step are issued BEFORE those loads (memory returns in order: waiting for a gather issued behind the
+//     prefetch would wait for the prefetch) and travel during the one walk that touches the whole trace (the advance sum).
 // Records start on even bytes (12 + a sum of even sizes); one that does not is read byte by byte.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lds_i32_h(const unsigned char* p) {   // a 32-bit field on a 2-byte boundary
@@ -494,122 +504,192 @@ template <int TB> __device__ __forceinline__ int rec_field(const unsigned char* 
 }
 
 template <int TB, int STREAM_CAP>
-__global__ __launch_bounds__(WAVE) void k_trim_classify_image(int r_begin, int r_end, const int64_t* __restrict__ row_ptr,
-                                                              const unsigned char* __restrict__ image, int64_t image_readable,
-                                                              const int64_t* __restrict__ row_base /*[r_end - r_begin + 2]*/,
+__global__ __launch_bounds__(WAVE) void k_trim_classify_image(int64_t n_ovl, const unsigned char* __restrict__ image, int64_t image_readable,
+                                                              const int64_t* __restrict__ win_base /*[n_windows + 1]*/,
                                                               const unsigned* __restrict__ rec_rel /*[n_ovl]*/, const int* __restrict__ rlen,
                                                               int n_reads, const int2* __restrict__ eff, int aln_threshold, int theta, int theta2,
                                                               unsigned char* __restrict__ type_out /*[n_ovl] or nullptr*/,
                                                               ClassifyOut* __restrict__ full_out /*[n_ovl] or nullptr*/) {
+    constexpr int NL = STREAM_CAP / (16 * WAVE);
+    static_assert(NL * 16 * WAVE == STREAM_CAP, "the stage buffer is a whole number of wavefront-wide 16-byte loads");
     __shared__ uint4 stage4[STREAM_CAP / 16];
     const unsigned char* stage = reinterpret_cast<const unsigned char*>(stage4);
     const int lane = threadIdx.x;
-    for (int i = r_begin + (int)blockIdx.x; i <= r_end; i += (int)gridDim.x) {
-        const int64_t s = row_ptr[i], e = row_ptr[i + 1];
-        if (s == e) continue;
-        const int64_t rb = row_base[i - r_begin], rend = row_base[i - r_begin + 1];
-        const int2 ea = eff[i];
-        for (int64_t k0 = s; k0 < e; k0 += WAVE) {
-            const int64_t k = k0 + lane;
-            const bool live = k < e;
-            int64_t t0 = 0, t1 = 0;   // this lane's bytes of the image: its record, its trace (and whatever lies in front of the next kept record)
-            if (live) {
-                t0 = rb + (int64_t)rec_rel[k];
-                t1 = k + 1 < e ? rb + (int64_t)rec_rel[k + 1] : rend;
-            }
-            unsigned long long pending = ballot_of(live);
-            while (pending) {
-                const int first = __ffsll((long long)pending) - 1;
-                const int64_t base = __shfl(t0, first) & ~15ll;
-                const bool mine = ((pending >> lane) & 1ull) != 0;
-                const unsigned long long fits = ballot_of(mine && t0 >= base && t1 >= t0 + 40 && (t1 - base) <= (int64_t)STREAM_CAP);
-                const unsigned long long nofit = pending & ~fits;
-                const unsigned long long take = nofit ? (fits & ((1ull << (__ffsll((long long)nofit) - 1)) - 1ull)) : fits;
-                int2 av, bs, eb;
-                int comp, tl, b;
-                ClassifyOut o;
-                auto finish_record = [&](int bb_raw, int be_raw, unsigned flags) {   // strand flip, LAInterface.cpp:1619-1626
-                    comp = (int)(flags & 1u);
-                    b = min(max(b, 0), n_reads - 1);
-                    eb = eff[b];
-                    const int bl = comp ? rlen[b] : 0;
-                    bs = comp ? make_int2(bl - be_raw, bl - bb_raw) : make_int2(bb_raw, be_raw);
-                };
-                if (take == 0ull) {
-                    // one overlap whose record + trace exceed the stage buffer (> 5000 trace points), or a table that is not an
-                    // ascending chain: its lane walks global memory
-                    if (lane == first) {
-                        const unsigned char* rp = image + t0;
-                        int f[9];
-                        for (int q = 0; q < 9; q++) { unsigned v = 0; for (int c = 0; c < 4; c++) v |= (unsigned)rp[4 * q + c] << (8 * c); f[q] = (int)v; }
-                        tl = f[0]; av = make_int2(f[2], f[4]); b = f[8];
-                        if (t1 >= t0 + 40) tl = (int)min((int64_t)tl, (t1 - t0 - 40) / TB); else tl = 0;
-                        tl = max(tl, 0);
-                        finish_record(f[3], f[5], (unsigned)f[6]);
-                        const unsigned char* tp = rp + 40;
-                        auto adv = [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); };
-                        classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, [&](int cnt) { int T = 0; for (int j = 0; j < cnt; j++) T += adv(j); return T; },
-                                          aln_threshold, theta, theta2, 1, o);
-                        if (type_out) type_out[k] = (unsigned char)o.type;
-                        if (full_out) full_out[k] = o;
-                    }
-                    pending &= ~(1ull << first);
-                    continue;
-                }
-                const int last = 63 - __clzll((long long)take);
-                const int64_t end = __shfl(t1, last);
-                const int nchunk = (int)((end - base + 15) >> 4);
-                stage_image<STREAM_CAP>(stage4, image, base, nchunk, image_readable, lane);
-                __syncthreads();
-                if ((take >> lane) & 1ull) {
-                    const unsigned char* rp = stage + (int)(t0 - base);
-                    const bool al = ((unsigned)(t0 - base) & (TB == 2 ? 3u : 1u)) == 0u;
-                    tl = rec_field<TB>(rp, al);
-                    av.x = rec_field<TB>(rp + 8, al); const int bb_raw = rec_field<TB>(rp + 12, al);
-                    av.y = rec_field<TB>(rp + 16, al); const int be_raw = rec_field<TB>(rp + 20, al);
-                    const unsigned flags = (unsigned)rec_field<TB>(rp + 24, al);
-                    b = rec_field<TB>(rp + 32, al);
-                    tl = max(min(tl, (int)((t1 - t0 - 40) / TB)), 0);   // (a record that disagrees with the table reads nothing outside its own bytes)
-                    finish_record(bb_raw, be_raw, flags);
+    const int64_t n_win = (n_ovl + WAVE - 1) / WAVE, G = (int64_t)gridDim.x;
+    int64_t w_cur = (int64_t)blockIdx.x;
+    if (w_cur >= n_win) return;
+
+    // ---- the window whose sub-steps are being handed out, and the one behind it (already travelling) ----
+    auto bcast64 = [](int64_t v, int src /*uniform*/) -> int64_t {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, src);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), src);
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    int64_t t0 = 0, t1 = 0;                      // this lane's overlap of the window: its bytes [t0, t1) of the image
+    int64_t w_open = 0;                          // the window they belong to (uniform)
+    unsigned long long pending = 0ull;           // lanes of the window not yet handed out
+    unsigned n_rel = 0u; int64_t n_b0 = 0, n_b1 = 0, w_next = w_cur;   // the next window's offsets (loaded one window ahead)
+    auto fetch_window = [&](int64_t w) {         // issue the loads of window w's offsets
+        w_next = w;
+        if (w < n_win) {
+            const int64_t k = w * WAVE + lane;
+            n_rel = k < n_ovl ? rec_rel[k] : 0u;
+            n_b0 = win_base[w]; n_b1 = win_base[w + 1];
+        }
+    };
+    auto open_window = [&]() -> bool {           // make the fetched window the current one, fetch the one behind it
+        if (w_next >= n_win) return false;
+        w_open = w_next;
+        const int64_t kk = w_open * WAVE + lane;
+        const bool live = kk < n_ovl;
+        const unsigned nxt_rel = (unsigned)__shfl_down((int)n_rel, 1);
+        t0 = live ? n_b0 + (int64_t)n_rel : 0;
+        t1 = live ? ((lane < WAVE - 1 && kk + 1 < n_ovl) ? n_b0 + (int64_t)nxt_rel : n_b1) : 0;
+        pending = ballot_of(live);
+        fetch_window(w_open + G);
+        return true;
+    };
+    // one sub-step = the longest prefix of the pending lanes whose bytes fit the stage buffer together
+    struct Sub { int64_t base, win; unsigned long long take; int nchunk; int off0, len; bool valid; };   // off0, len: the lane's bytes behind `base`
+    auto next_sub = [&]() -> Sub {
+        Sub r; r.valid = false; r.base = 0; r.win = 0; r.take = 0ull; r.nchunk = 0; r.off0 = 0; r.len = 0;
+        while (true) {
+            if (!pending && !open_window()) return r;
+            const int first = __ffsll((long long)pending) - 1;
+            const int64_t base = bcast64(t0, first) & ~15ll;
+            const bool mine = ((pending >> lane) & 1ull) != 0;
+            const unsigned long long fits = ballot_of(mine && t0 >= base && t1 >= t0 + 40 && (t1 - base) <= (int64_t)STREAM_CAP);
+            const unsigned long long nofit = pending & ~fits;
+            const unsigned long long take = nofit ? (fits & ((1ull << (__ffsll((long long)nofit) - 1)) - 1ull)) : fits;
+            if (take == 0ull) {
+                // one overlap whose record + trace exceed the stage buffer (> 5000 trace points), or a table that is not an ascending
+                // chain: its lane walks global memory, here and now
+                if (lane == first) {
+                    const unsigned char* rp = image + t0;
+                    int f[9];
+                    for (int q = 0; q < 9; q++) { unsigned v = 0; for (int c = 0; c < 4; c++) v |= (unsigned)rp[4 * q + c] << (8 * c); f[q] = (int)v; }
+                    const int tl = t1 >= t0 + 40 ? (int)min((int64_t)max(f[0], 0), (t1 - t0 - 40) / TB) : 0;
+                    const int comp = f[6] & 1, b = min(max(f[8], 0), n_reads - 1);
+                    const int2 ea = eff[min(max(f[7], 0), n_reads - 1)], eb = eff[b];
+                    const int bl = rlen[b];
+                    const int2 av = make_int2(f[2], f[4]), bs = comp ? make_int2(bl - f[5], bl - f[3]) : make_int2(f[3], f[5]);
                     const unsigned char* tp = rp + 40;
-                    const unsigned lo = (unsigned)(t0 - base) + 40u;
                     auto adv = [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); };
-                    auto sum_words = [&](int cnt) {   // as in k_trim_classify_stream
-                        int T = 0;
-                        if (cnt <= 0) return 0;
-                        if (!al) { for (int j = 0; j < cnt; j++) T += adv(j); return T; }
-                        if (TB == 1) {
-                            const unsigned* W = reinterpret_cast<const unsigned*>(stage);
-                            const unsigned hi = lo + 2u * (unsigned)cnt;            // exclusive end, even
-                            const unsigned w0 = lo >> 2, w1 = (hi - 1u) >> 2;
-                            unsigned m0 = (lo & 2u) ? 0xff000000u : 0xff00ff00u;
-                            const unsigned m1 = (hi & 2u) ? 0x0000ff00u : 0xff00ff00u;
-                            if (w0 == w1) return (int)__builtin_amdgcn_sad_u8(W[w0] & m0 & m1, 0u, 0u);
-                            unsigned acc = __builtin_amdgcn_sad_u8(W[w0] & m0, 0u, 0u);
-                            unsigned w = w0 + 1;
-                            for (; w + 4 <= w1; w += 4) {
-                                const unsigned x0 = W[w], x1 = W[w + 1], x2 = W[w + 2], x3 = W[w + 3];
-                                acc = __builtin_amdgcn_sad_u8(x0 & 0xff00ff00u, 0u, acc);
-                                acc = __builtin_amdgcn_sad_u8(x1 & 0xff00ff00u, 0u, acc);
-                                acc = __builtin_amdgcn_sad_u8(x2 & 0xff00ff00u, 0u, acc);
-                                acc = __builtin_amdgcn_sad_u8(x3 & 0xff00ff00u, 0u, acc);
-                            }
-                            for (; w < w1; w++) acc = __builtin_amdgcn_sad_u8(W[w] & 0xff00ff00u, 0u, acc);
-                            return (int)__builtin_amdgcn_sad_u8(W[w1] & m1, 0u, acc);
-                        }
-                        const unsigned* W = reinterpret_cast<const unsigned*>(stage) + (lo >> 2);
-                        for (int j = 0; j < cnt; j++) T += (int)(W[j] >> 16);
-                        return T;
-                    };
-                    classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, sum_words, aln_threshold, theta, theta2, 1, o);
-                    if (type_out) type_out[k] = (unsigned char)o.type;
-                    if (full_out) full_out[k] = o;
+                    ClassifyOut o;
+                    classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, [&](int cnt) { int T = 0; for (int j = 0; j < cnt; j++) T += adv(j); return T; },
+                                      aln_threshold, theta, theta2, 1, o);
+                    const int64_t kk = w_open * WAVE + lane;
+                    if (type_out) type_out[kk] = (unsigned char)o.type;
+                    if (full_out) full_out[kk] = o;
                 }
-                __syncthreads();
-                pending &= ~take;
+                pending &= ~(1ull << first);
+                continue;
+            }
+            const int last = 63 - __clzll((long long)take);
+            r.base = base; r.win = w_open; r.take = take; r.nchunk = (int)((bcast64(t1, last) - base + 15) >> 4);
+            r.off0 = (int)(t0 - base); r.len = (int)(t1 - t0); r.valid = true;   // (meaningful on the lanes of `take`: both below STREAM_CAP)
+            pending &= ~take;
+            return r;
+        }
+    };
+    // the sub-step's image bytes into registers: every load in flight at once.  Exactly NL loads, whatever the sub-step: pieces
+    // behind its last one re-read that one, a piece that would cross the end of the buffer is read 16 bytes in front of it (land
+    // repairs it), no sub-step at all reads the current one's first piece again: nothing in a branch.
+    // (Twelve named registers, not an array: as an array the compiler kept it in scratch memory.)
+    static_assert(NL <= 12, "twelve staging registers");
+    uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11;
+    const long long lim = (long long)image_readable - 16;
+#define K4_LOAD(q) if (NL > q) w##q = *reinterpret_cast<const uint4*>(image + min(ib + 16ll * (long long)min(lane + q * WAVE, inc - 1), lim));
+#define K4_ISSUE(base_, nchunk_) { const long long ib = (long long)(base_); const int inc = (nchunk_); \
+        K4_LOAD(0) K4_LOAD(1) K4_LOAD(2) K4_LOAD(3) K4_LOAD(4) K4_LOAD(5) K4_LOAD(6) K4_LOAD(7) K4_LOAD(8) K4_LOAD(9) K4_LOAD(10) K4_LOAD(11) }
+#define K4_STORE(q) if (NL > q) stage4[lane + q * WAVE] = w##q;
+    auto repair = [&](const Sub& u) {            // (uniform) the image's last, partial 16 bytes: byte by byte
+        if (u.base + 16ll * u.nchunk > image_readable) {
+            for (int c = lane; c < u.nchunk; c += WAVE) {
+                const int64_t off = u.base + 16ll * c;
+                if (off + 16 <= image_readable) continue;
+                uint4 t = make_uint4(0, 0, 0, 0);
+                unsigned char* wb = reinterpret_cast<unsigned char*>(&t);
+                for (int q = 0; q < 16 && off + q < image_readable; q++) wb[q] = image[off + q];
+                stage4[c] = t;
             }
         }
+    };
+    // ... and from the registers into LDS (all of them, loaded or not: no wait hides in a branch)
+#define K4_LAND(u_) { K4_STORE(0) K4_STORE(1) K4_STORE(2) K4_STORE(3) K4_STORE(4) K4_STORE(5) K4_STORE(6) K4_STORE(7) K4_STORE(8) K4_STORE(9) K4_STORE(10) K4_STORE(11) repair(u_); }
+
+    fetch_window(w_cur);
+    Sub cur = next_sub();
+    if (cur.valid) K4_ISSUE(cur.base, cur.nchunk)
+    while (cur.valid) {
+        K4_LAND(cur)
+        __syncthreads();
+        const Sub nx = next_sub();               // (touches no LDS; its loads - the offsets of the window after next - are consumed a window later)
+        const bool on = ((cur.take >> lane) & 1ull) != 0;
+        const int off0 = on ? cur.off0 : 0, len = on ? cur.len : 40;          // (the other lanes read the buffer's first bytes: no branch)
+        const unsigned char* rp = stage + off0;
+        const bool al = ((unsigned)off0 & (TB == 2 ? 3u : 1u)) == 0u;
+        int tl = rec_field<TB>(rp, al);
+        const int2 av = make_int2(rec_field<TB>(rp + 8, al), rec_field<TB>(rp + 16, al));
+        const int bb_raw = rec_field<TB>(rp + 12, al), be_raw = rec_field<TB>(rp + 20, al);
+        const int comp = rec_field<TB>(rp + 24, al) & 1;
+        const int a_read = min(max(rec_field<TB>(rp + 28, al), 0), n_reads - 1);
+        const int b = min(max(rec_field<TB>(rp + 32, al), 0), n_reads - 1);
+        tl = max(min(tl, (len - 40) / TB), 0);   // (a record that disagrees with the table reads nothing outside its own bytes)
+        // the gathers: first used behind the advance sum
+        int ea_x = eff[a_read].x, ea_y = eff[a_read].y, eb_x = eff[b].x, eb_y = eff[b].y;
+        int bl = rlen[b];
+        K4_ISSUE(nx.valid ? nx.base : cur.base, nx.valid ? nx.nchunk : 1)   // the next sub-step's bytes travel during everything below
+        if (on) {
+            const unsigned char* tp = rp + 40;
+            const unsigned lo = (unsigned)off0 + 40u;
+            auto adv = [&](int j) { return TB == 1 ? (int)tp[2 * j + 1] : (int)(tp[4 * j + 2] | (tp[4 * j + 3] << 8)); };
+            auto sum_words = [&](int cnt) {   // as in k_trim_classify_stream
+                int T = 0;
+                if (cnt <= 0) return 0;
+                if (!al) { for (int j = 0; j < cnt; j++) T += adv(j); return T; }
+                if (TB == 1) {
+                    const unsigned* W = reinterpret_cast<const unsigned*>(stage);
+                    const unsigned hi = lo + 2u * (unsigned)cnt;            // exclusive end, even
+                    const unsigned w0 = lo >> 2, w1 = (hi - 1u) >> 2;
+                    unsigned m0 = (lo & 2u) ? 0xff000000u : 0xff00ff00u;
+                    const unsigned m1 = (hi & 2u) ? 0x0000ff00u : 0xff00ff00u;
+                    if (w0 == w1) return (int)__builtin_amdgcn_sad_u8(W[w0] & m0 & m1, 0u, 0u);
+                    unsigned acc = __builtin_amdgcn_sad_u8(W[w0] & m0, 0u, 0u);
+                    unsigned x = w0 + 1;
+                    for (; x + 4 <= w1; x += 4) {
+                        const unsigned x0 = W[x], x1 = W[x + 1], x2 = W[x + 2], x3 = W[x + 3];
+                        acc = __builtin_amdgcn_sad_u8(x0 & 0xff00ff00u, 0u, acc);
+                        acc = __builtin_amdgcn_sad_u8(x1 & 0xff00ff00u, 0u, acc);
+                        acc = __builtin_amdgcn_sad_u8(x2 & 0xff00ff00u, 0u, acc);
+                        acc = __builtin_amdgcn_sad_u8(x3 & 0xff00ff00u, 0u, acc);
+                    }
+                    for (; x < w1; x++) acc = __builtin_amdgcn_sad_u8(W[x] & 0xff00ff00u, 0u, acc);
+                    return (int)__builtin_amdgcn_sad_u8(W[w1] & m1, 0u, acc);
+                }
+                const unsigned* W = reinterpret_cast<const unsigned*>(stage) + (lo >> 2);
+                for (int j = 0; j < cnt; j++) T += (int)(W[j] >> 16);
+                return T;
+            };
+            // the one walk over the whole trace needs none of the gathered values: they are first touched behind it
+            int T = sum_words(max(tl / 2 - 1, 0));
+            asm volatile("" : "+v"(T), "+v"(bl), "+v"(ea_x), "+v"(ea_y), "+v"(eb_x), "+v"(eb_y));
+            const int2 ea = make_int2(ea_x, ea_y), eb = make_int2(eb_x, eb_y);
+            // (strand flip, LAInterface.cpp:1619-1626: the only use of rlen[B])
+            const int2 bs = comp ? make_int2(bl - be_raw, bl - bb_raw) : make_int2(bb_raw, be_raw);
+            ClassifyOut o;
+            classify_lane<TB>(av, bs, comp, ea, eb, tl, adv, [&](int) { return T; }, aln_threshold, theta, theta2, 1, o);
+            const int64_t kk = cur.win * WAVE + lane;
+            if (type_out) type_out[kk] = (unsigned char)o.type;
+            if (full_out) full_out[kk] = o;
+        }
+        __syncthreads();
+        cur = nx;
     }
+#undef K4_LOAD
+#undef K4_ISSUE
+#undef K4_STORE
+#undef K4_LAND
 }
 
 // GetMatchingPosition for a list of (overlap, pos_A) queries: one thread each (tiny lists: hinges x matches).

@@ -358,25 +358,25 @@ def pileups_from_las(recs: LasRecords, rlen: np.ndarray) -> Pileups:
     )
 
 
-def las_image_table(recs: LasRecords, pile: Pileups, r_begin: int, r_end: int):
-    """What hinge_set_las_image takes besides the file's bytes: (row_base[r_end - r_begin + 2], rec_rel[n_ovl]) - where every A
-    read's pile-up begins in the image (its first kept record; last entry: where the last kept overlap ends) and every kept
-    record's byte offset behind that.  The image itself is np.fromfile(path, np.uint8)."""
+def las_image_table(recs: LasRecords, pile: Pileups):
+    """What hinge_set_las_image takes besides the file's bytes: (win_base[(n + 63) // 64 + 1], rec_rel[n]) - the kept overlaps in
+    windows of 64: where every window's first record lies in the image (last entry: where the last kept overlap ends) and every
+    kept record's byte offset behind that.  The image itself is np.fromfile(path, np.uint8)."""
     tbytes = 1 if recs.tspace <= TRACE_XOVR else 2
     size = 40 + recs.rec["tlen"].astype(np.int64) * tbytes
     starts = 12 + np.concatenate([[0], np.cumsum(size)[:-1]]).astype(np.int64) if recs.novl else np.zeros(0, np.int64)
-    kept_start = starts[pile.las_index]
-    nr = r_end - r_begin + 1
-    row_base = np.zeros(nr + 1, np.int64)
-    n = pile.n_ovl
-    row_base[nr] = kept_start[n - 1] + size[pile.las_index[n - 1]] if n else 12
-    for q in range(nr - 1, -1, -1):
-        s, e = int(pile.row_ptr[r_begin + q]), int(pile.row_ptr[r_begin + q + 1])
-        row_base[q] = kept_start[s] if e > s else row_base[q + 1]
-    a_of = np.repeat(np.arange(pile.n_reads, dtype=np.int64), np.diff(pile.row_ptr).astype(np.int64))
-    rel = kept_start - row_base[a_of - r_begin] if n else np.zeros(0, np.int64)
+    return image_windows(starts[pile.las_index], size[pile.las_index])
+
+
+def image_windows(kept_start: np.ndarray, kept_size: np.ndarray):
+    n = len(kept_start)
+    nw = (n + 63) // 64
+    win_base = np.zeros(nw + 1, np.int64)
+    win_base[:nw] = kept_start[::64]
+    win_base[nw] = kept_start[n - 1] + kept_size[n - 1] if n else 12
+    rel = kept_start - np.repeat(win_base[:nw], 64)[:n] if n else np.zeros(0, np.int64)
     assert n == 0 or (rel.min() >= 0 and rel.max() < 2 ** 32)
-    return row_base, rel.astype(np.uint32)
+    return win_base, rel.astype(np.uint32)
 
 
 def _self_before(aread: np.ndarray, is_self: np.ndarray, n_reads: int) -> np.ndarray:

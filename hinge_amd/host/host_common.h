@@ -605,30 +605,28 @@ struct LasPart {
 
     int64_t n_kept() const { return (int64_t)b_flag.size(); }
 
-    // What hinge_set_las_image wants besides the mapped file: where every read's pile-up begins in the image (its first KEPT
-    // record; the last entry: where the last kept overlap ends) and every kept record's offset behind that, in 32 bits.
-    // false: a pile-up of 4 GiB+ - the caller keeps hinge_set_traces.
-    std::vector<int64_t> img_row_base;
+    // What hinge_set_las_image wants besides the mapped file: the kept overlaps in windows of 64 - where every window's first
+    // record lies in the image (last entry: where the last kept overlap ends) and every record's offset behind that, in 32 bits.
+    // false: a window of 4 GiB+ - the caller keeps hinge_set_traces.
+    std::vector<int64_t> img_win_base;
     UVec<uint32_t> img_rec_rel;
     bool build_image_table() {
         const int64_t kept = n_kept();
-        if (is_paf || r_end < r_begin || kept == 0 || trace_off.size() != (size_t)kept) return false;
-        const size_t nr = (size_t)(r_end - r_begin + 1);
-        img_row_base.assign(nr + 1, 0);
-        img_row_base[nr] = trace_off[(size_t)kept - 1] + (int64_t)tlen[(size_t)kept - 1] * tbytes;
-        for (size_t q = nr; q-- > 0;) {
-            const int64_t s = row_ptr[(size_t)r_begin + q], e = row_ptr[(size_t)r_begin + q + 1];
-            img_row_base[q] = e > s ? trace_off[(size_t)s] - 40 : img_row_base[q + 1];
-        }
+        if (is_paf || kept == 0 || trace_off.size() != (size_t)kept) return false;
+        const int64_t nw = (kept + 63) / 64;
+        img_win_base.assign((size_t)nw + 1, 0);
+        img_win_base[(size_t)nw] = trace_off[(size_t)kept - 1] + (int64_t)tlen[(size_t)kept - 1] * tbytes;
         img_rec_rel.resize((size_t)kept);
         std::atomic<int> bad(0);
-        parallel_dynamic((int64_t)nr, 256, [&](int64_t q0, int64_t q1) {
+        parallel_dynamic(nw, 1024, [&](int64_t w0, int64_t w1) {
             int64_t acc = 0;
-            for (int64_t q = q0; q < q1; q++) {
-                const int64_t s = row_ptr[(size_t)r_begin + (size_t)q], e = row_ptr[(size_t)r_begin + (size_t)q + 1], rb = img_row_base[(size_t)q];
-                for (int64_t k = s; k < e; k++) {
-                    const int64_t d = trace_off[(size_t)k] - 40 - rb;
-                    acc |= d >> 32;           // (negative: the sign bits)
+            for (int64_t w = w0; w < w1; w++) {
+                const int64_t wb = trace_off[(size_t)(64 * w)] - 40;
+                img_win_base[(size_t)w] = wb;
+                const int64_t e = std::min(kept, 64 * w + 64);
+                for (int64_t k = 64 * w; k < e; k++) {
+                    const int64_t d = trace_off[(size_t)k] - 40 - wb;
+                    acc |= d >> 32;                       // (negative: the sign bits)
                     img_rec_rel[(size_t)k] = (uint32_t)d;
                 }
             }

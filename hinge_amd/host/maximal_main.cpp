@@ -160,7 +160,7 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
             // the part form reads the .las image itself (k_trim_classify_image): one 32-bit offset per overlap goes up instead of
             // trace_off + tlen (12 bytes), and the kernel reads no SoA column.  HINGE_K4_SOA=1 / HINGE_K4_ROWS: the column form
             if (!las.is_paf && !getenv("HINGE_K4_SOA") && !getenv("HINGE_K4_ROWS") && las.build_image_table())
-                trace_rc = hinge_set_las_image(cx, las.file.p, (int64_t)las.file.n, las.img_row_base.data(), las.img_rec_rel.data(), las.tbytes, 0);
+                trace_rc = hinge_set_las_image(cx, las.file.p, (int64_t)las.file.n, las.img_win_base.data(), las.img_rec_rel.data(), las.tbytes, 0);
             else
                 trace_rc = hinge_set_traces(cx, las.is_paf ? no_trace : las.file.p, las.is_paf ? 1 : (int64_t)las.file.n, las.trace_off.data(), las.tlen.data(), las.tbytes, 0);
         };

@@ -215,15 +215,15 @@ int hinge_filter_counters(hinge_ctx* ctx, int64_t out[4]);
 int hinge_set_traces(hinge_ctx* ctx, const uint8_t* trace, int64_t trace_bytes, const int64_t* trace_off, const int32_t* tlen, int tbytes,
                      int on_device);
 /* The part form (hinge_trim_classify_part[_full]) straight from the .las image: `image` = the file's bytes as they lie on disk
- * (records - align.h:126-146 without the trace pointer, 40 bytes - and traces interleaved), row_base[r_end - r_begin + 2] = byte
- * offset of the first record of every A read's pile-up (the last entry: where the last pile-up ends; empty pile-ups repeat the next
- * value), rec_rel[n_ovl] = offset of every overlap's record behind its read's row_base (overlaps as set by hinge_set_pileups:
- * self-overlaps are not among them, their records are simply stepped over).  The kernel then reads tlen, the spans, the strand
- * flag and B from the image itself (getOverlap's strand flip, LAInterface.cpp:1619-1626, included): no hinge_set_traces, and 4
- * instead of 32 column bytes per overlap.  Replaces the source of trim_overlap's arguments in maximal.cpp:780-850; results are
- * those of hinge_set_traces + hinge_trim_classify_part.  Needs hinge_set_reads.
+ * (records - align.h:126-146 without the trace pointer, 40 bytes - and traces interleaved).  The overlaps set by
+ * hinge_set_pileups (storage order; self-overlaps are not among them, their records are simply stepped over) are cut into windows
+ * of 64: win_base[(n_ovl + 63) / 64 + 1] = byte offset of every window's first record (last entry: where the last overlap's trace
+ * ends), rec_rel[n_ovl] = offset of every overlap's record behind its window's win_base.  The kernel then reads tlen, the spans,
+ * the strand flag, A and B from the image itself (getOverlap's strand flip, LAInterface.cpp:1619-1626, included): no
+ * hinge_set_traces, and 4 instead of 32 column bytes per overlap.  Replaces the source of trim_overlap's arguments in
+ * maximal.cpp:780-850; results are those of hinge_set_traces + hinge_trim_classify_part.  Needs hinge_set_reads.
  * hinge_trim_classify / hinge_matching_position (list forms) still need hinge_set_traces.                                    */
-int hinge_set_las_image(hinge_ctx* ctx, const uint8_t* image, int64_t image_bytes, const int64_t* row_base, const uint32_t* rec_rel, int tbytes,
+int hinge_set_las_image(hinge_ctx* ctx, const uint8_t* image, int64_t image_bytes, const int64_t* win_base, const uint32_t* rec_rel, int tbytes,
                         int on_device);
 /* effective_start / effective_end of every read (the .mas file: maximal.cpp:524-531, hinging.cpp:867-874) */
 int hinge_set_eff_reads(hinge_ctx* ctx, const int32_t* eff);

@@ -88,7 +88,7 @@ def _image_ctx(datasets, oracle_lib, tmp_path, name, eff_override=None):
     ctx0, recs, pile, eff, a_of, toff, tlen = _setup(datasets, oracle_lib, tmp_path, name)
     src, d = datasets(name)
     image = np.fromfile(os.path.join(str(tmp_path / "w"), "G.las"), dtype=np.uint8)
-    row_base, rec_rel = formats.las_image_table(recs, pile, 0, d.n_reads - 1)
+    row_base, rec_rel = formats.las_image_table(recs, pile)
     ctx = capi.Context(0)
     ctx.set_reads(d.rlen, None)
     ctx.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)

@@ -81,15 +81,12 @@ class Part:
             owner = np.repeat(np.arange(n), tl * tbytes)
             within = np.arange(len(tr)) - np.repeat(toff_vals[:-1] * tbytes, tl * tbytes)
             image[starts[owner] + 40 + within] = tr
-        row_base = np.zeros(n_reads + 1, np.int64)
-        row_base[n_reads] = starts[-1]
-        for q in range(n_reads - 1, -1, -1):
-            row_base[q] = starts[row_ptr[q]] if row_ptr[q + 1] > row_ptr[q] else row_base[q + 1]
-        a_full = np.repeat(np.arange(n_reads), counts)
+        from hinge_amd import formats
+        win_base, rec_rel = formats.image_windows(starts[:-1], size)
         self.ctx_img = capi.Context(0)
         self.ctx_img.set_reads(rlen, None)
         self.ctx_img.set_pileups(0, n_reads - 1, row_ptr, np.ascontiguousarray(hdr[:, 0:2]), np.ascontiguousarray(hdr[:, 2:4]), b_flag)
-        self.ctx_img.set_las_image(image, row_base, (starts[:-1] - row_base[a_full]).astype(np.uint32), tbytes)
+        self.ctx_img.set_las_image(image, win_base, rec_rel, tbytes)
         self.ctx_img.set_eff_reads(eff)
 
     def all_forms(self, thr):

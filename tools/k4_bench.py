@@ -57,15 +57,12 @@ def main():
     cimg = capi.Context(0)
     cimg.set_reads(d.rlen, None)
     cimg.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
-    a_of = np.repeat(np.arange(d.n_reads, dtype=np.int64), np.diff(pile.row_ptr).astype(np.int64))
-    row_base = np.zeros(d.n_reads + 1, np.int64)
-    row_base[d.n_reads] = len(raw)
-    for q in range(d.n_reads - 1, -1, -1):
-        row_base[q] = rec_start[pile.row_ptr[q]] if pile.row_ptr[q + 1] > pile.row_ptr[q] else row_base[q + 1]
-    cimg.set_las_image(raw, row_base, (rec_start - row_base[a_of]).astype(np.uint32), 1)
+    from hinge_amd import formats
+    win_base, rec_rel = formats.image_windows(rec_start, 40 + tlen.astype(np.int64))
+    cimg.set_las_image(raw, win_base, rec_rel, 1)
     cimg.set_eff_reads(eff)
     out = {}
-    for name, env in (("image", "img"), ("image 16 w/CU", "imgwpc16"), ("image cap 8192", "imgcap8192"), ("image cap 12288", "imgcap12288"),
+    for name, env in (("image", "img"), ("image 12 w/CU", "imgwpc12"), ("image 8 w/CU", "imgwpc8"), ("image cap 8192", "imgcap8192"), ("image cap 12288", "imgcap12288"),
                       ("stream", None), ("stream 16 w/CU", "wpc16"), ("stream 32 w/CU", "wpc32"), ("stream cap 8192", "cap8192"), ("rows", "1")):
         use = ctx
         if env and env.startswith("img"):
