@@ -1281,6 +1281,7 @@ static HingePart hinge_part_of(hinge_ctx* ctx) {
     a.status = &sc(ctx)->status; a.work_next = &sc(ctx)->work_next; a.work_next_big = &sc(ctx)->work_next_big; a.work_next_small = &sc(ctx)->work_next_small;
     a.dbg = ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr;
     a.force_exact = ctx->force_exact;
+    a.span16 = (ctx->use_span16 && !getenv("HINGE_COUNT_INT32")) ? (const unsigned*)ctx->span16.p : (const unsigned*)nullptr;
     return a;
 }
 
