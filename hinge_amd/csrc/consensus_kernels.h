@@ -31,6 +31,8 @@ struct CnsAln {
     int blen;
     int seg0, nseg;                // its segments
     int dcap;                      // waves its segments may need: the largest recorded `diffs` of its trace (what the reference sizes its arrays from, LAInterface.cpp:3444-3456)
+    int tlen;                      // its trace: tlen 16-bit values from toff on ((diffs, B advance) pairs)
+    long long toff;
 };
 struct CnsSeg {
     int aln;
@@ -42,6 +44,7 @@ struct CnsSeg {
 constexpr int CNS_ST_WAVES = 1;    // a segment needed more waves than its alignment's recorded diffs allow (the reference overruns its arrays there)
 constexpr int CNS_ST_INDELS = 2;   // ... or more indel slots
 constexpr int CNS_ST_RANGE = 4;    // a coordinate outside its sequence
+constexpr int CNS_ST_TRACE = 8;    // trace points inconsistent with the alignment's coordinates (k_cns_segments)
 
 __device__ __forceinline__ int cns_base(const unsigned char* __restrict__ bps, long long boff, int p) {
     const unsigned b = bps[boff + (p >> 2)];
@@ -505,6 +508,64 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_call(CnsSeqs SA, const int* _
         atomicAdd(&st->clen, red[1] + red[2]);
         atomicAdd((unsigned long long*)&st->sum_cov, (unsigned long long)redl);
     }
+}
+
+// The segment table (computeTracePTS's loop bounds, LAInterface.cpp:3470-3500) on the device (round 5; the host built and uploaded it
+// before: 1.33 M segments = 37 MB over PCIe and 5 ms of a single thread per call, more than the kernels took).  One thread per
+// alignment, two walks over its trace: the largest recorded `diffs` (-> dcap), then the segments [ab, ae) x [bb, be) - A advances to
+// the next multiple of tspace, B by the trace's advance, the last segment ends at (aepos, bepos).  A segment's indel slots are
+// dcap + |m - n|; their per-alignment sums go to aln_slots for the scan that k_cns_seg_offsets turns into out_off.
+// gmax: [0] widest row of the launch, [1] largest dcap (both size k_cns_realign's wave storage: the host reads them back).
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_segments(CnsAln* __restrict__ alns, int n_aln, const unsigned short* __restrict__ trace, int tspace,
+                                                           const int* __restrict__ rlen_a, CnsSeg* __restrict__ segs, unsigned* __restrict__ aln_slots,
+                                                           int* __restrict__ gmax, int* __restrict__ status) {
+    const int x = blockIdx.x * CNS_BLOCK + threadIdx.x;
+    if (x >= n_aln) return;
+    CnsAln al = alns[x];
+    const unsigned short* __restrict__ pts = trace + al.toff;
+    const int alen = rlen_a[al.a], blen = al.blen;
+    int dmax = 0;
+    for (int d = 0; d < al.tlen; d += 2) dmax = max(dmax, (int)pts[d]);
+    alns[x].dcap = dmax;
+    int wmax = 4, at = al.seg0;
+    unsigned slots = 0;
+    bool ok = true;
+    auto add = [&](int ab, int ae, int bb, int be) {
+        if (ae < ab || be < bb || ae > alen || be > blen) { ok = false; return; }
+        CnsSeg g;
+        g.aln = x; g.a0 = ab; g.m = ae - ab; g.b0 = bb; g.n = be - bb;
+        const int del_abs = abs(g.m - g.n);
+        g.out_cap = dmax + del_abs;
+        g.out_off = 0u;
+        slots += (unsigned)g.out_cap;
+        wmax = max(wmax, cns_row_width(dmax, del_abs));
+        segs[at++] = g;
+    };
+    int ab = al.ab, ae = (ab / tspace) * tspace, bb = al.bb;
+    const int tl = al.tlen - 2;
+    for (int i = 1; i < tl && ok; i += 2) {
+        ae += tspace;
+        const int be = bb + (int)pts[i];
+        add(ab, ae, bb, be);
+        ab = ae; bb = be;
+    }
+    if (ok) add(ab, al.ae, bb, al.be);
+    if (!ok) {   // the rest of its slots stay empty segments: nothing of a refused call is used
+        atomicOr(status, CNS_ST_TRACE);
+        for (; at < al.seg0 + al.nseg; at++) { CnsSeg g; g.aln = x; g.a0 = al.ab; g.m = 0; g.b0 = al.bb; g.n = 0; g.out_off = 0u; g.out_cap = 0; segs[at] = g; }
+        slots = 0;
+    }
+    aln_slots[x] = slots;
+    atomicMax(&gmax[0], wmax);
+    atomicMax(&gmax[1], dmax);
+}
+// out_off of every segment: the alignment's base (the exclusive scan of aln_slots) + the slots of its earlier segments
+__global__ __launch_bounds__(CNS_BLOCK) void k_cns_seg_offsets(const CnsAln* __restrict__ alns, int n_aln, const unsigned* __restrict__ aln_base, CnsSeg* __restrict__ segs) {
+    const int x = blockIdx.x * CNS_BLOCK + threadIdx.x;
+    if (x >= n_aln) return;
+    const int s0 = alns[x].seg0, s1 = s0 + alns[x].nseg;
+    unsigned run = aln_base[x];
+    for (int s = s0; s < s1; s++) { segs[s].out_off = run; run += (unsigned)segs[s].out_cap; }
 }
 
 // exclusive scan of n values in place, one workgroup of 1024 threads; total to *total

@@ -79,7 +79,37 @@ def main():
     out["kernels_ms_sum"] = round(ksum, 4)
     out["aligned_bases_per_s_kernels"] = aligned / (ksum * 1e-3) if ksum else None
     out["segments_per_s_realign"] = n_seg / (out["kernels_ms"].get("k_cns_realign", 0) * 1e-3) if out["kernels_ms"].get("k_cns_realign") else None
+    out["roofline"] = realign_roofline(out["kernels_ms"].get("k_cns_realign"))
     print(json.dumps(out))
+
+
+def realign_roofline(ms):
+    """k_cns_realign against the bound that holds it: vector-instruction ISSUE (integer compares on 2-bit symbols, wave cells that
+    stay in L2: an HBM figure would say < 1 % and mean nothing).  achieved = wave-level vector instructions of one
+    launch (SQ_INSTS_VALU of the newest profiles/*_cns_rocprofv3_sq_summary.csv - a property of the instruction stream and the
+    data set, not of the box) / the launch time measured HERE with HIP events; peak = one wave64 vector instruction per SIMD per
+    4 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4."""
+    import csv
+    import glob
+    peak = 256 * 4 * 2.4e9 / 4
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cns_rocprofv3_sq_summary.csv")), key=lambda f: (os.path.basename(f)[:2], os.path.basename(f)))
+    if not files or not ms:
+        return None
+    valu = vmem = None
+    for row in csv.DictReader(open(files[-1])):
+        if "k_cns_realign" in row["kernel"]:
+            if row["counter"] == "SQ_INSTS_VALU":
+                valu = float(row["mean_value"])
+            if row["counter"] == "SQ_INSTS_VMEM_RD":
+                vmem = float(row["mean_value"])
+    if not valu:
+        return None
+    ach = valu / (ms * 1e-3)
+    return {"bound": "valu-issue", "kernel": "k_cns_realign", "achieved": ach, "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak,
+            "valu_instructions_per_launch": valu, "vector_loads_per_launch": vmem, "avg_launch_ms": ms, "counters_source": os.path.relpath(files[-1], ROOT),
+            "note": "neither the vector ALU nor the texture path is saturated (the latter ~56 % busy by TA_BUSY in r4r): the kernel is a per-lane "
+                    "dependent chain - wave cell -> L2-resident load -> compare -> next cell - 64 divergent lanes per wavefront; an HBM roofline "
+                    "does not apply (33 MB of packed bases, wave cells never leave L2)"}
 
 
 if __name__ == "__main__":

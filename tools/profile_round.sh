@@ -23,6 +23,9 @@ cp $OUT/bench.json $OUT/${TAG}_bench.json
 # `hinge consensus`: its kernels under the tracer, E. coli-sized draft
 (cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/trace_cns -o ${TAG}_cns --output-format csv -- python $R/tools/cns_bench.py --no-cpu --steps 5 > $OUT/trace_cns.log 2>&1)
 cp $(find $OUT/trace_cns -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cns_rocprofv3_kernel_stats.csv 2>/dev/null
+# ... and their instruction counters (the roofline tools/cns_bench.py states for k_cns_realign is vector-instruction issue: it reads the newest of these)
+(cd /tmp && timeout 420 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_cns -o ${TAG}_cns --output-format csv -- python $R/tools/cns_bench.py --no-cpu --steps 2 > $OUT/pmc_cns.log 2>&1)
+python $R/tools/pmc_summary.py $(find $OUT/pmc_cns -name "*counter_collection.csv") > $OUT/${TAG}_cns_rocprofv3_sq_summary.csv 2>/dev/null
 tail -1 $OUT/bench.json | cut -c1-400
 head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv
 cat $OUT/${TAG}_rocprofv3_pmc_summary.csv
