@@ -38,7 +38,9 @@ HINGE_HD inline int floor_log2(unsigned n) {
 }
 
 // ---- heap part (reached only when the introsort depth limit hits) --------------------------------
-HINGE_HD inline void push_heap_(int* a, int first, int hole, int top, int value, const KeyCmp& c) {
+// T = element type of the array, C = comparator on its elements (KeyCmp over an index array, PackedCmp over key | element words)
+template <typename T, typename C>
+HINGE_HD inline void push_heap_(T* a, int first, int hole, int top, T value, const C& c) {
     int parent = (hole - 1) / 2;
     while (hole > top && c(a[first + parent], value)) {
         a[first + hole] = a[first + parent];
@@ -48,7 +50,8 @@ HINGE_HD inline void push_heap_(int* a, int first, int hole, int top, int value,
     a[first + hole] = value;
 }
 
-HINGE_HD inline void adjust_heap_(int* a, int first, int hole, int len, int value, const KeyCmp& c) {
+template <typename T, typename C>
+HINGE_HD inline void adjust_heap_(T* a, int first, int hole, int len, T value, const C& c) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -65,12 +68,13 @@ HINGE_HD inline void adjust_heap_(int* a, int first, int hole, int len, int valu
     push_heap_(a, first, hole, top, value, c);
 }
 
-HINGE_HD inline void heapsort_(int* a, int first, int last, const KeyCmp& c) {   // __partial_sort(first,last,last)
+template <typename T, typename C>
+HINGE_HD inline void heapsort_(T* a, int first, int last, const C& c) {   // __partial_sort(first,last,last)
     int len = last - first;
     if (len >= 2) {                                                              // __make_heap
         int parent = (len - 2) / 2;
         while (true) {
-            int value = a[first + parent];
+            T value = a[first + parent];
             adjust_heap_(a, first, parent, len, value, c);
             if (parent == 0) break;
             parent--;
@@ -78,11 +82,17 @@ HINGE_HD inline void heapsort_(int* a, int first, int last, const KeyCmp& c) {  
     }
     while (last - first > 1) {                                                   // __sort_heap
         --last;
-        int value = a[last];                                                     // __pop_heap(first,last,last)
+        T value = a[last];                                                       // __pop_heap(first,last,last)
         a[last] = a[first];
         adjust_heap_(a, first, 0, last - first, value, c);
     }
 }
+
+// key | element in one word (pileup_order.h, the packed replay): comp(x, y) = key(x) > key(y) - the element bits never take part
+struct PackedCmp {
+    int shift;
+    HINGE_HD bool operator()(unsigned x, unsigned y) const { return (x >> shift) > (y >> shift); }
+};
 
 // ---- introsort -----------------------------------------------------------------------------------
 HINGE_HD inline void move_median_to_first_(int* a, int result, int x, int y, int z, const KeyCmp& c) {

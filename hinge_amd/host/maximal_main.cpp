@@ -259,12 +259,16 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
                     *out++ = (int32_t)(las.b_flag[(size_t)sel[(size_t)k]] & 0x7fffffffu);
                 }
         });
+        if (timed) tm.mark("candidate rows");
     };
 
     for (size_t w0 = 0; w0 < las_list.size(); w0 += (size_t)n_ranks) {
         const size_t w1 = std::min(las_list.size(), w0 + (size_t)n_ranks), nw = w1 - w0;
         std::vector<PartOut> outs(nw);
-        if (nw == 1) part_work(ctxs[0], w0, outs[0], true);
+        if (nw == 1) {
+            part_work(ctxs[0], w0, outs[0], true);
+            tm.mark("part teardown");   // (121 ms for a 3.5 GB part: its columns and the mapped .las go back; left to _exit() instead, the kernel spends the same at exit - measured, round 5)
+        }
         else {
             std::vector<std::thread> th;
             for (size_t k = 0; k < nw; k++) th.emplace_back([&, k] { part_work(ctxs[k], w0 + k, outs[k], false); });

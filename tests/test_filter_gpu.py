@@ -202,9 +202,13 @@ def test_pileup_order_replays_std_sort(oracle_lib):
     ip = ctypes.POINTER(ctypes.c_int)
     sizes = [0, 1, 2, 15, 16, 17, 18, 33, 64, 65, 100, 257, 1000, 2048, 4095, 4096] + [int(x) for x in rng.integers(17, 4096, size=40)]
     for n in sizes:
-        for kind in range(6):
+        for kind in range(8):      # kinds 0-5, 7: the packed replay (key | element in one LDS word); 6: keys that span 2^20+ (wide form)
             if kind == 0:
                 key = rng.integers(0, 4, size=n)
+            elif kind == 6:
+                key = rng.integers(-(1 << 30), 1 << 30, size=n) // (1 if n % 2 else 1 << 12) * (1 if n % 2 else 1 << 12)
+            elif kind == 7:
+                key = rng.integers(-70000, -69000 + n // 8, size=n)
             elif kind == 1:
                 key = rng.integers(0, max(1, n // 8) + 1, size=n)
             elif kind == 2:
