@@ -185,6 +185,18 @@ def end_to_end(d, workload):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def describe_workload(name):
+    """What the synthetic read sets of `--workload name` restate (hinge_amd/synth.py CONFIGS): from the spec itself."""
+    from hinge_amd import synth
+    c = synth.CONFIGS[name]
+    what = {"cfg2_ecoli160": "synthetic restatement of E. coli P6-C4 160x", "cfg1_ecoli_demo": "synthetic restatement of the ecoli_demo plumbing case",
+            "cfg3_nctc": "synthetic restatement of a repeat-rich NCTC-like bacterial set", "cfg4_yeast": "synthetic restatement of a yeast-like set"}.get(name, "synthetic read set")
+    reps = "%d repeat famil%s of %d-%d bp in %d-%d copies" % (c.n_repeat_families, "y" if c.n_repeat_families == 1 else "ies", c.repeat_len[0], c.repeat_len[1],
+                                                             c.repeat_copies[0], c.repeat_copies[1])
+    return "%s (G=%.1f Mb at %dx, %s reads mean %d bp, %s%s)" % (what, c.genome_len / 1e6, c.coverage, c.len_dist, c.len_mean, reps,
+                                                                 ", %.0f %% chimeric reads" % (100 * c.chimera_frac) if getattr(c, "chimera_frac", 0) else "")
+
+
 def main():
     args = parse_args()
     import torch
@@ -465,7 +477,7 @@ def main():
                 consensus = {"error": str(ex)[-800:]}
         collectives = batch.collectives
         out = {
-            "metric": "overlaps/sec through filter+hinge-detect, E. coli 160x",
+            "metric": "overlaps/sec through filter+hinge-detect, E. coli 160x" if args.workload == "cfg2_ecoli160" else "overlaps/sec through filter+hinge-detect, %s (NOT the headline configuration)" % args.workload,
             "value": value,
             "unit": "overlaps/s",
             "n_gpus": world,
@@ -478,9 +490,9 @@ def main():
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": ("%s: synthetic restatement of E. coli P6-C4 160x (G=4.6 Mb, lognormal reads mean 8.5 kb, 7 x 5 kb repeat copies); "
+                "workload": ("%s: %s; "
                              "a step = one whole filter + hinge-detect pass over each of %d distinct such read sets per GPU, all resident in HBM"
-                             % (args.workload, R)) +
+                             % (args.workload, describe_workload(args.workload), R)) +
                             ("" if world == 1 else "; N > 1: teams of two ranks share a 2-block data set of twice the genome (same reads and overlaps per GPU; "
                                                    "half of every pile-up's B reads are on the team mate: hinge_amd/benchsets.py)"),
                 "parts_per_step": R,

@@ -1852,6 +1852,17 @@ __device__ __forceinline__ void overhangs(int2 bs, int comp, int2 mb, int& L, in
     else { R = max(bs.x - mb.x, 0); L = max(mb.y - bs.y, 0); }
 }
 
+// The 16|16 copy of b_span for the hinge kernels (round 5): bad[0] is set when a coordinate does not fit (the copy is then not used)
+__global__ __launch_bounds__(BLOCK) void k_pack_bspan(long long n_ovl, const int2* __restrict__ b_span, unsigned* __restrict__ out, unsigned* __restrict__ bad) {
+    bool any = false;
+    for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < n_ovl; k += (long long)gridDim.x * BLOCK) {
+        const int2 v = b_span[k];
+        any = any || ((unsigned)v.x > 65535u) || ((unsigned)v.y > 65535u);
+        out[k] = ((unsigned)v.x & 0xffffu) | ((unsigned)v.y << 16);
+    }
+    if (__any(any) && lane_id() == 0) atomicOr(bad, 1u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3 exact path: one thread per queued (read, annotation).  Replays the reference literally:
 // std::sort of the pile-up by compare_overlap, supporters collected in that order, std::sort by

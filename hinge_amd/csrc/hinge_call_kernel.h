@@ -56,7 +56,10 @@ struct HingePart {
     // second tier (round 4): what k_hinge_call_light could not settle, for k_hinge_call<CAP> (front / back by pile-up size as in `heavy`)
     HeavyItem* heavy2; unsigned* heavy2_count; unsigned* heavy2_count_big; unsigned* work_next_light;
     unsigned* work_next_small;     // round 5: the cursor of the PO_CAP_MINI instance
-    const unsigned* span16;        // round 5: the part's 16|16 copy of a_span (nullptr if it has none): k_hinge_count reads 4 instead of 8 bytes per overlap
+    // round 5: the part's 16|16 copies of a_span and b_span (both or neither; nullptr if a read has 65 536+ bases or a coordinate lies
+    // outside [0, 65535]): k_hinge_count and k_hinge_call_light move 3 TB/s of pile-up columns - 12 instead of 20 bytes per overlap
+    const unsigned* span16;
+    const unsigned* bspan16;
 };
 constexpr int HEAVY_TIES = 0x40000000;   // in HeavyItem::anno of a second-tier item: k_hinge_call_light evaluated it and the tie order decides
                                          // (the same evaluation in k_hinge_call<CAP> would say the same: it goes straight to the replay)
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
     unsigned char* __restrict__ hinge_flag = A.hinge_flag; HeavyItem* __restrict__ heavy = A.heavy;
     unsigned* __restrict__ heavy_count = A.heavy_count; unsigned* __restrict__ heavy_count_big = A.heavy_count_big;
     const unsigned heavy_cap = A.heavy_cap; const int force_exact = A.force_exact; unsigned* __restrict__ dbg = A.dbg;
-    const unsigned* __restrict__ span16 = A.span16;
+    const unsigned* __restrict__ span16 = A.span16; const unsigned* __restrict__ bspan16 = A.bspan16;
     (void)row_ptr;
     __shared__ int s_sup[PRE_MAXA][WAVES_PER_BLOCK], s_near[PRE_MAXA][WAVES_PER_BLOCK], s_minf[PRE_MAXA][WAVES_PER_BLOCK];
     const int tid = threadIdx.x;
@@ -152,15 +155,15 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
                 bool nearw[GATHER_LOADS];
                 // (the B-side fields are loaded with the spans, needed or not: 12 more bytes per overlap of a work-list read - 1-2 % of
                 // the part - buy one dependent round trip less per batch)
-                if (span16) {   // (uniform) the kernel moves 3 TB/s of pile-up columns: the packed copy of the spans where the part has one
+                if (span16) {   // (uniform) the kernel moves 3 TB/s of pile-up columns: the packed copies of the spans where the part has them
 #pragma unroll
                     for (int u = 0; u < GATHER_LOADS; u++) {
                         const int64_t k = k0 + u * WAVE + lane;
                         const bool in = k < k_hi;
-                        const unsigned sv = in ? span16[k] : 0u;
+                        const unsigned sv = in ? span16[k] : 0u, bv = in ? bspan16[k] : 0u;
                         av[u] = make_int2((int)(sv & 0xffffu), (int)(sv >> 16));
                         bf[u] = in ? b_flag[k] : 0u;
-                        bs[u] = in ? b_span[k] : make_int2(0, 0);
+                        bs[u] = make_int2((int)(bv & 0xffffu), (int)(bv >> 16));
                     }
                 } else {
 #pragma unroll
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call_light(FilterDev P, HingeBa
     const HeavyItem* __restrict__ heavy = A.heavy; HeavyItem* __restrict__ heavy2 = A.heavy2;
     unsigned char* __restrict__ hinge_flag = A.hinge_flag;
     const unsigned heavy_cap = A.heavy_cap;
+    const unsigned* __restrict__ span16 = A.span16; const unsigned* __restrict__ bspan16 = A.bspan16;
     __shared__ HingeLightLds S;
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -351,13 +355,25 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call_light(FilterDev P, HingeBa
                 int2 av[LIGHT_LOADS], bs[LIGHT_LOADS], mb[LIGHT_LOADS];
                 unsigned bf[LIGHT_LOADS];
                 bool nearw[LIGHT_LOADS];
+                if (span16) {   // (uniform) 12 instead of 20 bytes per overlap, as in k_hinge_count
 #pragma unroll
-                for (int u = 0; u < LIGHT_LOADS; u++) {
-                    const int64_t k = k0 + u * WAVE + lane;
-                    const bool in = k < k_hi;
-                    av[u] = in ? a_span[k] : make_int2(0, 0);
-                    bf[u] = in ? b_flag[k] : 0u;
-                    bs[u] = in ? b_span[k] : make_int2(0, 0);
+                    for (int u = 0; u < LIGHT_LOADS; u++) {
+                        const int64_t k = k0 + u * WAVE + lane;
+                        const bool in = k < k_hi;
+                        const unsigned sv = in ? span16[k] : 0u, bv = in ? bspan16[k] : 0u;
+                        av[u] = make_int2((int)(sv & 0xffffu), (int)(sv >> 16));
+                        bf[u] = in ? b_flag[k] : 0u;
+                        bs[u] = make_int2((int)(bv & 0xffffu), (int)(bv >> 16));
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < LIGHT_LOADS; u++) {
+                        const int64_t k = k0 + u * WAVE + lane;
+                        const bool in = k < k_hi;
+                        av[u] = in ? a_span[k] : make_int2(0, 0);
+                        bf[u] = in ? b_flag[k] : 0u;
+                        bs[u] = in ? b_span[k] : make_int2(0, 0);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < LIGHT_LOADS; u++) {
