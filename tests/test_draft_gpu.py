@@ -151,3 +151,38 @@ def test_dispatcher_runs_draft_path_and_draft(oracle_lib, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert open(os.path.join(wd, "G.draft.fasta"), "rb").read() == dc.run_oracle(lib, wd)[0]
+
+
+def test_chain_layout_to_consensus_recovers_the_genome(oracle_lib, tmp_path):
+    """layout -> clip(G2) -> draft-path -> draft -> consensus END TO END through the executables on noisy reads (10 % errors) off a
+    planted genome: `hinge filter | maximal | layout` (GPU), `hinge clip`, `hinge draft-path`, `hinge draft` (GPU), then `hinge
+    consensus` (GPU) over contig-vs-read alignments composed from the generator's edit scripts (tests/chain_common.py: the
+    reference's pipeline runs DALIGNER there).  The consensus FASTA is the CPU oracle's byte for byte, and every contig equals the
+    planted genome in >= 99.9 % of the positions of its interior (6 kb left out at either end; the draft: ~97-98 %) - physics, not a pin."""
+    import ctypes
+    import subprocess
+    import chain_common as cc
+    lib = dc.bind(oracle_lib)
+    wd = str(tmp_path)
+    d = dc.prepare(lib, "draft_noisy", wd, stages="executables")
+    draft_fa, _ = dc.run_product(wd)
+    exe = os.path.join(dc.ROOT, "hinge_amd", "bin", "consensus")
+
+    def run(wd):
+        r = subprocess.run([exe, "draft", "G", "draft.G.las", "cns.fasta", "nominal.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        return open(os.path.join(wd, "cns.fasta"), "rb").read()
+    res = cc.polish(d, wd, draft_fa, run)
+    assert len(res) >= 2
+    for nm, before, after, seq in res:
+        (ident, span), (ident0, _) = after.inner_identity(6000), before.inner_identity(6000)
+        assert span > 0.5 * d.spec.genome_len, (nm, span)
+        assert ident >= 0.999 and ident > ident0 and after.identity > before.identity, (nm, ident0, ident, before.identity, after.identity)
+    lib.oracle_consensus.argtypes = [ctypes.c_char_p] * 7
+    old = os.getcwd()
+    os.chdir(wd)
+    try:
+        assert lib.oracle_consensus(b"draft", b"G", b"draft.G.las", b"ora.fasta", b"nominal.ini", b"ora.log", None) == 0
+    finally:
+        os.chdir(old)
+    assert open(os.path.join(wd, "ora.fasta"), "rb").read() == open(os.path.join(wd, "cns.fasta"), "rb").read()

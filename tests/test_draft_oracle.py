@@ -135,3 +135,33 @@ def test_draft_path_records_on_hand_built_graphs(tmp_path):
     g2 = dp.read_graphml(p)
     assert sorted(g2.nodes(), key=str) == sorted(g.nodes(), key=str)
     assert g2.out[(7, 0, "B")][(8, 1)]["length"] == 5 and g2.out[(0, 0)][(1, 0)]["read_a_match_start"] == 300
+
+
+def test_chain_through_consensus_recovers_the_genome(oracle_lib, tmp_path):
+    """The WHOLE chain on noisy reads (10 % errors), oracle / host code: filter -> maximal -> layout -> clip(G2) -> draft-path -> draft ->
+    consensus.  The contig-vs-read alignments `hinge consensus` needs come from the generator's edit scripts (tests/chain_common.py:
+    DALIGNER's job in the reference's pipeline); every contig's polished consensus must equal the planted genome in at least 99.9 %
+    of the positions of its interior (6 kb left out at either end: a draft's ends are its weakest part), and be closer to it than the draft was - a property no reference
+    build is needed to pin."""
+    import ctypes
+    import chain_common as cc
+    lib = dc.bind(oracle_lib)
+    wd = str(tmp_path)
+    d = dc.prepare(lib, "draft_noisy", wd)
+    draft_fa, _ = dc.run_oracle(lib, wd)
+
+    def run(wd):
+        lib.oracle_consensus.argtypes = [ctypes.c_char_p] * 7
+        old = os.getcwd()
+        os.chdir(wd)
+        try:
+            assert lib.oracle_consensus(b"draft", b"G", b"draft.G.las", b"cns.fasta", b"nominal.ini", b"cns.log", None) == 0
+        finally:
+            os.chdir(old)
+        return open(os.path.join(wd, "cns.fasta"), "rb").read()
+    res = cc.polish(d, wd, draft_fa, run)
+    assert len(res) >= 2
+    for nm, before, after, seq in res:
+        (ident, span), (ident0, _) = after.inner_identity(6000), before.inner_identity(6000)
+        assert span > 0.5 * d.spec.genome_len, (nm, span)
+        assert ident >= 0.999 and ident > ident0 and after.identity > before.identity, (nm, ident0, ident, before.identity, after.identity)
