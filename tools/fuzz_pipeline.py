@@ -95,6 +95,14 @@ def random_paths(rng, spec):
     if rng.random() < 0.2:
         env["HINGE_K2_HEAVY"] = str(int(rng.choice([0, 1])))   # the deep pile-ups first / left in storage order (default: spread over the first 60 %)
     paf = spec.n_blocks == 1 and rng.random() < 0.2
+    # round 5 (drawn after everything above, so the earlier rounds' cases keep their draws)
+    if rng.random() < 0.25:
+        env["HINGE_K4_SOA"] = "1"                    # `hinge maximal` through the column form (k_trim_classify_stream) instead of the .las image
+    elif rng.random() < 0.3:
+        env["HINGE_K4_WAVES_PER_CU"] = str(int(rng.choice([1, 3, 7])))   # few persistent wavefronts in k_trim_classify_image: long window sequences per wavefront
+        env["HINGE_K4_CAP"] = str(int(rng.choice([8192, 10240, 12288])))
+    if rng.random() < 0.2:
+        env["HINGE_COUNT_INT32"] = "1"               # the hinge kernels on the int32 span columns instead of the 16|16 copies
     return env, paf
 
 
