@@ -66,8 +66,6 @@ struct hinge_ctx {
     int final_batched = 1;                    // HINGE_FINAL_BATCH=0: one MODE_FINAL launch per part
     int count_waves = 2;                      // wavefronts per work-list read in k_hinge_count (HINGE_COUNT_WAVES=4: rounds 1-3)
     int hinge_light = 1;                      // HINGE_CALL_LIGHT=0: every open annotation straight to k_hinge_call<CAP> (rounds 1-3)
-    hipStream_t side_stream = nullptr;        // HINGE_CALL_MINI=2: the quarter-size instance runs on this stream BESIDE the half-size one
-    hipEvent_t side_fork = nullptr, side_join = nullptr;
     int hinge_mini = 0;                       // HINGE_CALL_MINI=1: a quarter-size (1024-overlap) instance behind the light kernel, four workgroups per CU (measured: no gain - the replay is bound by its slowest item, not by the workgroups in flight)
     int light_occ = 0;
     int k2_batch = 1;                         // HINGE_K2_BATCH=0: one k_mask_annotate_q20 launch per part of a batched sweep
@@ -325,7 +323,6 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c,
                      &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch, &ctx->heavy2_list, &ctx->img_row_base, &ctx->img_rec_rel, &ctx->bspan16};
     for (DevBuf* b : all) release(*b);
-    if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->side_fork); (void)hipEventDestroy(ctx->side_join); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -1376,18 +1373,6 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
     // workgroups per CU, the instance behind it only takes the rest.  No gain on the repeat-rich config (the replay is bound by its
     // slowest item, and an item gets slower with more workgroups on its CU), +5 us of empty launch on config 2.
     const bool mini = light && ctx->hinge_mini != 0;
-    const bool mini_beside = mini && ctx->hinge_mini == 2;
-    if (mini_beside) {   // fork: the quarter-size instance on a side stream, from where the light kernel ends
-        if (!ctx->side_stream) {
-            CK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-            CK(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-            CK(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
-        }
-        CK(hipEventRecord(ctx->side_fork, ctx->stream));
-        CK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-        hipLaunchKernelGGL(k_hinge_call<PO_CAP_MINI>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->side_stream, to_dev(p), B, 0, 1, 0, PO_CAP_MINI, 1);
-        CK(hipEventRecord(ctx->side_join, ctx->side_stream));
-    } else
     if (mini) hipLaunchKernelGGL(k_hinge_call<PO_CAP_MINI>, dim3(std::max(n, (4 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, 1, 0, PO_CAP_MINI, 1);
     bool any_mid = false;
     for (int k = 0; k < n; k++) any_mid = any_mid || ctxs[k]->max_pile > (unsigned)PO_CAP_MINI;
@@ -1398,12 +1383,8 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         // behind the light kernel ONE second-tier launch: the full-size instance takes both ends of the list (an empty launch is 5 us)
         hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 2, n_min, INT_MAX, 0);
     } else {
-        hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, ((mini_beside ? 1 : 2) * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0, n_min, INT_MAX, 0);
+        hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0, n_min, INT_MAX, 0);
         if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 0, 0, INT_MAX, 0);
-    if (mini_beside) {
-        // (the half-size instance then runs with ONE workgroup per CU - 75 KiB - beside two quarter-size ones - 2 x 37 KiB)
-        CK(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
-    }
     } }
     CK(hipGetLastError());
     // the serial exact path takes pile-ups or supporter lists beyond PO_CAP (and everything under force_exact == 1): per part
