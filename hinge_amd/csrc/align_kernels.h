@@ -564,11 +564,17 @@ __global__ __launch_bounds__(WAVE) void k_trim_classify_image(int64_t n_ovl, con
             if (take == 0ull) {
                 // one overlap whose record + trace exceed the stage buffer (> 5000 trace points), or a table that is not an ascending
                 // chain: its lane walks global memory, here and now
-                if (lane == first) {
+                if (lane == first && (t0 < 0 || t0 + 40 > image_readable)) {
+                    // (a table entry that points outside the image: the caller's bug - nothing is read, the overlap is reported inactive)
+                    const int64_t kk = w_open * WAVE + lane;
+                    if (type_out) type_out[kk] = (unsigned char)MT_NOT_ACTIVE;
+                    if (full_out) { ClassifyOut o = {0, 0, 0, 0, MT_NOT_ACTIVE, 0, 0, 0, 0, 0}; full_out[kk] = o; }
+                } else if (lane == first) {
                     const unsigned char* rp = image + t0;
                     int f[9];
                     for (int q = 0; q < 9; q++) { unsigned v = 0; for (int c = 0; c < 4; c++) v |= (unsigned)rp[4 * q + c] << (8 * c); f[q] = (int)v; }
-                    const int tl = t1 >= t0 + 40 ? (int)min((int64_t)max(f[0], 0), (t1 - t0 - 40) / TB) : 0;
+                    const int64_t room = min(t1, (int64_t)image_readable) - t0 - 40;      // trace bytes that are this overlap's AND inside the image
+                    const int tl = room > 0 ? (int)min((int64_t)max(f[0], 0), room / TB) : 0;
                     const int comp = f[6] & 1, b = min(max(f[8], 0), n_reads - 1);
                     const int2 ea = eff[min(max(f[7], 0), n_reads - 1)], eb = eff[b];
                     const int bl = rlen[b];

@@ -120,6 +120,39 @@ def test_trim_classify_image_form_equals_the_list_form(datasets, oracle_lib, tmp
     ctx0.close(); ctx.close()
 
 
+def test_trim_classify_image_form_survives_a_bad_offset_table(datasets, oracle_lib, tmp_path):
+    """Entries of rec_rel that point outside the image (a caller's bug): nothing is read there - those overlaps come back inactive,
+    every other overlap keeps its result (the overlap in front of a bad entry loses its end bound and walks global memory)."""
+    from hinge_amd import capi, formats
+    ctx0, recs, pile, eff, a_of, toff, tlen = _setup(datasets, oracle_lib, tmp_path, "chimera")
+    src, d = datasets("chimera")
+    image = np.fromfile(os.path.join(str(tmp_path / "w"), "G.las"), dtype=np.uint8)
+    win_base, rec_rel = formats.las_image_table(recs, pile)
+    n = pile.n_ovl
+    rng = np.random.default_rng(3)
+    bad = np.unique(rng.integers(0, n, size=40))
+    bad = bad[bad % 64 != 0]                                   # (a window's first entry is win_base itself)
+    rr = rec_rel.copy()
+    rr[bad] = np.uint32(0xFFFFFF00)
+    ctx = capi.Context(0)
+    ctx.set_reads(d.rlen, None)
+    ctx.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+    ctx.set_las_image(image, win_base, rr, 1)
+    ctx.set_eff_reads(eff)
+    full = ctx0.trim_classify(np.arange(n, dtype=np.int64), a_of, 1000, 300, 0)
+    got = ctx.trim_classify_part_full(n, 1000, 300, 0)
+    good = np.ones(n, bool)
+    good[bad] = False
+    assert np.array_equal(got[good], full[good]), np.nonzero((got != full).any(axis=1) & good)[0][:10]
+    assert (got[bad, 4] == 6).all() and (got[bad, 5] == 0).all()      # MT_NOT_ACTIVE, inactive
+    # a win_base that is not ascending is refused by the host check
+    wb = win_base.copy()
+    wb[1] = wb[0] - 2
+    with pytest.raises(capi.HingeError):
+        ctx.set_las_image(image, wb, rec_rel, 1)
+    ctx0.close(); ctx.close()
+
+
 def test_trim_classify_image_form_with_masks_that_cut_deep(datasets, oracle_lib, tmp_path):
     ctx0, ctx, pile, eff, a_of, tlen = _image_ctx(datasets, oracle_lib, tmp_path, "long_reads")
     n = pile.n_ovl
