@@ -97,7 +97,9 @@ struct HingeCallLdsT {
 // ------------------------------------------------------------------------------------------------
 // CW wavefronts per workgroup (= per work-list read): four, one slice each, or two with two consecutive slices each - half the
 // wavefronts per read, twice the reads in flight (the kernel is bound by the reads it has in flight: a chain of round trips per read)
-template <int CW>
+// PK: every part of the batch has the 16|16 copies of its span columns (a template parameter: as a run-time branch both load forms'
+// registers were live at once - 158 VGPRs, three wavefronts per SIMD; the kernel lives on the reads it has in flight)
+template <int CW, bool PK>
 __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBatch B) {
     static_assert(CW == 2 || CW == 4, "two or four wavefronts per read");
     constexpr int SPW = WAVES_PER_BLOCK / CW;   // slices per wavefront
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
                 bool nearw[GATHER_LOADS];
                 // (the B-side fields are loaded with the spans, needed or not: 12 more bytes per overlap of a work-list read - 1-2 % of
                 // the part - buy one dependent round trip less per batch)
-                if (span16) {   // (uniform) the kernel moves 3 TB/s of pile-up columns: the packed copies of the spans where the part has them
+                if (PK) {   // the kernel moves TB/s of pile-up columns: the packed copies of the spans where the parts have them
 #pragma unroll
                     for (int u = 0; u < GATHER_LOADS; u++) {
                         const int64_t k = k0 + u * WAVE + lane;

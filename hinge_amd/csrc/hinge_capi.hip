@@ -1348,8 +1348,16 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
     }
 #endif
     { ProfScope _ps(ctx, KID_HINGE_COUNT);
-    if (ctx->count_waves == 2) hipLaunchKernelGGL(k_hinge_count<2>, dim3(std::max(n, (ctx->n_cu * 16 / n) * n)), dim3(2 * WAVE), 0, ctx->stream, to_dev(p), B);
-    else hipLaunchKernelGGL(k_hinge_count<4>, dim3(std::max(n, (ctx->n_cu * 8 / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B); }
+    bool all_packed = true;      // (a batch with a part that has no packed copies runs the int32 form for all: the copies are both or neither per part)
+    for (int k = 0; k < n; k++) all_packed = all_packed && B.part[k].span16 != nullptr;
+    if (!all_packed) for (int k = 0; k < n; k++) { B.part[k].span16 = nullptr; B.part[k].bspan16 = nullptr; }
+    if (ctx->count_waves == 2) {
+        if (all_packed) hipLaunchKernelGGL((k_hinge_count<2, true>), dim3(std::max(n, (ctx->n_cu * 16 / n) * n)), dim3(2 * WAVE), 0, ctx->stream, to_dev(p), B);
+        else hipLaunchKernelGGL((k_hinge_count<2, false>), dim3(std::max(n, (ctx->n_cu * 16 / n) * n)), dim3(2 * WAVE), 0, ctx->stream, to_dev(p), B);
+    } else {
+        if (all_packed) hipLaunchKernelGGL((k_hinge_count<4, true>), dim3(std::max(n, (ctx->n_cu * 8 / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B);
+        else hipLaunchKernelGGL((k_hinge_count<4, false>), dim3(std::max(n, (ctx->n_cu * 8 / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B);
+    } }
     CK(hipGetLastError());
     // Undecided annotations: pile-ups of up to PO_CAP_SMALL overlaps go through the 72 KiB instance, two workgroups per CU (one
     // round instead of two on the E. coli restatement); larger ones through the 144 KiB instance, launched only if a part has
