@@ -41,6 +41,10 @@ int main(int argc, char** argv) {
     put(f, las.span16);
     const std::vector<int64_t> facts = {(int64_t)las.max_pile, las.spans_in_range ? 1 : 0};
     put(f, facts);
+    // what hinge_set_las_image gets besides the mapped file (round 5): the 64-overlap windows of the kept overlaps
+    const bool img = !paf && las.build_image_table();
+    const std::vector<int64_t> img_ok = {img ? 1 : 0};
+    put(f, img_ok); put(f, las.img_win_base); put(f, las.img_rec_rel);
     fclose(f);
     return 0;
 }

@@ -31,7 +31,7 @@ def _read_dump(path):
     hdr = np.frombuffer(raw, np.int64, 4)
     pos = 32
     cols = []
-    for dt in (np.int64, np.int32, np.int32, np.uint32, np.int64, np.int32, np.int64, np.int32, np.int64, np.int32, np.int32, np.uint32, np.int64):
+    for dt in (np.int64, np.int32, np.int32, np.uint32, np.int64, np.int32, np.int64, np.int32, np.int64, np.int32, np.int32, np.uint32, np.int64, np.int64, np.int64, np.uint32):
         n = int(np.frombuffer(raw, np.int64, 1, pos)[0])
         pos += 8
         cols.append(np.frombuffer(raw, dt, n, pos).copy())
@@ -53,7 +53,13 @@ def test_ingest_matches_numpy_reader(datasets, ingest_dump, tmp_path, name, las)
         assert _dump(ingest_dump, db, lasp, out, threads, how) == 0
         assert how == ["sequential" if threads == 1 else "pieces"], how
         hdr, c = _read_dump(out)
-        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span, span16, facts = c
+        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span, span16, facts, img_ok, win_base, rec_rel = c
+        # the image windows of hinge_set_las_image (LasPart::build_image_table) == the numpy helper the GPU tests use
+        if pile.n_ovl:
+            want_wb, want_rel = formats.las_image_table(recs, pile)
+            assert img_ok.tolist() == [1]
+            np.testing.assert_array_equal(win_base, want_wb)
+            np.testing.assert_array_equal(rec_rel, want_rel)
         # what hinge_set_pileups_packed gets besides the columns: the numpy restatement (capi.pack_spans) must agree
         from hinge_amd import capi
         want16, want_pile, want_in_range = capi.pack_spans(pile.row_ptr, pile.a_span, d.rlen)
@@ -162,7 +168,8 @@ def test_fasta_and_paf_ingest_matches_the_oracle(datasets, ingest_dump, oracle_l
         out = str(tmp_path / "paf.bin")
         assert subprocess.run([ingest_dump, "--paf", fa, paf, out], stdout=subprocess.DEVNULL).returncode == 0
         hdr, c = _read_dump(out)
-        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span, span16, facts = c
+        row_ptr, a_span, b_span, b_flag, trace_off, tlen, rec_row_ptr, rec_b, rec_kept, self_a, self_span, span16, facts, img_ok, _, _ = c
+        assert img_ok.tolist() == [0]                          # (PAF input has no .las image: maximal keeps hinge_set_traces)
         assert hdr[0] == n_rec and hdr[2] == x[0, 0] and hdr[3] == x[-1, 0]
         order = np.argsort(x[:, 0], kind="stable")           # the reference files every line under its A read, in file order
         xs = x[order]
