@@ -69,6 +69,32 @@ def test_inconsistent_diffs_are_refused(tmp_path):
     assert e.value.code == capi.HINGE_E_RANGE
 
 
+def test_inconsistent_trace_advances_are_refused_by_the_device_table(tmp_path):
+    """The segment table is made on the device (k_cns_segments, round 5): B advances that run past bepos / the read's end -
+    trace points inconsistent with the alignment's coordinates - are refused with HINGE_E_RANGE as the host loop refused them, the
+    context stays usable (the same alignments with their real trace then run and give the stored indel lists), and an alignment
+    without any trace pair is ONE segment (computeTracePTS's last add, LAInterface.cpp:3470-3500)."""
+    from hinge_amd import capi, formats
+    wd = str(tmp_path)
+    cc.make("cns_tiny", wd)
+    ctx = capi.Context(0)
+    cns = capi.Consensus(ctx, os.path.join(wd, "draft"), os.path.join(wd, "reads"))
+    las = formats.read_las(os.path.join(wd, "draft.reads.las"))
+    picks = list(range(len(las.rec)))
+    good = las.trace.copy()
+    las.trace[1::2] = 250                                  # every segment advances B by 250: far past bepos
+    with pytest.raises(capi.HingeError) as e:
+        cns.run(las, picks)
+    assert e.value.code == capi.HINGE_E_RANGE and "inconsistent" in str(e.value)
+    las.trace[:] = good
+    cns.run(las, picks)
+    first = [cns.indels(k).copy() for k in range(min(len(picks), 20))]
+    cns.run(las, picks)                                    # a second call on the same context: same lists (buffers are reused)
+    for k, w in enumerate(first):
+        assert np.array_equal(cns.indels(k), w)
+    ctx.close()
+
+
 def test_consensus_cli_error_paths(tmp_path):
     """An unreadable config: "Can't load <name>" on stdout and exit code 1 as consensus.cpp:88-93 (the output file exists by then:
     the ofstream is the program's first statement); too few arguments: usage, exit 1 (the reference reads argv[5] unchecked)."""
