@@ -72,7 +72,7 @@ struct hinge_ctx {
     int k2_steal = 2;                         // the persistent workgroups of a batched launch: 0 stay with their own part, 1 go round the parts from their own, 2 all sweep part 0, 1, ... (HINGE_K2_STEAL)
     DevBuf cov_tot, redo_list, spec_sample;   // int[n_reads] coverage sums, int[n_reads] guard-band list, int[spec_ns] sample means
     int spec_band = 1;        // the sweep is exact for every MIN_COV within +- this of the prediction (HINGE_SPEC_BAND)
-    int spec_ns = 4096;       // reads k_spec_predict samples per part (HINGE_SPEC_SAMPLE)
+    int spec_ns = 1024;       // reads k_spec_predict samples per part (HINGE_SPEC_SAMPLE; round 5: 1024 instead of 4096 - the sample median moves by +-0.6 of a coverage unit, MIN_COV is a third of it and the band is +-1: 21.5 -> 16.7 us, no miss)
     int spec_bias = 0;        // tests: added to the prediction (hinge_debug_spec)
     int pass_mode = 0;        // what the current pass's first sweep was: 0 classic, 1 one-sweep through k_mask_annotate_q20<SPEC>, 2 one-sweep through the general kernel
     DevBuf med;       // median histogram scratch (k_median_hist)
