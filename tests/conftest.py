@@ -90,6 +90,17 @@ def datasets(tmp_path_factory):
     return get
 
 
+def free_port():
+    """A TCP port nobody listens on right now, for a test's torch.distributed rendezvous on 127.0.0.1.  (Ports derived from the
+    pid collided: half of the old choices lay in the kernel's ephemeral range, where any outgoing connection of the box may sit -
+    `EADDRINUSE` once in a few hundred runs, and with `pytest -x` the end of the suite.)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def run_in(wd, fn, *args):
     old = os.getcwd()
     os.chdir(wd)

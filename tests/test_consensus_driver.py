@@ -6,6 +6,8 @@ import os
 import re
 
 import pytest
+
+import conftest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -103,7 +105,7 @@ def test_contigs_sharded_over_two_ranks(oracle_lib, tmp_path):
     table = _parse_reference(fasta, log)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 37100 + os.getpid() % 800
+    port = conftest.free_port()
     mp.spawn(_worker, args=(2, port, wd, table, fasta, ret), nprocs=2, join=True)
     got = sorted(ret.get() for _ in range(2))
     assert all(g[1] for g in got)

@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 import pytest
+
+import conftest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -199,7 +201,7 @@ def test_step_pipelined_keeps_jobs_apart():
         mask_all = np.stack([rng.integers(0, 100, n), rng.integers(100, 9000, n)], axis=1).astype(np.int32) + 1000 * k
         v = np.sort(mean_all[mean_all != MEAN_SENTINEL])
         tables.append((mean_all, mask_all, max(5, int(v[len(v) // 2]) // 3)))
-    port = 29500 + (os.getpid() % 400) + 7
+    port = conftest.free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, first, tables, ret)) for r in range(world)]
@@ -272,7 +274,7 @@ def test_part_batch_batches_the_exchanges(R, G):
             v = np.sort(mean_g[ids][mean_g[ids] != MEAN_SENTINEL])
             expect[cut[gi] + j] = max(5, int(v[len(v) // 2]) // 3)
         tables.append((mean_g, mask_g, expect))
-    port = 29500 + (os.getpid() % 400) + 31 + R + 3 * G
+    port = conftest.free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     procs = [ctx.Process(target=_batch_worker, args=(r, world, port, R, G, S, tables, ret)) for r in range(world)]
@@ -315,7 +317,7 @@ def test_sharded_filter_exchanges(oracle_lib, tmp_path, mode, median, equal_bloc
         expect = mlas_min_cov(5, [med(first[k], first[k + 1]) for k in range(2)])
     else:
         expect = [max(5, int(med(0, d.n_reads) / 3))] * 2
-    port = 29500 + (os.getpid() % 2000) + (7 if mlas else 0) + (11 if median == "gather" else 0) + (23 if equal_blocks else 0)
+    port = conftest.free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, mode, median, first, mean_all, mask_all, rows, expect, ret), nprocs=2, join=True)
@@ -402,7 +404,7 @@ def test_sharded_maximal_mask(oracle_lib, tmp_path):
     want = np.zeros(d.n_reads, np.uint8)
     want[np.loadtxt(os.path.join(wd, "G.max"), dtype=np.int64)] = 1
     assert 0 < want.sum() < d.n_reads
-    port = 31500 + (os.getpid() % 2000)
+    port = conftest.free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     want_contained = open(os.path.join(wd, "G.contained.txt")).read().split("\n")[:-1]
@@ -589,7 +591,7 @@ def test_sharded_layout_files(oracle_lib, tmp_path):
     assert run_in(wd, oracle_lib.oracle_layout, b"G", b"G", 1, b"G", b"G", b"nominal.ini") == 0
     n_edges = len(open(os.path.join(wd, "G.edges.hinges")).read().split("\n")) - 1
     assert n_edges > 50 and os.path.getsize(os.path.join(wd, "G.hgraph")) > 0
-    port = 32900 + (os.getpid() % 2000)
+    port = conftest.free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_layout_worker, args=(2, port, wd, list(d.block_first), d.rlen, ret), nprocs=2, join=True)

@@ -16,6 +16,8 @@ import sys
 import numpy as np
 import pytest
 
+import conftest
+
 from conftest import run_in, write_ini
 
 pytestmark = pytest.mark.gpu
@@ -128,7 +130,7 @@ def test_sharded_filter_hip_three_ranks(oracle_lib, tmp_path, mode, median):
     """Three ranks (processes), one block each, B reads everywhere: masks, annotations and the gathered hinge list equal the
     oracle's .mas / .cmas / .repeat.txt / .hinges.txt of ONE run over all blocks (merged .las, or the --mlas loop)."""
     wd, d = _dataset(tmp_path, oracle_lib, mode == "mlas")
-    port = 30100 + (os.getpid() % 1500) + {"hist": 0, "gather": 3}[median] + (5 if mode == "mlas" else 0)
+    port = conftest.free_port()
     ret = _spawn(_sharded_filter_worker, 3, (port, "gloo", wd, list(d.block_first), mode, median, False))
     assert len(set(ret.values())) == 1 and ret[0] > 0
 
@@ -137,7 +139,7 @@ def test_sharded_filter_hip_three_ranks(oracle_lib, tmp_path, mode, median):
 def test_sharded_filter_hip_rccl_forced(oracle_lib, tmp_path, median):
     """One rank, the collectives forced: the same checks with every exchange going through RCCL."""
     wd, d = _dataset(tmp_path, oracle_lib, False, n_blocks=1)
-    port = 31700 + (os.getpid() % 1500) + (1 if median == "gather" else 0)
+    port = conftest.free_port()
     ret = _spawn(_sharded_filter_worker, 1, (port, "nccl", wd, [0, d.n_reads], "merged", median, True))
     assert ret[0] > 0
 
@@ -277,7 +279,7 @@ def test_part_batch_hip_ranks_share_one_gpu(oracle_lib, world, G):
     part of every rank gives the oracle's hinges (count + row digest), and all ranks end with the same mask tables."""
     R = 3
     want = _oracle_expectation(oracle_lib, "chimera", world, R)
-    port = 33300 + (os.getpid() % 1500) + 10 * world + G
+    port = conftest.free_port()
     ret = _spawn(_batch_worker, world, (port, "gloo", "chimera", R, G, False, want))
     assert all(v == ret[0] for v in ret.values()), "mask tables differ between ranks"
 
@@ -333,7 +335,7 @@ def _run_bench(extra_env, workload="chimera", nproc=2):
     env = dict(os.environ)
     env.update({"HINGE_BENCH_BACKEND": "gloo", "HINGE_BENCH_ONE_DEVICE": "1", "HINGE_BENCH_EXPECT": extra_env.pop("expect")})
     env.update(extra_env)
-    port = 36500 + (os.getpid() % 1500) + (7 if extra_env else 0)
+    port = conftest.free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--workload", workload, "--parts", "2"]
     return subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
