@@ -124,6 +124,46 @@ void ref_process_alignment(const int* in, const uint16_t* trace, int tlen, int a
     delete m;
 }
 
+// The whole .las through the reference's OWN reader and its own trim / classify: LAInterface::getOverlap parses the file (records,
+// strand flip, trace points - LAInterface.cpp:1519-1634), then the body of ProcessAlignment (maximal.cpp:65-134) as above with the
+// effective read bounds eff[n_reads][2] (the .mas file, maximal.cpp:524-531).  out[n][12] = A, B, then the ten fields of
+// ref_process_alignment, one row per record in file order (self-overlaps included).  What tests/test_ref_direct_gpu.py holds
+// k_trim_classify_image against: the same FILE on both sides, no array of ours in between.
+long ref_process_las(const char* name_db, const char* las_path, const int* eff, int aln_threshold, int theta, int theta2, int* out, long cap) {
+    LAInterface la;
+    la.openDB(name_db);
+    int n_read = la.getReadNumber();
+    la.openAlignmentFile(las_path);
+    la.resetAlignment();
+    std::vector<LOverlap*> aln;
+    la.getOverlap(aln, 0, n_read);
+    long n = (long)aln.size();
+    for (long i = 0; i < n && i < cap; i++) {
+        LOverlap* m = aln[i];
+        const int a = m->read_A_id_, b = m->read_B_id_;
+        m->eff_read_A_read_start_ = eff[2 * a]; m->eff_read_A_read_end_ = eff[2 * a + 1];
+        m->eff_read_B_read_start_ = eff[2 * b]; m->eff_read_B_read_end_ = eff[2 * b + 1];
+        m->trim_overlap();
+        if (((m->eff_read_B_match_end_ - m->eff_read_B_match_start_) < aln_threshold) ||
+            ((m->eff_read_A_match_end_ - m->eff_read_A_match_start_) < aln_threshold) || (!m->active)) {
+            m->active = false;
+            m->match_type_ = NOT_ACTIVE;
+        } else {
+            m->AddTypesAsymmetric(theta, theta2);
+        }
+        m->weight = m->eff_read_A_match_end_ - m->eff_read_A_match_start_ + m->eff_read_B_match_end_ - m->eff_read_B_match_start_;
+        m->length = m->read_A_match_end_ - m->read_A_match_start_ + m->read_B_match_end_ - m->read_B_match_start_;
+        int* o = out + 12 * i;
+        o[0] = a; o[1] = b;
+        o[2] = m->eff_read_A_match_start_; o[3] = m->eff_read_A_match_end_;
+        o[4] = m->eff_read_B_match_start_; o[5] = m->eff_read_B_match_end_;
+        o[6] = (int)m->match_type_; o[7] = m->active ? 1 : 0; o[8] = m->weight; o[9] = m->length;
+        o[10] = m->eff_start_trace_point_index_; o[11] = m->eff_end_trace_point_index_;
+    }
+    for (auto o : aln) delete o;
+    return n;
+}
+
 int ref_matching_position(int ab, int ae, int bb, int be, int comp, const uint16_t* trace, int tlen, int pos_A) {
     LOverlap* m = make_ovl(ab, ae, bb, be, comp, trace, tlen);
     int r = m->GetMatchingPosition(pos_A);

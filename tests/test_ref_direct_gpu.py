@@ -334,6 +334,52 @@ def test_live_process_alignment_and_matching_position(ref_lib, tspace, tbytes, s
     part.close()
 
 
+@pytest.mark.parametrize("name", ["chimera", "tspace200", "edges", "long_reads"])
+def test_live_las_file_reference_reader_against_the_image_kernel(ref_lib, datasets, tmp_path, name):
+    """The same .las FILE on both sides, no array of ours in between: the reference opens the DB and the file, parses every record
+    and its trace points with its own LAInterface::getOverlap (strand flip included, LAInterface.cpp:1519-1634) and runs its own
+    trim_overlap + AddTypesAsymmetric (ref_process_las: the body of maximal.cpp:65-134); k_trim_classify_image gets the file's bytes
+    and one offset per overlap (hinge_set_las_image) and decodes the records on the device.  All ten fields of every non-self
+    overlap, jittered traces, one- and two-byte traces, both strands, self-overlap records in between, reads of 100 kb."""
+    from conftest import clone_dataset
+    from hinge_amd import capi, formats
+    src, d = datasets(name)
+    wd = clone_dataset(src, str(tmp_path / "w"))
+    recs = formats.read_las(os.path.join(wd, "G.las"))
+    pile = formats.pileups_from_las(recs, d.rlen)
+    rng = np.random.default_rng(5)
+    # effective read bounds as `hinge filter` would write them: masks that cut a few hundred bases, some reads cut deep
+    eff = np.stack([rng.integers(0, 600, size=d.n_reads), d.rlen - rng.integers(0, 600, size=d.n_reads)], axis=1).astype(np.int32)
+    deep = rng.random(d.n_reads) < 0.2
+    eff[deep, 0] += rng.integers(0, 3000, size=int(deep.sum())).astype(np.int32)
+    eff[:, 1] = np.maximum(eff[:, 1], eff[:, 0])
+    eff = np.ascontiguousarray(eff)
+    ref_lib.ref_process_las.restype = ctypes.c_long
+    ref_lib.ref_process_las.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ctypes.c_long]
+    image = np.fromfile(os.path.join(wd, "G.las"), dtype=np.uint8)
+    win_base, rec_rel = formats.las_image_table(recs, pile)
+    ctx = capi.Context(0)
+    ctx.set_reads(d.rlen, None)
+    ctx.set_pileups(0, d.n_reads - 1, pile.row_ptr, pile.a_span, pile.b_span, pile.b_flag)
+    ctx.set_las_image(image, win_base, rec_rel, 1 if recs.tspace <= 125 else 2)
+    ctx.set_eff_reads(eff)
+    types = set()
+    for thr in ((1000, 300, 0), (2500, 50, 100)):
+        want = np.zeros((recs.novl, 12), np.int32)
+        n = ref_lib.ref_process_las(os.path.join(wd, "G").encode(), os.path.join(wd, "G.las").encode(), eff.ctypes.data_as(ip), thr[0], thr[1], thr[2],
+                                    want.ctypes.data_as(ip), recs.novl)
+        assert n == recs.novl
+        want = want[pile.las_index]                                   # the kept (non-self) records, file order = storage order
+        assert np.array_equal(want[:, 1], (pile.b_flag & 0x7FFFFFFF).astype(np.int32))
+        got = ctx.trim_classify_part_full(pile.n_ovl, *thr)
+        bad = np.nonzero((got != want[:, 2:]).any(axis=1))[0]
+        assert len(bad) == 0, (name, thr, len(bad), bad[:5], got[bad[:3]], want[bad[:3]])
+        types |= set(want[:, 6].tolist())
+    assert len(types) >= 5, types
+    assert (pile.b_flag >> 31).any() and not (pile.b_flag >> 31).all()
+    ctx.close()
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_live_profile_coverage(ref_lib, seed):
     """>= 10^5 pile-ups' worth of bins: k_coverage_bins at cut-offs 0, 300 and one that is no multiple of 20, and the bins K2
