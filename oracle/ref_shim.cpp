@@ -164,6 +164,37 @@ long ref_process_las(const char* name_db, const char* las_path, const int* eff, 
     return n;
 }
 
+// .coverage.txt of a .las as `hinge filter` prints it (filter.cpp:599-602), from the reference's own reader and its own
+// profileCoverage: getOverlap over the file, the pile-ups of filter.cpp:529-548 (self-overlaps dropped), then for every read from the
+// first to the last A read of the file "read i pos,cov pos,cov ... \n" of profileCoverage(pile-up, reso, cutoff 0).  What
+// tests/test_ref_direct_gpu.py holds the file written by the GPU executable against, byte for byte.
+int ref_coverage_txt_las(const char* name_db, const char* las_path, int reso, const char* out_path) {
+    LAInterface la;
+    la.openDB(name_db);
+    int n_read = la.getReadNumber();
+    la.openAlignmentFile(las_path);
+    la.resetAlignment();
+    std::vector<LOverlap*> aln;
+    la.getOverlap(aln, 0, n_read);
+    if (aln.empty()) return 1;
+    const int r_begin = aln.front()->read_A_id_, r_end = aln.back()->read_A_id_;
+    std::vector<std::vector<LOverlap*>> pile((size_t)n_read);
+    for (auto o : aln)
+        if (o->read_A_id_ != o->read_B_id_) pile[(size_t)o->read_A_id_].push_back(o);
+    FILE* f = fopen(out_path, "w");
+    if (!f) return 2;
+    for (int i = r_begin; i <= r_end; i++) {
+        std::vector<std::pair<int, int>> coverage;
+        la.profileCoverage(pile[(size_t)i], coverage, reso, 0);
+        fprintf(f, "read %d ", i);
+        for (size_t j = 0; j < coverage.size(); j++) fprintf(f, "%d,%d ", coverage[j].first, coverage[j].second);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    for (auto o : aln) delete o;
+    return 0;
+}
+
 int ref_matching_position(int ab, int ae, int bb, int be, int comp, const uint16_t* trace, int tlen, int pos_A) {
     LOverlap* m = make_ovl(ab, ae, bb, be, comp, trace, tlen);
     int r = m->GetMatchingPosition(pos_A);

@@ -380,3 +380,44 @@ def test_live_reference_two_byte_traces(oracle_lib, ref_lib, datasets):
         assert np.array_equal(_pa(oracle_lib, "oracle", hdr, trace, 1000, 300, 0), _pa(ref_lib, "ref", hdr, trace, 1000, 300, 0))
         for pos in rng.integers(hdr[0] - 20, hdr[1] + 20, size=3):
             assert _mp(oracle_lib, "oracle", hdr, trace, pos) == _mp(ref_lib, "ref", hdr, trace, pos)
+
+
+@pytest.mark.parametrize("name", ["tiny", "edges", "tspace200"])
+def test_live_reference_whole_file_coverage_and_classification(oracle_lib, ref_lib, datasets, tmp_path, name):
+    """Two whole-file pins of the oracle (round 5), each with the reference's OWN reader over the same .las - no array of ours in
+    between: (i) the `.coverage.txt` the oracle's `hinge filter` writes == the text of ref_coverage_txt_las (getOverlap, the
+    pile-ups of filter.cpp:529-548, profileCoverage, the print loop of :599-602), byte for byte; (ii) the oracle's ProcessAlignment
+    of every record == ref_process_las (getOverlap + trim_overlap + AddTypesAsymmetric with the `.mas` bounds the oracle's filter
+    wrote)."""
+    from conftest import clone_dataset, run_in
+    from hinge_amd import formats
+    src, d = datasets(name)
+    wd = clone_dataset(src, str(tmp_path / "w"))
+    assert run_in(wd, oracle_lib.oracle_filter, b"G", b"G.las", 0, b"G", b"nominal.ini", b"") == 0
+    ref_lib.ref_coverage_txt_las.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    want = os.path.join(wd, "ref.coverage.txt")
+    assert ref_lib.ref_coverage_txt_las(os.path.join(wd, "G").encode(), os.path.join(wd, "G.las").encode(), 40, want.encode()) == 0
+    assert open(os.path.join(wd, "G.coverage.txt"), "rb").read() == open(want, "rb").read()
+    # (ii)
+    eff = np.ascontiguousarray(np.loadtxt(os.path.join(wd, "G.mas"), dtype=np.int64)[:, 1:].astype(np.int32))
+    recs = formats.read_las(os.path.join(wd, "G.las"))
+    ref_lib.ref_process_las.restype = ctypes.c_long
+    ref_lib.ref_process_las.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ctypes.c_long]
+    got = np.zeros((recs.novl, 12), np.int32)
+    assert ref_lib.ref_process_las(os.path.join(wd, "G").encode(), os.path.join(wd, "G.las").encode(), P(eff), 1000, 300, 0, P(got), recs.novl) == recs.novl
+    pile = formats.pileups_from_las(recs, d.rlen)
+    got = got[pile.las_index]
+    a_of = np.repeat(np.arange(d.n_reads), np.diff(pile.row_ptr).astype(np.int64))
+    toff = recs.trace_off[:-1][pile.las_index]
+    tlen = recs.rec["tlen"][pile.las_index]
+    tb = 1 if recs.tspace <= 125 else 2
+    u16p = ctypes.POINTER(ctypes.c_uint16)
+    rng = np.random.default_rng(2)
+    for k in rng.integers(0, pile.n_ovl, size=4000):
+        b, comp, a = int(pile.b_flag[k] & 0x7FFFFFFF), int(pile.b_flag[k] >> 31), int(a_of[k])
+        hdr = np.array([pile.a_span[k, 0], pile.a_span[k, 1], pile.b_span[k, 0], pile.b_span[k, 1], comp, eff[a, 0], eff[a, 1], eff[b, 0], eff[b, 1]], np.int32)
+        raw = recs.trace[toff[k]:toff[k] + tlen[k] * tb]
+        tr = raw.astype(np.uint16) if tb == 1 else np.ascontiguousarray(raw).view("<u2").astype(np.uint16)
+        o = np.zeros(10, np.int32)
+        oracle_lib.oracle_process_alignment(P(hdr), tr.ctypes.data_as(u16p), len(tr), 1000, 300, 0, P(o))
+        assert got[k, 0] == a and got[k, 1] == b and np.array_equal(o, got[k, 2:]), (k, o, got[k])

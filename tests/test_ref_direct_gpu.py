@@ -380,6 +380,25 @@ def test_live_las_file_reference_reader_against_the_image_kernel(ref_lib, datase
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["tiny", "edges", "long_reads", "tspace200"])
+def test_live_coverage_txt_of_the_executable_against_the_reference_reader(ref_lib, datasets, tmp_path, name):
+    """`.coverage.txt` as the GPU executable `hinge filter` writes it (the bins k_mask_annotate_q20 stores from its scan registers;
+    reads handed to the general kernel: its own) against the same text made by the reference's own LAInterface::getOverlap +
+    profileCoverage over the same .las (ref_coverage_txt_las: the loop of filter.cpp:529-548, 599-602) - byte for byte."""
+    import subprocess
+    from conftest import clone_dataset
+    src, d = datasets(name)
+    wd = clone_dataset(src, str(tmp_path / "w"))
+    hinge = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hinge_amd", "bin", "hinge")
+    r = subprocess.run([hinge, "filter", "--db", "G", "--las", "G.las", "-x", "G", "--config", "nominal.ini"], cwd=wd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-1500:]
+    ref_lib.ref_coverage_txt_las.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    want_path = os.path.join(wd, "ref.coverage.txt")
+    assert ref_lib.ref_coverage_txt_las(os.path.join(wd, "G").encode(), os.path.join(wd, "G.las").encode(), 40, want_path.encode()) == 0
+    got, want = open(os.path.join(wd, "G.coverage.txt"), "rb").read(), open(want_path, "rb").read()
+    assert len(want) > 10000 and got == want, (len(got), len(want))
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_live_profile_coverage(ref_lib, seed):
     """>= 10^5 pile-ups' worth of bins: k_coverage_bins at cut-offs 0, 300 and one that is no multiple of 20, and the bins K2
