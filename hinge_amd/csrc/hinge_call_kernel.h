@@ -20,7 +20,7 @@
 namespace hinge {
 
 constexpr int HC_SMALL = 64;    // lists up to this size try the tie-free shortcut
-constexpr int PRE_MAXA = 4;     // annotations covered by the count-only sweep
+constexpr int PRE_MAXA = 2;     // annotations covered by one count-only sweep (round 5: two instead of four - 1.2 annotations per work-list read; the registers buy a wavefront per SIMD)
 // (the sort-free scan evaluation bins f - f[0] at 1 bp into 2 * CAP bins of LDS scratch)
 constexpr int GATHER_LOADS = 8;       // pile-up loads a lane of k_hinge_call keeps in flight
 
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
                     it.f0 = min(min(s_minf[tid][0], s_minf[tid][1]), min(s_minf[tid][2], s_minf[tid][3]));
                     it.n = (int)(e - s); it.row = s; it.mask_lo = mk.x; it.mask_hi = mk.y;
                     {   // (the annotation is in registers already - indexed by a lane-varying tid, so by selects - not a dependent re-load)
-                        static_assert(PRE_MAXA == 4, "select chain below");
-                        it.pos = tid == 0 ? apos[0] : tid == 1 ? apos[1] : tid == 2 ? apos[2] : apos[3];
-                        it.type = tid == 0 ? atype[0] : tid == 1 ? atype[1] : tid == 2 ? atype[2] : atype[3];
+                        static_assert(PRE_MAXA == 2, "select chain below");
+                        it.pos = tid == 0 ? apos[0] : apos[1];
+                        it.type = tid == 0 ? atype[0] : atype[1];
                     }
                     it.slot = off + a0 + tid;
                     // pile-ups that fit the half-size instance of k_hinge_call from the front, the others from the back
