@@ -2,7 +2,8 @@
 devices - what `hinge filter --mlas` runs with one rank per visible GPU (filter_main.cpp:103,294; the reference's counterpart is the
 sequential loop over the parts, filter.cpp:474,534,778-787).  Needs two GPUs: on the single-GPU boxes of this build every test
 here is skipped with that reason (the one-rank form runs in tests/test_capi_library.py); tools/scale_smoke.sh runs this file first
-on the first multi-GPU node it meets."""
+on the first multi-GPU node it meets.  (Named to sort LAST: under `pytest -x` a first-contact failure between devices must not hide
+the rest of the suite.)"""
 import ctypes as C
 import itertools
 

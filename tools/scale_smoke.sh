@@ -2,7 +2,7 @@
 # First contact with an N-GPU node: ONE command that yields a scaling curve AND a correctness verdict.
 #   tools/scale_smoke.sh [N]        N = GPUs to use (default: all visible)        output: gpurun_out/scale_smoke/ (or $OUT)
 # What it runs, in order, and what each step proves:
-#   1. pytest -m gpu tests/test_comm_multi_gpu.py     the C++ hosts' RCCL branch (hinge_comm_create / hinge_comm_exchange_mask_rows)
+#   1. pytest -m gpu tests/test_zz_comm_multi_gpu.py     the C++ hosts' RCCL branch (hinge_comm_create / hinge_comm_exchange_mask_rows)
 #                                                     between DISTINCT devices, every device order, results against the host exchange
 #   2. bench.py --gpus n (weak) for n = 1, 2, 4 .. N  one process per GPU over RCCL; every run asserts per part and rank the hinge
 #                                                     counts + digests against the CPU oracle's expectations (tests/golden/bench_expect.json)
@@ -29,7 +29,7 @@ note() { echo "$1" | tee -a "$OUT/summary.txt"; }
 note "scale_smoke: $NVIS visible GPU(s), using $N; tree $(git rev-parse --short HEAD 2>/dev/null || echo '?')"
 if [ "$N" -lt 2 ]; then note "fewer than 2 GPUs: the multi-device steps would only repeat the single-GPU suite - nothing to do"; exit 3; fi
 
-python -m pytest tests/test_comm_multi_gpu.py -x -q -m gpu > "$OUT/1_comm.log" 2>&1; note "1 comm between devices: rc=$?"
+python -m pytest tests/test_zz_comm_multi_gpu.py -x -q -m gpu > "$OUT/1_comm.log" 2>&1; note "1 comm between devices: rc=$?"
 
 PORT=29610
 n=1
