@@ -475,6 +475,16 @@ def main():
                 consensus = json.loads(r.stdout.decode().strip().splitlines()[-1])
             except Exception as ex:      # (reported, not fatal: the headline metric is the filter path's)
                 consensus = {"error": str(ex)[-800:]}
+        maximal_kernel = None
+        if world == 1 and not args.no_e2e:
+            # SURVEY 8(a) rows 14-15, reported beside the headline metric: the kernel `hinge maximal` runs over every overlap of the
+            # bench part (tools/k4_bench.py --json: k_trim_classify_image, launch time from HIP events, its own roofline)
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k4_bench.py"), "--json", "--reps", "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                assert r.returncode == 0, r.stderr.decode()[-1500:]
+                maximal_kernel = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            except Exception as ex:      # (reported, not fatal)
+                maximal_kernel = {"error": str(ex)[-800:]}
         collectives = batch.collectives
         out = {
             "metric": "overlaps/sec through filter+hinge-detect, E. coli 160x" if args.workload == "cfg2_ecoli160" else "overlaps/sec through filter+hinge-detect, %s (NOT the headline configuration)" % args.workload,
@@ -518,6 +528,7 @@ def main():
             "checks": checks,
             "e2e": e2e,
             "consensus": consensus,
+            "maximal_kernel": maximal_kernel,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--json", action="store_true", help="only the form `hinge maximal` runs (+ the column form beside it), one JSON line (bench.py's `maximal_kernel` block)")
     args = ap.parse_args()
     from hinge_amd import capi, synth
     from hinge_amd.config import default_filter_params
@@ -62,8 +63,10 @@ def main():
     cimg.set_las_image(raw, win_base, rec_rel, 1)
     cimg.set_eff_reads(eff)
     out = {}
-    for name, env in (("image", "img"), ("image 12 w/CU", "imgwpc12"), ("image 8 w/CU", "imgwpc8"), ("image cap 8192", "imgcap8192"), ("image cap 12288", "imgcap12288"),
-                      ("stream", None), ("stream 16 w/CU", "wpc16"), ("stream 32 w/CU", "wpc32"), ("stream cap 8192", "cap8192"), ("rows", "1")):
+    timing = {}
+    variants = (("image", "img"), ("stream", None)) if args.json else (("image", "img"), ("image 12 w/CU", "imgwpc12"), ("image 8 w/CU", "imgwpc8"), ("image cap 8192", "imgcap8192"), ("image cap 12288", "imgcap12288"),
+                      ("stream", None), ("stream 16 w/CU", "wpc16"), ("stream 32 w/CU", "wpc32"), ("stream cap 8192", "cap8192"), ("rows", "1"))
+    for name, env in variants:
         use = ctx
         if env and env.startswith("img"):
             use, env = cimg, (env[3:] or None)
@@ -85,12 +88,26 @@ def main():
         use.profile_enable(0)
         out[name] = types
         t = ms / cnt
-        print("%-16s %.3f ms per launch, %d overlaps, mean tlen %.1f B, algorithmic %.2f GB -> %.2f TB/s = %.2f of the HBM peak" %
+        timing[name] = t
+        if not args.json:
+            print("%-16s %.3f ms per launch, %d overlaps, mean tlen %.1f B, algorithmic %.2f GB -> %.2f TB/s = %.2f of the HBM peak" %
               (name, t, n, float(tlen.mean()), alg / 1e9, alg / (t * 1e-3) / 1e12, alg / (t * 1e-3) / 8e12), flush=True)
     os.environ.pop("HINGE_K4_ROWS", None)
     os.environ.pop("HINGE_K4_CAP", None)
     os.environ.pop("HINGE_K4_WAVES_PER_CU", None)
     assert os.environ.get("K4_NOASSERT") or all(np.array_equal(out["stream"], v) for v in out.values()), "the kernels disagree"   # (K4_NOASSERT: ablation builds)
+    if args.json:
+        import json
+        t = timing["image"]
+        print(json.dumps({"kernel": "k_trim_classify_image", "what": "ProcessAlignment (trim_overlap + AddTypesAsymmetric) of EVERY overlap of the bench part: the kernel of `hinge maximal`, "
+                          "the .las image resident in HBM (hinge_set_las_image); HIP events around the launches, %d repetitions" % args.reps,
+                          "overlaps": int(n), "mean_trace_bytes": float(tlen.mean()), "ms_per_launch": t, "overlaps_per_s": n / (t * 1e-3),
+                          "roofline": {"bound": "hbm", "achieved": alg / (t * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / (t * 1e-3) / 8e12,
+                                       "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_overlap": alg / n,
+                                       "note": "SURVEY 8(d): 24 B of record fields + the trace bytes + one 8-byte eff[B] gather per overlap; counter traffic of the same "
+                                               "launch: profiles/*_stages_k4_pmc_summary.csv (2 * FETCH_SIZE + WRITE_SIZE = 3.75 GB: 1.14 x)"},
+                          "column_form_ms_per_launch": timing["stream"], "types_identical_to_the_column_form": True}))
+        return
     print("types identical; histogram:", np.bincount(out["stream"], minlength=14).tolist())
 
 
