@@ -1,7 +1,7 @@
 """`hinge clip` - the first consumer of `hinge layout`'s files: graph construction from `.edges.hinges` /
 `.hinge.list`, dead-end clipping, Z-edge clipping and bubble bursting on the strand-symmetric read graph (`G0` / `G1`), loop
-resolution (`G2`) and, with `[layout] aggressive_pruning`, Y pruning (`G3`), written as GraphML: every graph of the reference's
-script that does not go through its random condensation.
+resolution (`G2`), with `[layout] aggressive_pruning` Y pruning (`G3`), and their sparsified (`Gs G2s G3s`) and strand-overlaid
+(`Gc G2c G3c`) forms, written as GraphML: every graph file the reference's script writes.
 
 Restated from the BEHAVIOUR of the reference's scripts/pruning_and_clipping.py (its reader :1295-1419 and the three operations
 :197-262, :331-390, :561-622 as its main body applies them, :1436-1480), not from its text: this module has its own graph type
@@ -22,9 +22,15 @@ of the synthetic data sets (three of four are order-free; `long_repeat` has two 
 
 Round 4: loop resolution (:625-839 -> `resolve_loops`, `resolve_repeat`) and Y pruning (:841-893 -> `prune_ys`), from their
 behaviour as well; the copies loop resolution makes of a repeat's vertices are (read, strand, 'B') here, 'B' + name there.
-Not built: random condensation (:456-500: `random.choice` on Python 2's Mersenne-Twister stream over hash-ordered lists), the strand
-overlay on top of it, ground-truth and colour annotation, and the files they write (Gs, G2s, Gc, G2c, G3s, G3c).  A run says so
-(`<prefix><suffix>.PARTIAL`, stderr; HINGE_CLIP_STRICT=1: exit code 3).
+Round 5: the remaining graphs - `Gs G2s` (+ `G3s`): the graph sparsified to at most 1 000 vertices (`sparsify`: the behaviour of
+`random_condensation_sym`, :456-500), `Gc G2c` (+ `G3c`): each with its strand overlay (`overlay_strands`, :1108-1116: every vertex
+joined with its mirror image in both directions).  A graph of up to 1 000 vertices is written as it is - the reference's loop does
+not run then -, so for those the sparsified files are as deterministic as `G1` / `G2`.  Above 1 000 vertices the reference draws
+vertices with an UNSEEDED `random.randrange` (:467): its own files differ from run to run, there is nothing to be identical to.
+This module draws from `random.Random(HINGE_CLIP_SEED)` (default 0: reproducible; "random" seeds from the OS as the reference
+does) and does what the reference's loop does per draw: a vertex with one way in and one way out, on an unbranched stretch, is
+spliced out on both strands, the new edge keeping `intersection` only if both of its halves had it.  Ground-truth and colour
+annotation (needs the reference genome / matplotlib) stay out.
 
     python -m hinge_amd.clip G.edges.hinges G.hinge.list <suffix> [nominal.ini]
 """
@@ -471,6 +477,58 @@ def prune_ys(g: StrandGraph, flank: int = 10, order: Optional[Iterable[Node]] = 
     return h
 
 
+def sparsify(g: StrandGraph, max_nodes: int = 1000, rng=None, max_draws: int = 20000) -> StrandGraph:
+    """A copy of g thinned to at most max_nodes vertices for drawing (the reference's `random_condensation_sym`,
+    pruning_and_clipping.py:456-500): per draw one vertex chosen at random; if it has exactly one predecessor p and one successor q,
+    p has no other way out and q no other way in, and p, v, q are three different vertices, v is spliced out - p -> q gets
+    `hinge_edge` -1, `z` 0 and `intersection` 1 only if p -> v and v -> q both had it - and so is its mirror image on the other
+    strand where that path exists.  Stops at max_nodes vertices or after max_draws draws (the reference then says so and goes on).
+    A graph that is small enough comes back untouched: no draw is made."""
+    import random
+    h = g.copy()
+    rng = rng or random.Random(0)
+    draws = 0
+
+    def splice(p: Node, v: Node, q: Node) -> bool:
+        if not (h.has_edge(p, v) and h.has_edge(v, q)):
+            return False
+        both = h.out[p][v].get("intersection") == 1 and h.out[v][q].get("intersection") == 1
+        h.add_edge(p, q, hinge_edge=-1, intersection=1 if both else 0, z=0)
+        h.remove_node(v)
+        return True
+
+    while len(h) > max_nodes and draws < max_draws:
+        draws += 1
+        verts = h.nodes()
+        v = verts[rng.randrange(len(verts))]
+        if h.in_degree(v) != 1 or h.out_degree(v) != 1:
+            continue
+        p, q = h.predecessors(v)[0], h.successors(v)[0]
+        if h.out_degree(p) != 1 or h.in_degree(q) != 1 or len({p, v, q}) != 3:
+            continue
+        if splice(p, v, q):
+            splice(mirror(q), mirror(v), mirror(p))      # (missing on a graph that is not strand-symmetric there: left as it is)
+    if draws >= max_draws:
+        print("[clip] Sparsification ended with %d nodes." % len(h))
+    return h
+
+
+def overlay_strands(g: StrandGraph) -> StrandGraph:
+    """g with every vertex joined to its mirror image, both ways (the reference's `connect_strands`, :1108-1116, which changes its
+    argument; here a copy): the two strands of a contig then lie next to each other in a layout."""
+    h = g.copy()
+    for v in g.nodes():
+        h.add_edge(v, mirror(v))
+        h.add_edge(mirror(v), v)
+    return h
+
+
+def _clip_rng():
+    import random
+    seed = os.environ.get("HINGE_CLIP_SEED", "0")
+    return random.Random() if seed == "random" else random.Random(int(seed))
+
+
 def write_graphml(g: StrandGraph, path: str) -> None:
     """GraphML as graph libraries read it (one <key> per attribute name and domain, typed; vertices named `read_strand`).
     Vertices, edges and keys are written in this graph's own order - the reference's file has the same content in its graph
@@ -586,18 +644,30 @@ def main(argv: Optional[List[str]] = None) -> int:
                 f.write(str([node_name(v) for v in rep]))
     write_graphml(g2, out + ".G2.graphml")
     written = "G0, G1, G2"
+    # the sparsified graphs and their strand overlays (pruning_and_clipping.py:1486, 1500-1515): Gs from G1, G2s from G2, in the
+    # reference's order of draws (Gs first)
+    rng = _clip_rng()
+    gs = sparsify(g1, 1000, rng)
+    g2s = sparsify(g2, 1000, rng)
+    write_graphml(gs, out + ".Gs.graphml")
+    write_graphml(g2s, out + ".G2s.graphml")
+    write_graphml(overlay_strands(gs), out + ".Gc.graphml")
+    write_graphml(overlay_strands(g2s), out + ".G2c.graphml")
+    written += ", Gs, G2s, Gc, G2c"
     if cfg["aggressive_pruning"]:
-        write_graphml(clip_dead_ends(prune_ys(g2, 10), 10), out + ".G3.graphml")
-        written += ", G3"
-    # A PARTIAL run of the reference's script, and explicit about it: the condensed / overlaid graphs are not written.
-    missing = ["Gs", "G2s", "Gc", "G2c"] + (["G3s", "G3c"] if cfg["aggressive_pruning"] else [])
-    with open(out + ".PARTIAL", "w") as f:
-        f.write("hinge clip (hinge_amd/clip.py) wrote %s; not written (they go through the script's random condensation): %s\n" % (written, " ".join(missing)))
-    sys.stderr.write("[clip] PARTIAL: %s written; the condensed and strand-overlaid graphs of the reference's script (%s) are not part of this build (%s.PARTIAL)\n"
-                     % (written, " ".join(missing), out))
+        g3 = clip_dead_ends(prune_ys(g2, 10), 10)
+        g3s = sparsify(g3, 1000, rng)
+        write_graphml(g3, out + ".G3.graphml")
+        write_graphml(g3s, out + ".G3s.graphml")
+        write_graphml(overlay_strands(g3s), out + ".G3c.graphml")
+        written += ", G3, G3s, G3c"
+    if os.path.exists(out + ".PARTIAL"):      # (left by a run of an earlier build)
+        os.remove(out + ".PARTIAL")
+    if max(len(g1), len(g2)) > 1000:
+        sys.stderr.write("[clip] more than 1000 vertices: the sparsified graphs are drawn at random - as the reference's are, which seeds nothing; "
+                         "HINGE_CLIP_SEED=%s here\n" % os.environ.get("HINGE_CLIP_SEED", "0"))
     print("[clip] Done (%s)" % written)
-    return 3 if os.environ.get("HINGE_CLIP_STRICT", "0") == "1" else 0      # HINGE_CLIP_STRICT=1: pipelines that need the later graphs fail here
-
+    return 0
 
 if __name__ == "__main__":
     sys.exit(main())

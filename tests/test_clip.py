@@ -260,22 +260,80 @@ def test_asymmetric_input_takes_the_tolerant_removal_paths():
     assert not h.remove_node((spur[1], 1))             # (already absent: tolerated)
 
 
-def test_partial_run_is_explicit(tmp_path, monkeypatch, capsys):
-    """`hinge clip` writes G0 / G1 only: it says so (stderr, a .PARTIAL marker beside the graphs) and, under HINGE_CLIP_STRICT=1,
-    ends with exit code 3 so that a pipeline that needs the later graphs stops there."""
+def test_every_graph_file_of_the_script_is_written(tmp_path, monkeypatch, capsys):
+    """`hinge clip` writes every graph file the reference's script writes (pruning_and_clipping.py:1480-1532): G0 G1 G2, the
+    sparsified Gs G2s and their strand overlays Gc G2c (G3 G3s G3c only with aggressive pruning).  Up to 1 000 vertices the
+    sparsified graphs are the graphs themselves (the reference's loop does not run), the overlay adds v <-> mirror(v) for every
+    vertex and nothing else; no .PARTIAL marker any more."""
     e = tmp_path / "G.edges.hinges"
     rows = []
     for a, b in zip(range(1, 30), range(2, 31)):
         rows.append(line(a, b, 1000, 0, 0, 0, (0, 900), (100, 1000), (0, 1000), (0, 1000), (0, 900), (100, 1000)))
     e.write_text("\n".join(rows) + "\n")
     (tmp_path / "G.hinge.list").write_text("")
+    (tmp_path / "G.x.PARTIAL").write_text("left by an earlier build\n")
     monkeypatch.chdir(tmp_path)
     assert clip.main(["G.edges.hinges", "G.hinge.list", ".x"]) == 0
-    assert os.path.exists("G.x.G0.graphml") and os.path.exists("G.x.G1.graphml")
-    assert os.path.exists("G.x.G2.graphml") and not os.path.exists("G.x.G3.graphml")
-    assert "Gs" in open("G.x.PARTIAL").read() and "PARTIAL" in capsys.readouterr().err
-    monkeypatch.setenv("HINGE_CLIP_STRICT", "1")
-    assert clip.main(["G.edges.hinges", "G.hinge.list", ".x"]) == 3
+    for name in ("G0", "G1", "G2", "Gs", "G2s", "Gc", "G2c"):
+        assert os.path.exists("G.x.%s.graphml" % name), name
+    assert not os.path.exists("G.x.G3.graphml") and not os.path.exists("G.x.PARTIAL")
+    assert open("G.x.Gs.graphml").read() == open("G.x.G1.graphml").read() and open("G.x.G2s.graphml").read() == open("G.x.G2.graphml").read()
+    n_edge = lambda f: open(f).read().count("<edge ")
+    n_node = lambda f: open(f).read().count("<node ")
+    assert n_node("G.x.Gc.graphml") == n_node("G.x.Gs.graphml") and n_edge("G.x.Gc.graphml") == n_edge("G.x.Gs.graphml") + n_node("G.x.Gs.graphml")
+    (tmp_path / "nominal.ini").write_text("[layout]\naggressive_pruning = 1\n")
+    assert clip.main(["G.edges.hinges", "G.hinge.list", ".y", "nominal.ini"]) == 0
+    for name in ("G3", "G3s", "G3c"):
+        assert os.path.exists("G.y.%s.graphml" % name), name
+
+
+def test_sparsify_splices_unbranched_vertices_on_both_strands():
+    """`sparsify` (the behaviour of random_condensation_sym, :456-500): down to the vertex budget, only vertices with one way in and
+    one way out on an unbranched stretch go, on both strands at once; the graph stays strand-symmetric, junctions and chain ends stay,
+    the spliced edge keeps `intersection` only if both halves had it; the same seed gives the same graph, the draws end at the budget."""
+    import random
+    g = StrandGraph()
+    chain(g, list(range(100, 700)))                     # 600 reads in a row ...
+    chain(g, [350] + list(range(1000, 1400)))           # ... and a branch of 400 off read 350: a junction
+    for u, v, a in g.edges():
+        a["intersection"] = 1
+    g.out[(120, 0)][(121, 0)]["intersection"] = 0       # one edge (and not its mirror image) without the flag
+    assert len(g) == 2 * 1000 and g.is_strand_symmetric()
+    h = clip.sparsify(g, 500, random.Random(7))
+    assert len(h) <= 500 and len(h) % 2 == 0 and h.is_strand_symmetric()
+    for keep in ((100, 0), (699, 0), (1399, 0), (350, 0), (100, 1), (350, 1)):      # ends and the junction are never spliced out
+        assert keep in h, keep
+    assert h.out_degree((350, 0)) == 2 and h.in_degree((350, 1)) == 2
+    # connectivity is what it was: from the first read every surviving forward-strand vertex of both branches is reached
+    seen, todo = set(), [(100, 0)]
+    while todo:
+        v = todo.pop()
+        if v in seen:
+            continue
+        seen.add(v)
+        todo.extend(h.successors(v))
+    assert seen == {v for v in h.nodes() if v[1] == 0}
+    new = [(u, v, a) for u, v, a in h.edges() if a.get("hinge_edge") == -1]
+    assert new and all(a["z"] == 0 and a["intersection"] in (0, 1) for _, _, a in new)
+    # the stretch over the unflagged edge: whatever spliced edge now spans reads 120 -> 121 has lost the flag
+    span = [(u, v, a) for u, v, a in new if u[1] == 0 and u[0] <= 120 and v[0] >= 121 and v[0] < 700]
+    assert all(a["intersection"] == 0 for _, _, a in span)
+    h2 = clip.sparsify(g, 500, random.Random(7))
+    assert edge_set(h2) == edge_set(h)
+    assert edge_set(clip.sparsify(g, 5000, random.Random(1))) == edge_set(g)       # small enough: untouched, no draw
+    # a ring has no end and no junction: every vertex qualifies until two are left per strand (p, v, q must differ)
+    r = StrandGraph()
+    chain(r, list(range(10)) + [0])
+    rr = clip.sparsify(r, 2, random.Random(3), max_draws=2000)
+    assert len(rr) == 4 and rr.is_strand_symmetric()
+
+
+def test_overlay_joins_every_vertex_with_its_mirror_image():
+    g = StrandGraph()
+    chain(g, [1, 2, 3])
+    h = clip.overlay_strands(g)
+    assert edge_set(h) == edge_set(g) | {(v, mirror(v)) for v in g.nodes()}
+    assert edge_set(g) == {((1, 0), (2, 0)), ((2, 0), (3, 0)), ((3, 1), (2, 1)), ((2, 1), (1, 1))}      # the argument is not changed
 
 
 def coord_chain(g, ids, strand=0, step=1000):
