@@ -27,7 +27,7 @@ mkdir -p "$OUT"
 : > "$OUT/summary.txt"; : > "$OUT/scale.jsonl"
 note() { echo "$1" | tee -a "$OUT/summary.txt"; }
 note "scale_smoke: $NVIS visible GPU(s), using $N; tree $(git rev-parse --short HEAD 2>/dev/null || echo '?')"
-if [ "$N" -lt 2 ]; then note "fewer than 2 GPUs: the multi-device steps would only repeat the single-GPU suite - nothing to do"; exit 3; fi
+if [ "$N" -lt 2 ] && [ "${SCALE_SMOKE_DRY:-0}" != "1" ]; then note "fewer than 2 GPUs: the multi-device steps would only repeat the single-GPU suite - nothing to do (SCALE_SMOKE_DRY=1 runs the script's steps on one GPU anyway: a rehearsal of the script, not a scaling result)"; exit 3; fi
 
 python -m pytest tests/test_zz_comm_multi_gpu.py -x -q -m gpu > "$OUT/1_comm.log" 2>&1; note "1 comm between devices: rc=$?"
 
@@ -40,7 +40,8 @@ while [ "$n" -le "$N" ]; do
   note "2 bench weak n=$n: rc=$rc $(tail -1 "$OUT/2_bench_n$n.json" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("value=%.4g ms_per_step=%.4f checks=%s" % (d["value"], d["ms_per_step"], d["checks"]["hinges_and_digests_match_cpu_oracle"]))' 2>/dev/null)"
   PORT=$((PORT + 1)); n=$((n * 2))
 done
-python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus "$N" --scaling strong --no-e2e > "$OUT/3_bench_strong_n$N.json" 2> "$OUT/3_bench_strong_n$N.err"
+if [ "$N" -ge 2 ]; then python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus "$N" --scaling strong --no-e2e > "$OUT/3_bench_strong_n$N.json" 2> "$OUT/3_bench_strong_n$N.err"
+else python bench.py --gpus 1 --scaling strong --no-e2e > "$OUT/3_bench_strong_n$N.json" 2> "$OUT/3_bench_strong_n$N.err"; fi
 rc=$?; tail -1 "$OUT/3_bench_strong_n$N.json" >> "$OUT/scale.jsonl"; note "3 bench strong n=$N: rc=$rc"
 
 python tools/mlas_rccl_check.py > "$OUT/4_mlas_rccl.log" 2>&1; note "4a filter --mlas, RCCL == host exchange: rc=$? ($(tail -1 "$OUT/4_mlas_rccl.log"))"
