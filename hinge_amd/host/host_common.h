@@ -1089,7 +1089,9 @@ struct PartLoader {
 // the SoA columns and the HIP runtime's own teardown: ~0.1 s of a sub-second run.  HINGE_SLOW_EXIT=1 keeps the
 // orderly path (leak checkers).
 inline int finish(hinge_ctx* ctx, PhaseTimer& tm, int code = 0) {
-    if (pipeline().on) { tm.mark("(stage end)"); hinge_ctx_destroy(ctx); return code; }   // the next stage follows in this process
+    // the next stage follows in this process: the context (its device buffers: a few GB of 288) is left to the process's exit -
+    // giving them back costs the NEXT stage 25-30 ms of hipFree (round 5, tools/probes/pipeline_timing.sh); HINGE_SLOW_EXIT=1 frees
+    if (pipeline().on) { tm.mark("(stage end)"); if (getenv("HINGE_SLOW_EXIT")) hinge_ctx_destroy(ctx); return code; }
     if (getenv("HINGE_SLOW_EXIT")) { hinge_ctx_destroy(ctx); return code; }
     tm.mark("(exit)");
     tm.~PhaseTimer();
