@@ -129,6 +129,7 @@ def end_to_end(d, workload):
             t0 = time.perf_counter(); rc = lib.oracle_layout(b"G", b"G.las", 0, b"O", b"O", b"nominal.ini"); t["layout"] = time.perf_counter() - t0; assert rc == 0, rc
         finally:
             os.chdir(cwd)
+        ref_slice = reference_slice(d, tmp)
         hinge = os.path.join(ROOT, "hinge_amd", "bin", "hinge")
         # every stage three times in a row, the median quoted: a stage is 0.3-0.8 s of which 0.1-0.3 s is the HIP runtime's
         # start-up in a fresh process, the noisy part (all three samples are reported)
@@ -167,6 +168,10 @@ def end_to_end(d, workload):
             "speedup_all_three_one_process": sum(t.values()) / sorted(pipe_runs)[1],
             "speedup_filter_layout": (t["filter"] + t["layout"]) / (g["filter"] + g["layout"]),
             "speedup_all_three": sum(t.values()) / sum(g.values()),
+            "speedup_filter_vs_reference_lower_bound": (ref_slice["seconds_full_file"] / g["filter"]) if ref_slice else None,
+            "speedup_filter_vs_reference_lower_bound_note": "the reference's OWN getOverlap + pile-up sort + profileCoverage x2 (cpu_baseline.reference_slice: a strict "
+                                                            "subset of what its `hinge filter` does) over the same .las on this host, one thread, divided by the GPU executable's "
+                                                            "whole `hinge filter` wall clock (ingest, HIP start-up, kernels, text output)",
             "byte_identical": not differing,
             "files_compared": E2E_FILES,
             "files_differing": differing,
@@ -179,10 +184,67 @@ def end_to_end(d, workload):
             "kind": "port",
             "sample": "oracle_filter (CPU restatement of filter.cpp incl. .las parse + text output) on the FULL %s data set: %d reads / %d overlaps, %.1f s wall"
                       % (workload, d.n_reads, d.novl, t["filter"]),
+            "reference_slice": ref_slice,
         }
         return e2e, cpu, oracle_hinges
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def reference_slice(d, tmp):
+    """The reference's OWN code on this host (oracle/_ref/libhinge_ref.so: LAInterface.cpp, DB.c, align.c compiled unmodified; the
+    comparator of filter.cpp through LAInterface.h): `ref_filter_slice` of oracle/ref_shim.cpp - getOverlap over the .las, the pile-up
+    index + std::sort(compare_overlap), profileCoverage twice per read - one thread, timed phase by phase.  The whole file by default;
+    HINGE_BENCH_REF_SLICE=quarter (or less than 32 GB of free host memory: the reference keeps one heap LOverlap + one trace
+    allocation per record, 12.8 GB for this file) runs it on a .las holding the first quarter of the A reads and scales by the
+    record count.  None when oracle/_ref was never built."""
+    import ctypes
+    import numpy as np
+    import oracle
+    from hinge_amd import synth
+    lib = oracle.ref_lib()
+    if lib is None or not hasattr(lib, "ref_filter_slice"):
+        return None
+    mode = os.environ.get("HINGE_BENCH_REF_SLICE", "")
+    if not mode:
+        try:
+            avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")][0] * 1024
+        except Exception:
+            avail = 0
+        mode = "full" if avail >= 32 * 2 ** 30 else "quarter"
+    if mode == "none":
+        return None
+    las = os.path.join(tmp, "G.las")
+    n_rec = d.novl
+    if mode != "full":
+        sel = np.nonzero(d.aread < d.n_reads // 4)[0]
+        las = os.path.join(tmp, "Q.las")
+        synth.write_las_file(d, las, sel)
+        n_rec = int(len(sel))
+    lib.ref_filter_slice.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
+    lib.ref_filter_slice.restype = ctypes.c_int
+    secs = (ctypes.c_double * 3)()
+    cnt = (ctypes.c_longlong * 3)()
+    rc = lib.ref_filter_slice(os.path.join(tmp, "G").encode(), las.encode(), 40, 300, secs, cnt)
+    if rc != 0 or cnt[0] != n_rec:
+        return {"error": "ref_filter_slice rc=%d records=%d (expected %d)" % (rc, cnt[0], n_rec)}
+    total = sum(secs)
+    return {
+        "kind": "reference",
+        "cores": 1,
+        "sample": "%s: %d of %d overlap records (%s)" % (os.path.basename(las), n_rec, d.novl, "the whole file" if mode == "full" else "A reads of the first quarter, scaled by records"),
+        "seconds": total,
+        "seconds_by_phase": {"openDB + getOverlap": secs[0], "pile-up index + std::sort(compare_overlap)": secs[1], "profileCoverage x2 per read": secs[2]},
+        "seconds_full_file": total * d.novl / n_rec,
+        "value": n_rec / total,
+        "unit": "overlaps/s",
+        "covers": "filter.cpp:474-512 (openDB, openAlignmentFile, getOverlap: LAInterface.cpp:1519-1634), :527-548 (pile-up index, self-overlaps dropped), "
+                  ":565-567 (std::sort with compare_overlap), :588-598 (profileCoverage with CUT_OFF and with 0: LAInterface.cpp:4298-4320)",
+        "omits": "inline code of filter.cpp's main() (needs spdlog: unbuildable here): idx_ab maps + dedup pile-up (:569-583), .coverage.txt text + gradient (:599-610), "
+                 "median / MIN_COV (:642-678), coverage + QV masks (:696-789), repeat annotation + merge + gate (:796-865), hinge calling (:867-1068), writers - "
+                 "so this is a LOWER bound on the reference's `hinge filter` time on this host",
+        "checksum": int(cnt[2]),
+    }
 
 
 def describe_workload(name):

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -191,6 +192,52 @@ int ref_coverage_txt_las(const char* name_db, const char* las_path, int reso, co
         fprintf(f, "\n");
     }
     fclose(f);
+    for (auto o : aln) delete o;
+    return 0;
+}
+
+// A TIMED slice of `hinge filter` through the reference's OWN code only (bench.py's cpu_baseline.reference_slice): what
+// filter.cpp's main() does with library calls and its comparator, in its order, on one thread:
+//   secs[0]  LAInterface::openDB + openAlignmentFile + getOverlap(aln, 0, n_read)            filter.cpp:474-512, LAInterface.cpp:1519-1634
+//   secs[1]  the pile-up index (self-overlaps dropped) + std::sort(compare_overlap) per read   filter.cpp:527-548, 565-567
+//   secs[2]  profileCoverage(pile-up, CUT_OFF) + profileCoverage(pile-up, 0) per read          filter.cpp:588-598, LAInterface.cpp:4298-4320
+// OMITTED (inline code of main(), unbuildable here: spdlog): the idx_ab maps and the dedup pile-up (:569-583), the .coverage.txt text
+// and the gradient (:599-610), median / MIN_COV (:642-678), the masks (:696-789), repeat annotation + merge (:796-865), hinge calling
+// (:867-1068), the writers.  So secs[0..2] is a LOWER bound on the reference's filter time for this file.  counts = {records,
+// reads with a pile-up, checksum of the coverage values (keeps the calls alive)}.
+int ref_filter_slice(const char* name_db, const char* las_path, int reso, int cut_off, double* secs, long long* counts) {
+    struct timespec t0, t1, t2, t3;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    LAInterface la;
+    la.openDB(name_db);
+    int n_read = la.getReadNumber();
+    la.openAlignmentFile(las_path);
+    la.resetAlignment();
+    std::vector<LOverlap*> aln;
+    la.getOverlap(aln, 0, n_read);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (aln.empty()) return 1;
+    const int r_begin = aln.front()->read_A_id_, r_end = aln.back()->read_A_id_;
+    std::vector<std::vector<LOverlap*>> idx_pileup((size_t)n_read);
+    for (size_t i = 0; i < aln.size(); i++) {
+        if (aln[i]->read_A_id_ == aln[i]->read_B_id_) aln[i]->active = false;
+        if (aln[i]->active) idx_pileup[(size_t)aln[i]->read_A_id_].push_back(aln[i]);
+    }
+    for (int i = 0; i < n_read; i++) std::sort(idx_pileup[i].begin(), idx_pileup[i].end(), compare_overlap);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    long long sum = 0, with_pile = 0;
+    for (int i = r_begin; i <= r_end; i++) {
+        std::vector<std::pair<int, int>> coverage, cutoff_coverage;
+        la.profileCoverage(idx_pileup[(size_t)i], cutoff_coverage, reso, cut_off);
+        la.profileCoverage(idx_pileup[(size_t)i], coverage, reso, 0);
+        for (size_t j = 0; j < coverage.size(); j++) sum += coverage[j].second;
+        for (size_t j = 0; j < cutoff_coverage.size(); j++) sum += 3 * cutoff_coverage[j].second;
+        with_pile += idx_pileup[(size_t)i].empty() ? 0 : 1;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    auto dt = [](const timespec& a, const timespec& b) { return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); };
+    secs[0] = dt(t0, t1); secs[1] = dt(t1, t2); secs[2] = dt(t2, t3);
+    counts[0] = (long long)aln.size(); counts[1] = with_pile; counts[2] = sum;
     for (auto o : aln) delete o;
     return 0;
 }

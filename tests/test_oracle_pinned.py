@@ -421,3 +421,31 @@ def test_live_reference_whole_file_coverage_and_classification(oracle_lib, ref_l
         o = np.zeros(10, np.int32)
         oracle_lib.oracle_process_alignment(P(hdr), tr.ctypes.data_as(u16p), len(tr), 1000, 300, 0, P(o))
         assert got[k, 0] == a and got[k, 1] == b and np.array_equal(o, got[k, 2:]), (k, o, got[k])
+
+
+def test_live_reference_filter_slice_is_the_same_calls_as_the_coverage_pin(oracle_lib, ref_lib, datasets, tmp_path):
+    """bench.py's cpu_baseline.reference_slice times ref_filter_slice (oracle/ref_shim.cpp): the reference's own getOverlap +
+    pile-up sort + profileCoverage with CUT_OFF and with 0.  Its checksum = sum of the cutoff-0 bins + 3 x sum of the cutoff bins;
+    the cutoff-0 sum is read back from the text ref_coverage_txt_las prints of the same calls, the cutoff sum from the oracle's
+    pinned profileCoverage over the same pile-ups."""
+    from conftest import clone_dataset
+    from hinge_amd import formats
+    src, d = datasets("tiny")
+    wd = clone_dataset(src, str(tmp_path / "w"))
+    ref_lib.ref_filter_slice.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
+    secs = (ctypes.c_double * 3)()
+    cnt = (ctypes.c_longlong * 3)()
+    assert ref_lib.ref_filter_slice(os.path.join(wd, "G").encode(), os.path.join(wd, "G.las").encode(), 40, 300, secs, cnt) == 0
+    recs = formats.read_las(os.path.join(wd, "G.las"))
+    assert cnt[0] == recs.novl and all(x >= 0 for x in secs)
+    ref_lib.ref_coverage_txt_las.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    txt = os.path.join(wd, "ref.coverage.txt")
+    assert ref_lib.ref_coverage_txt_las(os.path.join(wd, "G").encode(), os.path.join(wd, "G.las").encode(), 40, txt.encode()) == 0
+    sum0 = sum(int(pc.split(",")[1]) for line in open(txt) for pc in line.split()[2:])
+    pile = formats.pileups_from_las(recs, d.rlen)
+    sumc = 0
+    for i in range(d.n_reads):
+        s, e = int(pile.row_ptr[i]), int(pile.row_ptr[i + 1])
+        if e > s:
+            sumc += int(_cov(ref_lib, "ref", e - s, pile.a_span[s:e, 0], pile.a_span[s:e, 1], 300)[1].sum())
+    assert cnt[2] == sum0 + 3 * sumc
