@@ -104,6 +104,7 @@ SYMBOLS = [
     ("hinge_pick_pairs", C.c_int64, [C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int64]),
     ("hinge_comm_create", C.c_int, [C.POINTER(_VP), C.c_int32]),
     ("hinge_comm_exchange_mask_rows", C.c_int, [C.POINTER(_VP), C.c_int32, _VP, _VP, C.c_int32]),
+    ("hinge_comm_allgather_rows", C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(_VP), _VP, C.c_int32, _VP, C.c_int64, _VP]),
     ("hinge_consensus_set_db", C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int64]),
     ("hinge_consensus_run", C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int64, C.c_int32]),
     ("hinge_consensus_get_contig", C.c_int, [_VP, C.c_int32, _VP, C.c_int64, C.POINTER(C.c_int64), _VP]),

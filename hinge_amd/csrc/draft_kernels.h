@@ -29,6 +29,29 @@ __device__ __forceinline__ int draft_base(const unsigned char* __restrict__ bps,
     return s.strand ? 3 - cns_base(bps, s.boff, s.rlen - 1 - p) : cns_base(bps, s.boff, p);
 }
 
+// 16 consecutive bases x .. x + 15 of a sequence in ITS frame as one word, the first base in the top two bits (cns_window's form; the
+// complemented strand as CnsPair::winB makes it).  What lies behind the sequence's end is whatever follows: callers bound their use.
+__device__ __forceinline__ unsigned draft_window(const unsigned char* __restrict__ bps, const DraftSeq& s, int x) {
+    const int p0 = s.start + x;
+    if (!s.strand) return cns_window(bps, s.boff, p0);
+    const int p = s.rlen - 1 - p0;            // base x + t is the complement of read base p - t
+    unsigned v;
+    if (p >= 15) v = cns_window(bps, s.boff, p - 15);
+    else { v = 0; for (int t = 0; t <= p; t++) v |= (unsigned)cns_base(bps, s.boff, t) << (2 * (p - t)); }
+    v = __brev(v);
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    return ~v;
+}
+// words of a staged sequence: bases 16 i .. 16 i + 15 in word i, one spare word behind the last base's word
+__host__ __device__ inline int draft_words(int len) { return (len + 15) / 16 + 1; }
+// bases x .. x + 15 out of the staged words (x < len)
+__device__ __forceinline__ unsigned draft_lds_window(const unsigned* W, int x) {
+    const int i = x >> 4;
+    const unsigned long long two = ((unsigned long long)W[i] << 32) | W[i + 1];
+    return (unsigned)((two << (2 * (x & 15))) >> 32);
+}
+__device__ __forceinline__ int draft_lds_base(const unsigned* W, int x) { return (int)((W[x >> 4] >> (30 - 2 * (x & 15))) & 3u); }
+
 constexpr unsigned DRAFT_GAP = 0x80000000u;
 
 __global__ __launch_bounds__(CNS_BLOCK) void k_draft_map(const CnsAln* __restrict__ alns, const CnsSeg* __restrict__ segs, int n_seg, const int* __restrict__ indels,
@@ -70,7 +93,14 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
         const int q_len = J.q.len, t_len = J.t.len, max_d = J.max_d;
         int* V = lds;                       // [2 * max_d + 1]
         int* U = lds + (2 * max_d + 1);
+        // Round 6: both sequences staged in LDS, 16 bases per word in their own frame (strand applied once here, not per base), so a
+        // snake compares 16 base pairs per step - two LDS words per side, one XOR, one count of leading zeros - instead of two
+        // dependent byte loads from global memory per base pair (12 % errors: a snake is ~8 bases, i.e. ONE step).
+        unsigned* Wq = reinterpret_cast<unsigned*>(lds + 2 * (2 * max_d + 1));
+        unsigned* Wt = Wq + draft_words(q_len);
         for (int i = lane; i < 2 * (2 * max_d + 1); i += 64) lds[i] = 0;
+        for (int i = lane; i < draft_words(q_len); i += 64) Wq[i] = draft_window(bps, J.q, 16 * i);
+        for (int i = lane; i < draft_words(t_len); i += 64) Wt[i] = draft_window(bps, J.t, 16 * i);
         __syncthreads();
         const int k_off = max_d, band_size = band_tol * 2;
         unsigned* __restrict__ E = ents + J.ent_off;
@@ -99,7 +129,14 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                     else { pre_minus = 1u; x = V[k - 1 + k_off] + 1; }
                     y = x - k;
                     const int x1 = x;
-                    while (x < q_len && y < t_len && draft_base(bps, J.q, x) == draft_base(bps, J.t, y)) { x++; y++; }
+                    while (true) {          // the snake, 16 base pairs at a time
+                        const int rem = min(q_len - x, t_len - y);
+                        if (rem <= 0) break;
+                        const unsigned df = draft_lds_window(Wq, x) ^ draft_lds_window(Wt, y);
+                        const int m = min(df ? (int)(__clz(df) >> 1) : 16, rem);
+                        x += m; y += m;
+                        if (m < 16) break;
+                    }
                     E[n_ent + idx] = ((unsigned)x1 << 17) | (pre_minus << 16) | (unsigned)x;      // x1 (15 bits) | came from k - 1 | x2 (16 bits)
                     fin = x >= q_len || y >= t_len;
                 }
@@ -158,7 +195,7 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                     if (x_step) {
                         jj += 1;
                         if (jj >= 255) bad_delta = true;
-                        if (lane == 0) TG[n_col] = draft_tag(py, jj & 255, draft_base(bps, J.q, px));
+                        if (lane == 0) TG[n_col] = draft_tag(py, jj & 255, draft_lds_base(Wq, px));
                         px += 1;
                     } else {
                         jj = 0;
@@ -170,7 +207,7 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                 const int run = x2 - x1;    // the snake: run matched pairs
                 if (run > 0) {
                     if (n_col + run > q_len + t_len + 2) { overflow = true; break; }
-                    for (int t = lane; t < run; t += 64) TG[n_col + t] = draft_tag(py + 1 + t, 0, draft_base(bps, J.q, px + t));
+                    for (int t = lane; t < run; t += 64) TG[n_col + t] = draft_tag(py + 1 + t, 0, draft_lds_base(Wq, px + t));
                     n_col += run; px += run; py += run; jj = 0;
                 }
             }

@@ -136,6 +136,7 @@ struct hinge_ctx {
     void* comm = nullptr;               // ncclComm_t of this context among the contexts of its process (comm_capi.inc)
     int comm_rank = -1, comm_size = 0;
     DevBuf comm_stage;                  // all-gathered mask rows [comm_size + 1][S][2]
+    DevBuf comm_rows;                   // hinge_comm_allgather_rows: [comm_size + 1][S] rows (the last block is this rank's send block) + the counts
     int64_t comm_staged_S = 0;          // rows per rank of the last phase-0 exchange (0: nothing staged), and every rank's rows
     std::vector<int32_t> comm_staged_lo, comm_staged_hi;   // in it: phase 1 places from that stage and must be given the same layout
 };

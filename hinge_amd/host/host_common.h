@@ -1049,6 +1049,46 @@ static inline int rank_count(size_t n_parts, bool sequential_only) {
     const int n = e ? atoi(e) : hinge_device_count();
     return std::max(1, std::min(n, (int)n_parts));
 }
+// What the ranks of a --mlas wave hand to the one sequential pass that follows them (containment candidates, classified matches):
+// with a communicator over the ranks' GPUs the rows are all-gathered over RCCL (hinge_comm_allgather_rows) and the pass reads the
+// gathered copy; refused (ranks share a device, no librccl, HINGE_HOST_EXCHANGE=1) they are concatenated on the host - the same
+// bytes either way (tools/mlas_rccl_check.py runs both and compares the stage's files).  HINGE_COMM_ONE_RANK=1 sends a one-rank
+// run's rows through a one-rank communicator too (what a 1-GPU box can exercise of this path).
+struct RowGather {
+    bool rccl = false;
+    std::vector<hinge_ctx*>* ctxs = nullptr;
+    long long waves = 0, rows_moved = 0;
+    Log* log = nullptr;
+    void init(std::vector<hinge_ctx*>& c, const char* what, Log& console) {
+        ctxs = &c;
+        log = &console;
+        const bool one = getenv("HINGE_COMM_ONE_RANK") && atoi(getenv("HINGE_COMM_ONE_RANK")) != 0;
+        rccl = (c.size() > 1 || one) && hinge_comm_create(c.data(), (int32_t)c.size()) == HINGE_OK;
+        if (c.size() > 1 || one) console.info("%zu ranks, %s %s", c.size(), what, rccl ? "over RCCL (one all-gather per wave)" : "through the host");
+    }
+    // parts[k] = rank k's rows (row_bytes each); returns all rows in rank order and, in offs[k], where rank k's begin (in rows)
+    bool gather(const std::vector<const void*>& parts, const std::vector<int64_t>& counts, int row_bytes, std::vector<char>& out, std::vector<int64_t>& offs) {
+        const size_t nw = parts.size();
+        offs.assign(nw + 1, 0);
+        for (size_t k = 0; k < nw; k++) offs[k + 1] = offs[k] + counts[k];
+        out.assign((size_t)std::max<int64_t>(offs[nw], 1) * (size_t)row_bytes, 0);
+        if (rccl && nw == ctxs->size()) {
+            std::vector<int64_t> got(nw, 0);
+            if (hinge_comm_allgather_rows(ctxs->data(), (int32_t)nw, parts.data(), counts.data(), row_bytes, out.data(), offs[nw], got.data()) == HINGE_OK) {
+                waves++; rows_moved += offs[nw];
+                return true;
+            }
+            log->warn("row all-gather failed (%s): this wave's rows go through the host", hinge_last_error((*ctxs)[0]));
+        }
+        for (size_t k = 0; k < nw; k++)
+            if (counts[k]) memcpy(out.data() + (size_t)offs[k] * (size_t)row_bytes, parts[k], (size_t)counts[k] * (size_t)row_bytes);
+        return false;
+    }
+    void report(const char* what) const {
+        if (waves) log->info("%s: %lld rows of %lld wave(s) exchanged over RCCL", what, rows_moved, waves);
+    }
+};
+
 // the first part is loaded before the context is joined; later parts when their turn comes
 struct PartLoader {
     std::unique_ptr<LasPart> first;

@@ -260,6 +260,10 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
         for (int i = 0; i < n_read; i++) active[(size_t)i] = active[(size_t)i] && maximal[(size_t)i];
     }
     std::vector<std::vector<Match>> matches_forward((size_t)n_read), matches_backward((size_t)n_read);
+    // the ranks' classified overlaps reach the one sequential consume pass (hinging.cpp:917-936: matches_forward / _backward in read
+    // order, reads dropped on the way) as ONE all-gather over RCCL per wave; HINGE_HOST_EXCHANGE=1 / shared devices: host data
+    RowGather gather_rows;
+    gather_rows.init(ctxs, "classified matches", console);
     std::vector<LasPart*> parts(las_list.size(), nullptr);
     std::vector<PackedPart*> packed(las_list.size(), nullptr);   // the selected overlaps of every part (GetMatchingPosition needs their traces again)
     int resident_part = -1;            // which packed part the GPU context `ctx` currently holds
@@ -374,6 +378,18 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
             for (auto& t : th) t.join();
             tm.mark("wave: ingest + pick_pairs + upload + classify");
         }
+        {   // every rank's classification rows to every rank: consume() below reads the gathered copy
+            std::vector<const void*> ptrs(nw);
+            std::vector<int64_t> cnts(nw), offs;
+            std::vector<char> all;
+            bool ok = true;
+            for (size_t k = 0; k < nw; k++) { ptrs[k] = fronts[k].cls.data(); cnts[k] = (int64_t)fronts[k].n_sel; ok = ok && fronts[k].code == 0; }
+            if (ok && gather_rows.rccl && gather_rows.gather(ptrs, cnts, (int)sizeof(Classified), all, offs)) {
+                for (size_t k = 0; k < nw; k++)
+                    if (cnts[k]) memcpy(fronts[k].cls.data(), all.data() + (size_t)offs[k] * sizeof(Classified), (size_t)cnts[k] * sizeof(Classified));
+                tm.mark("classified rows all-gather");
+            }
+        }
         bool stale = false;   // a part of this wave deactivated a read: the later fronts were made for an activity that no longer holds
         for (size_t k = 0; k < nw; k++) {
             if (stale) front_half(ctxs[0], w0 + k, fronts[k], false);
@@ -386,6 +402,7 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
 #undef PART_FAIL
 
     tm.mark("matches");
+    gather_rows.report("classified matches");
     auto by_weight = [](const Match& x, const Match& y) { return x.c.weight > y.c.weight; };   // compare_overlap_weight
     for (int i = 0; i < n_read; i++)
         if (active[(size_t)i]) {

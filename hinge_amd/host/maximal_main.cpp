@@ -111,6 +111,10 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
         HH_CHECK(ctxs[(size_t)r], hinge_set_eff_reads(ctxs[(size_t)r], eff.data()));
     }
     tm.mark("ctx_create + set_reads");
+    // the ranks' containment candidates reach the one sequential resolution pass as ONE all-gather over RCCL per wave (maximal.cpp:805-857
+    // is that pass; HINGE_HOST_EXCHANGE=1 or ranks that share a device: host concatenation)
+    RowGather gather_rows;
+    gather_rows.init(ctxs, "containment candidates", console);
 
     struct PartOut {
         int code = 0;
@@ -275,6 +279,16 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
             for (auto& t : th) t.join();
             tm.mark("wave: ingest + H2D + bins + pick_pairs + classify");
         }
+        // every rank's candidate rows (A, B) to every rank; the resolution below reads the gathered copy, part by part
+        std::vector<char> all_pairs;
+        std::vector<int64_t> pair_off;
+        {
+            std::vector<const void*> ptrs(nw);
+            std::vector<int64_t> cnts(nw);
+            bool ok = true;
+            for (size_t k = 0; k < nw; k++) { ptrs[k] = outs[k].pairs.data(); cnts[k] = (int64_t)(outs[k].pairs.size() / 2); ok = ok && outs[k].code == 0; }
+            if (ok) { gather_rows.gather(ptrs, cnts, 2 * (int)sizeof(int32_t), all_pairs, pair_off); if (gather_rows.rccl) tm.mark("candidate rows all-gather"); }
+        }
         for (size_t k = 0; k < nw; k++) {
             PartOut& o = outs[k];
             console.info("name of las: %s", las_list[w0 + k].c_str());
@@ -286,7 +300,8 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
             if (!cov_writer.joinable()) { write_coverage_txt(f_cov, r_begin, o.nb, o.cov, reso); tm.mark("coverage.txt"); }
             // sequential containment resolution, maximal.cpp:780-858
             std::vector<int32_t> containing((size_t)n_read);
-            if (hinge_resolve_containment(n_read, active.data(), (int64_t)(o.pairs.size() / 2), o.pairs.data(), containing.data()) != HINGE_OK) {
+            const int32_t* part_pairs = all_pairs.empty() ? o.pairs.data() : (const int32_t*)all_pairs.data() + 2 * pair_off[k];
+            if (hinge_resolve_containment(n_read, active.data(), (int64_t)(o.pairs.size() / 2), part_pairs, containing.data()) != HINGE_OK) {
                 console.error("containment resolution: malformed candidate list");
                 if (cov_writer.joinable()) cov_writer.join();
                 return 2;
@@ -302,5 +317,6 @@ int HINGE_STAGE_MAIN(int argc, char* argv[]) {
         }
     }
     fclose(f_cov); fclose(f_contained); fclose(f_max);
+    gather_rows.report("containment candidates");
     return finish(ctx, tm);
 }

@@ -313,6 +313,15 @@ int hinge_filter_check(hinge_ctx* ctx);
  * phase 1: the rows of the contexts after it (no further collective).  Synchronises every context's stream.                   */
 int hinge_comm_create(hinge_ctx** ctxs, int32_t n);
 int hinge_comm_exchange_mask_rows(hinge_ctx** ctxs, int32_t n, const int32_t* lo, const int32_t* hi, int32_t phase);
+/* hinge_comm_allgather_rows (round 6): rank k holds counts[k] rows of row_bytes bytes at rows[k] (HOST memory: what its host half made of
+ * its device's results - the containment candidates of `hinge maximal`, maximal.cpp:805-857; the classified matches / hinge rows of
+ * `hinge layout`, hinging.cpp:917-936, :1694-1704).  Two grouped ncclAllGathers over xGMI on the ranks' streams (the counts, then the
+ * rows padded to the largest count) give EVERY rank's device all rows; `out` (host, room for out_cap_rows rows) receives them in
+ * rank order - what the reference's sequential part loop would have accumulated - and out_counts[k] (may be NULL) rank k's count as
+ * delivered.  The order-dependent resolution stays host code on the gathered rows.  Needs hinge_comm_create first; the
+ * executables fall back to plain host concatenation where that was refused (HINGE_HOST_EXCHANGE=1, ranks sharing a device).      */
+int hinge_comm_allgather_rows(hinge_ctx** ctxs, int32_t n, const void* const* rows, const int64_t* counts, int32_t row_bytes, void* out, int64_t out_cap_rows,
+                              int64_t* out_counts);
 
 /* ---- hinge consensus (consensus/consensus.cpp:77-288) --------------------------------------------------
  * The per-contig pile-up vote over base-level realignments.  Replaces, for the alignments the caller selected:

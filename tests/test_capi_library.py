@@ -110,3 +110,46 @@ def test_rccl_between_contexts_one_rank():
     assert b"share a device" in lib.hinge_last_error(ctx.h)
     other.close()
     ctx.close()
+
+
+def _allgather_rows(lib, ctxs, rows):
+    """hinge_comm_allgather_rows over the given contexts: rows[k] = rank k's (n_k, w) int32 array.  Returns the gathered array."""
+    import ctypes as C
+    import numpy as np
+    n = len(ctxs)
+    arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+    w = rows[0].shape[1]
+    ptrs = (C.c_void_p * n)(*[r.ctypes.data_as(C.c_void_p).value if len(r) else None for r in rows])
+    counts = np.array([len(r) for r in rows], np.int64)
+    out = np.full((max(int(counts.sum()), 1), w), -1, np.int32)
+    got = np.zeros(n, np.int64)
+    rc = lib.hinge_comm_allgather_rows(arr, n, ptrs, counts.ctypes.data_as(C.c_void_p), 4 * w, out.ctypes.data_as(C.c_void_p), int(counts.sum()),
+                                       got.ctypes.data_as(C.c_void_p))
+    assert rc == 0, lib.hinge_last_error(ctxs[0].h)
+    assert np.array_equal(got, counts)
+    return out[:int(counts.sum())]
+
+
+@pytest.mark.gpu
+def test_rccl_allgather_rows_one_rank():
+    """hinge_comm_allgather_rows (round 6: containment candidates / classified matches of the executables' ranks over RCCL) as far
+    as a 1-GPU box can run it: a one-rank communicator, both grouped ncclAllGathers, the rows back unchanged; empty and one-row
+    inputs; without a communicator it is refused."""
+    import ctypes as C
+    import numpy as np
+    from hinge_amd import capi
+    lib = capi.load_library()
+    ctx = capi.Context(0)
+    arr = (C.c_void_p * 1)(ctx.h)
+    rng = np.random.default_rng(1)
+    rows = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(12345, 10), dtype=np.int64).astype(np.int32)
+    ptrs = (C.c_void_p * 1)(rows.ctypes.data_as(C.c_void_p).value)
+    cnt = np.array([len(rows)], np.int64)
+    out = np.zeros_like(rows)
+    assert lib.hinge_comm_allgather_rows(arr, 1, ptrs, cnt.ctypes.data_as(C.c_void_p), 40, out.ctypes.data_as(C.c_void_p), len(rows), None) == capi.HINGE_E_ARG
+    assert b"hinge_comm_create" in lib.hinge_last_error(ctx.h)
+    assert lib.hinge_comm_create(arr, 1) == 0, lib.hinge_last_error(ctx.h)
+    for r in (rows, rows[:1], rows[:0], rows[:777, :2].copy()):
+        assert np.array_equal(_allgather_rows(lib, [ctx], [r]), r)
+    assert lib.hinge_comm_allgather_rows(arr, 1, ptrs, cnt.ctypes.data_as(C.c_void_p), 40, out.ctypes.data_as(C.c_void_p), len(rows) - 1, None) == capi.HINGE_E_CAPACITY
+    ctx.close()

@@ -258,3 +258,24 @@ def test_hinge_pipeline_in_one_process(datasets, oracle_lib, tmp_path, name, mla
     # no config file: `hinge filter` returns 1 ("Can't load"), and so does the pipeline, before any later stage runs
     r = subprocess.run([HINGE, "pipeline", "--db", "G"] + las + ["-x", "Q", "--config", "missing.ini", "-o", "Q"], cwd=wd_h, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 1 and not os.path.exists(os.path.join(wd_h, "Q.max"))
+
+
+@pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_mlas", True)])
+def test_cli_rows_through_a_one_rank_communicator(datasets, oracle_lib, tmp_path, name, mlas):
+    """Round 6: `hinge maximal` / `hinge layout` hand their ranks' rows (containment candidates, classified matches) to the sequential
+    pass through hinge_comm_allgather_rows.  A 1-GPU box has one rank: HINGE_COMM_ONE_RANK=1 sends the rows through a one-rank
+    communicator (both grouped ncclAllGathers run); the logs must say so and every file must still equal the oracle's."""
+    src, _ = datasets(name)
+    wd_o = clone_dataset(src, str(tmp_path / "oracle"))
+    wd_h = clone_dataset(src, str(tmp_path / "hip"))
+    assert _oracle(oracle_lib, wd_o, mlas, "nominal.ini") == [0, 0, 0]
+    las = ["--las", "G", "--mlas"] if mlas else ["--las", "G.las"]
+    env = dict(os.environ, HINGE_COMM_ONE_RANK="1", HINGE_RANKS="1")
+    for sub, extra, what in (("filter", [], None), ("maximal", [], "containment candidates"), ("layout", ["-o", "G"], "classified matches")):
+        r = subprocess.run([HINGE, sub, "--db", "G"] + las + ["-x", "G", "--config", "nominal.ini"] + extra, cwd=wd_h, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        text = r.stdout.decode()
+        assert r.returncode == 0, text[-2000:]
+        if what:
+            assert "%s over RCCL" % what in text and "exchanged over RCCL" in text, text[-1500:]
+    bad = [f for f in FILES if not filecmp.cmp(os.path.join(wd_o, f), os.path.join(wd_h, f), shallow=False)]
+    assert not bad, "differs from the oracle: %s" % bad

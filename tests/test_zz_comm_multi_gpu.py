@@ -93,3 +93,24 @@ def test_two_contexts_on_one_device_are_refused():
     assert b"share a device" in lib.hinge_last_error(ctxs[0].h)
     for c in ctxs:
         c.close()
+
+
+def test_allgather_rows_between_devices_every_order():
+    """hinge_comm_allgather_rows (the containment candidates of `hinge maximal --mlas`, the classified matches of `hinge layout --mlas`,
+    maximal.cpp:805-857 / hinging.cpp:917-936) between distinct devices: ragged and empty blocks, every rank order."""
+    from test_capi_library import _allgather_rows
+    nd = _n_devices()
+    if nd < 2:
+        pytest.skip("one visible GPU: RCCL takes one rank per device (the one-rank form is in tests/test_capi_library.py)")
+    use = min(nd, 4)
+    rng = np.random.default_rng(3)
+    for devs in itertools.islice(itertools.permutations(range(nd), use), 6):
+        lib, ctxs = _contexts(devs, 100)
+        arr = (C.c_void_p * use)(*[c.h for c in ctxs])
+        assert lib.hinge_comm_create(arr, use) == 0, lib.hinge_last_error(ctxs[0].h)
+        for sizes in ([5000, 1, 0, 70000][:use], [0] * use, [3] * use, [1, 200000, 2, 3][:use]):
+            rows = [rng.integers(-1000, 1000, size=(s, 10)).astype(np.int32) + 100000 * k for k, s in enumerate(sizes)]
+            want = np.concatenate(rows) if sum(sizes) else np.zeros((0, 10), np.int32)
+            assert np.array_equal(_allgather_rows(lib, ctxs, rows), want), (devs, sizes)
+        for c in ctxs:
+            c.close()

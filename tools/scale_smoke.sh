@@ -2,14 +2,14 @@
 # First contact with an N-GPU node: ONE command that yields a scaling curve AND a correctness verdict.
 #   tools/scale_smoke.sh [N]        N = GPUs to use (default: all visible)        output: gpurun_out/scale_smoke/ (or $OUT)
 # What it runs, in order, and what each step proves:
-#   1. pytest -m gpu tests/test_zz_comm_multi_gpu.py     the C++ hosts' RCCL branch (hinge_comm_create / hinge_comm_exchange_mask_rows)
-#                                                     between DISTINCT devices, every device order, results against the host exchange
+#   1. pytest -m gpu tests/test_zz_comm_multi_gpu.py     the C++ hosts' RCCL branch (hinge_comm_create / hinge_comm_exchange_mask_rows /
+#                                                     hinge_comm_allgather_rows) between DISTINCT devices, every device order, results against the host exchange
 #   2. bench.py --gpus n (weak) for n = 1, 2, 4 .. N  one process per GPU over RCCL; every run asserts per part and rank the hinge
 #                                                     counts + digests against the CPU oracle's expectations (tests/golden/bench_expect.json)
 #   3. bench.py --gpus N --scaling strong             the same total work cut N ways
-#   4. tools/mlas_rccl_check.py + the cfg4 digest test `hinge filter --mlas` with one rank per visible GPU: the log must say "mask rows over RCCL"
-#                                                     and the files must equal a HINGE_HOST_EXCHANGE=1 run's; then all three stages, 8 blocks,
-#                                                     20 files against the CPU oracle's committed digests
+#   4. tools/mlas_rccl_check.py + the cfg4 digest test `hinge filter | maximal | layout --mlas` with one rank per visible GPU: the logs must say "mask rows /
+#                                                     containment candidates / classified matches over RCCL" and the files must equal a
+#                                                     HINGE_HOST_EXCHANGE=1 run's; then all three stages, 8 blocks, 20 files against the CPU oracle's committed digests
 #   5. tests/test_dist_gpu.py                         hinge_amd/dist.py's sharded filter / maximal / layout over real RCCL
 # Every step's exit code goes to summary.txt; the JSON lines of 2-3 to scale.jsonl (efficiency is the reader's to compute).
 set -u
@@ -44,7 +44,8 @@ if [ "$N" -ge 2 ]; then python -m torch.distributed.run --nnodes=1 --nproc-per-n
 else python bench.py --gpus 1 --scaling strong --no-e2e > "$OUT/3_bench_strong_n$N.json" 2> "$OUT/3_bench_strong_n$N.err"; fi
 rc=$?; tail -1 "$OUT/3_bench_strong_n$N.json" >> "$OUT/scale.jsonl"; note "3 bench strong n=$N: rc=$rc"
 
-python tools/mlas_rccl_check.py > "$OUT/4_mlas_rccl.log" 2>&1; note "4a filter --mlas, RCCL == host exchange: rc=$? ($(tail -1 "$OUT/4_mlas_rccl.log"))"
+if [ "$N" -ge 2 ]; then python tools/mlas_rccl_check.py > "$OUT/4_mlas_rccl.log" 2>&1; else python tools/mlas_rccl_check.py --one-rank > "$OUT/4_mlas_rccl.log" 2>&1; fi
+note "4a filter / maximal / layout --mlas, RCCL == host exchange: rc=$? ($(tail -1 "$OUT/4_mlas_rccl.log"))"
 python -m pytest "tests/test_full_size_gpu.py::test_configs_at_their_full_size_against_committed_digests[cfg4_yeast]" -x -q -m gpu > "$OUT/4_cfg4_digests.log" 2>&1
 note "4b cfg4 (8 blocks, --mlas, one rank per visible GPU) against the oracle's digests: rc=$?"
 
