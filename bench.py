@@ -537,6 +537,18 @@ def main():
                 consensus = json.loads(r.stdout.decode().strip().splitlines()[-1])
             except Exception as ex:      # (reported, not fatal: the headline metric is the filter path's)
                 consensus = {"error": str(ex)[-800:]}
+        draft = None
+        if world == 1 and not args.no_e2e:
+            # SURVEY 8(f-4), `hinge draft`'s ladder step at E. coli size (tools/draft_bench.py): k_draft_align + k_draft_cns on 5 000
+            # ladders of ~25 members against the reference's OWN falcon (oracle/_ref: falcon.c + DW_banded.c unmodified) on a sample
+            # of the same ladders, byte-identical or the run fails
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "draft_bench.py")] + (["--no-cpu"] if args.no_cpu_baseline else []),
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                assert r.returncode == 0, r.stderr.decode()[-1500:]
+                draft = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            except Exception as ex:      # (reported, not fatal)
+                draft = {"error": str(ex)[-800:]}
         maximal_kernel = None
         if world == 1 and not args.no_e2e:
             # SURVEY 8(a) rows 14-15, reported beside the headline metric: the kernel `hinge maximal` runs over every overlap of the
@@ -589,6 +601,7 @@ def main():
             "roofline": roofline,
             "checks": checks,
             "e2e": e2e,
+            "draft": draft,
             "consensus": consensus,
             "maximal_kernel": maximal_kernel,
             "cpu_baseline": cpu,

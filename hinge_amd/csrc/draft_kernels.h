@@ -88,7 +88,14 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                                                     int* __restrict__ status) {
     extern __shared__ int lds[];
     const int lane = threadIdx.x;
-    for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
+    // jobs are DRAWN (status[1] is the cursor, zero at launch): an alignment's time follows its edit distance - the template against
+    // itself is over at d = 0, a diverged member takes 250 rounds - and with a fixed stride the launch waited for its unluckiest
+    // wavefront at twice the mean (SQ_WAVE_CYCLES / waves = 51 % of the launch, profiles/r6f_draft_*)
+    while (true) {
+        int jb = 0;
+        if (lane == 0) jb = atomicAdd(status + 1, 1);
+        jb = __builtin_amdgcn_readfirstlane(jb);
+        if (jb >= n_jobs) break;
         const DraftJob J = jobs[jb];
         const int q_len = J.q.len, t_len = J.t.len, max_d = J.max_d;
         int* V = lds;                       // [2 * max_d + 1]
@@ -235,7 +242,11 @@ __global__ __launch_bounds__(64) void k_draft_cns(const DraftJob* __restrict__ j
                                                   int* __restrict__ out_len, unsigned min_cov, int* __restrict__ status) {
     __shared__ int S2[2][256][5];           // doubled scores of the columns of the current and the previous template position
     const int lane = threadIdx.x;
-    for (int ld = blockIdx.x; ld < n_ladders; ld += gridDim.x) {
+    while (true) {                           // ladders are drawn (status[2], zero at launch): their times differ with their members
+        int ld = 0;
+        if (lane == 0) ld = atomicAdd(status + 2, 1);
+        ld = __builtin_amdgcn_readfirstlane(ld);
+        if (ld >= n_ladders) break;
         const DraftLadder L = ladders[ld];
         const bool member = lane < L.n;
         const unsigned* __restrict__ TG = member ? tags + jobs[L.job0 + lane].tag_off : tags;

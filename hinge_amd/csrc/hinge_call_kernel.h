@@ -60,7 +60,14 @@ struct HingePart {
     // outside [0, 65535]): k_hinge_count and k_hinge_call_light move 3 TB/s of pile-up columns - 12 instead of 20 bytes per overlap
     const unsigned* span16;
     const unsigned* bspan16;
+    // round 6: the second-tier items chained BY READ, so that k_hinge_call<CAP> replays a read's pile-up sort once for all of its open
+    // annotations (the order depends on the read only, filter.cpp:565-567).  k_hinge_call_light's pass_on links every item it appends
+    // into its read's chain - rd_head[read] = stamp << 32 | newest item, rd_next2[item] = the one before it - and the FIRST item of a
+    // read files the read in rl2 (front / back by pile-up size, like heavy2); k_hinge_call<CAP> then draws READS.  `stamp` changes with
+    // every launch, so rd_head is never cleared.  rd_head == nullptr: items are drawn one by one as before.
+    unsigned long long* rd_head; unsigned* rd_next2; unsigned* rl2; unsigned* rl2_count; unsigned* rl2_count_big; unsigned stamp;
 };
+constexpr unsigned CHAIN_END = 0xffffffffu;
 constexpr int HEAVY_TIES = 0x40000000;   // in HeavyItem::anno of a second-tier item: k_hinge_call_light evaluated it and the tie order decides
                                          // (the same evaluation in k_hinge_call<CAP> would say the same: it goes straight to the replay)
 constexpr int HINGE_BATCH_MAX = 8;
@@ -311,8 +318,17 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call_light(FilterDev P, HingeBa
     const unsigned long long t_start = wall_clock64();
 #endif
     auto pass_on = [&](const HeavyItem& it) {   // (one thread)
-        if (it.n <= PO_CAP_SMALL) heavy2[atomicAdd(A.heavy2_count, 1u)] = it;
-        else heavy2[heavy_cap - 1u - atomicAdd(A.heavy2_count_big, 1u)] = it;
+        const bool small = it.n <= PO_CAP_SMALL;
+        const unsigned idx = small ? atomicAdd(A.heavy2_count, 1u) : heavy_cap - 1u - atomicAdd(A.heavy2_count_big, 1u);
+        heavy2[idx] = it;
+        if (A.rd_head) {   // the item joins its read's chain; the first item of a read files the read
+            const unsigned long long old = atomicExch(&A.rd_head[it.read], ((unsigned long long)A.stamp << 32) | idx);
+            if ((unsigned)(old >> 32) == A.stamp) A.rd_next2[idx] = (unsigned)old;
+            else {
+                A.rd_next2[idx] = CHAIN_END;
+                A.rl2[small ? atomicAdd(A.rl2_count, 1u) : heavy_cap - 1u - atomicAdd(A.rl2_count_big, 1u)] = (unsigned)it.read;
+            }
+        }
     };
     {   // the bins are zero between items: cleared here once, and after an item only where it counted
         uint4* z = reinterpret_cast<uint4*>(S.cnt);
@@ -517,7 +533,9 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
     const unsigned long long lmask = (1ull << lane) - 1ull;
     // tier2 == 2: ONE instance for both ends of the second-tier list (behind k_hinge_call_light little is left, and an empty launch
     // costs 5 us): first the back (the pile-ups only this instance holds), then the front
-    const unsigned n_first = *heavy_count, n_other = tier2 == 2 ? *(from_back ? A.heavy2_count : A.heavy2_count_big) : 0u;
+    const bool grouped = tier2 != 0 && A.rd_head != nullptr;     // the work list holds READS, every read's items hang on its chain
+    const unsigned n_first = grouped ? *(from_back ? A.rl2_count_big : A.rl2_count) : *heavy_count;
+    const unsigned n_other = tier2 == 2 ? (grouped ? *(from_back ? A.rl2_count : A.rl2_count_big) : *(from_back ? A.heavy2_count : A.heavy2_count_big)) : 0u;
     const unsigned nwork = n_first + n_other;
     while (true) {
         // dynamic work distribution: annotations differ by orders of magnitude in cost
@@ -531,7 +549,12 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
 #endif
         const bool back = w < n_first ? from_back != 0 : from_back == 0;
         const unsigned wi_ = w < n_first ? w : w - n_first;
-        const HeavyItem item = heavy[back ? heavy_cap - 1u - wi_ : wi_];
+        unsigned chain = back ? heavy_cap - 1u - wi_ : wi_;
+        if (grouped) chain = (unsigned)A.rd_head[A.rl2[chain]];
+        bool order_valid = false;        // S.ppos holds this read's pile-up order (block-uniform)
+        for (bool first_of_read = true; chain != CHAIN_END; chain = grouped ? A.rd_next2[chain] : CHAIN_END, first_of_read = false) {
+        if (!first_of_read) __syncthreads();   // (the previous item's scan reads the lists the next gather overwrites)
+        const HeavyItem item = heavy[chain];
         const int i = item.read, a = item.anno & ~HEAVY_TIES;
         const bool ties_known = (item.anno & HEAVY_TIES) != 0;
         const int64_t s = item.row;
@@ -781,7 +804,8 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
 #ifdef HINGE_TIMING
             const unsigned long long tr0 = wall_clock64();
 #endif
-            if (need_order) {
+            if (need_order && !order_valid) {
+                order_valid = true;
                 if (tid == 0 && dbg) atomicAdd(&dbg[4], 1u);
                 for (int64_t k = s + tid; k < e; k += BLOCK) {
                     const int2 av = a_span[k];
@@ -858,6 +882,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
 #endif
             }
         }
+        }   // the read's chain
     }
 }
 

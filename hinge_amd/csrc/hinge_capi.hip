@@ -51,6 +51,9 @@ struct hinge_ctx {
     int no_span16 = 0;         // HINGE_NO_SPAN16=1: keep the streaming kernels on the int32 spans
     bool has_keep = false;
     DevBuf anno_buf, anno_off, anno_cnt, hinge_flag, work_list, heavy_list, heavy2_list, fallback_list, bucket_list, k2_heads;
+    DevBuf rd_head, rd_next2, rl2;      // round 6: the second-tier items chained by read (HingePart::rd_head ...)
+    unsigned pass_stamp = 0;            // ... and the stamp of the last hinge launch (rd_head entries of other launches are stale)
+    int group_reads = 1;                // HINGE_CALL_GROUP=0: k_hinge_call<CAP> draws items one by one (round 5)
     unsigned anno_cap = 0;               // annotation slots (a multiple of N_SHARD: every shard allocates from its own 1 / N_SHARD of them)
     unsigned work_cap = 0;               // work-list slots (the list is interleaved over the shards: n_reads + room for their imbalance)
     DevBuf exact_queue;
@@ -193,6 +196,8 @@ struct Scalars {
     unsigned heavy2_count;              // what it passed on to k_hinge_call<CAP>: front / back of heavy2_list
     unsigned heavy2_count_big;
     unsigned work_next_small;           // the 1024-overlap instance's cursor over the front of heavy2_list (round 5)
+    unsigned rl2_count;                 // round 6: reads with second-tier items (front / back of rl2, like heavy2_list): k_hinge_call<CAP> draws reads
+    unsigned rl2_count_big;
     unsigned redo_count;                // one-sweep pass: length of the guard-band list
     int spec_state;                     // one-sweep pass: 1 = the exact MIN_COV fell outside the band (SpecVerify)
     int status;
@@ -296,6 +301,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_K2_BATCH")) ctx->k2_batch = atoi(g);
     if (const char* g = getenv("HINGE_CALL_LIGHT")) ctx->hinge_light = atoi(g);
     if (const char* g = getenv("HINGE_CALL_MINI")) ctx->hinge_mini = atoi(g);
+    if (const char* g = getenv("HINGE_CALL_GROUP")) ctx->group_reads = atoi(g);
     if (const char* g = getenv("HINGE_COUNT_WAVES")) ctx->count_waves = atoi(g) == 4 ? 4 : 2;
     if (const char* g = getenv("HINGE_K2_STEAL")) ctx->k2_steal = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
@@ -322,7 +328,7 @@ void hinge_ctx_destroy(hinge_ctx* ctx) {
                      &ctx->cmask, &ctx->rflags, &ctx->nbins0, &ctx->anno_buf, &ctx->anno_off, &ctx->anno_cnt, &ctx->hinge_flag,
                      &ctx->work_list, &ctx->heavy_list, &ctx->fallback_list, &ctx->bucket_list, &ctx->k2_heads, &ctx->keep, &ctx->span16, &ctx->exact_queue, &ctx->arena, &ctx->scalars, &ctx->med, &ctx->wave_totals, &ctx->trace, &ctx->trace_off, &ctx->tlen,
                      &ctx->eff_reads, &ctx->pair_sel, &ctx->pair_a, &ctx->pair_out, &ctx->cov_buf, &ctx->cov_off_d, &ctx->cov_nb, &ctx->k2c,
-                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch, &ctx->heavy2_list, &ctx->img_row_base, &ctx->img_rec_rel, &ctx->bspan16};
+                     &ctx->cov_tot, &ctx->redo_list, &ctx->spec_sample, &ctx->final_batch, &ctx->heavy2_list, &ctx->rd_head, &ctx->rd_next2, &ctx->rl2, &ctx->img_row_base, &ctx->img_rec_rel, &ctx->bspan16};
     for (DevBuf* b : all) release(*b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -369,6 +375,8 @@ int hinge_set_reads(hinge_ctx* ctx, int32_t n_reads, const int32_t* rlen, const 
     if ((rc = ensure(ctx, ctx->nbins0, sizeof(int) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_off, sizeof(unsigned) * n))) return rc;
     if ((rc = ensure(ctx, ctx->anno_cnt, sizeof(int) * n))) return rc;
+    if ((rc = ensure(ctx, ctx->rd_head, sizeof(unsigned long long) * n))) return rc;
+    CK(hipMemsetAsync(ctx->rd_head.p, 0, sizeof(unsigned long long) * n, ctx->stream));   // stamp 0 = no launch
     ctx->work_cap = (unsigned)std::min<size_t>(n + (size_t)N_SHARD * 256, 0x7fffffffu);
     if ((rc = ensure(ctx, ctx->work_list, sizeof(WorkItem) * (size_t)ctx->work_cap))) return rc;
     if ((rc = ensure(ctx, ctx->fallback_list, sizeof(int) * n))) return rc;
@@ -428,6 +436,8 @@ static int set_pileups_impl(hinge_ctx* ctx, int32_t r_begin, int32_t r_end, int6
         if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
         if ((rc = ensure(ctx, ctx->heavy2_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->rd_next2, sizeof(unsigned) * (size_t)ctx->anno_cap))) return rc;
+        if ((rc = ensure(ctx, ctx->rl2, sizeof(unsigned) * (size_t)ctx->anno_cap))) return rc;
     }
     if (ctx->exact_cap == 0) {
         ctx->exact_cap = 4096;
@@ -922,6 +932,8 @@ static int grow_annotations(hinge_ctx* ctx) {
     if ((rc = ensure(ctx, ctx->hinge_flag, (size_t)ctx->anno_cap))) return rc;
     if ((rc = ensure(ctx, ctx->heavy_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
     if ((rc = ensure(ctx, ctx->heavy2_list, sizeof(HeavyItem) * (size_t)ctx->anno_cap))) return rc;
+    if ((rc = ensure(ctx, ctx->rd_next2, sizeof(unsigned) * (size_t)ctx->anno_cap))) return rc;
+    if ((rc = ensure(ctx, ctx->rl2, sizeof(unsigned) * (size_t)ctx->anno_cap))) return rc;
     ctx->work_cap = ctx->work_cap * 2;
     return ensure(ctx, ctx->work_list, sizeof(WorkItem) * (size_t)ctx->work_cap);
 }
@@ -1281,6 +1293,12 @@ static HingePart hinge_part_of(hinge_ctx* ctx) {
     a.hinge_flag = (unsigned char*)ctx->hinge_flag.p;
     a.heavy = (HeavyItem*)ctx->heavy_list.p; a.heavy_count = &sc(ctx)->heavy_count; a.heavy_count_big = &sc(ctx)->heavy_count_big; a.heavy_cap = ctx->anno_cap;
     a.heavy2 = (HeavyItem*)ctx->heavy2_list.p; a.heavy2_count = &sc(ctx)->heavy2_count; a.heavy2_count_big = &sc(ctx)->heavy2_count_big; a.work_next_light = &sc(ctx)->work_next_light;
+    if (ctx->group_reads && ctx->rd_head.p && ctx->rd_next2.p && ctx->rl2.p) {
+        a.rd_head = (unsigned long long*)ctx->rd_head.p; a.rd_next2 = (unsigned*)ctx->rd_next2.p; a.rl2 = (unsigned*)ctx->rl2.p;
+        a.rl2_count = &sc(ctx)->rl2_count; a.rl2_count_big = &sc(ctx)->rl2_count_big;
+        if (++ctx->pass_stamp == 0) ctx->pass_stamp = 1;
+        a.stamp = ctx->pass_stamp;
+    }
     a.exact_queue = (int2*)ctx->exact_queue.p; a.exact_count = &sc(ctx)->exact_count; a.exact_cap = ctx->exact_cap;
     a.status = &sc(ctx)->status; a.work_next = &sc(ctx)->work_next; a.work_next_big = &sc(ctx)->work_next_big; a.work_next_small = &sc(ctx)->work_next_small;
     a.dbg = ctx->debug_paths ? sc(ctx)->dbg : (unsigned*)nullptr;
@@ -1439,7 +1457,7 @@ int hinge_filter_hinges(hinge_ctx* ctx, const hinge_filter_params* p) {
     CK(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 16; attempt++) {
         CK(hipMemsetAsync(&sc(ctx)->status, 0, sizeof(int), ctx->stream));
-        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 9 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count, work_next_big, heavy_count_big, work_next_light, heavy2_count, heavy2_count_big, work_next_small
+        CK(hipMemsetAsync(&sc(ctx)->exact_count, 0, 11 * sizeof(unsigned), ctx->stream));   // + work_next, heavy_count, work_next_big, heavy_count_big, work_next_light, heavy2_count, heavy2_count_big, work_next_small, rl2_count, rl2_count_big
         CK(hipMemsetAsync(&sc(ctx)->arena_used, 0, sizeof(unsigned long long), ctx->stream));
         if ((rc = launch_hinges(ctx, p))) return rc;
         int rerun = 0;
