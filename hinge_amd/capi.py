@@ -42,6 +42,7 @@ class CovEstimate(C.Structure):
 _VP = C.c_void_p
 SYMBOLS = [
     ("hinge_device_count", C.c_int, []),
+    ("hinge_ctx_device_memory", C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("hinge_ctx_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
     ("hinge_ctx_destroy", None, [_VP]),
     ("hinge_last_error", C.c_char_p, [_VP]),

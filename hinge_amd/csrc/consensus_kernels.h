@@ -103,7 +103,21 @@ __host__ __device__ inline long long cns_cells(int dcap, int width) { return (lo
 
 // iter_np (LAInterface.cpp:3152-3404) for the segment A[a0, a0 + M) x B[b0, b0 + N).  Writes the indel list (1-based absolute
 // positions: +B position for a gap in B, -(A position) for a gap in A) to out[0..), returns its length, or -1 / -2 on overflow.
-__device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N, CnsWaves w, int dcap, int* __restrict__ out, int out_cap, int& n_ins) {
+// Round 6: LA / LB (may be nullptr) = the segment's two sequences staged in LDS by the caller, 16 bases per word, word j of this lane
+// at L[j * CNS_BLOCK] (bases a0 + 16 j .. of aseq, b0 + 16 j .. of bseq; CNS_LDS_WORDS words each, i.e. M, N <= CNS_LDS_BASES).  The
+// slide then reads two LDS words per side instead of two global words per side for every 16 base pairs it compares, and the
+// trace-back's re-slides single bases out of the same words.
+constexpr int CNS_LDS_WORDS = 12;
+constexpr int CNS_LDS_BASES = 16 * (CNS_LDS_WORDS - 1);
+__device__ __forceinline__ unsigned cns_lds_window(const unsigned* L, int x) {
+    const unsigned* q = L + (x >> 4) * 256;
+    const unsigned long long two = ((unsigned long long)q[0] << 32) | q[256];
+    return (unsigned)((two << (2 * (x & 15))) >> 32);
+}
+__device__ __forceinline__ int cns_lds_base(const unsigned* L, int x) { return (int)((L[(x >> 4) * 256] >> (30 - 2 * (x & 15))) & 3u); }
+
+__device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N, CnsWaves w, int dcap, int* __restrict__ out, int out_cap, int& n_ins,
+                                  const unsigned* LA = nullptr, const unsigned* LB = nullptr) {
     const int del = M - N;
     int low = del >= 0 ? 0 : del, hgh = del >= 0 ? del : 0;
     w.lo0 = low;
@@ -132,7 +146,7 @@ __device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N
             // the slide, 16 bases per step: XOR of the two packed windows, the leading equal pairs counted
             if (j >= 0)
                 while (j < lim) {
-                    const unsigned x = S.winA(a0 + j + k) ^ S.winB(b0 + j);
+                    const unsigned x = LA ? (cns_lds_window(LA, j + k) ^ cns_lds_window(LB, j)) : (S.winA(a0 + j + k) ^ S.winB(b0 + j));
                     const int eq = x ? (__clz((int)x) >> 1) : 16;
                     const int room = lim - j;
                     j += eq < room ? eq : room;
@@ -163,7 +177,8 @@ __device__ inline int cns_iter_np(const CnsPair& S, int a0, int M, int b0, int N
                 int m = k < 0 ? -k : 0;
                 const int vh = w.v(D, h);
                 if (vh <= c) c = vh - 1;
-                while (c >= m && S.A(a0 + c + k) == S.B(b0 + c)) c -= 1;
+                if (LA) { while (c >= m && cns_lds_base(LA, c + k) == cns_lds_base(LB, c)) c -= 1; }
+                else while (c >= m && S.A(a0 + c + k) == S.B(b0 + c)) c -= 1;
                 if (e < 1) {
                     if (c <= w.v(D + 2, k + 1)) { e = 4; h = k + 1; D = D + 2; }
                     else if (c == w.v(D + 1, k)) { e = 0; h = k; D = D + 1; }
@@ -213,6 +228,8 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_realign(CnsSeqs SA, CnsSeqs S
                                                            int* __restrict__ n_indel, int* __restrict__ n_ins_out, int* __restrict__ status) {
     const long long lane_g = (long long)blockIdx.x * CNS_BLOCK + threadIdx.x;
     const long long n_lanes = (long long)gridDim.x * CNS_BLOCK;
+    static_assert(CNS_BLOCK == 256, "cns_lds_window's word stride");
+    __shared__ unsigned LW[2][CNS_LDS_WORDS][CNS_BLOCK];   // 24 KiB: this lane's segment, both sequences, 16 bases per word (lane-private columns: no barrier)
     CnsWaves w;
     w.W = scratch + (lane_g >> 6) * ((long long)rows * row_width * 64) + (lane_g & 63); w.width = row_width; w.lo0 = 0;
     for (long long s = lane_g; s < n_seg; s += n_lanes) {
@@ -224,7 +241,15 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_realign(CnsSeqs SA, CnsSeqs S
         int dcap = al.dcap;
         if (cns_row_width(dcap, del_abs) > row_width || dcap + 3 > rows) { atomicOr(status, CNS_ST_WAVES); n_indel[s] = 0; n_ins_out[s] = 0; continue; }
         int nins = 0;
-        const int cnt = cns_iter_np(S, g.a0, g.m, g.b0, g.n, w, dcap, indels + g.out_off, g.out_cap, nins);
+        // the segment's bases to LDS (independent loads, issued together) unless it is longer than the staging area
+        const bool staged = g.m <= CNS_LDS_BASES && g.n <= CNS_LDS_BASES;
+        if (staged) {
+            const int na = (g.m + 15) / 16 + 1, nb = (g.n + 15) / 16 + 1;
+            for (int j = 0; j < na; j++) LW[0][j][threadIdx.x] = S.winA(g.a0 + 16 * j);
+            for (int j = 0; j < nb; j++) LW[1][j][threadIdx.x] = S.winB(g.b0 + 16 * j);
+        }
+        const int cnt = cns_iter_np(S, g.a0, g.m, g.b0, g.n, w, dcap, indels + g.out_off, g.out_cap, nins,
+                                    staged ? &LW[0][0][threadIdx.x] : (const unsigned*)nullptr, staged ? &LW[1][0][threadIdx.x] : (const unsigned*)nullptr);
         if (cnt < 0) { atomicOr(status, cnt == -1 ? CNS_ST_WAVES : CNS_ST_INDELS); n_indel[s] = 0; n_ins_out[s] = 0; continue; }
         n_indel[s] = cnt;
         n_ins_out[s] = nins;

@@ -566,6 +566,15 @@ int hinge_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+int hinge_ctx_device_memory(hinge_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return HINGE_E_ARG;
+    CK(hipSetDevice(ctx->device));
+    size_t fr = 0, tot = 0;
+    CK(hipMemGetInfo(&fr, &tot));
+    *free_bytes = (int64_t)fr; *total_bytes = (int64_t)tot;
+    return HINGE_OK;
+}
+
 int hinge_set_pile_bins(hinge_ctx* ctx, int32_t reso, const int32_t* nbins, int on_device) {
     if (!ctx || reso <= 0 || !nbins || ctx->r_end < ctx->r_begin || !ctx->nbins0.p) return fail(ctx, HINGE_E_ARG, "hinge_set_pile_bins: bad arguments (call hinge_set_pileups first)");
     CK(hipSetDevice(ctx->device));

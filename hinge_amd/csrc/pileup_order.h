@@ -53,7 +53,6 @@ struct WaveSortLdsT {
     unsigned char small_depth[SEG_CAP];
     int small_cnt;
     int krange[2][4];              // per wavefront: smallest / largest key (the packed form needs their span)
-    int coop[12];                  // round 6, a level with ONE segment partitioned by all four wavefronts: pivot, then per wavefront left / right stoppers, swaps
 };
 typedef WaveSortLdsT<PO_CAP> WaveSortLds;
 
@@ -156,7 +155,6 @@ __device__ inline void wave_small_sort_wide(WS& o, int F, int Lst, int depth0, i
     }
 }
 constexpr int PO_SMALL_SEG = 64;        // segments up to this size are finished by wave_small_sort
-constexpr int PO_COOP_MIN = 256;        // a level's ONLY segment, longer than this, is partitioned by all four wavefronts (round 6)
 
 // The replay with key and element in separate arrays (any 32-bit keys): what block_std_sort_desc falls back to when the keys span
 // 2^20 or more.  Call from ALL threads of a 256-thread workgroup (contains __syncthreads).  On return
@@ -404,99 +402,6 @@ __device__ inline void block_std_sort_desc_packed(WS& o, int n, int tid, int kmi
         const int nc = o.seg_cnt[cur];
         if (nc == 0) break;
         const int nxt = cur ^ 1;
-#ifndef HINGE_SORT_NO_COOP
-        if (nc == 1 && o.seg_depth[cur][0] != 0 && (int)o.seg_last[cur][0] - (int)o.seg_first[cur][0] > PO_COOP_MIN) {
-            // ---- round 6: a level with ONE segment (the top of every sort, and wherever one side of a cut stays big) is partitioned by
-            // ALL FOUR wavefronts - the walk above gives it to one and lets three wait.  The same partition: stoppers are a property of
-            // the segment's content, their ranks are prefix counts, so every wavefront sweeps a quarter of the segment, keeps its
-            // ballots in registers, and after ONE exchange of the four quarter counts writes its stoppers at their global ranks.
-            const int first = o.seg_first[cur][0], last = o.seg_last[cur][0];
-            const int depth = (int)o.seg_depth[cur][0] - 1;
-            if (wib == 0) {
-                const int mid = first + (last - first) / 2;
-                const int cpos = lane == 0 ? first + 1 : (lane == 1 ? mid : last - 1);
-                unsigned cw = 0u;
-                if (lane < 3) cw = pk[cpos];
-                const int ckey = (int)(cw >> PK_SHIFT);
-                const int ka = __builtin_amdgcn_readlane(ckey, 0), kb = __builtin_amdgcn_readlane(ckey, 1), kc = __builtin_amdgcn_readlane(ckey, 2);
-                int msel;
-                if (ka > kb) { if (kb > kc) msel = 1; else if (ka > kc) msel = 2; else msel = 0; }
-                else if (ka > kc) msel = 0;
-                else if (kb > kc) msel = 2;
-                else msel = 1;
-                const int mpos = msel == 0 ? first + 1 : (msel == 1 ? mid : last - 1);
-                const unsigned mw = (unsigned)__builtin_amdgcn_readlane((int)cw, msel);
-                if (lane == 0) { const unsigned fw = pk[first]; pk[first] = mw; pk[mpos] = fw; o.coop[0] = msel == 0 ? ka : (msel == 1 ? kb : kc); }
-            }
-            __syncthreads();
-            const int pivot = o.coop[0];
-            const int lo = first + 1, hi = last;
-            constexpr int COOP_IT = (WS::SEG_CAP * 8 / 4 + 63) / 64;      // sweep iterations of one wavefront at most (a quarter of CAP)
-            const int qlen = (((hi - lo) + 3) / 4 + 63) / 64 * 64;         // quarter, a multiple of 64
-            const int c_lo = lo + wib * qlen, c_hi = min(hi, c_lo + qlen);
-            unsigned long long bl[COOP_IT], br[COOP_IT];
-            int myL = 0, myR = 0;
-#pragma unroll
-            for (int it = 0; it < COOP_IT; it++) {
-                const int p = c_lo + it * 64 + lane;
-                int x = 0;
-                if (p < c_hi) x = (int)(pk[p] >> PK_SHIFT);
-                bl[it] = __ballot(p < c_hi && x <= pivot);
-                br[it] = __ballot(p < c_hi && x >= pivot);
-                myL += __popcll(bl[it]); myR += __popcll(br[it]);
-            }
-            if (lane == 0) { o.coop[1 + wib] = myL; o.coop[5 + wib] = myR; }
-            __syncthreads();
-            int offL = 0, offR = 0, totalL = 0, totalR = 0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) { const int l = o.coop[1 + w], r = o.coop[5 + w]; if (w < wib) { offL += l; offR += r; } totalL += l; totalR += r; }
-#pragma unroll
-            for (int it = 0; it < COOP_IT; it++) {
-                const int p = c_lo + it * 64 + lane;
-                if ((bl[it] >> lane) & 1ull) o.pl[lo + offL + __popcll(bl[it] & lmask)] = (unsigned short)p;
-                if ((br[it] >> lane) & 1ull) o.pr[lo + offR + __popcll(br[it] & lmask)] = (unsigned short)p;
-                offL += __popcll(bl[it]); offR += __popcll(br[it]);
-            }
-            __syncthreads();
-            // swaps are the prefix of k with LS[k] < RS[k] (monotone): every thread tests its k, the trues are counted
-            const int kmax = min(totalL, totalR);
-            int mine = 0;
-            for (int k = tid; k < kmax; k += 256) mine += (o.pl[lo + k] < o.pr[lo + totalR - 1 - k]) ? 1 : 0;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-            if (lane == 0) o.coop[1 + wib] = mine;        // (the quarter counts are consumed: every wavefront passed the barrier above)
-            __syncthreads();
-            const int t = o.coop[1] + o.coop[2] + o.coop[3] + o.coop[4];
-            int cut = 0x7fffffff;
-            if (t < totalL) cut = o.pl[lo + t];
-            if (t >= 1) cut = min(cut, (int)o.pr[lo + totalR - t]);
-            for (int k = tid; k < t; k += 256) {
-                const int a = o.pl[lo + k], b = o.pr[lo + totalR - 1 - k];
-                const unsigned tmp = pk[a]; pk[a] = pk[b]; pk[b] = tmp;
-            }
-            if (wib == 0) {
-                const bool big_l = cut - first > PO_SMALL_SEG, big_r = last - cut > PO_SMALL_SEG;
-                const bool sm_l = !big_l && cut - first > 16, sm_r = !big_r && last - cut > 16;
-                if (!big_l && !sm_l) mark_leaf(o, first, cut, lane);
-                if (!big_r && !sm_r) mark_leaf(o, cut, last, lane);
-                if (lane == 0 && (sm_l || sm_r)) {
-                    int slot = atomicAdd(&o.small_cnt, (int)sm_l + (int)sm_r);
-                    if (sm_l) { o.small_first[slot] = (unsigned short)first; o.small_last[slot] = (unsigned short)cut; o.small_depth[slot] = (unsigned char)depth; ++slot; }
-                    if (sm_r) { o.small_first[slot] = (unsigned short)cut; o.small_last[slot] = (unsigned short)last; o.small_depth[slot] = (unsigned char)depth; }
-                }
-                if (lane == 0 && (big_l || big_r)) {
-                    int slot = atomicAdd(&o.seg_cnt[nxt], (int)big_l + (int)big_r);
-                    if (big_l) { o.seg_first[nxt][slot] = (unsigned short)first; o.seg_last[nxt][slot] = (unsigned short)cut; o.seg_depth[nxt][slot] = (unsigned char)depth; ++slot; }
-                    if (big_r) { o.seg_first[nxt][slot] = (unsigned short)cut; o.seg_last[nxt][slot] = (unsigned short)last; o.seg_depth[nxt][slot] = (unsigned char)depth; }
-                }
-            }
-            __syncthreads();
-            if (tid == 0) o.seg_cnt[cur] = 0;
-            cur = nxt;
-            __syncthreads();
-            continue;
-        }
-#endif
         for (int j = wib; j < nc; j += 4) {
             const int first = o.seg_first[cur][j], last = o.seg_last[cur][j];
             int depth = o.seg_depth[cur][j];

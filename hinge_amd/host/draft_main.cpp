@@ -150,7 +150,11 @@ int main(int argc, char* argv[]) {
         Mapped& las = *maps.back();
         if (!las.open(parts[part]) || las.n < 12) { gpu.join(); die("cannot read the .las file", 1); }
         const int64_t novl = rd<int64_t>(las.p);
-        tspace = rd<int32_t>(las.p + 8);
+        {   //  hinge_draft_mappings takes ONE trace spacing: parts that disagree would be realigned with the wrong segments
+            const int ts = rd<int32_t>(las.p + 8);
+            if (part > 0 && ts != tspace) { gpu.join(); die("the .las parts have different trace spacings", 1); }
+            tspace = ts;
+        }
         const int tbytes = tspace <= 125 ? 1 : 2;
         n_aln += novl;
         console.info("# Alignments: %lld", (long long)novl);
@@ -169,6 +173,8 @@ int main(int argc, char* argv[]) {
             q.a = a; q.b = b; q.comp = (int)(rd<uint32_t>(r + 24) & 1u);
             q.ab = rd<int32_t>(r + 8); q.bb = rd<int32_t>(r + 12); q.ae = rd<int32_t>(r + 16); q.be = rd<int32_t>(r + 20);
             q.alen = db.rlen[(size_t)a]; q.blen = db.rlen[(size_t)b];
+            //  the coordinates index per-base tables below (coverage_of, substr): a corrupt or foreign .las stops here
+            if (q.ab < 0 || q.ab > q.ae || q.ae > q.alen || q.bb < 0 || q.bb > q.be || q.be > q.blen) die("an alignment's coordinates lie outside its reads");
             if (q.comp) { q.bbf = q.blen - q.be; q.bef = q.blen - q.bb; } else { q.bbf = q.bb; q.bef = q.be; }
             q.tlen = tlen; q.tr = r + 40; q.tbytes = tbytes;
             recs.push_back(q);

@@ -1131,7 +1131,19 @@ struct PartLoader {
 inline int finish(hinge_ctx* ctx, PhaseTimer& tm, int code = 0) {
     // the next stage follows in this process: the context (its device buffers: a few GB of 288) is left to the process's exit -
     // giving them back costs the NEXT stage 25-30 ms of hipFree (round 5, tools/probes/pipeline_timing.sh); HINGE_SLOW_EXIT=1 frees
-    if (pipeline().on) { tm.mark("(stage end)"); if (getenv("HINGE_SLOW_EXIT")) hinge_ctx_destroy(ctx); return code; }
+    // (the stages' buffers then add up - on a device that is running short (less than HINGE_PIPELINE_KEEP_FRACTION, default a
+    // quarter, of its memory free) the context IS destroyed: the next stage pays the hipFree, and fits)
+    if (pipeline().on) {
+        tm.mark("(stage end)");
+        bool give_back = getenv("HINGE_SLOW_EXIT") != nullptr;
+        int64_t fr = 0, tot = 0;
+        if (!give_back && hinge_ctx_device_memory(ctx, &fr, &tot) == HINGE_OK && tot > 0) {
+            const double keep = getenv("HINGE_PIPELINE_KEEP_FRACTION") ? atof(getenv("HINGE_PIPELINE_KEEP_FRACTION")) : 0.25;
+            give_back = (double)fr < keep * (double)tot;
+        }
+        if (give_back) hinge_ctx_destroy(ctx);
+        return code;
+    }
     if (getenv("HINGE_SLOW_EXIT")) { hinge_ctx_destroy(ctx); return code; }
     tm.mark("(exit)");
     tm.~PhaseTimer();

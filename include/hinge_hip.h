@@ -68,6 +68,9 @@ typedef struct hinge_cov_estimate {
 /* ---- context ------------------------------------------------------------------------------- */
 int hinge_device_count(void);       /* visible HIP devices (0 if the runtime cannot be initialised) */
 int hinge_ctx_create(int device, hinge_ctx** out);
+/* free / total device memory of the context's GPU in bytes (round 6: `hinge pipeline` keeps a finished stage's buffers for speed and
+ * gives them back only when the device is running short; no counterpart in the reference, which has no device)                    */
+int hinge_ctx_device_memory(hinge_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 void hinge_ctx_destroy(hinge_ctx* ctx);
 const char* hinge_last_error(const hinge_ctx* ctx);
 /* Run all launches on this hipStream_t (e.g. torch's current stream); NULL = the null stream. */
@@ -381,8 +384,11 @@ typedef struct hinge_draft_rung { int32_t read, strand, start, end; } hinge_draf
  *   over template length + 1 positions with min_cov 1 (lib/falcon.c:246-517) - ties, the link-index quirk of its last base and the
  *   lower case of thinly covered bases included.  out_off[l] = where ladder l's string goes in `out` (caller-laid-out slots of at
  *   least 2 * (template length + 1) bytes: out_off[n_ladders] = the buffer's size), out_len[l] = its length.
- *   HINGE_E_CAPACITY: more than 64 members / a member of 32768+ bases; HINGE_E_RANGE: 255+ inserted bases in a row (the
- *   reference's tags are undefined there); HINGE_E_UNDEFINED: its assert(g_best_score != -1). */
+ *   Limits (the reference has none; draft.cpp's ladders are `[draft] tspace` ~ 900-base windows at the data set's coverage):
+ *   HINGE_E_CAPACITY: more than 64 members (one lane per member in the vote), a member of 32768+ bases, or member + template beyond
+ *   ~32 000 bases together (the aligner's V / U arrays, 16 x 0.3 x (q + t) bytes, live in the CU's 160 KB of LDS); HINGE_E_RANGE: 255+
+ *   inserted bases in a row (the reference's tags are undefined there, falcon.c:96); HINGE_E_UNDEFINED: its assert(g_best_score != -1).
+ *   Any of them fails the CALL (all ladders): `draft_assembly` stops as the reference does on its own asserts. */
 int hinge_draft_ladders(hinge_ctx* ctx, int64_t n_ladders, const int64_t* rung_off, const hinge_draft_rung* rungs, const int32_t* template_rung, int32_t band_tolerance,
                         const int64_t* out_off, char* out, int32_t* out_len);
 
