@@ -360,9 +360,6 @@ class PartBatch:
         self.backends: List[Optional[object]] = [None] * self.R
         self.after_gather = None     # test rigs only (bench.py's fault injection): called with the group index after exchange 2; never set by product code
         self.one_sweep = os.environ.get("HINGE_ONE_SWEEP", "1") != "0"     # 0: the two-sweep pass of rounds 1-3 (k_cov_stats first)
-        self.halves = os.environ.get("HINGE_STEP_HALVES", "0") == "1"      # two half-batches on two streams (experiment, see step())
-        self._side = None
-        self._ev = None
 
     # ---- id space ---------------------------------------------------------------------------------------------
     def n_ids(self, p: int) -> int:
@@ -408,36 +405,6 @@ class PartBatch:
             # the one-sweep pass (include/hinge_hip.h): per part ONE sweep over the pile-ups with a predicted MIN_COV that also
             # yields the coverage sums, the exact median as verification (exchange 1 sums its histograms over the ranks), then
             # the ~1 % guard-band reads with the exact MIN_COV
-            if not self.collectives and self.halves and len(B) >= 2:
-                # HINGE_STEP_HALVES=1 (round 6, measured in profiles/EXPERIMENTS.md C6): the parts as two half-batches on two streams,
-                # so that the second half's sweep runs under the first half's latency-bound chain (median -> guard band -> count ->
-                # light -> call).  Nothing crosses a step: both streams start behind the step's first event and the caller's stream
-                # waits for the side stream at the end.
-                main = torch.cuda.current_stream()
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("HINGE_STEP_SIDE_PRIORITY", "0")))
-                    self._ev = (torch.cuda.Event(), torch.cuda.Event())
-                side = self._side
-                h = (len(B) + 1) // 2
-                first, second = B[:h], B[h:]
-                self._ev[0].record(main)
-                side.wait_event(self._ev[0])
-                for b in first:
-                    b.begin()
-                with torch.cuda.stream(side):
-                    for b in second:
-                        b.begin()
-                first[0].sweep_batch(first)
-                with torch.cuda.stream(side):
-                    second[0].sweep_batch(second)
-                first[0].finish_batch(first)
-                first[0].hinges_batch(first)
-                with torch.cuda.stream(side):
-                    second[0].finish_batch(second)
-                    second[0].hinges_batch(second)
-                    self._ev[1].record(side)
-                main.wait_event(self._ev[1])
-                return
             for b in B:
                 b.begin()
             if not self.collectives:
