@@ -44,14 +44,6 @@ __device__ __forceinline__ unsigned draft_window(const unsigned char* __restrict
 }
 // words of a staged sequence: bases 16 i .. 16 i + 15 in word i, one spare word behind the last base's word
 __host__ __device__ inline int draft_words(int len) { return (len + 15) / 16 + 1; }
-// The trace-back's view of the (d, k) records in LDS (round 6): per round d one word n_ent << 12 | (min_k + 2048) - where the round's
-// records start and its first diagonal - and per RECORD one bit, "came from k - 1".  DRAFT_TB_ROUNDS rounds and DRAFT_TB_RECORDS
-// records fit; an alignment that needs more walks the records in HBM as before.
-constexpr int DRAFT_TB_ROUNDS = 320;
-constexpr int DRAFT_TB_RECORDS = 32768;
-constexpr int DRAFT_TB_WORDS = DRAFT_TB_ROUNDS + DRAFT_TB_RECORDS / 32;
-// dynamic LDS of k_draft_align for one job, in ints: V, U, both staged sequences, the trace-back's tables
-__host__ __device__ inline int draft_align_lds_ints(int max_d, int q_len, int t_len) { return 2 * (2 * max_d + 1) + draft_words(q_len) + draft_words(t_len) + DRAFT_TB_WORDS; }
 // bases x .. x + 15 out of the staged words (x < len)
 __device__ __forceinline__ unsigned draft_lds_window(const unsigned* W, int x) {
     const int i = x >> 4;
@@ -113,13 +105,7 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
         // dependent byte loads from global memory per base pair (12 % errors: a snake is ~8 bases, i.e. ONE step).
         unsigned* Wq = reinterpret_cast<unsigned*>(lds + 2 * (2 * max_d + 1));
         unsigned* Wt = Wq + draft_words(q_len);
-        // ... and the trace-back's tables: the path is one dependent look-up per round - ~250 of them, each a round trip to HBM when the
-        // records are only there (two per round with the round table: ~0.4 ms per alignment, most of the kernel's time before this)
-        unsigned* TBD = Wt + draft_words(t_len);        // [DRAFT_TB_ROUNDS]
-        unsigned* TBB = TBD + DRAFT_TB_ROUNDS;          // [DRAFT_TB_RECORDS / 32]
-        bool tb_lds = max_d <= 2047;                    // (min_k + 2048 in 12 bits)
         for (int i = lane; i < 2 * (2 * max_d + 1); i += 64) lds[i] = 0;
-        for (int i = lane; i < DRAFT_TB_RECORDS / 32; i += 64) TBB[i] = 0u;
         for (int i = lane; i < draft_words(q_len); i += 64) Wq[i] = draft_window(bps, J.q, 16 * i);
         for (int i = lane; i < draft_words(t_len); i += 64) Wt[i] = draft_window(bps, J.t, 16 * i);
         __syncthreads();
@@ -135,8 +121,6 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
             const int nk = (max_k - min_k) / 2 + 1;
             if (n_ent + nk > J.ent_cap) { overflow = true; break; }
             if (lane == 0) { DT[2 * d] = n_ent; DT[2 * d + 1] = min_k; }
-            tb_lds = tb_lds && d < DRAFT_TB_ROUNDS && n_ent + nk <= DRAFT_TB_RECORDS && n_ent < (1 << 20);
-            if (tb_lds && lane == 0) TBD[d] = ((unsigned)n_ent << 12) | (unsigned)(min_k + 2048);
             int my_best = -1;
             unsigned long long done_any = 0ull;
             int done_at = 0;
@@ -161,7 +145,6 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                         if (m < 16) break;
                     }
                     E[n_ent + idx] = ((unsigned)x1 << 17) | (pre_minus << 16) | (unsigned)x;      // x1 (15 bits) | came from k - 1 | x2 (16 bits)
-                    if (tb_lds && pre_minus) atomicOr(&TBB[(n_ent + idx) >> 5], 1u << ((n_ent + idx) & 31));
                     fin = x >= q_len || y >= t_len;
                 }
                 __syncthreads();            // (one wavefront: orders the LDS reads above before the writes below)
@@ -197,33 +180,19 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
             __syncthreads();
             if (lane == 0) {
                 int ck = fin_k;
-                if (tb_lds) {
-                    for (int cd = fin_d; cd >= 0; cd--) {
-                        const unsigned w = TBD[cd];
-                        const int at = (int)(w >> 12) + (ck - ((int)(w & 4095u) - 2048)) / 2;
-                        path[cd] = at;
-                        ck = ((TBB[at >> 5] >> (at & 31)) & 1u) ? ck - 1 : ck + 1;
-                    }
-                } else {
-                    for (int cd = fin_d; cd >= 0; cd--) {
-                        const int at = DT[2 * cd] + (ck - DT[2 * cd + 1]) / 2;
-                        path[cd] = at;
-                        ck = ((E[at] >> 16) & 1u) ? ck - 1 : ck + 1;
-                    }
+                for (int cd = fin_d; cd >= 0; cd--) {
+                    const int at = DT[2 * cd] + (ck - DT[2 * cd + 1]) / 2;
+                    path[cd] = at;
+                    ck = ((E[at] >> 16) & 1u) ? ck - 1 : ck + 1;
                 }
             }
-            __syncthreads();
-            // the path's records into LDS (the U half of the V / U space: fin_d < max_d), all lanes at once: the column loop below
-            // read them one by one from HBM, one round trip per round
-            unsigned* EP = reinterpret_cast<unsigned*>(lds + (2 * max_d + 1));
-            for (int cd = lane; cd <= fin_d; cd += 64) EP[cd] = E[path[cd]];
             __syncthreads();
             int jj = 0;                     // consecutive inserted bases in front of the next column
             int py = 0;                     // target bases consumed so far
             int px = 0;
             bool bad_delta = false;
             for (int cd = 0; cd <= fin_d; cd++) {
-                const unsigned e = EP[cd];
+                const unsigned e = E[path[cd]];
                 const int x1 = (int)(e >> 17), x2 = (int)(e & 0xffffu);
                 const int k = x1 - 0;       // (y1 follows from the step kind below)
                 (void)k;
