@@ -98,14 +98,16 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
         if (jb >= n_jobs) break;
         const DraftJob J = jobs[jb];
         const int q_len = J.q.len, t_len = J.t.len, max_d = J.max_d;
-        int* V = lds;                       // [2 * max_d + 1]
-        int* U = lds + (2 * max_d + 1);
+        // V / U as 16-bit cells (x < 32768: a member has fewer bases; x + y < 65536): half the LDS of 32-bit cells, i.e. twice the
+        // wavefronts per CU for a kernel whose wavefronts wait half their cycles (a latency chain per round)
+        unsigned short* V = reinterpret_cast<unsigned short*>(lds);                 // [2 * max_d + 1]
+        unsigned short* U = V + (2 * max_d + 2);
         // Round 6: both sequences staged in LDS, 16 bases per word in their own frame (strand applied once here, not per base), so a
         // snake compares 16 base pairs per step - two LDS words per side, one XOR, one count of leading zeros - instead of two
         // dependent byte loads from global memory per base pair (12 % errors: a snake is ~8 bases, i.e. ONE step).
-        unsigned* Wq = reinterpret_cast<unsigned*>(lds + 2 * (2 * max_d + 1));
+        unsigned* Wq = reinterpret_cast<unsigned*>(lds + (2 * max_d + 2));
         unsigned* Wt = Wq + draft_words(q_len);
-        for (int i = lane; i < 2 * (2 * max_d + 1); i += 64) lds[i] = 0;
+        for (int i = lane; i < 2 * max_d + 2; i += 64) lds[i] = 0;
         for (int i = lane; i < draft_words(q_len); i += 64) Wq[i] = draft_window(bps, J.q, 16 * i);
         for (int i = lane; i < draft_words(t_len); i += 64) Wt[i] = draft_window(bps, J.t, 16 * i);
         __syncthreads();
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                 bool fin = false;
                 if (on) {
                     unsigned pre_minus;
-                    if (k == min_k || (k != max_k && V[k - 1 + k_off] < V[k + 1 + k_off])) { pre_minus = 0u; x = V[k + 1 + k_off]; }
-                    else { pre_minus = 1u; x = V[k - 1 + k_off] + 1; }
+                    if (k == min_k || (k != max_k && V[k - 1 + k_off] < V[k + 1 + k_off])) { pre_minus = 0u; x = (int)V[k + 1 + k_off]; }
+                    else { pre_minus = 1u; x = (int)V[k - 1 + k_off] + 1; }
                     y = x - k;
                     const int x1 = x;
                     while (true) {          // the snake, 16 base pairs at a time
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                     fin = x >= q_len || y >= t_len;
                 }
                 __syncthreads();            // (one wavefront: orders the LDS reads above before the writes below)
-                if (on) { V[k + k_off] = x; U[k + k_off] = x + y; my_best = max(my_best, x + y); }
+                if (on) { V[k + k_off] = (unsigned short)x; U[k + k_off] = (unsigned short)(x + y); my_best = max(my_best, x + y); }
                 done_any = __ballot(on && fin);
                 if (done_any) done_at = it * 64 + (int)__builtin_ctzll(done_any);
                 __syncthreads();
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
             int lo = max_k, hi = min_k;
             for (int idx = lane; idx < nk; idx += 64) {
                 const int k2 = min_k + 2 * idx;
-                if (U[k2 + k_off] >= best_m - band_tol) { lo = min(lo, k2); hi = max(hi, k2); }
+                if ((int)U[k2 + k_off] >= best_m - band_tol) { lo = min(lo, k2); hi = max(hi, k2); }
             }
             for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
             max_k = hi + 1; min_k = lo - 1;

@@ -386,7 +386,8 @@ typedef struct hinge_draft_rung { int32_t read, strand, start, end; } hinge_draf
  *   least 2 * (template length + 1) bytes: out_off[n_ladders] = the buffer's size), out_len[l] = its length.
  *   Limits (the reference has none; draft.cpp's ladders are `[draft] tspace` ~ 900-base windows at the data set's coverage):
  *   HINGE_E_CAPACITY: more than 64 members (one lane per member in the vote), a member of 32768+ bases, or member + template beyond
- *   ~32 000 bases together (the aligner's V / U arrays, 16 x 0.3 x (q + t) bytes, live in the CU's 160 KB of LDS); HINGE_E_RANGE: 255+
+ *   ~61 000 bases together (the aligner's V / U arrays - 16-bit cells, 8 x 0.3 x (q + t) bytes - and both sequences at 2 bits per base
+ *   live in the CU's 160 KB of LDS); HINGE_E_RANGE: 255+
  *   inserted bases in a row (the reference's tags are undefined there, falcon.c:96); HINGE_E_UNDEFINED: its assert(g_best_score != -1).
  *   Any of them fails the CALL (all ladders): `draft_assembly` stops as the reference does on its own asserts. */
 int hinge_draft_ladders(hinge_ctx* ctx, int64_t n_ladders, const int64_t* rung_off, const hinge_draft_rung* rungs, const int32_t* template_rung, int32_t band_tolerance,
