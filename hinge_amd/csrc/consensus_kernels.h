@@ -107,7 +107,10 @@ __host__ __device__ inline long long cns_cells(int dcap, int width) { return (lo
 // at L[j * CNS_BLOCK] (bases a0 + 16 j .. of aseq, b0 + 16 j .. of bseq; CNS_LDS_WORDS words each, i.e. M, N <= CNS_LDS_BASES).  The
 // slide then reads two LDS words per side instead of two global words per side for every 16 base pairs it compares, and the
 // trace-back's re-slides single bases out of the same words.
-constexpr int CNS_LDS_WORDS = 12;
+#ifndef HINGE_CNS_LDS_WORDS
+#define HINGE_CNS_LDS_WORDS 12
+#endif
+constexpr int CNS_LDS_WORDS = HINGE_CNS_LDS_WORDS;      // 12 words per side: segments of up to 176 bases, 24 KiB per workgroup (9 / 10 / 12 words measure the same: profiles/EXPERIMENTS.md C6)
 constexpr int CNS_LDS_BASES = 16 * (CNS_LDS_WORDS - 1);
 __device__ __forceinline__ unsigned cns_lds_window(const unsigned* L, int x) {
     const unsigned* q = L + (x >> 4) * 256;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(CNS_BLOCK) void k_cns_realign(CnsSeqs SA, CnsSeqs S
     const long long lane_g = (long long)blockIdx.x * CNS_BLOCK + threadIdx.x;
     const long long n_lanes = (long long)gridDim.x * CNS_BLOCK;
     static_assert(CNS_BLOCK == 256, "cns_lds_window's word stride");
-    __shared__ unsigned LW[2][CNS_LDS_WORDS][CNS_BLOCK];   // 24 KiB: this lane's segment, both sequences, 16 bases per word (lane-private columns: no barrier)
+    __shared__ unsigned LW[2][CNS_LDS_WORDS][CNS_BLOCK];   // 2 x CNS_LDS_WORDS KiB: this lane's segment, both sequences, 16 bases per word (lane-private columns: no barrier)
     CnsWaves w;
     w.W = scratch + (lane_g >> 6) * ((long long)rows * row_width * 64) + (lane_g & 63); w.width = row_width; w.lo0 = 0;
     for (long long s = lane_g; s < n_seg; s += n_lanes) {
