@@ -103,6 +103,11 @@ def random_paths(rng, spec):
         env["HINGE_K4_CAP"] = str(int(rng.choice([8192, 10240, 12288])))
     if rng.random() < 0.2:
         env["HINGE_COUNT_INT32"] = "1"               # the hinge kernels on the int32 span columns instead of the 16|16 copies
+    # round 6 (drawn after everything above)
+    if rng.random() < 0.25:
+        env["HINGE_CALL_GROUP"] = "0"                # k_hinge_call<CAP> draws items one by one instead of reads with their item chains
+    if rng.random() < 0.3:
+        env["HINGE_COMM_ONE_RANK"] = "1"             # maximal / layout send their rows through a one-rank RCCL communicator (hinge_comm_allgather_rows)
     return env, paf
 
 
