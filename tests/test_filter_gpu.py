@@ -30,12 +30,16 @@ def _compare(wd_o, wd_h):
 
 @pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("tiny_mlas", True), ("tiny_mlas", False),
                                        ("ties", False), ("chimera", False), ("long_repeat", False), ("tspace200", False), ("edges", False)])
-@pytest.mark.parametrize("exact", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("exact", [0, 1, 2, 3, 4, 5])
 def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, monkeypatch, name, mlas, exact):
     """exact: 0 the shipped route (k_hinge_count, then k_hinge_call_light - the order-independent evaluation on sorted supporters -,
     then k_hinge_call<CAP> for what is left), 1 the serial exact kernel, 2 the exact replay in
     LDS, 3 without the light kernel (k_hinge_call<CAP>'s own binned evaluation, rounds 1-3), 4 with the quarter-size instance
-    k_hinge_call<1024> in front of the second tier (HINGE_CALL_MINI=1)."""
+    k_hinge_call<1024> in front of the second tier (HINGE_CALL_MINI=1), 5 the second tier drawing ITEMS as in round 5 instead of reads with
+    their item chains (HINGE_CALL_GROUP=0; the shipped route, 0, draws reads: one sort replay per read)."""
+    if exact == 5:
+        monkeypatch.setenv("HINGE_CALL_GROUP", "0")
+        exact = 0
     if exact == 3:
         monkeypatch.setenv("HINGE_CALL_LIGHT", "0")
         exact = 0
