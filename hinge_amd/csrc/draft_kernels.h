@@ -238,11 +238,16 @@ struct DraftLadder {
     int col_cap;
 };
 constexpr unsigned DRAFT_NONE = 0xffffffffu;
+constexpr int DRAFT_S2_LDS = 32;     // deltas (consecutive inserted bases in front of a template position) whose column scores live in LDS
 
 __global__ __launch_bounds__(64) void k_draft_cns(const DraftJob* __restrict__ jobs, const DraftLadder* __restrict__ ladders, int n_ladders, const unsigned* __restrict__ tags,
                                                   const int* __restrict__ n_tags, unsigned* __restrict__ cols, int* __restrict__ tbase, char* __restrict__ out,
-                                                  int* __restrict__ out_len, unsigned min_cov, int* __restrict__ status) {
-    __shared__ int S2[2][256][5];           // doubled scores of the columns of the current and the previous template position
+                                                  int* __restrict__ out_len, unsigned min_cov, int* __restrict__ status, int* __restrict__ s2_far) {
+    // doubled scores of the columns of the current and the previous template position.  Round 6: the columns of the first
+    // DRAFT_S2_LDS deltas in LDS (1.3 instead of 10 KiB per wavefront: 32 instead of 16 wavefronts per CU for a kernel that is one
+    // dependent chain per ladder), the rest - 32+ inserted bases in a row - in a per-workgroup stretch of s2_far
+    __shared__ int S2[2][DRAFT_S2_LDS][5];
+    int* __restrict__ const S2F = s2_far + (size_t)blockIdx.x * (2 * 256 * 5);
     const int lane = threadIdx.x;
     while (true) {                           // ladders are drawn (status[2], zero at launch): their times differ with their members
         int ld = 0;
@@ -275,7 +280,10 @@ __global__ __launch_bounds__(64) void k_draft_cns(const DraftJob* __restrict__ j
                 const int base = (int)(tg & 7u);
                 // this lane's predecessor score (doubled); a first tag has none
                 int ps = 0;
-                if (has && prev != DRAFT_NONE) ps = S2[(prev >> 11) & 1u][(prev >> 3) & 255u][prev & 7u];
+                if (has && prev != DRAFT_NONE) {
+                    const unsigned pt = (prev >> 11) & 1u, pd = (prev >> 3) & 255u, pb = prev & 7u;
+                    ps = pd < (unsigned)DRAFT_S2_LDS ? S2[pt][pd][pb] : S2F[(pt * 256 + pd) * 5 + pb];
+                }
                 for (int kk = 0; kk < 5; kk++) {
                     unsigned long long M = __ballot(has && base == kk);
                     int best = -2;
@@ -291,7 +299,10 @@ __global__ __launch_bounds__(64) void k_draft_cns(const DraftJob* __restrict__ j
                         ck++;
                         M &= ~same;
                     }
-                    if (lane == 0) { S2[t & 1][delta][kk] = best; C[slot * 5 + kk] = best_p; }
+                    if (lane == 0) {
+                        if (delta < DRAFT_S2_LDS) S2[t & 1][delta][kk] = best; else S2F[((t & 1) * 256 + delta) * 5 + kk] = best;
+                        C[slot * 5 + kk] = best_p;
+                    }
                     if (best > g_best) { g_best = best; g_col = (unsigned)(slot * 5 + kk); g_ck = best_ck; g_t = t; }
                 }
                 __syncthreads();

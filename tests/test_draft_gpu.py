@@ -64,6 +64,14 @@ def test_ladder_consensus_matches_the_reference_live(oracle_lib, ref_lib, tmp_pa
     for n, L in ((40, 300), (64, 120), (3, 4000)):
         truth = "".join("acgt"[i] for i in rng.integers(0, 4, L))
         cases.append(([dc.noisy(rng, truth, 0.12) for _ in range(n)], int(rng.integers(0, n))))
+    # runs of 32+ inserted bases in front of one template position (round 6: their column scores live outside LDS in k_draft_cns):
+    # most members carry the same 40- / 100- / 200-base insertion the template lacks, noise on top
+    for ins_len in (33, 40, 100, 200):
+        truth = "".join("acgt"[i] for i in rng.integers(0, 4, 400))
+        ins = "".join("acgt"[i] for i in rng.integers(0, 4, ins_len))
+        with_ins = truth[:200] + ins + truth[200:]
+        mem = [truth] + [dc.noisy(rng, with_ins, e) for e in (0.0, 0.0, 0.02, 0.05, 0.05)] + [dc.noisy(rng, truth, 0.02)]
+        cases.append((mem, 0))
     db, rungs = _db_of_members(str(tmp_path), [m for m, _ in cases])
     ctx = capi.Context(0)
     dr = capi.Draft(ctx, db)
