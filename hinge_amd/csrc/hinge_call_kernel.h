@@ -106,8 +106,13 @@ struct HingeCallLdsT {
 // wavefronts per read, twice the reads in flight (the kernel is bound by the reads it has in flight: a chain of round trips per read)
 // PK: every part of the batch has the 16|16 copies of its span columns (a template parameter: as a run-time branch both load forms'
 // registers were live at once - 158 VGPRs, three wavefronts per SIMD; the kernel lives on the reads it has in flight)
+// (round 6: five wavefronts per SIMD by decree - amdgpu_waves_per_eu(5, 5): 96 VGPRs, 17 of them spilled into the per-overlap loop -
+// takes 68 us where the compiler's own 113 VGPRs take 52.5; -DHINGE_COUNT_WAVES_ATTR=... to try another)
+#ifndef HINGE_COUNT_WAVES_ATTR
+#define HINGE_COUNT_WAVES_ATTR
+#endif
 template <int CW, bool PK>
-__global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBatch B) {
+__global__ __launch_bounds__(CW * WAVE) HINGE_COUNT_WAVES_ATTR void k_hinge_count(FilterDev P, HingeBatch B) {
     static_assert(CW == 2 || CW == 4, "two or four wavefronts per read");
     constexpr int SPW = WAVES_PER_BLOCK / CW;   // slices per wavefront
     const unsigned n_parts = (unsigned)B.n;
@@ -159,8 +164,13 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
             }
             for (int64_t k0 = k_lo; k0 < k_hi; k0 += GATHER_LOADS * WAVE) {
                 // three dependent round trips per GATHER_LOADS * 64 overlaps (spans, B-side fields, mask[B]) instead of per 64
-                int2 av[GATHER_LOADS], bs[GATHER_LOADS], mb[GATHER_LOADS];
+                // (round 6, PK: the span words stay PACKED in their registers - 16 instead of 32 for a batch - and are taken apart where
+                // they are used: the kernel lives on the reads it has in flight, i.e. on wavefronts per SIMD)
+                int2 avw[PK ? 1 : GATHER_LOADS], bsw[PK ? 1 : GATHER_LOADS], mb[GATHER_LOADS];
+                unsigned svp[PK ? GATHER_LOADS : 1], bvp[PK ? GATHER_LOADS : 1];
                 unsigned bf[GATHER_LOADS];
+                auto AV = [&](int u) { return PK ? make_int2((int)(svp[u] & 0xffffu), (int)(svp[u] >> 16)) : avw[u]; };
+                auto BS = [&](int u) { return PK ? make_int2((int)(bvp[u] & 0xffffu), (int)(bvp[u] >> 16)) : bsw[u]; };
                 bool nearw[GATHER_LOADS];
                 // (the B-side fields are loaded with the spans, needed or not: 12 more bytes per overlap of a work-list read - 1-2 % of
                 // the part - buy one dependent round trip less per batch)
@@ -169,19 +179,18 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
                     for (int u = 0; u < GATHER_LOADS; u++) {
                         const int64_t k = k0 + u * WAVE + lane;
                         const bool in = k < k_hi;
-                        const unsigned sv = in ? span16[k] : 0u, bv = in ? bspan16[k] : 0u;
-                        av[u] = make_int2((int)(sv & 0xffffu), (int)(sv >> 16));
+                        svp[u] = in ? span16[k] : 0u;
+                        bvp[u] = in ? bspan16[k] : 0u;
                         bf[u] = in ? b_flag[k] : 0u;
-                        bs[u] = make_int2((int)(bv & 0xffffu), (int)(bv >> 16));
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < GATHER_LOADS; u++) {
                         const int64_t k = k0 + u * WAVE + lane;
                         const bool in = k < k_hi;
-                        av[u] = in ? a_span[k] : make_int2(0, 0);
+                        avw[u] = in ? a_span[k] : make_int2(0, 0);
                         bf[u] = in ? b_flag[k] : 0u;
-                        bs[u] = in ? b_span[k] : make_int2(0, 0);
+                        bsw[u] = in ? b_span[k] : make_int2(0, 0);
                     }
                 }
 #pragma unroll
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
 #pragma unroll
                     for (int a = 0; a < PRE_MAXA; a++) {
                         if (a >= na) break;
-                        const int c = atype[a] == -1 ? av[u].y : av[u].x;
+                        const int c = atype[a] == -1 ? AV(u).y : AV(u).x;
                         nr = nr || ((c > apos[a] - P.tol) && (c < apos[a] + P.tol));
                     }
                     nearw[u] = nr && k < k_hi;
@@ -202,17 +211,17 @@ __global__ __launch_bounds__(CW * WAVE) void k_hinge_count(FilterDev P, HingeBat
                 for (int u = 0; u < GATHER_LOADS; u++) {
                     if (!nearw[u]) continue;
                     int L, R;
-                    overhangs(bs[u], (int)(bf[u] >> 31), mb[u], L, R);
+                    overhangs(BS(u), (int)(bf[u] >> 31), mb[u], L, R);
 #pragma unroll
                     for (int a = 0; a < PRE_MAXA; a++) {
                         if (a >= na) break;
-                        const int c = atype[a] == -1 ? av[u].y : av[u].x;
+                        const int c = atype[a] == -1 ? AV(u).y : AV(u).x;
                         if ((c > apos[a] - P.tol) && (c < apos[a] + P.tol)) {
                             const bool sup = atype[a] == -1 ? (R > P.theta) : (L > P.theta);
                             if (sup) {
                                 csup[a]++;
                                 if (SPW == 2) csup_hi[a] += (k0 + u * WAVE + lane >= k_mid);
-                                const int f = atype[a] == -1 ? av[u].x : -av[u].y;
+                                const int f = atype[a] == -1 ? AV(u).x : -AV(u).y;
                                 const int m0 = atype[a] == -1 ? mk.x : -mk.y;
                                 cnear[a] += (f - m0 < P.bin_len);
                                 cminf[a] = min(cminf[a], f);
