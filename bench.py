@@ -261,6 +261,7 @@ def describe_workload(name):
 
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the host driver only supports dmabuf IPC: RCCL between processes needs it)
     import torch
     import torch.distributed as dist
 
