@@ -161,14 +161,19 @@ __global__ __launch_bounds__(64) void k_draft_align(const unsigned char* __restr
                 break;
             }
             n_ent += nk;
-            for (int o = 32; o; o >>= 1) my_best = max(my_best, __shfl_xor(my_best, o));
-            best_m = max(best_m, my_best);
+            best_m = max(best_m, wave_max(my_best));          // (DPP reduction; the kernel issues 0.71 of the vector peak: instructions count)
+            // the band's new ends: first / last diagonal within band_tol of the best anti-diagonal - one ballot per 64 diagonals, the
+            // ends read off the mask on the scalar side (was: two 64-lane shuffle reductions per round)
             int lo = max_k, hi = min_k;
-            for (int idx = lane; idx < nk; idx += 64) {
-                const int k2 = min_k + 2 * idx;
-                if ((int)U[k2 + k_off] >= best_m - band_tol) { lo = min(lo, k2); hi = max(hi, k2); }
+            for (int c = 0; c * 64 < nk; c++) {
+                const int idx = c * 64 + lane;
+                const bool ok = idx < nk && (int)U[min_k + 2 * idx + k_off] >= best_m - band_tol;
+                const unsigned long long Bm = __ballot(ok);
+                if (Bm) {
+                    lo = min(lo, min_k + 2 * (c * 64 + (int)__builtin_ctzll(Bm)));
+                    hi = max(hi, min_k + 2 * (c * 64 + 63 - (int)__builtin_clzll(Bm)));
+                }
             }
-            for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
             max_k = hi + 1; min_k = lo - 1;
             __syncthreads();
         }
