@@ -1819,7 +1819,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // m0 = mask.first resp. -mask.second.  `ord` is an optional indirection (position -> element).
 // Returns 1 = bridged, 0 = not bridged.   filter.cpp:920-963 / 1019-1062.
 // ------------------------------------------------------------------------------------------------
-HINGE_HD inline int hinge_scan(const int* f, const int* sec, const int* ord, int s, int m0, int BIN, int TH, int UNB, int PIL) {
+template <typename OrdT>
+HINGE_HD inline int hinge_scan(const int* f, const int* sec, const OrdT* ord, int s, int m0, int BIN, int TH, int UNB, int PIL) {
     int considered = 0, to_end = 0;
     const int f0 = f[ord ? ord[0] : 0];
     for (int id = 0; id < s; ++id) {

@@ -76,16 +76,19 @@ struct HingeBatch {
     int n;
 };
 
-template <int CAP>
+// LEAN (round 6): the instance behind k_hinge_call_light - no key array, no pile-up-order copies of the supporters (an order list in
+// sK instead), no sort-free evaluation (its items come flagged: the tie order decides) - 52 instead of 77 KiB at CAP = 2048: THREE
+// workgroups per CU for a replay that is bound by the workgroups it has in flight
+template <int CAP, bool LEAN = false>
 struct HingeCallLdsT {
-    WaveSortLdsT<CAP> ws;
+    WaveSortLdsT<CAP, LEAN> ws;
     unsigned short ppos[CAP];      // position of every overlap of the read in the sorted pile-up
     alignas(16) int sF[CAP];       // supporters in .las order: other end in scan-ascending form ...
     alignas(16) int sS[CAP];       // ... and the overhang on the far side; reused for the sorted lists
     unsigned short sK[CAP];        // ... and the local overlap index
     int sL[HC_SMALL];              // length sums of the first HC_SMALL supporters
-    int wF[CAP];                   // supporters in pile-up order
-    int wS[CAP];
+    int wF[LEAN ? 1 : CAP];        // supporters in pile-up order
+    int wS[LEAN ? 1 : CAP];
     int wcnt[2][WAVES_PER_BLOCK];
     int cnt;
     int need_order;
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call_light(FilterDev P, HingeBa
 // CAP: capacity of the LDS lists (pile-up size, supporters) = half the number of 1-bp bins.  The host launches the
 // PO_CAP_SMALL instance (72 KiB of LDS: two workgroups per CU) over the items whose pile-up fits it - they are appended from
 // the front of `heavy` - and the PO_CAP instance (one workgroup per CU) over the rest, appended from the back (`from_back`).
-template <int CAP>
+template <int CAP, bool LEAN = false>
 __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B, int from_back, int tier2 /*1: the items k_hinge_call_light passed on*/,
                                                       int n_min, int n_max /*only items with n_min <= pile-up size <= n_max*/, int small_cursor) {
     const HingePart& A = B.part[blockIdx.x % (unsigned)B.n];
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
     unsigned* __restrict__ dbg = A.dbg; const unsigned heavy_cap = A.heavy_cap;
     (void)row_ptr; (void)anno_off; (void)anno_buf;
     constexpr int SF_BINS = 2 * CAP;   // 1-bp bins of f - f[0] for the sort-free scan evaluation
-    __shared__ HingeCallLdsT<CAP> S;
+    __shared__ HingeCallLdsT<CAP, LEAN> S;
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                         bf[u] = in ? b_flag[k] : 0u;
                         bs[u] = in ? b_span[k] : make_int2(0, 0);
                     }
-                    if (k0 == k_lo) {   // the sort-free evaluation's bins are cleared while the first loads are in flight
+                    if (!LEAN && k0 == k_lo) {   // the sort-free evaluation's bins are cleared while the first loads are in flight
                         int4* z23 = reinterpret_cast<int4*>(bin23);
                         int4* z0 = reinterpret_cast<int4*>(bin0);
                         for (int b = tid; b < SF_BINS / 4; b += BLOCK) z23[b] = make_int4(0, 0, 0, 0);
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                         slot0 += __popcll(bal);
                     }
                 }
-                if (k_lo >= k_hi) {   // an empty slice still clears its share of the bins
+                if (!LEAN && k_lo >= k_hi) {   // an empty slice still clears its share of the bins
                     int4* z23 = reinterpret_cast<int4*>(bin23);
                     int4* z0 = reinterpret_cast<int4*>(bin0);
                     for (int b = tid; b < SF_BINS / 4; b += BLOCK) z23[b] = make_int4(0, 0, 0, 0);
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
             else if (sup > CAP || force_exact == 1) action = 2;
             else action = 1;
             bool need_order = false;
-            if (action == 1 && force_exact == 0 && sup <= CAP && !ties_known) {
+            if (!LEAN && action == 1 && force_exact == 0 && sup <= CAP && !ties_known) {
                 // ---- sort-free evaluation of the scan (filter.cpp:932-963 / 1031-1062) -----------------
                 // Past the first-branch prefix (c1 = near_end <= UNB elements) the scan walks the remaining
                 // supporters by ascending f.  With cat = 2 (sec < TH), 3 (sec > TH), 0 (sec == TH):
@@ -816,13 +819,31 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
             if (need_order && !order_valid) {
                 order_valid = true;
                 if (tid == 0 && dbg) atomicAdd(&dbg[4], 1u);
-                for (int64_t k = s + tid; k < e; k += BLOCK) {
-                    const int2 av = a_span[k];
-                    const int2 bs = b_span[k];
-                    S.ws.key[k - s] = av.y - av.x + bs.y - bs.x;   // compare_overlap key
+                bool sorted = true;
+                if constexpr (LEAN) {
+                    sorted = block_std_sort_desc_keys(S.ws, n, tid, [&](int p) {
+                        const int2 av = a_span[s + p];
+                        const int2 bs = b_span[s + p];
+                        return av.y - av.x + bs.y - bs.x;              // compare_overlap key
+                    });
+                } else {
+                    for (int64_t k = s + tid; k < e; k += BLOCK) {
+                        const int2 av = a_span[k];
+                        const int2 bs = b_span[k];
+                        S.ws.key[k - s] = av.y - av.x + bs.y - bs.x;   // compare_overlap key
+                    }
+                    __syncthreads();
+                    block_std_sort_desc(S.ws, n, tid);
                 }
-                __syncthreads();
-                block_std_sort_desc(S.ws, n, tid);
+                if (!sorted) {   // (block-uniform; keys spanning 2^20: the serial exact kernel takes the annotation)
+                    order_valid = false;
+                    if (tid == 0) {
+                        const unsigned q = atomicAdd(exact_count, 1u);
+                        if (q < exact_cap) exact_queue[q] = make_int2(i, a);
+                        else atomicOr(status, ST_QUEUE_CAP);
+                    }
+                    continue;
+                }
                 for (int p = tid; p < n; p += BLOCK) S.ppos[p] = S.ws.pl[p];
                 __syncthreads();
             }
@@ -830,7 +851,7 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
 #ifdef HINGE_TIMING
             const unsigned long long tr1 = wall_clock64();
 #endif
-            // ---- supporters in pile-up order -> wF / wS (one wave) --------------------------------
+            // ---- supporters in pile-up order -> wF / wS (one wave); LEAN: their ORDER -> sK (no copies) ----
             if (wib == 0) {
                 if (need_order) {
                     unsigned short* slot_of = S.ws.seglo;   // scratch: pile-up position -> supporter + 1
@@ -843,22 +864,24 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
                         const unsigned long long bal = __ballot(v != 0);
                         if (v) {
                             const int dst = r + __popcll(bal & lmask);
-                            S.wF[dst] = S.sF[v - 1];
-                            S.wS[dst] = S.sS[v - 1];
+                            if constexpr (LEAN) S.sK[dst] = (unsigned short)(v - 1);      // (sK was read into slot_of above: free)
+                            else { S.wF[dst] = S.sF[v - 1]; S.wS[dst] = S.sS[v - 1]; }
                         }
                         r += __popcll(bal);
                     }
                 } else {
-                    for (int t = lane; t < sup; t += WAVE) {
+                    int rank_of = 0;
+                    for (int t = lane; t < sup; t += WAVE) {       // (sup <= HC_SMALL = 64: one pass)
                         const int Lt = S.sL[t];
                         int rank = 0;
                         for (int u = 0; u < sup; u++) {
                             const int Lu = S.sL[u];
                             rank += (Lu > Lt) || (Lu == Lt && u < t);   // .las order breaks (harmless) ties
                         }
-                        S.wF[rank] = S.sF[t];
-                        S.wS[rank] = S.sS[t];
+                        rank_of = rank;
+                        if constexpr (!LEAN) { S.wF[rank] = S.sF[t]; S.wS[rank] = S.sS[t]; }
                     }
+                    if constexpr (LEAN) { if (lane < sup) S.sK[rank_of] = (unsigned short)lane; }
                 }
             }
             __syncthreads();
@@ -866,20 +889,36 @@ __global__ __launch_bounds__(BLOCK) void k_hinge_call(FilterDev P, HingeBatch B,
             const unsigned long long tr2 = wall_clock64();
 #endif
             // ---- std::sort(pairAscend / pairDescend): ascending f == descending -f --------------------
-            for (int t = tid; t < sup; t += BLOCK) S.ws.key[t] = -S.wF[t];
-            __syncthreads();
-            block_std_sort_desc(S.ws, sup, tid);
-            for (int t = tid; t < sup; t += BLOCK) {
-                const int p = S.ws.pl[t];
-                S.sF[p] = S.wF[t];
-                S.sS[p] = S.wS[t];
+            if constexpr (LEAN) {
+                // the list in pile-up order is sK's order of sF: its keys through the order, the sorted list as an order again (seglo)
+                const bool sorted = block_std_sort_desc_keys(S.ws, sup, tid, [&](int r) { return -S.sF[S.sK[r]]; });
+                if (!sorted) {
+                    if (tid == 0) {
+                        const unsigned q = atomicAdd(exact_count, 1u);
+                        if (q < exact_cap) exact_queue[q] = make_int2(i, a);
+                        else atomicOr(status, ST_QUEUE_CAP);
+                    }
+                    continue;
+                }
+                for (int r = tid; r < sup; r += BLOCK) S.ws.seglo[S.ws.pl[r]] = S.sK[r];
+                __syncthreads();
+            } else {
+                for (int t = tid; t < sup; t += BLOCK) S.ws.key[t] = -S.wF[t];
+                __syncthreads();
+                block_std_sort_desc(S.ws, sup, tid);
+                for (int t = tid; t < sup; t += BLOCK) {
+                    const int p = S.ws.pl[t];
+                    S.sF[p] = S.wF[t];
+                    S.sS[p] = S.wS[t];
+                }
+                __syncthreads();
             }
-            __syncthreads();
 #ifdef HINGE_TIMING
             const unsigned long long tr3 = wall_clock64();
 #endif
             if (tid == 0) {
-                const int r = hinge_scan(S.sF, S.sS, nullptr, sup, m0, P.bin_len, P.theta, P.unb, P.pil);
+                const int r = LEAN ? hinge_scan(S.sF, S.sS, S.ws.seglo, sup, m0, P.bin_len, P.theta, P.unb, P.pil)
+                                   : hinge_scan(S.sF, S.sS, (const unsigned short*)nullptr, sup, m0, P.bin_len, P.theta, P.unb, P.pil);
                 hinge_flag[item.slot] = r == 0 ? 1 : 0;   // emit iff not bridged (support > SUP holds)
 #ifdef HINGE_TIMING
                 if (dbg) {

@@ -54,6 +54,7 @@ struct hinge_ctx {
     DevBuf rd_head, rd_next2, rl2;      // round 6: the second-tier items chained by read (HingePart::rd_head ...)
     unsigned pass_stamp = 0;            // ... and the stamp of the last hinge launch (rd_head entries of other launches are stale)
     int group_reads = 1;                // HINGE_CALL_GROUP=0: k_hinge_call<CAP> draws items one by one (round 5)
+    int hinge_lean = 1;                 // HINGE_CALL_LEAN=0: the full-size k_hinge_call<2048> behind the light kernel instead of the LEAN one
     unsigned anno_cap = 0;               // annotation slots (a multiple of N_SHARD: every shard allocates from its own 1 / N_SHARD of them)
     unsigned work_cap = 0;               // work-list slots (the list is interleaved over the shards: n_reads + room for their imbalance)
     DevBuf exact_queue;
@@ -302,6 +303,7 @@ int hinge_ctx_create(int device, hinge_ctx** out) {
     if (const char* g = getenv("HINGE_CALL_LIGHT")) ctx->hinge_light = atoi(g);
     if (const char* g = getenv("HINGE_CALL_MINI")) ctx->hinge_mini = atoi(g);
     if (const char* g = getenv("HINGE_CALL_GROUP")) ctx->group_reads = atoi(g);
+    if (const char* g = getenv("HINGE_CALL_LEAN")) ctx->hinge_lean = atoi(g);
     if (const char* g = getenv("HINGE_COUNT_WAVES")) ctx->count_waves = atoi(g) == 4 ? 4 : 2;
     if (const char* g = getenv("HINGE_K2_STEAL")) ctx->k2_steal = atoi(g);
     if (const char* g = getenv("HINGE_SPEC_BAND")) ctx->spec_band = std::max(0, atoi(g));
@@ -1419,7 +1421,9 @@ static int launch_hinges_batch(hinge_ctx** ctxs, int n, const hinge_filter_param
         // behind the light kernel ONE second-tier launch: the full-size instance takes both ends of the list (an empty launch is 5 us)
         hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 2, n_min, INT_MAX, 0);
     } else {
-        hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0, n_min, INT_MAX, 0);
+        // behind the light kernel: the LEAN instance (52 KiB of LDS: three workgroups per CU; HINGE_CALL_LEAN=0: the full one, two per CU)
+        if (light && ctx->hinge_lean) hipLaunchKernelGGL((k_hinge_call<PO_CAP_SMALL, true>), dim3(std::max(n, (3 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, 1, n_min, INT_MAX, 0);
+        else hipLaunchKernelGGL(k_hinge_call<PO_CAP_SMALL>, dim3(std::max(n, (2 * ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 0, light ? 1 : 0, n_min, INT_MAX, 0);
         if (any_big) hipLaunchKernelGGL(k_hinge_call<PO_CAP>, dim3(std::max(n, (ctx->n_cu / n) * n)), dim3(BLOCK), 0, ctx->stream, to_dev(p), B, 1, 0, 0, INT_MAX, 0);
     } }
     CK(hipGetLastError());

@@ -36,10 +36,11 @@ constexpr int PO_CAP = 4096;            // longest list sorted in LDS
 constexpr int PO_CAP_SMALL = 2048;      // the half-size instance: two workgroups of k_hinge_call per CU
 constexpr int PO_CAP_MINI = 1024;       // the quarter-size instance behind k_hinge_call_light: four per CU
 
-template <int CAP>
+// LEAN (round 6): no key array - the keys come from a functor (block_std_sort_desc_keys) and live inside the packed words only
+template <int CAP, bool LEAN = false>
 struct WaveSortLdsT {
     static constexpr int SEG_CAP = CAP / 8;   // segments alive on one level (each is > 16 long)
-    int key[CAP];                  // sort key by element index (never permuted)
+    int key[LEAN ? 1 : CAP];       // sort key by element index (never permuted)
     int perm[CAP];                 // perm[p] = element at position p
     unsigned short pl[CAP];        // left stopper positions by rank (scratch); on return: position of every element
     unsigned short pr[CAP];        // right stopper positions by rank from the left (scratch)
@@ -373,13 +374,13 @@ __device__ inline void wave_small_sort_packed(WS& o, unsigned* __restrict__ pk, 
     }
 }
 
-template <typename WS>
-__device__ inline void block_std_sort_desc_packed(WS& o, int n, int tid, int kmin) {
+template <typename WS, typename KeyOf>
+__device__ inline void block_std_sort_desc_packed(WS& o, int n, int tid, int kmin, KeyOf key_of) {
     const int lane = tid & 63;
     const int wib = tid >> 6;
     const unsigned long long lmask = (1ull << lane) - 1ull;
     unsigned* __restrict__ pk = reinterpret_cast<unsigned*>(o.perm);       // pk[p] = (key - kmin) << PK_SHIFT | element at position p
-    for (int p = tid; p < n; p += 256) pk[p] = ((unsigned)(o.key[p] - kmin) << PK_SHIFT) | (unsigned)p;
+    for (int p = tid; p < n; p += 256) pk[p] = ((unsigned)(key_of(p) - kmin) << PK_SHIFT) | (unsigned)p;
     if (tid == 0) {
         o.seg_cnt[0] = 0;
         o.seg_cnt[1] = 0;
@@ -518,9 +519,31 @@ __device__ inline void block_std_sort_desc(WS& o, int n, int tid) {
     kmax = max(max(o.krange[1][0], o.krange[1][1]), max(o.krange[1][2], o.krange[1][3]));
     __syncthreads();
 #ifndef HINGE_SORT_WIDE
-    if (n > 0 && (long long)kmax - (long long)kmin < (1ll << (32 - PK_SHIFT))) { block_std_sort_desc_packed(o, n, tid, kmin); return; }
+    if (n > 0 && (long long)kmax - (long long)kmin < (1ll << (32 - PK_SHIFT))) { block_std_sort_desc_packed(o, n, tid, kmin, [&](int p) { return o.key[p]; }); return; }
 #endif
     block_std_sort_desc_wide(o, n, tid);
+}
+
+// The same for a list whose keys come from a functor (the LEAN work space has no key array): the keys are staged once in the stopper
+// scratch (pl .. pr: CAP ints, free until the walk starts), their range is reduced, the packed words are built from the stage.
+// Returns false - nothing sorted - when the keys span 2^(32 - PK_SHIFT) or more (the caller takes another route: never seen on
+// length sums or other ends, both below 2^18).  Call from ALL threads of a 256-thread workgroup.
+template <typename WS, typename KeyOf>
+__device__ inline bool block_std_sort_desc_keys(WS& o, int n, int tid, KeyOf key_of) {
+    static_assert(sizeof(o.pl) == sizeof(o.pr), "pl and pr: one stretch of CAP ints");
+    int* __restrict__ stage = reinterpret_cast<int*>(o.pl);
+    int kmin = 0x7fffffff, kmax = (int)0x80000000;
+    for (int p = tid; p < n; p += 256) { const int k = key_of(p); stage[p] = k; kmin = min(kmin, k); kmax = max(kmax, k); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { kmin = min(kmin, __shfl_xor(kmin, d)); kmax = max(kmax, __shfl_xor(kmax, d)); }
+    if ((tid & 63) == 0) { o.krange[0][tid >> 6] = kmin; o.krange[1][tid >> 6] = kmax; }
+    __syncthreads();
+    kmin = min(min(o.krange[0][0], o.krange[0][1]), min(o.krange[0][2], o.krange[0][3]));
+    kmax = max(max(o.krange[1][0], o.krange[1][1]), max(o.krange[1][2], o.krange[1][3]));
+    __syncthreads();
+    if (n > 0 && (long long)kmax - (long long)kmin >= (1ll << (32 - PK_SHIFT))) return false;
+    block_std_sort_desc_packed(o, n, tid, kmin, [&](int p) { return stage[p]; });
+    return true;
 }
 
 }  // namespace hinge
