@@ -108,6 +108,8 @@ def random_paths(rng, spec):
         env["HINGE_CALL_GROUP"] = "0"                # k_hinge_call<CAP> draws items one by one instead of reads with their item chains
     if rng.random() < 0.3:
         env["HINGE_COMM_ONE_RANK"] = "1"             # maximal / layout send their rows through a one-rank RCCL communicator (hinge_comm_allgather_rows)
+    if rng.random() < 0.25:
+        env["HINGE_CALL_LEAN"] = "0"                 # the full-size replay instance behind the light kernel instead of the 52-KiB one
     return env, paf
 
 
