@@ -30,7 +30,7 @@ def _compare(wd_o, wd_h):
 
 @pytest.mark.parametrize("name,mlas", [("tiny", False), ("tiny_qv", False), ("tiny_mlas", True), ("tiny_mlas", False),
                                        ("ties", False), ("chimera", False), ("long_repeat", False), ("tspace200", False), ("edges", False)])
-@pytest.mark.parametrize("exact", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("exact", [0, 1, 2, 3, 4, 5, 6])
 def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, monkeypatch, name, mlas, exact):
     """exact: 0 the shipped route (k_hinge_count, then k_hinge_call_light - the order-independent evaluation on sorted supporters -,
     then k_hinge_call<CAP> for what is left), 1 the serial exact kernel, 2 the exact replay in
@@ -39,6 +39,9 @@ def test_filter_matches_oracle(datasets, oracle_lib, tmp_path, monkeypatch, name
     their item chains (HINGE_CALL_GROUP=0; the shipped route, 0, draws reads: one sort replay per read)."""
     if exact == 5:
         monkeypatch.setenv("HINGE_CALL_GROUP", "0")
+        exact = 0
+    if exact == 6:      # the full-size replay instance (76 KiB of LDS) behind the light kernel instead of k_hinge_call<2048, LEAN>
+        monkeypatch.setenv("HINGE_CALL_LEAN", "0")
         exact = 0
     if exact == 3:
         monkeypatch.setenv("HINGE_CALL_LIGHT", "0")
